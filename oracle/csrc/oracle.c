@@ -1,0 +1,329 @@
+/*
+ * CPU oracle (plain C) for the two pixel-producing stages of the render-and-compare
+ * path.  TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Built by oracle/Makefile
+ * into oracle/_build/liboracle.so; loaded by oracle/native.py.
+ *
+ *  - hp_oracle_roi_align : torchvision 0.14.1 `roi_align` (aligned=False) as the
+ *    reference calls it (TB/lib3d/cropping.py:155-197, CP/lib3d/cropping.py:129-134:
+ *    output (240,320), sampling_ratio=4, spatial_scale=1).  PARITY UNPINNED (torchvision
+ *    is not importable in the build container; restated from its published CPU kernel).
+ *  - hp_oracle_rasterize : the DEFINITION of what the HIP rasteriser must output -- an
+ *    analytic pinhole rasterisation of one textured mesh per view with the camera model,
+ *    clip range, two-sidedness, depth decode, mask and eye-normal colour code of the
+ *    reference's Panda3D renderer (TB/renderer/types.py:92-137,
+ *    TB/renderer/utils.py:46-79, TB/renderer/panda3d_scene_renderer.py:59-141,221-230,
+ *    320-390, TB/renderer/panda3d_batch_renderer.py:62-125,194-286).  PIXEL PARITY
+ *    UNPINNED (Panda3D/OpenGL cannot run here and no reference test pins pixels).
+ *    Known, documented deviations from Panda3D: one sample at the pixel centre instead of
+ *    MSAAx4, bilinear level-0 texture filtering instead of trilinear-mipmap+aniso16.
+ *
+ * All arithmetic is float32 with explicit fmaf() so that the HIP kernels can follow the
+ * same operation order; built with -ffp-contract=off.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* roi_align                                                                            */
+/* ------------------------------------------------------------------------------------ */
+static inline float bilinear_tv(const float* plane, int H, int W, float y, float x) {
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.0f;
+  if (y <= 0.0f) y = 0.0f;
+  if (x <= 0.0f) x = 0.0f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+  float ly = y - (float)y_low, lx = x - (float)x_low;
+  float hy = 1.0f - ly, hx = 1.0f - lx;
+  float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+  return w1 * plane[y_low * W + x_low] + w2 * plane[y_low * W + x_high] +
+         w3 * plane[y_high * W + x_low] + w4 * plane[y_high * W + x_high];
+}
+
+/* images [Bi][C][H][W]; boxes [n][4] (x1,y1,x2,y2); im_ids [n]; out [n][C][oh][ow]. */
+void hp_oracle_roi_align(const float* images, int Bi, int C, int H, int W,
+                         const float* boxes, const int32_t* im_ids, int n,
+                         int oh, int ow, int sampling_ratio, float* out) {
+  (void)Bi;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int r = 0; r < n; ++r) {
+    const float x1 = boxes[4 * r + 0], y1 = boxes[4 * r + 1];
+    const float x2 = boxes[4 * r + 2], y2 = boxes[4 * r + 3];
+    float roi_w = x2 - x1, roi_h = y2 - y1;
+    if (roi_w < 1.0f) roi_w = 1.0f; /* aligned=False */
+    if (roi_h < 1.0f) roi_h = 1.0f;
+    const float bin_h = roi_h / (float)oh, bin_w = roi_w / (float)ow;
+    const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_h / (float)oh);
+    const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_w / (float)ow);
+    const float count = (float)(gh * gw > 1 ? gh * gw : 1);
+    for (int c = 0; c < C; ++c) {
+      const float* plane = images + ((size_t)im_ids[r] * C + c) * H * W;
+      float* o = out + ((size_t)r * C + c) * oh * ow;
+      for (int ph = 0; ph < oh; ++ph)
+        for (int pw = 0; pw < ow; ++pw) {
+          float acc = 0.0f;
+          for (int iy = 0; iy < gh; ++iy) {
+            const float y = y1 + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+              const float x = x1 + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+              acc += bilinear_tv(plane, H, W, y, x);
+            }
+          }
+          o[ph * ow + pw] = acc / count;
+        }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* rasteriser                                                                           */
+/* ------------------------------------------------------------------------------------ */
+#define HP_R_NORMALS 1
+#define HP_R_DEPTH 2
+#define HP_R_MASK 4
+#define HP_R_QUANT8 8 /* emulate the 8-bit framebuffer: round(c*255)/255 */
+
+typedef struct {
+  const float* verts;    /* [Vtot][3] metres, object frame */
+  const float* normals;  /* [Vtot][3] unit, object frame */
+  const float* uvs;      /* [Vtot][2] (v up, OpenGL convention) */
+  const uint8_t* colors; /* [Vtot][4] RGBA vertex colours (used when tex_off < 0) */
+  const int32_t* faces;  /* [Ftot][3] vertex ids local to the object */
+  const uint8_t* tex;    /* texture pool, RGBA8 row-major, row 0 = top */
+  const int64_t* obj;    /* [n_obj][8]: vert_off n_verts face_off n_faces tex_off tex_w tex_h pad */
+  int n_obj;
+} hp_oracle_meshes;
+
+#define Z_NEAR 0.1f
+#define Z_FAR 10.0f
+#define KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* cross product of homogeneous screen vertices with a canonical operand order (lower
+ * vertex id first) so the edge function of a shared edge is bit-identical (up to sign) in
+ * both triangles: no cracks between neighbours. */
+static inline void edge_fn(const float* A, int ia, const float* B, int ib, float* e) {
+  const float* P = A; const float* Q = B; float sgn = 1.0f;
+  if (ib < ia) { P = B; Q = A; sgn = -1.0f; }
+  e[0] = sgn * fmaf(P[1], Q[2], -(P[2] * Q[1]));
+  e[1] = sgn * fmaf(P[2], Q[0], -(P[0] * Q[2]));
+  e[2] = sgn * fmaf(P[0], Q[1], -(P[1] * Q[0]));
+}
+
+static inline float quant8(float c, int on) {
+  c = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+  if (!on) return c;
+  return floorf(fmaf(c, 255.0f, 0.5f)) / 255.0f;
+}
+
+/* value of the 32^3 "normal code" 3-D texture along one axis (it is separable): texel i
+ * holds floor(i*255/32) (TB/renderer/utils.py:63-79), repeat wrap, linear filter. */
+static inline float normal_code(float n) {
+  float s = n - floorf(n);             /* repeat wrap */
+  float x = fmaf(s, 32.0f, -0.5f);
+  float xf = floorf(x);
+  float f = x - xf;
+  int i0 = ((int)xf + 32) & 31, i1 = (i0 + 1) & 31;
+  float t0 = floorf((float)i0 * 255.0f / 32.0f), t1 = floorf((float)i1 * 255.0f / 32.0f);
+  return fmaf(f, t1 - t0, t0) / 255.0f;
+}
+
+static inline void tex_fetch(const uint8_t* tex, int tw, int th, float u, float v, float* rgb) {
+  float x = fmaf(u, (float)tw, -0.5f);
+  float y = fmaf(1.0f - v, (float)th, -0.5f);
+  float xf = floorf(x), yf = floorf(y);
+  float fx = x - xf, fy = y - yf;
+  int x0 = (int)xf % tw; if (x0 < 0) x0 += tw;
+  int y0 = (int)yf % th; if (y0 < 0) y0 += th;
+  int x1 = x0 + 1 == tw ? 0 : x0 + 1;
+  int y1 = y0 + 1 == th ? 0 : y0 + 1;
+  const uint8_t* p00 = tex + 4 * ((size_t)y0 * tw + x0);
+  const uint8_t* p01 = tex + 4 * ((size_t)y0 * tw + x1);
+  const uint8_t* p10 = tex + 4 * ((size_t)y1 * tw + x0);
+  const uint8_t* p11 = tex + 4 * ((size_t)y1 * tw + x1);
+  for (int c = 0; c < 3; ++c) {
+    float a = fmaf(fx, (float)p01[c] - (float)p00[c], (float)p00[c]);
+    float b = fmaf(fx, (float)p11[c] - (float)p10[c], (float)p10[c]);
+    rgb[c] = fmaf(fy, b - a, a) / 255.0f;
+  }
+}
+
+/*
+ * obj_ids [n]; TCO [n][16]; K [n][9]; ambient [n][3]; n_lights point lights per view:
+ * light_pos [n][n_lights][3] (object frame, metres), light_col [n][n_lights][3].
+ * Outputs are addressed as base + view*sv + chan*sc + row*sr + col*sp (element strides), so
+ * NCHW (sc=h*w, sr=w, sp=1) and NHWC slices are both expressible.  Any output pointer may
+ * be NULL.  mask is uint8 with the same (sv, sr, sp) strides divided by... its own strides.
+ */
+void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_ids,
+                         const float* TCO, const float* K, const float* ambient,
+                         int n_lights, const float* light_pos, const float* light_col,
+                         int h, int w, int flags,
+                         float* rgb, float* nrm, float* depth, uint8_t* mask,
+                         int64_t sv, int64_t sc, int64_t sr, int64_t sp,
+                         int64_t dsv, int64_t dsr, int64_t dsp) {
+  const float depth_max = Z_NEAR / (1.0f - (1.0f - 1e-3f) * (Z_FAR - Z_NEAR) / Z_FAR);
+#pragma omp parallel
+  {
+    uint64_t* zbuf = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)h * w);
+    float* sv3 = NULL; size_t sv_cap = 0;
+#pragma omp for schedule(dynamic, 1)
+    for (int view = 0; view < n; ++view) {
+      const float* T = TCO + 16 * view;
+      const float* Kv = K + 9 * view;
+      int finite = 1;
+      for (int i = 0; i < 16; ++i) finite &= isfinite(T[i]) ? 1 : 0;
+      for (int i = 0; i < 9; ++i) finite &= isfinite(Kv[i]) ? 1 : 0;
+      const int64_t* ob = M->obj + 8 * obj_ids[view];
+      const int64_t voff = ob[0], nv = ob[1], foff = ob[2], nf = ob[3], toff = ob[4];
+      const int tw = (int)ob[5], th = (int)ob[6];
+      for (size_t p = 0; p < (size_t)h * w; ++p) zbuf[p] = KEY_EMPTY;
+      if ((size_t)nv * 3 > sv_cap) { sv_cap = (size_t)nv * 3; sv3 = (float*)realloc(sv3, sv_cap * 4); }
+
+      if (finite) {
+        /* vertex stage: homogeneous pixel coordinates (Xh, Yh, W) = K * (R p + t) */
+        for (int64_t i = 0; i < nv; ++i) {
+          const float* p = M->verts + 3 * (voff + i);
+          float cx = fmaf(T[0], p[0], fmaf(T[1], p[1], fmaf(T[2], p[2], T[3])));
+          float cy = fmaf(T[4], p[0], fmaf(T[5], p[1], fmaf(T[6], p[2], T[7])));
+          float cz = fmaf(T[8], p[0], fmaf(T[9], p[1], fmaf(T[10], p[2], T[11])));
+          sv3[3 * i + 0] = fmaf(Kv[0], cx, fmaf(Kv[1], cy, Kv[2] * cz));
+          sv3[3 * i + 1] = fmaf(Kv[4], cy, Kv[5] * cz);
+          sv3[3 * i + 2] = cz;
+        }
+        /* coverage + depth: 2-D homogeneous rasterisation (no explicit clipping) */
+        for (int64_t f = 0; f < nf; ++f) {
+          const int32_t* tri = M->faces + 3 * (foff + f);
+          const float* V0 = sv3 + 3 * tri[0];
+          const float* V1 = sv3 + 3 * tri[1];
+          const float* V2 = sv3 + 3 * tri[2];
+          float zmin = fminf(V0[2], fminf(V1[2], V2[2])), zmax = fmaxf(V0[2], fmaxf(V1[2], V2[2]));
+          if (!(zmax >= Z_NEAR) || !(zmin <= Z_FAR)) continue;
+          float e0[3], e1[3], e2[3];
+          edge_fn(V1, tri[1], V2, tri[2], e0);
+          edge_fn(V2, tri[2], V0, tri[0], e1);
+          edge_fn(V0, tri[0], V1, tri[1], e2);
+          float det = fmaf(V0[0], e0[0], fmaf(V0[1], e0[1], V0[2] * e0[2]));
+          if (!(det != 0.0f) || !isfinite(det)) continue;
+          int x0 = 0, x1 = w - 1, y0 = 0, y1 = h - 1;
+          if (zmin > 1e-6f) { /* all in front: tight screen bbox */
+            float u0 = V0[0] / V0[2], u1 = V1[0] / V1[2], u2 = V2[0] / V2[2];
+            float v0 = V0[1] / V0[2], v1 = V1[1] / V1[2], v2 = V2[1] / V2[2];
+            float umin = fminf(u0, fminf(u1, u2)), umax = fmaxf(u0, fmaxf(u1, u2));
+            float vmin = fminf(v0, fminf(v1, v2)), vmax = fmaxf(v0, fmaxf(v1, v2));
+            if (!(umax >= 0.0f) || !(umin <= (float)w) || !(vmax >= 0.0f) || !(vmin <= (float)h)) continue;
+            /* pixel centre j+0.5 in [umin, umax]  <=>  j in [ceil(umin-0.5), floor(umax-0.5)] */
+            float a = ceilf(umin - 0.5f), b = floorf(umax - 0.5f);
+            float c = ceilf(vmin - 0.5f), d = floorf(vmax - 0.5f);
+            x0 = a < 0.0f ? 0 : (int)a; x1 = b > (float)(w - 1) ? w - 1 : (int)b;
+            y0 = c < 0.0f ? 0 : (int)c; y1 = d > (float)(h - 1) ? h - 1 : (int)d;
+          }
+          for (int i = y0; i <= y1; ++i) {
+            const float pv = (float)i + 0.5f;
+            for (int j = x0; j <= x1; ++j) {
+              const float pu = (float)j + 0.5f;
+              float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
+              float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
+              float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
+              float s = l0 + l1 + l2;
+              int in_pos = (l0 >= 0.0f) & (l1 >= 0.0f) & (l2 >= 0.0f) & (s > 0.0f);
+              int in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (s < 0.0f);
+              if (!(in_pos | in_neg)) continue;
+              float Z = det / s;
+              if (!(Z >= Z_NEAR) || !(Z <= Z_FAR)) continue;
+              uint64_t key = ((uint64_t)f2u(Z) << 32) | (uint32_t)f;
+              uint64_t* zp = zbuf + (size_t)i * w + j;
+              if (key < *zp) *zp = key;
+            }
+          }
+        }
+      }
+
+      /* resolve: attributes of the nearest triangle at every covered pixel */
+      const float* amb = ambient + 3 * view;
+      for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+          const uint64_t key = zbuf[(size_t)i * w + j];
+          float o_rgb[3] = {0, 0, 0}, o_n[3] = {0, 0, 0}, o_d = 0.0f;
+          if (key != KEY_EMPTY) {
+            const int64_t f = (int64_t)(key & 0xFFFFFFFFull);
+            const int32_t* tri = M->faces + 3 * (foff + f);
+            const float* V0 = sv3 + 3 * tri[0];
+            const float* V1 = sv3 + 3 * tri[1];
+            const float* V2 = sv3 + 3 * tri[2];
+            float e0[3], e1[3], e2[3];
+            edge_fn(V1, tri[1], V2, tri[2], e0);
+            edge_fn(V2, tri[2], V0, tri[0], e1);
+            edge_fn(V0, tri[0], V1, tri[1], e2);
+            const float pu = (float)j + 0.5f, pv = (float)i + 0.5f;
+            float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
+            float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
+            float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
+            float s = l0 + l1 + l2;
+            float b0 = l0 / s, b1 = l1 / s, b2 = l2 / s; /* perspective-correct barycentrics */
+            float Z = u2f((uint32_t)(key >> 32));
+            const int64_t g0 = voff + tri[0], g1 = voff + tri[1], g2 = voff + tri[2];
+            /* albedo */
+            float alb[3];
+            if (toff >= 0) {
+              float tu = fmaf(b0, M->uvs[2 * g0], fmaf(b1, M->uvs[2 * g1], b2 * M->uvs[2 * g2]));
+              float tv = fmaf(b0, M->uvs[2 * g0 + 1], fmaf(b1, M->uvs[2 * g1 + 1], b2 * M->uvs[2 * g2 + 1]));
+              tex_fetch(M->tex + toff, tw, th, tu, tv, alb);
+            } else {
+              for (int c = 0; c < 3; ++c)
+                alb[c] = fmaf(b0, (float)M->colors[4 * g0 + c],
+                              fmaf(b1, (float)M->colors[4 * g1 + c], b2 * (float)M->colors[4 * g2 + c])) / 255.0f;
+            }
+            /* interpolated object-space normal -> camera (OpenCV) frame, unit length */
+            float no[3], nc[3];
+            for (int c = 0; c < 3; ++c)
+              no[c] = fmaf(b0, M->normals[3 * g0 + c], fmaf(b1, M->normals[3 * g1 + c], b2 * M->normals[3 * g2 + c]));
+            nc[0] = fmaf(T[0], no[0], fmaf(T[1], no[1], T[2] * no[2]));
+            nc[1] = fmaf(T[4], no[0], fmaf(T[5], no[1], T[6] * no[2]));
+            nc[2] = fmaf(T[8], no[0], fmaf(T[9], no[1], T[10] * no[2]));
+            float nn = sqrtf(fmaf(nc[0], nc[0], fmaf(nc[1], nc[1], nc[2] * nc[2])));
+            if (nn > 0.0f) { nc[0] /= nn; nc[1] /= nn; nc[2] /= nn; }
+            /* lighting: ambient + Lambert point lights (no attenuation) */
+            float lit[3] = {amb[0], amb[1], amb[2]};
+            if (n_lights > 0) {
+              /* camera-space position of the surface point */
+              float py = (pv - Kv[5]) * Z / Kv[4];
+              float px = ((pu - Kv[2]) * Z - Kv[1] * py) / Kv[0];
+              for (int l = 0; l < n_lights; ++l) {
+                const float* lp = light_pos + 3 * ((size_t)view * n_lights + l);
+                const float* lc = light_col + 3 * ((size_t)view * n_lights + l);
+                float lx = fmaf(T[0], lp[0], fmaf(T[1], lp[1], fmaf(T[2], lp[2], T[3]))) - px;
+                float ly = fmaf(T[4], lp[0], fmaf(T[5], lp[1], fmaf(T[6], lp[2], T[7]))) - py;
+                float lz = fmaf(T[8], lp[0], fmaf(T[9], lp[1], fmaf(T[10], lp[2], T[11]))) - Z;
+                float ln = sqrtf(fmaf(lx, lx, fmaf(ly, ly, lz * lz)));
+                float ndl = ln > 0.0f ? fmaf(nc[0], lx, fmaf(nc[1], ly, nc[2] * lz)) / ln : 0.0f;
+                if (ndl > 0.0f) for (int c = 0; c < 3; ++c) lit[c] = fmaf(lc[c], ndl, lit[c]);
+              }
+            }
+            for (int c = 0; c < 3; ++c) o_rgb[c] = quant8(alb[c] * lit[c], flags & HP_R_QUANT8);
+            /* eye-normal colour code; Panda/GL eye space is (x right, y up, z backward) */
+            o_n[0] = quant8(normal_code(nc[0]), flags & HP_R_QUANT8);
+            o_n[1] = quant8(normal_code(-nc[1]), flags & HP_R_QUANT8);
+            o_n[2] = quant8(normal_code(-nc[2]), flags & HP_R_QUANT8);
+            o_d = Z > depth_max ? 0.0f : Z;
+          }
+          const int64_t base = (int64_t)view * sv + (int64_t)i * sr + (int64_t)j * sp;
+          if (rgb) for (int c = 0; c < 3; ++c) rgb[base + c * sc] = o_rgb[c];
+          if (nrm && (flags & HP_R_NORMALS)) for (int c = 0; c < 3; ++c) nrm[base + c * sc] = o_n[c];
+          const int64_t dbase = (int64_t)view * dsv + (int64_t)i * dsr + (int64_t)j * dsp;
+          if (depth && (flags & HP_R_DEPTH)) depth[dbase] = o_d;
+          if (mask && (flags & HP_R_MASK)) mask[(size_t)view * h * w + (size_t)i * w + j] = o_d > 0.0f;
+        }
+    }
+    free(zbuf);
+    free(sv3);
+  }
+}
