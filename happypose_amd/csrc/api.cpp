@@ -1,0 +1,102 @@
+// C-ABI glue: error reporting, device queries and the device-resident mesh store.
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+
+namespace hp {
+
+static thread_local std::string g_error;
+
+void set_error(const std::string& msg) { g_error = msg; }
+
+}  // namespace hp
+
+using namespace hp;
+
+extern "C" int hp_version(void) { return 100; }
+
+extern "C" const char* hp_last_error(void) { return g_error.c_str(); }
+
+extern "C" int hp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int hp_device_name(char* buf, int len) {
+  HP_REQUIRE(buf && len > 0, "hp_device_name: bad buffer");
+  int dev = 0;
+  HP_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  HP_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  std::snprintf(buf, (size_t)len, "%s (%s)", prop.name, prop.gcnArchName);
+  return HP_OK;
+}
+
+namespace {
+
+template <typename T>
+int upload(T** dst, const T* src, size_t count) {
+  *dst = nullptr;
+  if (count == 0 || src == nullptr) return HP_OK;
+  HP_CHECK_HIP(hipMalloc((void**)dst, count * sizeof(T)));
+  HP_CHECK_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return HP_OK;
+}
+
+}  // namespace
+
+extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float* h_normals,
+                                               const float* h_uvs, const uint8_t* h_colors,
+                                               int64_t n_verts_total, const int32_t* h_faces,
+                                               int64_t n_faces_total, const uint8_t* h_tex,
+                                               int64_t tex_bytes, const int64_t* h_obj, int n_obj,
+                                               const float* h_points, int n_pad) {
+  if (!h_verts || !h_normals || !h_uvs || !h_colors || !h_faces || !h_obj || n_obj <= 0 ||
+      n_verts_total <= 0 || n_faces_total <= 0) {
+    set_error("hp_mesh_store_create: null or empty geometry");
+    return nullptr;
+  }
+  // validate the descriptor table: kernels index with it unchecked
+  for (int o = 0; o < n_obj; ++o) {
+    const int64_t* r = h_obj + 8 * o;
+    const bool tex_ok = r[4] < 0 || (r[5] > 0 && r[6] > 0 && r[4] + 4 * r[5] * r[6] <= tex_bytes && h_tex);
+    if (r[0] < 0 || r[1] <= 0 || r[0] + r[1] > n_verts_total || r[2] < 0 || r[3] <= 0 ||
+        r[2] + r[3] > n_faces_total || !tex_ok) {
+      set_error("hp_mesh_store_create: object descriptor " + std::to_string(o) + " out of range");
+      return nullptr;
+    }
+    for (int64_t f = 3 * r[2]; f < 3 * (r[2] + r[3]); ++f)
+      if (h_faces[f] < 0 || h_faces[f] >= r[1]) {
+        set_error("hp_mesh_store_create: face index out of range in object " + std::to_string(o));
+        return nullptr;
+      }
+  }
+  hp_mesh_store* s = new hp_mesh_store();
+  s->n_obj = n_obj;
+  s->n_pad = h_points ? n_pad : 0;
+  int rc = 0;
+  rc |= upload(&s->verts, h_verts, (size_t)n_verts_total * 3);
+  rc |= upload(&s->normals, h_normals, (size_t)n_verts_total * 3);
+  rc |= upload(&s->uvs, h_uvs, (size_t)n_verts_total * 2);
+  rc |= upload(&s->colors, h_colors, (size_t)n_verts_total * 4);
+  rc |= upload(&s->faces, h_faces, (size_t)n_faces_total * 3);
+  rc |= upload(&s->tex, h_tex, (size_t)(tex_bytes > 0 ? tex_bytes : 0));
+  rc |= upload(&s->obj, h_obj, (size_t)n_obj * 8);
+  if (h_points) rc |= upload(&s->points, h_points, (size_t)n_obj * n_pad * 3);
+  if (rc) {
+    hp_mesh_store_destroy(s);
+    return nullptr;
+  }
+  return s;
+}
+
+extern "C" void hp_mesh_store_destroy(hp_mesh_store* s) {
+  if (!s) return;
+  (void)hipFree(s->verts); (void)hipFree(s->normals); (void)hipFree(s->uvs); (void)hipFree(s->colors);
+  (void)hipFree(s->faces); (void)hipFree(s->tex); (void)hipFree(s->obj); (void)hipFree(s->points);
+  delete s;
+}
+
+extern "C" const float* hp_mesh_store_points(const hp_mesh_store* s) { return s ? s->points : nullptr; }

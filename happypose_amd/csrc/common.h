@@ -1,0 +1,60 @@
+// Shared helpers of the happypose_amd HIP library (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <string>
+
+#include "../../include/happypose_amd.h"
+
+namespace hp {
+
+void set_error(const std::string& msg);
+
+inline int fail(int code, const std::string& msg) {
+  set_error(msg);
+  return code;
+}
+
+#define HP_CHECK_HIP(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      return ::hp::fail(HP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    }                                                                                   \
+  } while (0)
+
+#define HP_REQUIRE(cond, msg)                               \
+  do {                                                      \
+    if (!(cond)) return ::hp::fail(HP_ERR_ARG, (msg));      \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(HP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  return HP_OK;
+}
+
+// device-resident object set (see include/happypose_amd.h)
+struct MeshStore {
+  float* verts = nullptr;
+  float* normals = nullptr;
+  float* uvs = nullptr;
+  uint8_t* colors = nullptr;
+  int32_t* faces = nullptr;
+  uint8_t* tex = nullptr;
+  int64_t* obj = nullptr;  // [n_obj][8]
+  float* points = nullptr; // [n_obj][n_pad][3]
+  float4* scratch_sv = nullptr;  // per-view transformed vertices (grown on demand)
+  size_t scratch_sv_elems = 0;
+  int n_obj = 0;
+  int n_pad = 0;
+  int64_t max_verts = 0;  // max vertices of a single object
+  int64_t max_faces = 0;
+};
+
+}  // namespace hp
+
+struct hp_mesh_store : hp::MeshStore {};

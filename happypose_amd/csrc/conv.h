@@ -1,0 +1,37 @@
+// Argument blocks and launchers of the conv-stack kernels (conv.hip), used by net.cpp.
+#pragma once
+
+#include "common.h"
+
+namespace hp {
+
+struct ConvArgs {
+  const float* x;          // NHWC [n][H][W][Cin]
+  const float* w;          // packed [Cout][Kpad]
+  const float* bias;       // [Cout] or null
+  const float* residual;   // NHWC [n][Ho][Wo][Cout] or null
+  const float* pre_scale;  // [Cin] or null  (x_act = relu(x * scale + shift))
+  const float* pre_shift;
+  const int4* lut;         // [Kpad/4] {offset, kh, kw, channel}; kh < 0 marks K padding
+  float* y;                // NHWC [n][Ho][Wo][Cout]
+  int64_t M;               // n * Ho * Wo
+  int H, W, Cin, Ho, Wo, Cout, stride, pad, Kpad, ktiles, relu;
+  int tiles_m, tiles_n;    // filled by launch_conv
+};
+
+struct HeadArgs {
+  const float* x;  // NHWC [b][HW][C]
+  int HW, C;
+  const float* fc_w; const float* fc_b;        // optional 512x512 fc (torchvision ResNet)
+  const float* pose_w; const float* pose_b; int pose_dim;
+  const float* logit_w; const float* logit_b; int n_logits;
+  float* pose_out; float* logit_out; float* features;
+};
+
+// variant 0: 128x128 block tile, variant 1: 128x64 (Cout == 64)
+int launch_conv(const ConvArgs& a, int variant, hipStream_t stream);
+int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
+int launch_head(const HeadArgs& a, int batch, hipStream_t stream);
+int conv_setup_once();
+
+}  // namespace hp

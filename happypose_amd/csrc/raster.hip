@@ -1,0 +1,385 @@
+// HIP rasteriser for gfx950: renders one textured mesh per view for thousands of views per
+// launch, straight into the (strided) tensors the conv stem reads.
+//
+// Replaces Panda3dBatchRenderer.render -> worker processes -> Panda3D/OpenGL
+// (TB/renderer/panda3d_batch_renderer.py:194-286, TB/renderer/panda3d_scene_renderer.py:320-390).
+// The arithmetic (operation order included) follows the CPU definition in
+// oracle/csrc/oracle.c so that coverage decisions agree pixel for pixel.
+//
+// Mapping to the hardware
+//   * one workgroup (256 threads = 4 waves) per (view, horizontal band of the image); the
+//     band's 64-bit z-buffer {depth bits : triangle id} lives in LDS (<= 76.8 KB, two
+//     workgroups per CU) and is updated with ds_min_u64 -- no z-buffer traffic to HBM;
+//   * a thread owns a triangle: it transforms the three vertices itself (9+6 FMAs each, the
+//     mesh is L2/MALL resident and shared by every view of the object), rejects it against
+//     the band, sets up the three homogeneous edge functions and walks its (tiny: ~3 px)
+//     bounding box; triangles with a large footprint are queued in LDS and walked by the
+//     whole workgroup so one lane never serialises thousands of pixels;
+//   * the resolve pass is pixel-parallel: consecutive lanes take consecutive columns, so
+//     NCHW planes are written with fully coalesced 256-B wave stores; texture, uv and
+//     normal gathers hit L2;
+//   * HBM traffic is therefore the output tensor (+ first touch of mesh/texture) -- the
+//     kernel's roofline is HBM bandwidth ("rasteriser").
+//   * workgroups are renumbered so that each XCD gets a contiguous range of views:
+//     consecutive hypotheses share an object, hence the mesh stays in that XCD's L2.
+#include "common.h"
+
+namespace hp {
+
+#pragma clang fp contract(off)
+
+constexpr float kZNear = 0.1f;
+constexpr float kZFar = 10.0f;
+constexpr unsigned long long kKeyEmpty = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kBandPixels = 9600;  // 76.8 KB of LDS z-buffer
+constexpr int kBigQueue = 1024;
+constexpr int kBigArea = 128;  // bbox pixels above which a triangle is walked cooperatively
+constexpr int kThreads = 256;
+
+struct RasterArgs {
+  const float* verts;
+  const float* normals;
+  const float* uvs;
+  const uint8_t* colors;
+  const int32_t* faces;
+  const uint8_t* tex;
+  const int64_t* obj;
+  const int32_t* obj_ids;
+  const float* TCO;
+  const float* K;
+  const float* ambient;
+  const float* light_pos;
+  const float* light_col;
+  const float* depth_norm_z;
+  float* rgb;
+  float* nrm;
+  float* depth;
+  uint8_t* mask;
+  hp_strides cs, ds;
+  int n, views_per_item, n_lights, h, w, flags, depth_norm_mode;
+  int band_rows, n_bands;
+  float depth_max;
+};
+
+__device__ __forceinline__ void edge_fn(const float* P0, int i0, const float* P1, int i1, float* e) {
+  const float* P = P0;
+  const float* Q = P1;
+  float sgn = 1.0f;
+  if (i1 < i0) { P = P1; Q = P0; sgn = -1.0f; }
+  e[0] = sgn * fmaf(P[1], Q[2], -(P[2] * Q[1]));
+  e[1] = sgn * fmaf(P[2], Q[0], -(P[0] * Q[2]));
+  e[2] = sgn * fmaf(P[0], Q[1], -(P[1] * Q[0]));
+}
+
+__device__ __forceinline__ void xform_vertex(const float* T, const float* Kv, const float* p, float* o) {
+  float cx = fmaf(T[0], p[0], fmaf(T[1], p[1], fmaf(T[2], p[2], T[3])));
+  float cy = fmaf(T[4], p[0], fmaf(T[5], p[1], fmaf(T[6], p[2], T[7])));
+  float cz = fmaf(T[8], p[0], fmaf(T[9], p[1], fmaf(T[10], p[2], T[11])));
+  o[0] = fmaf(Kv[0], cx, fmaf(Kv[1], cy, Kv[2] * cz));
+  o[1] = fmaf(Kv[4], cy, Kv[5] * cz);
+  o[2] = cz;
+}
+
+__device__ __forceinline__ float quant8(float c, int on) {
+  c = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+  if (!on) return c;
+  return floorf(fmaf(c, 255.0f, 0.5f)) / 255.0f;
+}
+
+__device__ __forceinline__ float normal_code(float n) {
+  float s = n - floorf(n);
+  float x = fmaf(s, 32.0f, -0.5f);
+  float xf = floorf(x);
+  float f = x - xf;
+  int i0 = ((int)xf + 32) & 31, i1 = (i0 + 1) & 31;
+  float t0 = floorf((float)i0 * 255.0f / 32.0f), t1 = floorf((float)i1 * 255.0f / 32.0f);
+  return fmaf(f, t1 - t0, t0) / 255.0f;
+}
+
+__device__ __forceinline__ void tex_fetch(const uint8_t* tex, int tw, int th, float u, float v, float* rgb) {
+  float x = fmaf(u, (float)tw, -0.5f);
+  float y = fmaf(1.0f - v, (float)th, -0.5f);
+  float xf = floorf(x), yf = floorf(y);
+  float fx = x - xf, fy = y - yf;
+  int x0 = (int)xf % tw; if (x0 < 0) x0 += tw;
+  int y0 = (int)yf % th; if (y0 < 0) y0 += th;
+  int x1 = x0 + 1 == tw ? 0 : x0 + 1;
+  int y1 = y0 + 1 == th ? 0 : y0 + 1;
+  const uchar4 p00 = *reinterpret_cast<const uchar4*>(tex + 4 * ((size_t)y0 * tw + x0));
+  const uchar4 p01 = *reinterpret_cast<const uchar4*>(tex + 4 * ((size_t)y0 * tw + x1));
+  const uchar4 p10 = *reinterpret_cast<const uchar4*>(tex + 4 * ((size_t)y1 * tw + x0));
+  const uchar4 p11 = *reinterpret_cast<const uchar4*>(tex + 4 * ((size_t)y1 * tw + x1));
+  const float c00[3] = {(float)p00.x, (float)p00.y, (float)p00.z};
+  const float c01[3] = {(float)p01.x, (float)p01.y, (float)p01.z};
+  const float c10[3] = {(float)p10.x, (float)p10.y, (float)p10.z};
+  const float c11[3] = {(float)p11.x, (float)p11.y, (float)p11.z};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float a = fmaf(fx, c01[c] - c00[c], c00[c]);
+    float b = fmaf(fx, c11[c] - c10[c], c10[c]);
+    rgb[c] = fmaf(fy, b - a, a) / 255.0f;
+  }
+}
+
+struct TriSetup {
+  float e0[3], e1[3], e2[3];
+  float det;
+  int x0, x1, y0, y1;  // inclusive pixel bbox clipped to the band; empty if x0 > x1
+};
+
+// Returns false when the triangle cannot touch rows [row0, row1] of this view.
+__device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const float* T, const float* Kv,
+                                               const float* vbase, const int32_t* tri, int row0,
+                                               int row1, TriSetup& s) {
+  float V0[3], V1[3], V2[3];
+  xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[0], V0);
+  xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[1], V1);
+  xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[2], V2);
+  float zmin = fminf(V0[2], fminf(V1[2], V2[2])), zmax = fmaxf(V0[2], fmaxf(V1[2], V2[2]));
+  if (!(zmax >= kZNear) || !(zmin <= kZFar)) return false;
+  s.x0 = 0; s.x1 = a.w - 1; s.y0 = 0; s.y1 = a.h - 1;
+  if (zmin > 1e-6f) {
+    float u0 = V0[0] / V0[2], u1 = V1[0] / V1[2], u2 = V2[0] / V2[2];
+    float v0 = V0[1] / V0[2], v1 = V1[1] / V1[2], v2 = V2[1] / V2[2];
+    float umin = fminf(u0, fminf(u1, u2)), umax = fmaxf(u0, fmaxf(u1, u2));
+    float vmin = fminf(v0, fminf(v1, v2)), vmax = fmaxf(v0, fmaxf(v1, v2));
+    if (!(umax >= 0.0f) || !(umin <= (float)a.w) || !(vmax >= 0.0f) || !(vmin <= (float)a.h)) return false;
+    float xa = ceilf(umin - 0.5f), xb = floorf(umax - 0.5f);
+    float ya = ceilf(vmin - 0.5f), yb = floorf(vmax - 0.5f);
+    s.x0 = xa < 0.0f ? 0 : (int)xa; s.x1 = xb > (float)(a.w - 1) ? a.w - 1 : (int)xb;
+    s.y0 = ya < 0.0f ? 0 : (int)ya; s.y1 = yb > (float)(a.h - 1) ? a.h - 1 : (int)yb;
+  }
+  if (s.y0 < row0) s.y0 = row0;
+  if (s.y1 > row1) s.y1 = row1;
+  if (s.y0 > s.y1 || s.x0 > s.x1) return false;
+  edge_fn(V1, tri[1], V2, tri[2], s.e0);
+  edge_fn(V2, tri[2], V0, tri[0], s.e1);
+  edge_fn(V0, tri[0], V1, tri[1], s.e2);
+  s.det = fmaf(V0[0], s.e0[0], fmaf(V0[1], s.e0[1], V0[2] * s.e0[2]));
+  if (!(s.det != 0.0f) || !isfinite(s.det)) return false;
+  return true;
+}
+
+__device__ __forceinline__ void shade_pixel(const TriSetup& s, int i, int j, uint32_t f,
+                                            unsigned long long* zb, int row0, int w) {
+  const float pv = (float)i + 0.5f, pu = (float)j + 0.5f;
+  float l0 = fmaf(s.e0[0], pu, fmaf(s.e0[1], pv, s.e0[2]));
+  float l1 = fmaf(s.e1[0], pu, fmaf(s.e1[1], pv, s.e1[2]));
+  float l2 = fmaf(s.e2[0], pu, fmaf(s.e2[1], pv, s.e2[2]));
+  float sum = l0 + l1 + l2;
+  bool in_pos = (l0 >= 0.0f) & (l1 >= 0.0f) & (l2 >= 0.0f) & (sum > 0.0f);
+  bool in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (sum < 0.0f);
+  if (!(in_pos | in_neg)) return;
+  float Z = s.det / sum;
+  if (!(Z >= kZNear) || !(Z <= kZFar)) return;
+  unsigned long long key = ((unsigned long long)__float_as_uint(Z) << 32) | f;
+  atomicMin(&zb[(i - row0) * w + j], key);
+}
+
+__global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
+  __shared__ unsigned long long zb[kBandPixels];
+  __shared__ int big_q[kBigQueue];
+  __shared__ int big_n;
+
+  // XCD-aware renumbering: dispatch order b -> XCD b % 8; give each XCD a contiguous range.
+  const int total = a.n * a.n_bands;
+  const int per_xcd = (total + 7) / 8;
+  const int lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (lin >= total) return;
+  const int view = lin / a.n_bands;
+  const int band = lin % a.n_bands;
+  const int row0 = band * a.band_rows;
+  const int row1 = min(a.h, row0 + a.band_rows) - 1;
+  const int npix = (row1 - row0 + 1) * a.w;
+  const int tid = threadIdx.x;
+
+  float T[12], Kv[9];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = a.TCO[16 * (int64_t)view + k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Kv[k] = a.K[9 * (int64_t)view + k];
+  bool finite = true;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) finite &= isfinite(T[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) finite &= isfinite(a.TCO[16 * (int64_t)view + 12 + k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) finite &= isfinite(Kv[k]);
+
+  const int item = view / a.views_per_item;
+  const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
+  const int64_t voff = ob[0], foff = ob[2], toff = ob[4];
+  const int nf = finite ? (int)ob[3] : 0;
+  const int tw = (int)ob[5], th = (int)ob[6];
+  const float* vbase = a.verts + 3 * voff;
+  const int32_t* fbase = a.faces + 3 * foff;
+
+  for (int p = tid; p < npix; p += kThreads) zb[p] = kKeyEmpty;
+  if (tid == 0) big_n = 0;
+  __syncthreads();
+
+  // ---- coverage + depth ----
+  for (int f = tid; f < nf; f += kThreads) {
+    int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
+    TriSetup s;
+    if (!setup_triangle(a, T, Kv, vbase, tri, row0, row1, s)) continue;
+    const int area = (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
+    if (area > kBigArea) {
+      int q = atomicAdd(&big_n, 1);
+      if (q < kBigQueue) { big_q[q] = f; continue; }
+    }
+    for (int i = s.y0; i <= s.y1; ++i)
+      for (int j = s.x0; j <= s.x1; ++j) shade_pixel(s, i, j, (uint32_t)f, zb, row0, a.w);
+  }
+  __syncthreads();
+  const int nbig = min(big_n, kBigQueue);
+  for (int q = 0; q < nbig; ++q) {
+    const int f = big_q[q];
+    int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
+    TriSetup s;
+    if (!setup_triangle(a, T, Kv, vbase, tri, row0, row1, s)) continue;
+    const int bw = s.x1 - s.x0 + 1;
+    const int area = bw * (s.y1 - s.y0 + 1);
+    for (int p = tid; p < area; p += kThreads)
+      shade_pixel(s, s.y0 + p / bw, s.x0 + p % bw, (uint32_t)f, zb, row0, a.w);
+  }
+  __syncthreads();
+
+  // ---- resolve ----
+  const int q8 = a.flags & HP_RASTER_QUANT8;
+  float amb[3] = {1.0f, 1.0f, 1.0f};
+  if (a.ambient) { amb[0] = a.ambient[3 * view]; amb[1] = a.ambient[3 * view + 1]; amb[2] = a.ambient[3 * view + 2]; }
+  const int64_t cbase = (int64_t)item * a.cs.s_item + (int64_t)(view % a.views_per_item) * a.cs.s_view;
+  const int64_t dbase = (int64_t)item * a.ds.s_item + (int64_t)(view % a.views_per_item) * a.ds.s_view;
+  const float zn = a.depth_norm_z ? a.depth_norm_z[item] : 1.0f;
+
+  for (int p = tid; p < npix; p += kThreads) {
+    const int i = row0 + p / a.w, j = p % a.w;
+    const unsigned long long key = zb[p];
+    float o_rgb[3] = {0.f, 0.f, 0.f}, o_n[3] = {0.f, 0.f, 0.f}, o_d = 0.0f;
+    if (key != kKeyEmpty) {
+      const int f = (int)(key & 0xFFFFFFFFull);
+      int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
+      float V0[3], V1[3], V2[3], e0[3], e1[3], e2[3];
+      xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[0], V0);
+      xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[1], V1);
+      xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[2], V2);
+      edge_fn(V1, tri[1], V2, tri[2], e0);
+      edge_fn(V2, tri[2], V0, tri[0], e1);
+      edge_fn(V0, tri[0], V1, tri[1], e2);
+      const float pu = (float)j + 0.5f, pv = (float)i + 0.5f;
+      float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
+      float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
+      float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
+      float sum = l0 + l1 + l2;
+      float b0 = l0 / sum, b1 = l1 / sum, b2 = l2 / sum;
+      float Z = __uint_as_float((uint32_t)(key >> 32));
+      const int64_t g0 = voff + tri[0], g1 = voff + tri[1], g2 = voff + tri[2];
+      float alb[3];
+      if (toff >= 0) {
+        const float2 t0 = *reinterpret_cast<const float2*>(a.uvs + 2 * g0);
+        const float2 t1 = *reinterpret_cast<const float2*>(a.uvs + 2 * g1);
+        const float2 t2 = *reinterpret_cast<const float2*>(a.uvs + 2 * g2);
+        float tu = fmaf(b0, t0.x, fmaf(b1, t1.x, b2 * t2.x));
+        float tv = fmaf(b0, t0.y, fmaf(b1, t1.y, b2 * t2.y));
+        tex_fetch(a.tex + toff, tw, th, tu, tv, alb);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          alb[c] = fmaf(b0, (float)a.colors[4 * g0 + c],
+                        fmaf(b1, (float)a.colors[4 * g1 + c], b2 * (float)a.colors[4 * g2 + c])) / 255.0f;
+      }
+      float no[3], nc[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        no[c] = fmaf(b0, a.normals[3 * g0 + c], fmaf(b1, a.normals[3 * g1 + c], b2 * a.normals[3 * g2 + c]));
+      nc[0] = fmaf(T[0], no[0], fmaf(T[1], no[1], T[2] * no[2]));
+      nc[1] = fmaf(T[4], no[0], fmaf(T[5], no[1], T[6] * no[2]));
+      nc[2] = fmaf(T[8], no[0], fmaf(T[9], no[1], T[10] * no[2]));
+      float nn = sqrtf(fmaf(nc[0], nc[0], fmaf(nc[1], nc[1], nc[2] * nc[2])));
+      if (nn > 0.0f) { nc[0] /= nn; nc[1] /= nn; nc[2] /= nn; }
+      float lit[3] = {amb[0], amb[1], amb[2]};
+      if (a.n_lights > 0) {
+        float py = (pv - Kv[5]) * Z / Kv[4];
+        float px = ((pu - Kv[2]) * Z - Kv[1] * py) / Kv[0];
+        for (int l = 0; l < a.n_lights; ++l) {
+          const float* lp = a.light_pos + 3 * ((int64_t)view * a.n_lights + l);
+          const float* lc = a.light_col + 3 * ((int64_t)view * a.n_lights + l);
+          float lx = fmaf(T[0], lp[0], fmaf(T[1], lp[1], fmaf(T[2], lp[2], T[3]))) - px;
+          float ly = fmaf(T[4], lp[0], fmaf(T[5], lp[1], fmaf(T[6], lp[2], T[7]))) - py;
+          float lz = fmaf(T[8], lp[0], fmaf(T[9], lp[1], fmaf(T[10], lp[2], T[11]))) - Z;
+          float ln = sqrtf(fmaf(lx, lx, fmaf(ly, ly, lz * lz)));
+          float ndl = ln > 0.0f ? fmaf(nc[0], lx, fmaf(nc[1], ly, nc[2] * lz)) / ln : 0.0f;
+          if (ndl > 0.0f) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lit[c] = fmaf(lc[c], ndl, lit[c]);
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o_rgb[c] = quant8(alb[c] * lit[c], q8);
+      o_n[0] = quant8(normal_code(nc[0]), q8);
+      o_n[1] = quant8(normal_code(-nc[1]), q8);
+      o_n[2] = quant8(normal_code(-nc[2]), q8);
+      o_d = Z > a.depth_max ? 0.0f : Z;
+    }
+    const int64_t co = cbase + (int64_t)i * a.cs.s_row + (int64_t)j * a.cs.s_col;
+    if (a.rgb) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.rgb[co + c * a.cs.s_chan] = o_rgb[c];
+    }
+    if (a.nrm) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.nrm[co + c * a.cs.s_chan] = o_n[c];
+    }
+    if (a.mask) a.mask[((int64_t)view * a.h + i) * a.w + j] = o_d > 0.0f ? 1 : 0;
+    if (a.depth) {
+      float d = o_d;
+      if (a.depth_norm_mode == 1) d = d / zn;
+      else if (a.depth_norm_mode == 2) d = fminf(fmaxf(d / zn, 0.0f), 2.0f) - 1.0f;
+      else if (a.depth_norm_mode == 3) d = fminf(fmaxf(d - zn, -2.0f), 2.0f);
+      a.depth[dbase + (int64_t)i * a.ds.s_row + (int64_t)j * a.ds.s_col] = d;
+    }
+  }
+}
+
+}  // namespace hp
+
+extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
+                            const int32_t* d_obj_ids, const float* d_TCO, const float* d_K,
+                            const float* d_ambient, int n_lights, const float* d_light_pos,
+                            const float* d_light_col, int h, int w, int flags, float* d_rgb,
+                            float* d_nrm, const hp_strides* color_strides, float* d_depth,
+                            const hp_strides* depth_strides, uint8_t* d_mask,
+                            const float* d_depth_norm_z, int depth_norm_mode, void* stream) {
+  using namespace hp;
+  HP_REQUIRE(store != nullptr, "hp_rasterize: null mesh store");
+  HP_REQUIRE(n >= 0 && views_per_item >= 1 && n % views_per_item == 0,
+             "hp_rasterize: n must be a multiple of views_per_item");
+  HP_REQUIRE(h > 0 && w > 0 && w <= kBandPixels, "hp_rasterize: unsupported resolution");
+  HP_REQUIRE(d_TCO && d_K && d_obj_ids, "hp_rasterize: null pose/intrinsics/object ids");
+  HP_REQUIRE(!(d_rgb || d_nrm) || color_strides, "hp_rasterize: colour strides missing");
+  HP_REQUIRE(!d_depth || depth_strides, "hp_rasterize: depth strides missing");
+  HP_REQUIRE(!d_mask || d_depth, "Binary mask can only be rendered if depth is rendered");
+  HP_REQUIRE(n_lights == 0 || (d_light_pos && d_light_col), "hp_rasterize: lights missing");
+  HP_REQUIRE(depth_norm_mode >= 0 && depth_norm_mode <= 3, "hp_rasterize: bad depth_norm_mode");
+  HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_rasterize: depth_norm_z missing");
+  if (n == 0) return HP_OK;
+  RasterArgs a{};
+  a.verts = store->verts; a.normals = store->normals; a.uvs = store->uvs; a.colors = store->colors;
+  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj;
+  a.obj_ids = d_obj_ids; a.TCO = d_TCO; a.K = d_K; a.ambient = d_ambient;
+  a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
+  a.rgb = d_rgb; a.nrm = d_nrm; a.depth = d_depth; a.mask = d_mask;
+  if (color_strides) a.cs = *color_strides;
+  if (depth_strides) a.ds = *depth_strides;
+  a.n = n; a.views_per_item = views_per_item; a.n_lights = n_lights; a.h = h; a.w = w;
+  a.flags = flags; a.depth_norm_mode = depth_norm_mode;
+  a.band_rows = kBandPixels / w;
+  a.n_bands = (h + a.band_rows - 1) / a.band_rows;
+  a.depth_max = kZNear / (1.0f - (1.0f - 1e-3f) * (kZFar - kZNear) / kZFar);
+  const int total = n * a.n_bands;
+  const int grid = 8 * ((total + 7) / 8);
+  hipLaunchKernelGGL(raster_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+  return check_launch("raster_kernel");
+}

@@ -1,0 +1,315 @@
+"""Thin torch-tensor front-ends of the C ABI (one function per entry point).
+
+torch is used for device memory and streams only; every computation below
+happens in the HIP library.  Each wrapper validates what the reference asserts
+(shapes, dtypes) and enqueues on the current torch stream.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _ffi
+from ._ffi import Strides, check, lib, ptr, stream_ptr
+from .mesh_store import MeshDataBase, PackedMeshes, RigidObjectDataset, sample_point_ids
+
+DEPTH_NORM = {None: 0, "none": 0, "tCR_scale": 1, "tCR_scale_clamp_center": 2, "tCR_center_clamp": 3}
+MULTIVIEW = {"TCO": (0, 1), "1view_TCO": (0, 1), "TCO+front_1view": (1, 2),
+             "TCO+front_3views": (3, 4), "TCO+front_5views": (5, 6)}
+ARCH = {"vanilla_resnet34": 0, "resnet34": 1, "resnet18": 2}
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _i32(t, device) -> torch.Tensor:
+    return torch.as_tensor(t).to(device=device, dtype=torch.int32).contiguous()
+
+
+class MeshStore:
+    """Device-resident object set: geometry/textures for the rasteriser and the padded
+    mesh-point table for the projection kernels (``hp_mesh_store``)."""
+
+    def __init__(self, object_ds: RigidObjectDataset, device="cuda"):
+        self.device = torch.device(device)
+        self.object_ds = object_ds
+        self.packed = PackedMeshes(object_ds)
+        self.mesh_db = MeshDataBase.from_object_ds(object_ds).batched()
+        self.labels = list(self.packed.labels)
+        self.label_to_id = dict(self.packed.label_to_id)
+        pts = np.ascontiguousarray(self.mesh_db.points, dtype=np.float32)
+        self.n_pad = pts.shape[1]
+        p = self.packed
+        with torch.cuda.device(self.device):
+            self._h = lib().hp_mesh_store_create(
+                _np_ptr(p.verts), _np_ptr(p.normals), _np_ptr(p.uvs), _np_ptr(p.colors), len(p.verts),
+                _np_ptr(p.faces), len(p.faces), _np_ptr(p.tex), p.tex.size, _np_ptr(p.obj), len(p.obj),
+                _np_ptr(pts), self.n_pad)
+        if not self._h:
+            raise _ffi.HipLibraryError("hp_mesh_store_create: " + lib().hp_last_error().decode())
+        self._point_ids: Dict[int, torch.Tensor] = {}
+        self.radius = torch.as_tensor(p.radius, device=self.device)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().hp_mesh_store_destroy(C.c_void_p(h))
+            except Exception:
+                pass
+
+    @property
+    def handle(self):
+        return C.c_void_p(self._h)
+
+    def ids_of(self, labels: Sequence[str]) -> torch.Tensor:
+        return torch.as_tensor([self.label_to_id[l] for l in labels], dtype=torch.int32, device=self.device)
+
+    def point_ids(self, n_points: int) -> torch.Tensor:
+        """ids of ``sample_points(n, deterministic=True)`` (TB/lib3d/mesh_ops.py:74-84)."""
+        if n_points not in self._point_ids:
+            ids = sample_point_ids(self.n_pad, n_points).astype(np.int32)
+            self._point_ids[n_points] = torch.as_tensor(ids, device=self.device)
+        return self._point_ids[n_points]
+
+
+def nchw_strides(c: int, h: int, w: int) -> Strides:
+    return Strides(c * h * w, 0, h * w, w, 1)
+
+
+def rasterize(store: MeshStore, obj_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor,
+              resolution: Tuple[int, int], render_normals=False, render_depth=False,
+              render_binary_mask=False, ambient: Optional[torch.Tensor] = None,
+              light_pos: Optional[torch.Tensor] = None, light_col: Optional[torch.Tensor] = None,
+              quant8: bool = True):
+    """NCHW outputs shaped like ``BatchRenderOutput`` (TB/renderer/types.py:45-56)."""
+    dev = store.device
+    n = TCO.shape[0]
+    assert TCO.shape == (n, 4, 4) and K.shape == (n, 3, 3)
+    assert obj_ids.shape == (n,)
+    if render_binary_mask:
+        assert render_depth, "Binary mask can only be rendered if depth is rendered"
+    h, w = resolution
+    TCO = _f32(TCO, dev)
+    K = _f32(K, dev)
+    obj_ids = _i32(obj_ids, dev)
+    rgb = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+    nrm = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev) if render_normals else None
+    dep = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev) if render_depth else None
+    msk = torch.empty((n, 1, h, w), dtype=torch.uint8, device=dev) if render_binary_mask else None
+    n_lights = 0
+    if light_pos is not None:
+        light_pos, light_col = _f32(light_pos, dev), _f32(light_col, dev)
+        n_lights = light_pos.shape[1]
+    if ambient is not None:
+        ambient = _f32(ambient, dev)
+    cs, ds = nchw_strides(3, h, w), nchw_strides(1, h, w)
+    with torch.cuda.device(dev):
+        check(lib().hp_rasterize(store.handle, n, 1, ptr(obj_ids), ptr(TCO), ptr(K), ptr(ambient), n_lights,
+                                 ptr(light_pos), ptr(light_col), h, w, 8 if quant8 else 0, ptr(rgb), ptr(nrm),
+                                 C.byref(cs), ptr(dep), C.byref(ds), ptr(msk), None, 0, stream_ptr(dev)),
+              "hp_rasterize")
+    return rgb, nrm, dep, (msk.bool() if msk is not None else None)
+
+
+def rasterize_into(store: MeshStore, x: torch.Tensor, chan0: int, obj_ids: torch.Tensor,
+                   TCV_O: torch.Tensor, KV: torch.Tensor, render_normals: bool, render_depth: bool,
+                   depth_norm_z: Optional[torch.Tensor] = None, depth_norm_mode: int = 0,
+                   ambient: Optional[torch.Tensor] = None) -> None:
+    """Render ``V`` views per hypothesis straight into channel slices of the NHWC network
+    input ``x [b,h,w,c_pad]``: view ``v`` occupies channels ``chan0 + v*C_r ...`` in the
+    reference's order rgb, normals, depth (MP/models/pose_rigid.py:437-453)."""
+    dev = store.device
+    b, h, w, cp = x.shape
+    V = TCV_O.shape[1]
+    assert TCV_O.shape == (b, V, 4, 4) and KV.shape == (b, V, 3, 3)
+    c_r = 3 + (3 if render_normals else 0) + (1 if render_depth else 0)
+    assert chan0 + V * c_r <= cp
+    TCV_O, KV, obj_ids = _f32(TCV_O, dev), _f32(KV, dev), _i32(obj_ids, dev)
+    cs = Strides(h * w * cp, c_r, 1, w * cp, cp)
+    base = x.data_ptr() + 4 * chan0
+    rgb_p = C.c_void_p(base)
+    nrm_p = C.c_void_p(base + 4 * 3) if render_normals else None
+    dep_p = C.c_void_p(base + 4 * (6 if render_normals else 3)) if render_depth else None
+    with torch.cuda.device(dev):
+        check(lib().hp_rasterize(store.handle, b * V, V, ptr(obj_ids), ptr(TCV_O), ptr(KV), ptr(ambient), 0,
+                                 None, None, h, w, 8, rgb_p, nrm_p, C.byref(cs), dep_p, C.byref(cs), None,
+                                 ptr(depth_norm_z), depth_norm_mode if render_depth else 0, stream_ptr(dev)),
+              "hp_rasterize")
+
+
+def pose_prep(store: MeshStore, TCO: torch.Tensor, K: torch.Tensor, im_ids: torch.Tensor,
+              obj_ids: torch.Tensor, im_size: Tuple[int, int], crop_size: Tuple[int, int] = (240, 320),
+              multiview_type: str = "TCO", normalize: bool = False, n_points: int = 2000,
+              n_points_extra: int = 200, lamb: float = 1.4):
+    """Returns ``dict(TCO, tCR, TCV_O [b,V,4,4], boxes_rend, boxes_crop, K_crop [b,V,3,3])``."""
+    dev = store.device
+    b = TCO.shape[0]
+    assert TCO.shape == (b, 4, 4) and K.dim() == 3 and K.shape[1:] == (3, 3)
+    mv, V = MULTIVIEW[multiview_type]
+    TCO, K = _f32(TCO, dev), _f32(K, dev)
+    im_ids, obj_ids = _i32(im_ids, dev), _i32(obj_ids, dev)
+    assert im_ids.shape == (b,) and obj_ids.shape == (b,)
+    f = dict(dtype=torch.float32, device=dev)
+    out = dict(TCO=torch.empty((b, 4, 4), **f), tCR=torch.empty((b, 3), **f),
+               TCV_O=torch.empty((b, V, 4, 4), **f), boxes_rend=torch.empty((b, 4), **f),
+               boxes_crop=torch.empty((b, 4), **f), K_crop=torch.empty((b, V, 3, 3), **f))
+    ids_main = store.point_ids(n_points)
+    ids_extra = store.point_ids(n_points_extra) if V > 1 else None
+    with torch.cuda.device(dev):
+        check(lib().hp_pose_prep(store.handle, b, V, mv, int(normalize), ptr(TCO), ptr(K), ptr(im_ids),
+                                 ptr(obj_ids), ptr(ids_main), n_points, ptr(ids_extra),
+                                 n_points_extra if V > 1 else 0, im_size[0], im_size[1], crop_size[0],
+                                 crop_size[1], C.c_float(lamb), ptr(out["TCO"]), ptr(out["tCR"]),
+                                 ptr(out["TCV_O"]), ptr(out["boxes_rend"]), ptr(out["boxes_crop"]),
+                                 ptr(out["K_crop"]), stream_ptr(dev)), "hp_pose_prep")
+    return out
+
+
+def crop_roi_align(images: torch.Tensor, boxes: torch.Tensor, im_ids: torch.Tensor,
+                   output_size=(240, 320), sampling_ratio: int = 4, out: Optional[torch.Tensor] = None,
+                   depth_norm_z: Optional[torch.Tensor] = None, depth_norm_mode: int = 0) -> torch.Tensor:
+    """``crop_images`` (TB/lib3d/cropping.py:155-197).  ``out=None`` -> NCHW ``[n,C,oh,ow]``;
+    otherwise ``out`` is the NHWC network input ``[n,oh,ow,c_pad]`` and channels 0..C-1 are
+    written."""
+    dev = images.device
+    Bi, Cc, H, W = images.shape
+    n = boxes.shape[0]
+    oh, ow = output_size
+    assert images.dtype == torch.float32 and images.is_contiguous()
+    boxes, im_ids = _f32(boxes, dev), _i32(im_ids, dev)
+    assert boxes.shape == (n, 4) and im_ids.shape == (n,)
+    if out is None:
+        res = torch.empty((n, Cc, oh, ow), dtype=torch.float32, device=dev)
+        st = Strides(Cc * oh * ow, 0, oh * ow, ow, 1)
+    else:
+        res = out
+        assert out.shape[:3] == (n, oh, ow) and out.shape[3] >= Cc and out.is_contiguous()
+        cp = out.shape[3]
+        st = Strides(oh * ow * cp, 0, 1, ow * cp, cp)
+    with torch.cuda.device(dev):
+        check(lib().hp_crop_roi_align(ptr(images), Bi, Cc, H, W, ptr(boxes), ptr(im_ids), n, oh, ow,
+                                      sampling_ratio, ptr(res), C.byref(st), ptr(depth_norm_z),
+                                      depth_norm_mode if Cc == 4 else 0, stream_ptr(dev)),
+              "hp_crop_roi_align")
+    return res
+
+
+def pose_update(TCO: torch.Tensor, K_crop: torch.Tensor, pose9: torch.Tensor,
+                tCR: Optional[torch.Tensor] = None) -> torch.Tensor:
+    dev = TCO.device
+    b = TCO.shape[0]
+    assert TCO.shape == (b, 4, 4) and pose9.shape == (b, 9)
+    assert K_crop.shape[0] == b and K_crop.shape[-2:] == (3, 3)
+    k_stride = K_crop[0].numel()
+    TCO, K_crop, pose9 = _f32(TCO, dev), _f32(K_crop, dev), _f32(pose9, dev)
+    if tCR is not None:
+        assert tCR.shape == (b, 3)
+        tCR = _f32(tCR, dev)
+    out = torch.empty_like(TCO)
+    with torch.cuda.device(dev):
+        check(lib().hp_pose_update(b, ptr(TCO), ptr(K_crop), k_stride, ptr(pose9), ptr(tCR), ptr(out),
+                                   stream_ptr(dev)), "hp_pose_update")
+    return out
+
+
+def tco_init_autodepth(store: MeshStore, boxes: torch.Tensor, K: torch.Tensor, im_ids, obj_ids,
+                       R: Optional[torch.Tensor] = None, box_ids=None, rot_ids=None) -> torch.Tensor:
+    dev = store.device
+    n = len(obj_ids)
+    boxes, K = _f32(boxes, dev), _f32(K, dev)
+    im_ids, obj_ids = _i32(im_ids, dev), _i32(obj_ids, dev)
+    box_ids = None if box_ids is None else _i32(box_ids, dev)
+    rot_ids = None if rot_ids is None else _i32(rot_ids, dev)
+    if R is not None:
+        R = _f32(R, dev)
+    out = torch.empty((n, 4, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().hp_tco_init_autodepth(store.handle, n, ptr(boxes), ptr(box_ids), ptr(K), ptr(im_ids),
+                                          ptr(obj_ids), ptr(R), ptr(rot_ids), ptr(out), stream_ptr(dev)),
+              "hp_tco_init_autodepth")
+    return out
+
+
+class Net:
+    """``hp_net``: backbone + heads with BN folded, on one device."""
+
+    def __init__(self, arch: str, n_inputs: int, state_dict: Dict[str, "np.ndarray | torch.Tensor"],
+                 max_batch: int = 128, device="cuda", h: int = 240, w: int = 320):
+        self.device = torch.device(device)
+        self.arch, self.n_inputs, self.h, self.w = arch, n_inputs, h, w
+        with torch.cuda.device(self.device):
+            self._h = lib().hp_net_create(ARCH[arch], n_inputs, h, w)
+            if not self._h:
+                raise _ffi.HipLibraryError("hp_net_create: " + lib().hp_last_error().decode())
+            for name, value in state_dict.items():
+                if name.endswith("num_batches_tracked"):
+                    continue
+                arr = value.detach().cpu().numpy() if isinstance(value, torch.Tensor) else np.asarray(value)
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+                check(lib().hp_net_set_param(self.handle, name.encode(), _np_ptr(arr), arr.size),
+                      f"hp_net_set_param({name})")
+            check(lib().hp_net_finalize(self.handle, max_batch), "hp_net_finalize")
+        self.c_pad = lib().hp_net_input_channels_padded(self.handle)
+        self.pose_dim = state_dict["pose_fc.weight"].shape[0] if "pose_fc.weight" in state_dict else 0
+        self.n_logits = (state_dict["views_logits_head.weight"].shape[0]
+                         if "views_logits_head.weight" in state_dict else 0)
+        self.flops_per_sample = lib().hp_net_flops_per_sample(self.handle)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().hp_net_destroy(C.c_void_p(h))
+            except Exception:
+                pass
+
+    @property
+    def handle(self):
+        return C.c_void_p(self._h)
+
+    def new_input(self, batch: int) -> torch.Tensor:
+        """Zeroed NHWC input buffer ``[batch,h,w,c_pad]`` (pad channels must stay 0)."""
+        return torch.zeros((batch, self.h, self.w, self.c_pad), dtype=torch.float32, device=self.device)
+
+    def forward(self, x: torch.Tensor, want_pose=True, want_logits=False, want_features=False):
+        b = x.shape[0]
+        assert x.shape == (b, self.h, self.w, self.c_pad) and x.is_contiguous() and x.dtype == torch.float32
+        f = dict(dtype=torch.float32, device=self.device)
+        pose = torch.empty((b, self.pose_dim), **f) if (want_pose and self.pose_dim) else None
+        logits = torch.empty((b, self.n_logits), **f) if (want_logits and self.n_logits) else None
+        feats = torch.empty((b, 512), **f) if want_features else None
+        with torch.cuda.device(self.device):
+            check(lib().hp_net_forward(self.handle, ptr(x), b, ptr(pose), ptr(logits), ptr(feats),
+                                       stream_ptr(self.device)), "hp_net_forward")
+        return pose, logits, feats
+
+    def set_profiling(self, on: bool):
+        check(lib().hp_net_set_profiling(self.handle, int(on)), "hp_net_set_profiling")
+
+    def last_conv_ms(self) -> float:
+        return lib().hp_net_last_conv_ms(self.handle)
+
+
+def conv2d_nhwc(x, w_packed, stride, pad, bias=None, residual=None, pre_scale=None, pre_shift=None, relu=False):
+    """Single conv layer (parity tests).  ``x [n,h,w,cin]``, ``w_packed [cout,kh,kw,cin]``."""
+    dev = x.device
+    n, h, w, cin = x.shape
+    cout, kh, kw, cin2 = w_packed.shape
+    assert cin == cin2
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().hp_conv2d_nhwc(ptr(x), n, h, w, cin, ptr(w_packed), cout, kh, kw, stride, pad, ptr(bias),
+                                   ptr(residual), ptr(pre_scale), ptr(pre_shift), int(relu), ptr(y),
+                                   stream_ptr(dev)), "hp_conv2d_nhwc")
+    return y

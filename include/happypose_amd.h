@@ -1,0 +1,212 @@
+/*
+ * happypose_amd -- C ABI of the MI355X-native render-and-compare refinement path.
+ *
+ * This header is the drop-in boundary.  The reference is pure
+ * Python with no FFI on this path, so each entry point replaces a Python-level
+ * interface of the reference; the citation next to it is the reference function it
+ * stands in for (paths relative to the reference root; TB/ = happypose/toolbox/,
+ * MP/ = happypose/pose_estimators/megapose/, CP/ = happypose/pose_estimators/cosypose/cosypose/).
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every `d_*` pointer is DEVICE memory (HBM), every
+ *    `h_*` pointer is host memory; float = IEEE fp32; poses are row-major 4x4, intrinsics
+ *    row-major 3x3.
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream) and returns without synchronising; no hidden allocations after create().
+ *  - return value 0 = success, negative = error (hp_last_error() gives the text).  Shape
+ *    or argument errors are reported, never silently repaired -- mirroring the reference's
+ *    asserts (e.g. TB/renderer/panda3d_batch_renderer.py:166-169).
+ *  - non-finite poses/intrinsics render as all-zero images, not an error
+ *    (TB/renderer/panda3d_batch_renderer.py:81-111).
+ */
+#ifndef HAPPYPOSE_AMD_H
+#define HAPPYPOSE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HP_OK 0
+#define HP_ERR_ARG -1
+#define HP_ERR_HIP -2
+#define HP_ERR_STATE -3
+
+int hp_version(void);
+const char* hp_last_error(void);
+/* number of visible HIP devices / name of the current one (diagnostics) */
+int hp_device_count(void);
+int hp_device_name(char* buf, int len);
+
+/* ------------------------------------------------------------------------------------
+ * Mesh store: device-resident geometry + textures of an object set, and the padded
+ * mesh-point database.  Replaces Panda3dBatchRenderer.__init__(asset_dataset, ...)
+ * (TB/renderer/panda3d_batch_renderer.py:129-142, worker start-up :288-330, model cache
+ * TB/renderer/panda3d_scene_renderer.py:206-219) and MeshDataBase.batched().to(device)
+ * (TB/lib3d/rigid_mesh_database.py:84-130).
+ *
+ * h_obj: [n_obj][8] int64 = vert_off, n_verts, face_off, n_faces, tex_off(-1 none),
+ *        tex_w, tex_h, 0.   faces hold vertex ids LOCAL to their object.
+ * h_points: [n_obj][n_pad][3] metres (may be NULL when only rendering is needed).
+ * ---------------------------------------------------------------------------------- */
+typedef struct hp_mesh_store hp_mesh_store;
+
+hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float* h_normals,
+                                    const float* h_uvs, const uint8_t* h_colors,
+                                    int64_t n_verts_total, const int32_t* h_faces,
+                                    int64_t n_faces_total, const uint8_t* h_tex,
+                                    int64_t tex_bytes, const int64_t* h_obj, int n_obj,
+                                    const float* h_points, int n_pad);
+void hp_mesh_store_destroy(hp_mesh_store* store);
+/* device pointer of the [n_obj][n_pad][3] point table (NULL if not uploaded) */
+const float* hp_mesh_store_points(const hp_mesh_store* store);
+
+/* ------------------------------------------------------------------------------------
+ * Rasteriser.  Replaces Panda3dBatchRenderer.render(labels, TCO, K, light_datas,
+ * resolution, render_normals, render_depth, render_binary_mask) -> BatchRenderOutput
+ * (TB/renderer/panda3d_batch_renderer.py:194-286; worker :62-125; scene renderer
+ * TB/renderer/panda3d_scene_renderer.py:320-390; camera model TB/renderer/types.py:92-137;
+ * depth decode / normal code TB/renderer/utils.py:46-79).
+ *
+ * One mesh per view, pinhole camera K, pose TCO, clip range [0.1, 10] m, two-sided,
+ * black background.  Outputs (each may be NULL = not rendered):
+ *   rgb   3 ch f32 in [0,1]   albedo * (ambient + Lambert point lights), 8-bit quantised
+ *   nrm   3 ch f32 in [0,1]   eye-space normal colour code
+ *   depth 1 ch f32 metres, 0 = background (or normalised, see below)
+ *   mask  u8 [n][h][w]        depth > 0   (requires depth, as the reference asserts)
+ * Addressing of the float outputs (element strides), view = 0..n-1:
+ *   off(view, c, row, col) = (view / views_per_item) * s_item + (view % views_per_item) * s_view
+ *                            + c * s_chan + row * s_row + col * s_col
+ * so both the reference's NCHW BatchRenderOutput tensors and channel slices of the
+ * NHWC network input are expressible.  depth uses (ds_item, ds_view, ds_row, ds_col).
+ * d_depth_norm_z (optional, [n / views_per_item]): fuses normalize_images
+ * (MP/models/pose_rigid.py:455-544) into the epilogue; depth_norm_mode selects
+ * 0 none, 1 tCR_scale (d/z), 2 tCR_scale_clamp_center (clamp(d/z,0,2)-1),
+ * 3 tCR_center_clamp (clamp(d-z,-2,2)).
+ * ---------------------------------------------------------------------------------- */
+#define HP_RASTER_QUANT8 8
+
+typedef struct {
+  int64_t s_item, s_view, s_chan, s_row, s_col;
+} hp_strides;
+
+int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
+                 const int32_t* d_obj_ids /* [n / views_per_item] */,
+                 const float* d_TCO /* [n][16] */, const float* d_K /* [n][9] */,
+                 const float* d_ambient /* [n][3] or NULL = (1,1,1) */, int n_lights,
+                 const float* d_light_pos /* [n][n_lights][3] object frame */,
+                 const float* d_light_col /* [n][n_lights][3] */, int h, int w, int flags,
+                 float* d_rgb, float* d_nrm, const hp_strides* color_strides,
+                 float* d_depth, const hp_strides* depth_strides, uint8_t* d_mask,
+                 const float* d_depth_norm_z, int depth_norm_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Iteration prologue ("pose prep"), one launch for all hypotheses and views:
+ *   [normalize_T]  TB/lib3d/transform_ops.py:107-120   (MP/models/pose_rigid.py:571)
+ *   tCR            MP/models/pose_rigid.py:574-576     (tOR = 0 -> tCR = tCO)
+ *   TCV_O          make_TCO_multiview, TB/lib3d/multiview.py:166-251 (:28-92)
+ *   per view: project_points_robust -> boxes_from_uv -> deepim_boxes -> get_K_crop_resize
+ *                  MP/models/pose_rigid.py:199-337 (crop_inputs, compute_crops_multiview),
+ *                  CP/models/pose.py:58-93; TB/lib3d/camera_geometry.py:40-122;
+ *                  TB/lib3d/cropping.py:27-75,113-152
+ * View 0 uses n_points_main sub-sampled mesh points (2000), the extra views
+ * n_points_extra (200); point ids are the deterministic RandomState(0) lists
+ * (TB/lib3d/mesh_ops.py:74-84) computed once on the host.
+ * multiview_type: 0 = single view (TCV_O = TCO), 1 = "TCO+front_1view",
+ * 3 = "TCO+front_3views", 5 = "TCO+front_5views"; n_views must be 1 / 2 / 4 / 6.
+ * Outputs: d_TCO_out [b][16] (normalised input pose), d_tCR [b][3], d_TCV_O [b][V][16],
+ * d_boxes_rend [b][4], d_boxes_crop [b][4], d_K_crop [b][V][9] (view 0 = K_crop).
+ * ---------------------------------------------------------------------------------- */
+int hp_pose_prep(const hp_mesh_store* store, int b, int n_views, int multiview_type,
+                 int normalize, const float* d_TCO_in, const float* d_K /* [Bi][9] */,
+                 const int32_t* d_im_ids /* [b] */, const int32_t* d_obj_ids /* [b] */,
+                 const int32_t* d_point_ids_main, int n_points_main,
+                 const int32_t* d_point_ids_extra, int n_points_extra, int im_h, int im_w,
+                 int crop_h, int crop_w, float lamb, float* d_TCO_out, float* d_tCR,
+                 float* d_TCV_O, float* d_boxes_rend, float* d_boxes_crop, float* d_K_crop,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Crop.  Replaces crop_images / torchvision.ops.roi_align(images, [k,x1,y1,x2,y2],
+ * (240,320), sampling_ratio=4, aligned=False)  (TB/lib3d/cropping.py:155-197,
+ * CP/lib3d/cropping.py:129-134) incl. the RGB-D rule (depth zeroed where the roi-aligned
+ * validity mask < 0.99) and, optionally, the depth normalisation of normalize_images.
+ * d_images: [Bi][C][H][W] f32 (the reference's ObservationTensor layout).  Output
+ * addressing as in hp_rasterize with views_per_item = 1 (s_view unused).
+ * ---------------------------------------------------------------------------------- */
+int hp_crop_roi_align(const float* d_images, int Bi, int C, int H, int W,
+                      const float* d_boxes /* [n][4] */, const int32_t* d_im_ids /* [n] */,
+                      int n, int out_h, int out_w, int sampling_ratio, float* d_out,
+                      const hp_strides* out_strides, const float* d_depth_norm_z,
+                      int depth_norm_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pose update.  Replaces PosePredictor.update_pose (MP/models/pose_rigid.py:339-350 ->
+ * TB/lib3d/rotations.py:22-36 + TB/lib3d/cosypose_ops.py:34-62) and CosyPose's
+ * apply_imagespace_predictions (CP/lib3d/cosypose_ops.py:18-42; d_tCR = NULL).
+ * d_K_crop is [b][k_stride floats] (k_stride = 9 * n_views when taken from hp_pose_prep).
+ * ---------------------------------------------------------------------------------- */
+int hp_pose_update(int b, const float* d_TCO, const float* d_K_crop, int k_stride,
+                   const float* d_pose9 /* [b][9] */, const float* d_tCR /* [b][3] or NULL */,
+                   float* d_TCO_out, void* stream);
+
+/* Coarse initialisation.  Replaces TCO_init_from_boxes_autodepth_with_R
+ * (TB/lib3d/cosypose_ops.py:184-238; d_R != NULL), TCO_init_from_boxes_zup_autodepth
+ * (:241-283; d_R = NULL) over the FULL padded point set of each object.
+ * Hypothesis i uses box d_boxes[d_box_ids ? d_box_ids[i] : i], intrinsics
+ * d_K[d_im_ids[i]], object d_obj_ids[i], rotation d_R[d_rot_ids ? d_rot_ids[i] : i]. */
+int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxes,
+                          const int32_t* d_box_ids, const float* d_K, const int32_t* d_im_ids,
+                          const int32_t* d_obj_ids, const float* d_R, const int32_t* d_rot_ids,
+                          float* d_TCO_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Network (backbone + heads).  Replaces PosePredictor.net_forward
+ * (MP/models/pose_rigid.py:352-374, CP/models/pose.py:108-114) for the backbones of
+ * MP/training/pose_models_cfg.py:106-122 / CP/training/pose_models_cfg.py:39-42:
+ *   HP_ARCH_VANILLA_RESNET34  MP/models/torchvision_resnet.py:191-344 (num_classes=512)
+ *   HP_ARCH_WIDE_RESNET34/18  MP/models/wide_resnet.py:68-154 == CP/models/wide_resnet.py
+ * Parameters are handed over by their reference state_dict names ("backbone.conv1.weight",
+ * "backbone.layer1.0.bn1.running_var", "pose_fc.weight", "views_logits_head.bias", ...;
+ * legacy names of TB/utils/models_compat.py are translated by the host side), fp32 host
+ * arrays in PyTorch layout ([Cout][Cin][kh][kw]).  hp_net_finalize folds eval-mode
+ * BatchNorm (eps 1e-5) and repacks to the kernels' layout.
+ * Input: d_x NHWC [batch][h][w][c_pad], c_pad = hp_net_input_channels_padded(), pad
+ * channels zero.  Outputs (each may be NULL): d_pose [batch][pose_dim],
+ * d_logits [batch][n_logits], d_features [batch][512].
+ * ---------------------------------------------------------------------------------- */
+#define HP_ARCH_VANILLA_RESNET34 0
+#define HP_ARCH_WIDE_RESNET34 1
+#define HP_ARCH_WIDE_RESNET18 2
+
+typedef struct hp_net hp_net;
+
+hp_net* hp_net_create(int arch, int n_inputs, int h, int w);
+void hp_net_destroy(hp_net* net);
+int hp_net_input_channels_padded(const hp_net* net);
+int hp_net_set_param(hp_net* net, const char* name, const float* h_data, int64_t numel);
+int hp_net_finalize(hp_net* net, int max_batch);
+int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d_pose, float* d_logits,
+                   float* d_features, void* stream);
+/* total multiply-accumulate FLOPs (2*MAC) of one sample through conv + linear layers */
+double hp_net_flops_per_sample(const hp_net* net);
+/* time (ms, HIP events on `stream`) spent in conv kernels during the last forward when
+ * profiling was enabled with hp_net_set_profiling(net, 1); 0 otherwise */
+int hp_net_set_profiling(hp_net* net, int enabled);
+double hp_net_last_conv_ms(const hp_net* net);
+
+/* Single layer entry (used by the parity tests of the conv kernel itself):
+ * y[n][ho][wo][cout] = act( conv(x_act, w) + bias + residual ),
+ * x_act = pre_scale ? relu(x * pre_scale[c] + pre_shift[c]) : x   (zero padding AFTER it).
+ * x NHWC [n][h][w][cin] (cin % 4 == 0), w packed [cout][kh][kw][cin], stride 1|2. */
+int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, const float* d_w, int cout,
+                   int kh, int kw, int stride, int pad, const float* d_bias,
+                   const float* d_residual, const float* d_pre_scale, const float* d_pre_shift,
+                   int relu, float* d_y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAPPYPOSE_AMD_H */

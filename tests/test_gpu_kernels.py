@@ -1,0 +1,385 @@
+"""Parity of every HIP kernel (through the C ABI) against the CPU oracle and the golden
+vectors of the reference.  Needs a real MI355X: ``pytest -m gpu``.
+
+Stated tolerances
+  * geometry (pose prep / update / init): fp32 formulas in a different association order
+    -> rtol 2e-5, atol 2e-3 px on pixel-valued quantities, 2e-6 on poses;
+  * rasteriser: the kernel follows the oracle's operation order, so coverage agrees pixel
+    for pixel except where a pixel centre lies within fp32 round-off of an edge; we allow
+    <= 0.05 % of pixels to differ in coverage and require colour (8-bit quantised) within
+    1/255 and depth within 1e-6 m elsewhere;
+  * roi_align: rtol 1e-5 / atol 1e-6 (same formula, same order);
+  * convolution / network: exact-fp32 MFMA with a different K order than oneDNN
+    -> |err| <= 2e-4 * max|ref| per tensor.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def scene_store(dev):
+    from happypose_amd.ops import MeshStore
+    from happypose_amd.synthetic import make_object_dataset
+
+    ds = make_object_dataset(3, seed=1, tex_size=256)
+    return MeshStore(ds, dev)
+
+
+def _poses(n, seed, zlo=0.35, zhi=0.8):
+    from happypose_amd.synthetic import random_rotations
+
+    rs = np.random.RandomState(seed)
+    T = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    T[:, :3, :3] = random_rotations(rs, n)
+    T[:, :3, 3] = np.stack([rs.uniform(-0.03, 0.03, n), rs.uniform(-0.03, 0.03, n), rs.uniform(zlo, zhi, n)], -1)
+    return T
+
+
+# ----------------------------------------------------------------------------- rasteriser
+def _compare_renders(gpu, ref, max_cov_mismatch=5e-4):
+    rgb, nrm, dep, msk = [None if t is None else t.cpu().numpy() for t in gpu]
+    cov_g = rgb.sum(1) > 0 if dep is None else dep[:, 0] > 0
+    cov_r = ref["rgbs"].sum(1) > 0 if ref["depths"] is None else ref["depths"][:, 0] > 0
+    mism = cov_g != cov_r
+    assert mism.mean() <= max_cov_mismatch, f"coverage mismatch {mism.mean():.2e}"
+    both = (~mism)[:, None]
+    np.testing.assert_allclose(np.where(both, rgb, 0), np.where(both, ref["rgbs"], 0), atol=1.01 / 255)
+    # colours are exactly equal on the overwhelming majority of pixels
+    assert (np.abs(rgb - ref["rgbs"]).max(1)[~mism] > 1e-6).mean() < 2e-3
+    if nrm is not None:
+        np.testing.assert_allclose(np.where(both, nrm, 0), np.where(both, ref["normals"], 0), atol=1.01 / 255)
+    if dep is not None:
+        d_ok = np.abs(dep - ref["depths"])[:, 0][~mism]
+        assert (d_ok > 1e-6).mean() < 1e-3 and d_ok.max() < 5e-3
+    if msk is not None:
+        assert (msk.cpu().numpy() if hasattr(msk, "cpu") else msk)[:, 0][~mism].tolist() == ref["binary_masks"][:, 0][~mism].tolist()
+
+
+def test_rasterizer_vs_oracle(dev, scene_store):
+    from happypose_amd import ops
+    from oracle import native
+
+    n = 12
+    T = _poses(n, 5)
+    K = np.tile(np.array([[900.0, 0, 160], [0, 900.0, 120], [0, 0, 1]], np.float32), (n, 1, 1))
+    K[:, 0, 2] += np.linspace(-20, 20, n)
+    obj = (np.arange(n) % 3).astype(np.int32)
+    gpu = ops.rasterize(scene_store, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), (240, 320),
+                        render_normals=True, render_depth=True, render_binary_mask=True)
+    ref = native.rasterize(scene_store.packed, obj, T, K, (240, 320), True, True, True)
+    assert gpu[0].shape == (n, 3, 240, 320) and gpu[0].dtype == torch.float32
+    assert gpu[3].dtype == torch.bool and gpu[2].shape == (n, 1, 240, 320)
+    assert (ref["depths"] > 0).mean() > 0.1  # the scene is not trivially empty
+    _compare_renders(gpu, ref)
+
+
+def test_rasterizer_reference_test_scene(dev, golden_dir):
+    """Scene and structural asserts of the reference's renderer test
+    (tests/test_batch_renderer_panda3d.py:43-69,105-122,166-179) on its own asset."""
+    from happypose_amd import ops
+    from happypose_amd.mesh_store import RigidObject, RigidObjectDataset
+    from oracle import geometry as G
+    from oracle import native
+
+    ds = RigidObjectDataset([RigidObject("my_favorite_object_label", golden_dir / "obj_000001.npz", mesh_units="mm"),
+                             RigidObject("NOT_USED", golden_dir / "obj_000001.npz", mesh_units="mm")])
+    store = ops.MeshStore(ds, dev)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = G.unitquat_to_rotmat(np.array([0.5, 0.5, -0.5, 0.5]))
+    T[:3, 3] = (0, 0, 0.3)
+    K = np.array([[300, 0, 320], [0, 300, 240], [0, 0, 1]], np.float32)
+    Nc = 4
+    TT, KK = np.tile(T, (Nc, 1, 1)), np.tile(K, (Nc, 1, 1))
+    rgb, nrm, dep, msk = ops.rasterize(store, torch.zeros(Nc, dtype=torch.int32), torch.as_tensor(TT),
+                                       torch.as_tensor(KK), (480, 640), True, True, True)
+    assert rgb.shape == (Nc, 3, 480, 640) and dep.shape == (Nc, 1, 480, 640) and msk.dtype == torch.bool
+    assert torch.equal(rgb[0], rgb[1]) and torch.equal(nrm[0], nrm[1]) and torch.equal(dep[0], dep[1])
+    assert rgb[0, :, 0, 0].tolist() == [0, 0, 0] and dep[0, 0, 0, 0] == 0 and not msk[0, 0, 0, 0]
+    assert nrm[0, :, 0, 0].tolist() == [0, 0, 0]
+    assert (rgb[0, :, 240, 320] > 0).all() and (nrm[0, :, 240, 320] > 0).all()
+    assert 0 < dep[0, 0, 240, 320] < 0.3 and msk[0, 0, 240, 320]
+    ref = native.rasterize(store.packed, np.zeros(Nc, np.int32), TT, KK, (480, 640), True, True, True)
+    _compare_renders((rgb, nrm, dep, msk), ref)
+    with pytest.raises(AssertionError):  # mask without depth (test_scene_renderer_panda3d.py:206-214)
+        ops.rasterize(store, torch.zeros(1, dtype=torch.int32), torch.as_tensor(TT[:1]), torch.as_tensor(KK[:1]),
+                      (480, 640), render_binary_mask=True)
+
+
+def test_rasterizer_edge_cases(dev, scene_store):
+    from happypose_amd import ops
+    from oracle import native
+
+    T = _poses(4, 9)
+    T[0, 0, 0] = np.nan           # non-finite pose -> zero image (panda3d_batch_renderer.py:81-111)
+    T[1, :3, 3] = (0, 0, 0.05)    # camera inside the object: near-plane clipping, huge triangles
+    T[2, :3, 3] = (0, 0, -0.5)    # behind the camera
+    T[3, :3, 3] = (0.5, 0.4, 0.6)  # mostly off-screen
+    K = np.tile(np.array([[600.0, 0, 160], [0, 600.0, 120], [0, 0, 1]], np.float32), (4, 1, 1))
+    obj = np.array([0, 1, 2, 0], np.int32)
+    gpu = ops.rasterize(scene_store, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), (240, 320),
+                        True, True, False)
+    ref = native.rasterize(scene_store.packed, obj, T, K, (240, 320), True, True, False)
+    assert float(gpu[0][0].abs().max()) == 0 and float(gpu[0][2].abs().max()) == 0
+    _compare_renders(gpu, ref, max_cov_mismatch=2e-3)
+    # empty batch
+    e = ops.rasterize(scene_store, torch.zeros(0, dtype=torch.int32), torch.zeros(0, 4, 4), torch.zeros(0, 3, 3), (240, 320))
+    assert e[0].shape == (0, 3, 240, 320)
+
+
+def test_rasterizer_lights_and_nhwc(dev, scene_store):
+    from happypose_amd import ops
+    from oracle import native
+
+    n = 4
+    T = _poses(n, 11)
+    K = np.tile(np.array([[800.0, 0, 160], [0, 800.0, 120], [0, 0, 1]], np.float32), (n, 1, 1))
+    obj = np.array([0, 1, 2, 1], np.int32)
+    amb = np.full((n, 3), 0.1, np.float32)
+    r = 10 * scene_store.packed.radius[obj]
+    dirs = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    lp = (dirs[None] * r[:, None, None]).astype(np.float32)
+    lc = np.full((n, 6, 3), 0.4, np.float32)
+    gpu = ops.rasterize(scene_store, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), (240, 320),
+                        ambient=torch.as_tensor(amb), light_pos=torch.as_tensor(lp), light_col=torch.as_tensor(lc))
+    ref = native.rasterize(scene_store.packed, obj, T, K, (240, 320), ambient=amb, light_pos=lp, light_col=lc)
+    _compare_renders(gpu, ref)
+    # NHWC slices, 2 views per item, fused depth normalisation
+    x = torch.zeros((2, 240, 320, 20), device=dev)
+    TV = torch.as_tensor(T).view(2, 2, 4, 4)
+    KV = torch.as_tensor(K).view(2, 2, 3, 3)
+    z = torch.tensor([0.5, 0.7], device=dev)
+    ops.rasterize_into(scene_store, x, 4, torch.as_tensor(obj[[0, 2]]), TV, KV, True, True, z, 2)
+    ref2 = native.rasterize(scene_store.packed, obj[[0, 0, 2, 2]], T, K, (240, 320), True, True)
+    xs = x.cpu().numpy()
+    assert np.all(xs[..., :4] == 0) and np.all(xs[..., 18:] == 0)
+    for it in range(2):
+        for v in range(2):
+            sl = xs[it, :, :, 4 + 7 * v: 4 + 7 * (v + 1)]
+            k = 2 * it + v
+            cov = ref2["depths"][k, 0] > 0
+            got_cov = sl[..., :3].sum(-1) > 0
+            assert (cov != got_cov).mean() < 5e-4
+            ok = cov == got_cov
+            np.testing.assert_allclose(sl[..., :3][ok], ref2["rgbs"][k].transpose(1, 2, 0)[ok], atol=1.01 / 255)
+            np.testing.assert_allclose(sl[..., 3:6][ok], ref2["normals"][k].transpose(1, 2, 0)[ok], atol=1.01 / 255)
+            dn = np.clip(ref2["depths"][k, 0] / float(z[it]), 0, 2) - 1
+            assert np.abs(sl[..., 6][ok] - dn[ok]).max() < 1e-2
+            assert (np.abs(sl[..., 6][ok] - dn[ok]) > 1e-5).mean() < 1e-3
+
+
+# ------------------------------------------------------------------------------------ crop
+def test_crop_vs_oracle(dev):
+    from happypose_amd import ops
+    from oracle import native
+
+    rs = np.random.RandomState(0)
+    img = rs.rand(2, 4, 480, 640).astype(np.float32)
+    img[:, 3] = np.where(rs.rand(2, 480, 640) < 0.2, 0.0, 0.3 + img[:, 3])  # depth with holes
+    boxes = np.array([[100.3, 80.2, 420.7, 320.1], [-50, -40, 300, 222.5], [500, 400, 700, 550],
+                      [10, 10, 10.5, 10.2], [0, 0, 640, 480], [300, 200, 340, 230]], np.float32)
+    ids = np.array([0, 1, 0, 1, 1, 0], np.int32)
+    for C in (3, 4):
+        im = np.ascontiguousarray(img[:, :C])
+        ref = native.crop_images(im, boxes, ids)
+        got = ops.crop_roi_align(torch.as_tensor(im, device=dev), torch.as_tensor(boxes), torch.as_tensor(ids))
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+    # NHWC destination + fused depth normalisation
+    net_in = torch.zeros((6, 240, 320, 8), device=dev)
+    z = torch.linspace(0.4, 0.9, 6, device=dev)
+    ops.crop_roi_align(torch.as_tensor(img, device=dev), torch.as_tensor(boxes), torch.as_tensor(ids), out=net_in,
+                       depth_norm_z=z, depth_norm_mode=2)
+    ref = native.crop_images(img, boxes, ids)
+    o = net_in.cpu().numpy()
+    np.testing.assert_allclose(o[..., :3], ref[:, :3].transpose(0, 2, 3, 1), rtol=1e-5, atol=1e-6)
+    dn = np.clip(ref[:, 3] / z.cpu().numpy()[:, None, None], 0, 2) - 1
+    np.testing.assert_allclose(o[..., 3], dn, rtol=1e-5, atol=1e-5)
+    assert np.all(o[..., 4:] == 0)
+    e = ops.crop_roi_align(torch.as_tensor(img, device=dev), torch.zeros(0, 4), torch.zeros(0, dtype=torch.int32))
+    assert e.shape == (0, 4, 240, 320)
+
+
+# -------------------------------------------------------------------------------- geometry
+def _store_from_points(pts_list, dev):
+    """objects whose vertices are the given point sets (faces are dummies)."""
+    from happypose_amd.mesh_io import MeshData
+    from happypose_amd.mesh_store import RigidObject, RigidObjectDataset
+    from happypose_amd.ops import MeshStore
+
+    objs = []
+    for i, p in enumerate(pts_list):
+        f = np.array([[0, 1, 2]], np.int32)
+        objs.append(RigidObject(f"o{i}", MeshData(vertices=p.astype(np.float64), faces=f,
+                                                  normals=np.tile([0, 0, 1.0], (len(p), 1)).astype(np.float32))))
+    return MeshStore(RigidObjectDataset(objs), dev)
+
+
+def test_pose_prep_golden_g7(dev, golden_dir):
+    """hp_pose_prep + hp_pose_update against the reference's own outputs (golden G7)."""
+    from happypose_amd import ops
+
+    g = np.load(golden_dir / "g7_iteration.npz")
+    b = len(g["T"])
+    store = _store_from_points(list(g["pts"]), dev)
+    assert store.n_pad == 2000
+    # the kernel sub-samples with the deterministic ids; G7 projected ALL 2000 points, which is
+    # the same set (a permutation) when n_points == n_pad
+    out = ops.pose_prep(store, torch.as_tensor(g["T"]), torch.as_tensor(g["K"]), torch.arange(b),
+                        torch.arange(b), (480, 640), normalize=True)
+    c = lambda t: t.cpu().numpy()  # noqa: E731
+    np.testing.assert_allclose(c(out["TCO"]), g["T_norm"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(c(out["boxes_rend"]), g["boxes_rend"], rtol=1e-5, atol=2e-3)
+    np.testing.assert_allclose(c(out["boxes_crop"]), g["boxes_crop"], rtol=1e-5, atol=3e-3)
+    np.testing.assert_allclose(c(out["K_crop"])[:, 0], g["K_crop"], rtol=2e-5, atol=3e-3)
+    np.testing.assert_allclose(c(out["tCR"]), g["T_norm"][:, :3, 3], rtol=2e-6, atol=2e-6)
+    upd = ops.pose_update(out["TCO"], out["K_crop"], torch.as_tensor(g["pose9"]), out["tCR"])
+    np.testing.assert_allclose(c(upd), g["T_out"], rtol=2e-5, atol=2e-6)
+
+
+def test_pose_update_and_init_golden_g4(dev, golden_dir):
+    from happypose_amd import ops
+
+    g = np.load(golden_dir / "g4_pose_update.npz")
+    T, Kc, p9 = (torch.as_tensor(g[k], device=dev) for k in ("T", "K_crop", "pose9"))
+    c = lambda t: t.cpu().numpy()  # noqa: E731
+    np.testing.assert_allclose(c(ops.pose_update(T, Kc, p9, torch.as_tensor(g["tCR"], device=dev))), g["upd_ref"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c(ops.pose_update(T, Kc, p9, None)), g["upd_cosy"], rtol=1e-5, atol=1e-6)
+    b = len(g["T"])
+    store = _store_from_points(list(g["mpts"]), dev)
+    ar = torch.arange(b)
+    got = ops.tco_init_autodepth(store, torch.as_tensor(g["det_boxes"]), torch.as_tensor(g["K"]), ar, ar,
+                                 R=torch.as_tensor(g["Rg"]))
+    np.testing.assert_allclose(c(got), g["init_R"], rtol=1e-5, atol=1e-6)
+    got = ops.tco_init_autodepth(store, torch.as_tensor(g["det_boxes"]), torch.as_tensor(g["K"]), ar, ar)
+    np.testing.assert_allclose(c(got), g["init_zup"], rtol=1e-5, atol=1e-6)
+
+
+def test_pose_prep_multiview_vs_oracle(dev, scene_store):
+    from happypose_amd import ops
+    from oracle import geometry as G
+
+    b = 9
+    T = _poses(b, 21)
+    T[:, :3, :3] += 0.02 * np.random.RandomState(1).normal(size=(b, 3, 3)).astype(np.float32)
+    K = np.array([[[600.0, 0, 320], [0, 600.0, 240], [0, 0, 1]]], np.float32)
+    obj = (np.arange(b) % 3).astype(np.int32)
+    out = ops.pose_prep(scene_store, torch.as_tensor(T), torch.as_tensor(K), torch.zeros(b, dtype=torch.int32),
+                        torch.as_tensor(obj), (480, 640), multiview_type="TCO+front_3views", normalize=True)
+    Tn = G.normalize_T(T)
+    tCR = Tn[:, :3, 3]
+    TCV = G.make_TCO_multiview(Tn, tCR, "TCO+front_3views", 4)
+    np.testing.assert_allclose(out["TCV_O"].cpu().numpy(), TCV, rtol=1e-5, atol=2e-6)
+    pts = scene_store.mesh_db.points[obj]
+    Kb = np.repeat(K, b, 0)
+    for v in range(4):
+        ids = G.sample_point_ids(scene_store.n_pad, 2000 if v == 0 else 200)
+        br, bc = G.crop_boxes_from_pose(pts[:, ids], Kb, TCV[:, v], TCV[:, v, :3, 3], (480, 640))
+        Kc = G.get_K_crop_resize(Kb, bc, (480, 640), (240, 320))
+        np.testing.assert_allclose(out["K_crop"][:, v].cpu().numpy(), Kc, rtol=5e-5, atol=5e-3)
+        if v == 0:
+            np.testing.assert_allclose(out["boxes_rend"].cpu().numpy(), br, rtol=1e-5, atol=2e-3)
+            np.testing.assert_allclose(out["boxes_crop"].cpu().numpy(), bc, rtol=1e-5, atol=3e-3)
+    # extra views look at the reference point: it projects to the crop centre
+    for v in range(1, 4):
+        Tv = out["TCV_O"][:, v].cpu().numpy()
+        assert np.allclose(Tv[:, :2, 3], 0, atol=1e-5)
+        assert np.allclose(np.linalg.norm(Tv[:, :3, 3], axis=1), np.linalg.norm(tCR, axis=1), rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- convolution
+def _conv_ref(x_nhwc, w_oihw, stride, pad, bias, residual, pre, relu):
+    import torch.nn.functional as F
+
+    x = torch.as_tensor(x_nhwc).permute(0, 3, 1, 2).double()
+    if pre is not None:
+        x = F.relu(x * torch.as_tensor(pre[0]).double().view(1, -1, 1, 1) + torch.as_tensor(pre[1]).double().view(1, -1, 1, 1))
+    y = F.conv2d(x, torch.as_tensor(w_oihw).double(), stride=stride, padding=pad)
+    if bias is not None:
+        y = y + torch.as_tensor(bias).double().view(1, -1, 1, 1)
+    y = y.permute(0, 2, 3, 1)
+    if residual is not None:
+        y = y + torch.as_tensor(residual).double()
+    if relu:
+        y = F.relu(y)
+    return y.numpy()
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=2, h=60, w=80, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=False, relu=True),
+    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),
+    dict(n=2, h=30, w=40, cin=128, cout=256, k=1, s=2, p=0, bias=False, res=False, pre=True, relu=False),
+    dict(n=1, h=15, w=20, cin=256, cout=512, k=3, s=2, p=1, bias=False, res=True, pre=False, relu=False),
+    dict(n=5, h=9, w=7, cin=32, cout=64, k=3, s=1, p=1, bias=True, res=False, pre=False, relu=False),  # ragged M
+    dict(n=2, h=31, w=23, cin=8, cout=64, k=2, s=1, p=0, bias=False, res=False, pre=False, relu=False),
+])
+def test_conv2d_vs_fp64(dev, case):
+    from happypose_amd import ops
+
+    rs = np.random.RandomState(3)
+    c = case
+    x = rs.normal(size=(c["n"], c["h"], c["w"], c["cin"])).astype(np.float32)
+    w = (rs.normal(size=(c["cout"], c["cin"], c["k"], c["k"])) / np.sqrt(c["cin"] * c["k"] ** 2)).astype(np.float32)
+    ho, wo = (c["h"] + 2 * c["p"] - c["k"]) // c["s"] + 1, (c["w"] + 2 * c["p"] - c["k"]) // c["s"] + 1
+    bias = rs.normal(size=c["cout"]).astype(np.float32) if c["bias"] else None
+    res = rs.normal(size=(c["n"], ho, wo, c["cout"])).astype(np.float32) if c["res"] else None
+    pre = (rs.uniform(0.5, 1.5, c["cin"]).astype(np.float32), rs.normal(size=c["cin"]).astype(np.float32)) if c["pre"] else None
+    ref = _conv_ref(x, w, c["s"], c["p"], bias, res, pre, c["relu"])
+    t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+    wp = np.ascontiguousarray(w.transpose(0, 2, 3, 1))
+    y = ops.conv2d_nhwc(t(x), t(wp), c["s"], c["p"], t(bias), t(res), t(pre[0]) if pre else None,
+                        t(pre[1]) if pre else None, c["relu"])
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
+
+
+@pytest.mark.parametrize("arch,cin,tag", [("vanilla_resnet34", 27, "vanilla_resnet34_27"),
+                                          ("vanilla_resnet34", 9, "vanilla_resnet34_9"),
+                                          ("resnet34", 6, "resnet34_6"), ("resnet18", 6, "resnet18_6")])
+def test_backbone_golden_g6(dev, golden_dir, arch, cin, tag):
+    """Whole backbone (BN folded, NHWC, MFMA) against the reference modules' outputs."""
+    from happypose_amd import ops
+    from happypose_amd.synthetic import named_weights
+    from oracle import backbones as ob
+
+    g = np.load(golden_dir / "g6_backbones.npz")
+    shapes = ob.param_shapes(arch, cin)
+    w = {f"backbone.{k}": v for k, v in named_weights(shapes, seed=0).items()}
+    net = ops.Net(arch, cin, w, max_batch=2, device=dev)
+    x = np.random.RandomState(100 + cin).uniform(-1, 1, size=(2, cin, 240, 320)).astype(np.float32)
+    xin = net.new_input(2)
+    xin[..., :cin] = torch.as_tensor(x, device=dev).permute(0, 2, 3, 1)
+    _, _, feats = net.forward(xin, want_pose=False, want_features=True)
+    ref = g[tag + "/out"]
+    if ref.ndim == 4:
+        ref = ref.reshape(2, 512, -1).mean(-1)
+    err = np.abs(feats.cpu().numpy() - ref).max()
+    assert err <= 2e-4 * np.abs(ref).max(), (err, np.abs(ref).max())
+    assert abs(net.flops_per_sample / 1e9 - {("vanilla_resnet34", 27): 14.236, ("vanilla_resnet34", 9): 12.068,
+                                              ("resnet34", 6): 11.352, ("resnet18", 6): 5.64}[(arch, cin)]) < 0.02
+
+
+def test_net_heads_and_batch_chunking(dev):
+    from happypose_amd import ops
+    from happypose_amd.synthetic import predictor_weights
+    from oracle import backbones as ob
+
+    shapes = ob.predictor_param_shapes("resnet18", 6, pose_dim=9, n_views_logits=1)
+    w = predictor_weights(shapes, seed=3, update_scale=0.05)
+    net = ops.Net("resnet18", 6, w, max_batch=2, device=dev)  # batch 5 -> chunks 2+2+1
+    x = np.random.RandomState(1).uniform(0, 1, size=(5, 6, 240, 320)).astype(np.float32)
+    xin = net.new_input(5)
+    xin[..., :6] = torch.as_tensor(x, device=dev).permute(0, 2, 3, 1)
+    pose, logits, _ = net.forward(xin, want_pose=True, want_logits=True)
+    with torch.no_grad():
+        ref = ob.net_forward(torch.as_tensor(x), w, "resnet18", heads=("pose", "renderings_logits"))
+    np.testing.assert_allclose(pose.cpu().numpy(), ref["pose"].numpy(), rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref["renderings_logits"].numpy(), rtol=1e-3, atol=2e-4)
