@@ -108,13 +108,14 @@ extern "C" int hp_crop_roi_align(const float* d_images, int Bi, int C, int H, in
                                  const hp_strides* out_strides, const float* d_depth_norm_z,
                                  int depth_norm_mode, void* stream) {
   using namespace hp;
-  HP_REQUIRE(d_images && d_boxes && d_im_ids && d_out && out_strides, "hp_crop_roi_align: null pointer");
+  HP_REQUIRE(d_images && out_strides, "hp_crop_roi_align: null pointer");
   HP_REQUIRE(C == 3 || C == 4, "hp_crop_roi_align: images must have 3 (rgb) or 4 (rgbd) channels");
   HP_REQUIRE(sampling_ratio >= 1 && sampling_ratio <= kMaxSR, "hp_crop_roi_align: sampling_ratio must be 1..4");
   HP_REQUIRE(n >= 0 && out_h > 0 && out_w > 0 && H > 0 && W > 0 && Bi > 0, "hp_crop_roi_align: bad sizes");
   HP_REQUIRE(depth_norm_mode >= 0 && depth_norm_mode <= 3, "hp_crop_roi_align: bad depth_norm_mode");
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_crop_roi_align: depth_norm_z missing");
   if (n == 0) return HP_OK;
+  HP_REQUIRE(d_boxes && d_im_ids && d_out, "hp_crop_roi_align: null pointer");
   CropArgs a{d_images, Bi, C, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio,
              d_out, *out_strides, d_depth_norm_z, depth_norm_mode};
   dim3 grid((out_h * out_w + 255) / 256, n);

@@ -300,6 +300,7 @@ extern "C" int hp_pose_prep(const hp_mesh_store* store, int b, int n_views, int 
   HP_REQUIRE((multiview_type == 0 && n_views == 1) || (multiview_type == 1 && n_views == 2) ||
                  (multiview_type == 3 && n_views == 4) || (multiview_type == 5 && n_views == 6),
              "hp_pose_prep: n_views does not match multiview_type");
+  if (b == 0) return HP_OK;
   HP_REQUIRE(d_TCO_in && d_K && d_im_ids && d_obj_ids && d_K_crop, "hp_pose_prep: null input");
   HP_REQUIRE(d_point_ids_main && n_points_main > 0 && n_points_main <= store->n_pad,
              "hp_pose_prep: n_points must be in (0, n_pad]");
@@ -319,6 +320,7 @@ extern "C" int hp_pose_update(int b, const float* d_TCO, const float* d_K_crop, 
                               void* stream) {
   using namespace hp;
   HP_REQUIRE(b >= 0 && k_stride >= 9, "hp_pose_update: bad sizes");
+  if (b == 0) return HP_OK;
   HP_REQUIRE(d_TCO && d_K_crop && d_pose9 && d_TCO_out, "hp_pose_update: null pointer");
   if (b == 0) return HP_OK;
   hipLaunchKernelGGL(pose_update_kernel, dim3((b + 63) / 64), dim3(64), 0, (hipStream_t)stream, b,
@@ -333,9 +335,9 @@ extern "C" int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const fl
                                      void* stream) {
   using namespace hp;
   HP_REQUIRE(store && store->points, "hp_tco_init_autodepth: mesh store has no point table");
-  HP_REQUIRE(n >= 0 && d_boxes && d_K && d_im_ids && d_obj_ids && d_TCO_out,
-             "hp_tco_init_autodepth: null input");
+  HP_REQUIRE(n >= 0, "hp_tco_init_autodepth: negative count");
   if (n == 0) return HP_OK;
+  HP_REQUIRE(d_boxes && d_K && d_im_ids && d_obj_ids && d_TCO_out, "hp_tco_init_autodepth: null input");
   InitArgs a{store->points, store->n_pad, n, d_boxes, d_box_ids, d_K, d_im_ids, d_obj_ids,
              d_R, d_rot_ids, d_TCO_out};
   hipLaunchKernelGGL(tco_init_kernel, dim3(n), dim3(kT), 0, (hipStream_t)stream, a);

@@ -344,7 +344,9 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
 extern "C" int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d_pose, float* d_logits,
                               float* d_features, void* stream) {
   HP_REQUIRE(net && net->finalized, "hp_net_forward: network not finalized");
-  HP_REQUIRE(d_x && batch >= 0, "hp_net_forward: bad input");
+  HP_REQUIRE(batch >= 0, "hp_net_forward: negative batch");
+  if (batch == 0) return HP_OK;
+  HP_REQUIRE(d_x, "hp_net_forward: null input");
   HP_REQUIRE(!d_pose || net->pose_dim > 0, "hp_net_forward: network has no pose head");
   HP_REQUIRE(!d_logits || net->n_logits > 0, "hp_net_forward: network has no logits head");
   hipStream_t st = (hipStream_t)stream;

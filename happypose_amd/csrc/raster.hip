@@ -357,6 +357,8 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   HP_REQUIRE(n >= 0 && views_per_item >= 1 && n % views_per_item == 0,
              "hp_rasterize: n must be a multiple of views_per_item");
   HP_REQUIRE(h > 0 && w > 0 && w <= kBandPixels, "hp_rasterize: unsupported resolution");
+  HP_REQUIRE(!d_mask || d_depth, "Binary mask can only be rendered if depth is rendered");
+  if (n == 0) return HP_OK;
   HP_REQUIRE(d_TCO && d_K && d_obj_ids, "hp_rasterize: null pose/intrinsics/object ids");
   HP_REQUIRE(!(d_rgb || d_nrm) || color_strides, "hp_rasterize: colour strides missing");
   HP_REQUIRE(!d_depth || depth_strides, "hp_rasterize: depth strides missing");
@@ -364,7 +366,6 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   HP_REQUIRE(n_lights == 0 || (d_light_pos && d_light_col), "hp_rasterize: lights missing");
   HP_REQUIRE(depth_norm_mode >= 0 && depth_norm_mode <= 3, "hp_rasterize: bad depth_norm_mode");
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_rasterize: depth_norm_z missing");
-  if (n == 0) return HP_OK;
   RasterArgs a{};
   a.verts = store->verts; a.normals = store->normals; a.uvs = store->uvs; a.colors = store->colors;
   a.faces = store->faces; a.tex = store->tex; a.obj = store->obj;

@@ -292,7 +292,9 @@ def test_pose_prep_multiview_vs_oracle(dev, scene_store):
     for v in range(1, 4):
         Tv = out["TCV_O"][:, v].cpu().numpy()
         assert np.allclose(Tv[:, :2, 3], 0, atol=1e-5)
-        assert np.allclose(np.linalg.norm(Tv[:, :3, 3], axis=1), np.linalg.norm(tCR, axis=1), rtol=1e-5)
+        # view 1 sits at camera 0's centre, views 2/3 one radius to its right/left
+        dist = np.linalg.norm(tCR, axis=1) * (1.0 if v == 1 else np.sqrt(2.0))
+        assert np.allclose(np.linalg.norm(Tv[:, :3, 3], axis=1), dist, rtol=1e-5)
 
 
 # ----------------------------------------------------------------------------- convolution
