@@ -46,12 +46,12 @@ _PROTOS = {
                                c_i32p, c_i32p, C.c_int, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                C.c_void_p]),
-    "hp_crop_roi_align": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int,
+    "hp_crop_roi_align": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, c_f32p, C.POINTER(Strides), c_f32p,
                                     C.c_int, C.c_void_p]),
     "hp_pose_update": (C.c_int, [C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "hp_tco_init_autodepth": (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p,
-                                        c_f32p, c_i32p, c_f32p, C.c_void_p]),
+                                        c_f32p, c_i32p, c_i32p, C.c_int, c_f32p, C.c_void_p]),
     "hp_net_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "hp_net_destroy": (None, [C.c_void_p]),
     "hp_net_input_channels_padded": (C.c_int, [C.c_void_p]),

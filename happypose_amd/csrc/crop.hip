@@ -16,7 +16,7 @@ namespace hp {
 #pragma clang fp contract(off)
 
 struct CropArgs {
-  const float* images; int Bi, C, H, W;
+  const float* images; int Bi, C, NC, H, W;
   const float* boxes; const int32_t* im_ids; int n, oh, ow, sr;
   float* out; hp_strides os;
   const float* depth_norm_z; int depth_norm_mode;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
   const float* img = a.images + (int64_t)a.im_ids[r] * a.C * H * W;
   const int64_t obase = (int64_t)r * a.os.s_item + (int64_t)ph * a.os.s_row + (int64_t)pw * a.os.s_col;
   float valid_acc = 0.0f;
-  for (int c = 0; c < a.C; ++c) {
+  for (int c = 0; c < a.NC; ++c) {
     const float* plane = img + (int64_t)c * H * W;
     float acc = 0.0f, vacc = 0.0f;
 #pragma unroll
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
 
 }  // namespace hp
 
-extern "C" int hp_crop_roi_align(const float* d_images, int Bi, int C, int H, int W,
+extern "C" int hp_crop_roi_align(const float* d_images, int Bi, int C, int n_channels, int H, int W,
                                  const float* d_boxes, const int32_t* d_im_ids, int n, int out_h,
                                  int out_w, int sampling_ratio, float* d_out,
                                  const hp_strides* out_strides, const float* d_depth_norm_z,
@@ -110,13 +110,14 @@ extern "C" int hp_crop_roi_align(const float* d_images, int Bi, int C, int H, in
   using namespace hp;
   HP_REQUIRE(d_images && out_strides, "hp_crop_roi_align: null pointer");
   HP_REQUIRE(C == 3 || C == 4, "hp_crop_roi_align: images must have 3 (rgb) or 4 (rgbd) channels");
+  HP_REQUIRE((n_channels == 3 || n_channels == 4) && n_channels <= C, "hp_crop_roi_align: n_channels must be 3 or 4 and <= C");
   HP_REQUIRE(sampling_ratio >= 1 && sampling_ratio <= kMaxSR, "hp_crop_roi_align: sampling_ratio must be 1..4");
   HP_REQUIRE(n >= 0 && out_h > 0 && out_w > 0 && H > 0 && W > 0 && Bi > 0, "hp_crop_roi_align: bad sizes");
   HP_REQUIRE(depth_norm_mode >= 0 && depth_norm_mode <= 3, "hp_crop_roi_align: bad depth_norm_mode");
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_crop_roi_align: depth_norm_z missing");
   if (n == 0) return HP_OK;
   HP_REQUIRE(d_boxes && d_im_ids && d_out, "hp_crop_roi_align: null pointer");
-  CropArgs a{d_images, Bi, C, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio,
+  CropArgs a{d_images, Bi, C, n_channels, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio,
              d_out, *out_strides, d_depth_norm_z, depth_norm_mode};
   dim3 grid((out_h * out_w + 255) / 256, n);
   hipLaunchKernelGGL(crop_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -240,6 +240,7 @@ struct InitArgs {
   const float* points; int n_pad; int n;
   const float* boxes; const int32_t* box_ids; const float* K; const int32_t* im_ids;
   const int32_t* obj_ids; const float* R; const int32_t* rot_ids; float* out;
+  const int32_t* point_ids; int n_points;  // optional deterministic sub-sample (null = all n_pad)
 };
 
 __global__ __launch_bounds__(kT) void tco_init_kernel(InitArgs a) {
@@ -259,8 +260,9 @@ __global__ __launch_bounds__(kT) void tco_init_kernel(InitArgs a) {
   float tx = ((bcx - cx) * z_guess) / fx, ty = ((bcy - cy) * z_guess) / fy;
   const float* pts = a.points + (int64_t)a.obj_ids[i] * a.n_pad * 3;
   float x1 = INFINITY, y1 = INFINITY, x2 = -INFINITY, y2 = -INFINITY;
-  for (int j = tid; j < a.n_pad; j += kT) {
-    const float* p = pts + 3 * (int64_t)j;
+  const int npts = a.point_ids ? a.n_points : a.n_pad;
+  for (int j = tid; j < npts; j += kT) {
+    const float* p = pts + 3 * (int64_t)(a.point_ids ? a.point_ids[j] : j);
     float X = fmaf(R[2], p[2], fmaf(R[1], p[1], R[0] * p[0])) + tx;
     float Y = fmaf(R[5], p[2], fmaf(R[4], p[1], R[3] * p[0])) + ty;
     x1 = fminf(x1, X); x2 = fmaxf(x2, X); y1 = fminf(y1, Y); y2 = fmaxf(y2, Y);
@@ -331,15 +333,18 @@ extern "C" int hp_pose_update(int b, const float* d_TCO, const float* d_K_crop, 
 extern "C" int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxes,
                                      const int32_t* d_box_ids, const float* d_K,
                                      const int32_t* d_im_ids, const int32_t* d_obj_ids,
-                                     const float* d_R, const int32_t* d_rot_ids, float* d_TCO_out,
+                                     const float* d_R, const int32_t* d_rot_ids,
+                                     const int32_t* d_point_ids, int n_points, float* d_TCO_out,
                                      void* stream) {
   using namespace hp;
   HP_REQUIRE(store && store->points, "hp_tco_init_autodepth: mesh store has no point table");
   HP_REQUIRE(n >= 0, "hp_tco_init_autodepth: negative count");
   if (n == 0) return HP_OK;
   HP_REQUIRE(d_boxes && d_K && d_im_ids && d_obj_ids && d_TCO_out, "hp_tco_init_autodepth: null input");
+  HP_REQUIRE(!d_point_ids || (n_points > 0 && n_points <= store->n_pad),
+             "hp_tco_init_autodepth: n_points must be in (0, n_pad]");
   InitArgs a{store->points, store->n_pad, n, d_boxes, d_box_ids, d_K, d_im_ids, d_obj_ids,
-             d_R, d_rot_ids, d_TCO_out};
+             d_R, d_rot_ids, d_TCO_out, d_point_ids, n_points};
   hipLaunchKernelGGL(tco_init_kernel, dim3(n), dim3(kT), 0, (hipStream_t)stream, a);
   return check_launch("tco_init_kernel");
 }

@@ -1,0 +1,127 @@
+"""Model factories: configuration + ``state_dict`` -> predictors on the device.
+
+Mirrors ``create_model_pose`` / ``check_update_config``
+(``MP/training/pose_models_cfg.py:36-142``), ``create_pose_model_cosypose``
+(``CP/training/pose_models_cfg.py:30-74``), the legacy key renames of
+``TB/utils/models_compat.py:17-27`` and the checkpoint layout read by
+``load_pose_models`` (``TB/inference/utils.py:84-161``: ``<run_dir>/config.yaml`` +
+``<run_dir>/checkpoint.pth.tar`` holding ``{"state_dict": ...}``).
+"""
+
+from __future__ import annotations
+
+from pathlib import Path
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .pose_predictor import CosyPosePosePredictor, PosePredictor
+from .renderer import BatchRenderer
+
+_ARCH_OF = {"vanilla_resnet34": "vanilla_resnet34", "resnet34": "resnet34", "resnet18": "resnet18"}
+
+
+def change_keys_of_older_models(state_dict: Dict) -> Dict:
+    """``TB/utils/models_compat.py:17-27``."""
+    out = {}
+    for k, v in state_dict.items():
+        if k.startswith("backbone.backbone"):
+            k = "backbone." + k[len("backbone.backbone."):]
+        elif k.startswith("backbone.head.0."):
+            k = "views_logits_head." + k[len("backbone.head.0."):]
+        out[k] = v
+    return out
+
+
+def check_update_config(cfg) -> SimpleNamespace:
+    """Defaults for configurations written by older training code
+    (``MP/training/pose_models_cfg.py:36-86``).  Accepts a dict or any attribute bag."""
+    d = dict(cfg) if isinstance(cfg, dict) else dict(vars(cfg))
+    d["is_coarse_compat"] = False
+    if d.get("input_strategy") == "input=obs+one_render":
+        d.update(is_coarse_compat=True, n_rendered_views=1, multiview_type="1view_TCO",
+                 predict_rendered_views_logits=True, remove_TCO_rendering=True, predict_pose_update=False)
+    mv = d.get("multiview_type")
+    if mv in ("front_3views", "front_5views", "front_1view"):
+        d["multiview_type"] = "TCO+" + mv
+    d.setdefault("predict_pose_update", True)
+    d.setdefault("remove_TCO_rendering", False)
+    d.setdefault("predict_rendered_views_logits", False)
+    if "n_rendered_views" not in d:
+        d["n_rendered_views"] = d.pop("n_views", 1)
+    d.setdefault("render_normals", False)
+    d.setdefault("render_depth", False)
+    d.setdefault("input_depth", False)
+    if "multiview_type" not in d:
+        d["multiview_type"] = "TCO"
+        assert not d["remove_TCO_rendering"]
+    d.setdefault("views_inplane_rotations", False)
+    if "depth_augmentation" not in d:  # configurations older than the depth-augmentation option
+        d["depth_normalization_type"] = "tCR_scale"
+    d.setdefault("depth_normalization_type", "tCR_scale_clamp_center")  # training_config.py:102
+    d.setdefault("renderer", "panda3d")
+    d.setdefault("backbone_str", "vanilla_resnet34")
+    return SimpleNamespace(**d)
+
+
+def n_input_channels(cfg) -> int:
+    """``MP/training/pose_models_cfg.py:94-103``."""
+    n_normals = 3 if cfg.render_normals else 0
+    n_rdepth = 1 if cfg.render_depth else 0
+    n_depth = 1 if cfg.input_depth else 0
+    return (3 + n_depth) + (3 + n_normals + n_rdepth) * cfg.n_rendered_views
+
+
+def _arch(backbone_str: str) -> str:
+    if backbone_str == "vanilla_resnet34":
+        return "vanilla_resnet34"
+    if backbone_str == "resnet34" or "resnet34" in backbone_str and "width" not in backbone_str:
+        return "resnet34"
+    if "resnet18" in backbone_str:
+        return "resnet18"
+    raise ValueError("Unknown backbone", backbone_str)  # e.g. efficientnet-b3: SURVEY.md section 8f
+
+
+def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Optional[Dict] = None,
+                      max_batch: int = 128) -> PosePredictor:
+    """MegaPose predictor (``MP/training/pose_models_cfg.py:89-142``).  ``state_dict`` holds the
+    reference's keys (``backbone.*``, ``pose_fc.*``, ``views_logits_head.*``)."""
+    cfg = check_update_config(cfg)
+    assert state_dict is not None, "weights are required (no training path here)"
+    sd = change_keys_of_older_models(state_dict)
+    net = ops.Net(_arch(cfg.backbone_str), n_input_channels(cfg), sd, max_batch=max_batch, device=renderer.device)
+    # the coarse compat model renders exactly the TCO view
+    mv = cfg.multiview_type if cfg.n_rendered_views > 1 else "TCO"
+    model = PosePredictor(
+        backbone=net, renderer=renderer, mesh_db=mesh_db, render_size=(240, 320),
+        n_rendered_views=cfg.n_rendered_views, views_inplane_rotations=cfg.views_inplane_rotations,
+        multiview_type=mv, render_normals=cfg.render_normals, render_depth=cfg.render_depth,
+        input_depth=cfg.input_depth, predict_rendered_views_logits=cfg.predict_rendered_views_logits,
+        remove_TCO_rendering=False, predict_pose_update=cfg.predict_pose_update,
+        depth_normalization_type=cfg.depth_normalization_type)
+    model.cfg = model.config = cfg
+    return model
+
+
+def create_pose_model_cosypose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Optional[Dict] = None,
+                               max_batch: int = 128) -> CosyPosePosePredictor:
+    """``CP/training/pose_models_cfg.py:30-53`` (6 input channels; ``n_pose_dims`` = 9)."""
+    d = dict(cfg) if isinstance(cfg, dict) else dict(vars(cfg))
+    d.setdefault("init_method", "v0")  # check_update_config, :24-27
+    d.setdefault("n_pose_dims", 9)
+    cfg = SimpleNamespace(**d)
+    assert state_dict is not None
+    net = ops.Net(_arch(cfg.backbone_str), 6, state_dict, max_batch=max_batch, device=renderer.device)
+    model = CosyPosePosePredictor(backbone=net, renderer=renderer, mesh_db=mesh_db, render_size=(240, 320),
+                                  pose_dim=cfg.n_pose_dims)
+    model.cfg = model.config = cfg
+    return model
+
+
+def load_checkpoint(run_dir) -> Dict[str, np.ndarray]:
+    """``<run_dir>/checkpoint.pth.tar`` -> ``{"state_dict": ...}`` (``TB/inference/utils.py:146-152``)."""
+    ckpt = torch.load(Path(run_dir) / "checkpoint.pth.tar", map_location="cpu", weights_only=False)
+    return {k: v for k, v in ckpt["state_dict"].items()}

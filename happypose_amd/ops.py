@@ -177,12 +177,14 @@ def pose_prep(store: MeshStore, TCO: torch.Tensor, K: torch.Tensor, im_ids: torc
 
 def crop_roi_align(images: torch.Tensor, boxes: torch.Tensor, im_ids: torch.Tensor,
                    output_size=(240, 320), sampling_ratio: int = 4, out: Optional[torch.Tensor] = None,
-                   depth_norm_z: Optional[torch.Tensor] = None, depth_norm_mode: int = 0) -> torch.Tensor:
+                   depth_norm_z: Optional[torch.Tensor] = None, depth_norm_mode: int = 0,
+                   n_channels: Optional[int] = None) -> torch.Tensor:
     """``crop_images`` (TB/lib3d/cropping.py:155-197).  ``out=None`` -> NCHW ``[n,C,oh,ow]``;
     otherwise ``out`` is the NHWC network input ``[n,oh,ow,c_pad]`` and channels 0..C-1 are
     written."""
     dev = images.device
-    Bi, Cc, H, W = images.shape
+    Bi, Ct, H, W = images.shape
+    Cc = Ct if n_channels is None else n_channels
     n = boxes.shape[0]
     oh, ow = output_size
     assert images.dtype == torch.float32 and images.is_contiguous()
@@ -197,7 +199,7 @@ def crop_roi_align(images: torch.Tensor, boxes: torch.Tensor, im_ids: torch.Tens
         cp = out.shape[3]
         st = Strides(oh * ow * cp, 0, 1, ow * cp, cp)
     with torch.cuda.device(dev):
-        check(lib().hp_crop_roi_align(ptr(images), Bi, Cc, H, W, ptr(boxes), ptr(im_ids), n, oh, ow,
+        check(lib().hp_crop_roi_align(ptr(images), Bi, Ct, Cc, H, W, ptr(boxes), ptr(im_ids), n, oh, ow,
                                       sampling_ratio, ptr(res), C.byref(st), ptr(depth_norm_z),
                                       depth_norm_mode if Cc == 4 else 0, stream_ptr(dev)),
               "hp_crop_roi_align")
@@ -223,7 +225,8 @@ def pose_update(TCO: torch.Tensor, K_crop: torch.Tensor, pose9: torch.Tensor,
 
 
 def tco_init_autodepth(store: MeshStore, boxes: torch.Tensor, K: torch.Tensor, im_ids, obj_ids,
-                       R: Optional[torch.Tensor] = None, box_ids=None, rot_ids=None) -> torch.Tensor:
+                       R: Optional[torch.Tensor] = None, box_ids=None, rot_ids=None,
+                       n_points: Optional[int] = None) -> torch.Tensor:
     dev = store.device
     n = len(obj_ids)
     boxes, K = _f32(boxes, dev), _f32(K, dev)
@@ -233,9 +236,11 @@ def tco_init_autodepth(store: MeshStore, boxes: torch.Tensor, K: torch.Tensor, i
     if R is not None:
         R = _f32(R, dev)
     out = torch.empty((n, 4, 4), dtype=torch.float32, device=dev)
+    pids = None if n_points is None else store.point_ids(n_points)
     with torch.cuda.device(dev):
         check(lib().hp_tco_init_autodepth(store.handle, n, ptr(boxes), ptr(box_ids), ptr(K), ptr(im_ids),
-                                          ptr(obj_ids), ptr(R), ptr(rot_ids), ptr(out), stream_ptr(dev)),
+                                          ptr(obj_ids), ptr(R), ptr(rot_ids), ptr(pids), n_points or 0,
+                                          ptr(out), stream_ptr(dev)),
               "hp_tco_init_autodepth")
     return out
 

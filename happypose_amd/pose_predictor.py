@@ -1,0 +1,305 @@
+"""Render-and-compare pose predictors (the refiner / coarse models).
+
+Host-side mirror of the reference's two ``PosePredictor`` classes -- same
+constructor arguments, ``forward`` / ``forward_coarse`` signatures, output
+dictionaries and error behaviour:
+
+* MegaPose  ``MP/models/pose_rigid.py:96-788``   -> :class:`PosePredictor`
+* CosyPose  ``CP/models/pose.py:33-199``         -> :class:`CosyPosePosePredictor`
+
+Every iteration is five asynchronous HIP launches on the current stream, with
+nothing leaving the device:
+
+  hp_pose_prep     normalize_T, tCR, multi-view cameras, projected boxes, crop box, K_crop
+  hp_crop_roi_align  observed crop  -> channels [0, C_img) of the NHWC network input
+  hp_rasterize     V rendered views -> channels [C_img, C_img + V*C_r)
+  hp_net_forward   BN-folded MFMA conv stack + heads
+  hp_pose_update   9-D update -> TCO_output
+
+The reference's per-iteration host work (pickling to renderer processes, numpy
+``make_TCO_multiview``, ``clone``/``cat``) has no counterpart here.
+"""
+
+from __future__ import annotations
+
+import time
+from collections import defaultdict
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .renderer import BatchRenderer
+
+
+@dataclass
+class PosePredictorOutput:
+    """``MP/models/pose_rigid.py:60-80``.  ``renders`` / ``images_crop`` (NCHW) are
+    materialised only when the predictor runs with ``keep_pixels=True``."""
+
+    TCO_output: torch.Tensor
+    TCO_input: torch.Tensor
+    renders: Optional[torch.Tensor]
+    images_crop: Optional[torch.Tensor]
+    TCV_O_input: torch.Tensor
+    KV_crop: torch.Tensor
+    tCR: torch.Tensor
+    labels: List[str]
+    K: torch.Tensor
+    K_crop: torch.Tensor
+    network_outputs: Dict[str, torch.Tensor]
+    boxes_rend: torch.Tensor
+    boxes_crop: torch.Tensor
+    renderings_logits: Optional[torch.Tensor] = None
+    timing_dict: Dict[str, float] = field(default_factory=dict)
+
+    # the CosyPose flavour is consumed with item access in parts of the reference
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+class _Timer:
+    """``SimpleTimer`` / ``CudaTimer`` (``MP/training/utils.py:218-277``)."""
+
+    def __init__(self, device, cuda: bool):
+        self.device, self.cuda = device, cuda
+        self._t = 0.0
+
+    def start(self):
+        if self.cuda:
+            self._e0 = torch.cuda.Event(enable_timing=True)
+            self._e1 = torch.cuda.Event(enable_timing=True)
+            self._e0.record(torch.cuda.current_stream(self.device))
+        else:
+            self._t0 = time.time()
+
+    def stop(self):
+        if self.cuda:
+            self._e1.record(torch.cuda.current_stream(self.device))
+            self._e1.synchronize()
+            self._t = self._e0.elapsed_time(self._e1) / 1000.0
+        else:
+            self._t = time.time() - self._t0
+
+    end = stop
+
+    def elapsed(self) -> float:
+        return self._t
+
+
+class _RenderAndCompare:
+    """Shared device pipeline of both predictors."""
+
+    def _setup(self, backbone: ops.Net, renderer: BatchRenderer, mesh_db, render_size):
+        assert isinstance(renderer, BatchRenderer), "renderer must be a happypose_amd BatchRenderer"
+        assert isinstance(backbone, ops.Net), "backbone must be a happypose_amd.ops.Net"
+        assert isinstance(backbone.n_features if hasattr(backbone, "n_features") else 512, int)
+        self.backbone = backbone
+        self.renderer = renderer
+        self.store = renderer.store
+        self.mesh_db = mesh_db if mesh_db is not None else self.store.mesh_db
+        self.render_size = tuple(render_size)
+        self.device = self.store.device
+        self.keep_pixels = False
+        self.debug = False
+        self._x: Optional[torch.Tensor] = None
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        assert torch.device(device).type == self.device.type, "models live on the device of their MeshStore"
+        return self
+
+    def _input_buffer(self, b: int) -> torch.Tensor:
+        if self._x is None or self._x.shape[0] < b:
+            self._x = self.backbone.new_input(b)  # zeroed once: pad channels are never written
+        return self._x[:b]
+
+    def _ids(self, images, K, labels, im_ids):
+        bsz = len(labels)
+        if im_ids is None:  # the reference passes images/K already gathered per hypothesis
+            assert images.shape[0] == bsz and K.shape[0] == bsz
+            im_ids = torch.arange(bsz, dtype=torch.int32, device=self.device)
+        else:
+            im_ids = torch.as_tensor(im_ids).to(device=self.device, dtype=torch.int32)
+            assert im_ids.shape == (bsz,)
+        return im_ids, self.store.ids_of(labels)
+
+    def _one_pass(self, images, K, im_ids, obj_ids, TCO_in, *, n_img_channels, multiview_type, normalize,
+                  render_normals, render_depth, depth_mode, want_pose, want_logits):
+        b = TCO_in.shape[0]
+        prep = ops.pose_prep(self.store, TCO_in, K, im_ids, obj_ids, tuple(images.shape[-2:]),
+                             self.render_size, multiview_type=multiview_type, normalize=normalize)
+        x = self._input_buffer(b)
+        z = prep["tCR"][:, 2].contiguous() if depth_mode else None
+        ops.crop_roi_align(images, prep["boxes_crop"], im_ids, self.render_size, out=x,
+                           depth_norm_z=z, depth_norm_mode=depth_mode if n_img_channels == 4 else 0,
+                           n_channels=n_img_channels)
+        t0 = time.time()
+        ops.rasterize_into(self.store, x, n_img_channels, obj_ids, prep["TCV_O"], prep["K_crop"],
+                           render_normals, render_depth, z, depth_mode)
+        render_time = time.time() - t0
+        pose, logits, _ = self.backbone.forward(x, want_pose=want_pose, want_logits=want_logits)
+        return prep, x, pose, logits, render_time
+
+    def _pixels(self, x, n_img_channels, n_render_channels):
+        if not self.keep_pixels:
+            return None, None
+        nchw = x.permute(0, 3, 1, 2)
+        return (nchw[:, :n_img_channels].contiguous(),
+                nchw[:, n_img_channels:n_img_channels + n_render_channels].contiguous())
+
+
+class PosePredictor(_RenderAndCompare):
+    """MegaPose predictor, ``MP/models/pose_rigid.py:96-788``."""
+
+    def __init__(self, backbone: ops.Net, renderer: BatchRenderer, mesh_db=None, render_size=(240, 320),
+                 multiview_type: str = "front_3views", views_inplane_rotations: bool = False,
+                 remove_TCO_rendering: bool = False, predict_pose_update: bool = True,
+                 predict_rendered_views_logits: bool = False, render_normals: bool = True,
+                 n_rendered_views: int = 1, input_depth: bool = False, render_depth: bool = False,
+                 depth_normalization_type: Optional[str] = None):
+        self._setup(backbone, renderer, mesh_db, render_size)
+        if views_inplane_rotations or remove_TCO_rendering:
+            raise NotImplementedError("views_inplane_rotations / remove_TCO_rendering (unused by the released models)")
+        # legacy names (MP/training/pose_models_cfg.py:48-53)
+        multiview_type = {"front_3views": "TCO+front_3views", "front_5views": "TCO+front_5views",
+                          "front_1view": "TCO+front_1view"}.get(multiview_type, multiview_type)
+        self.n_rendered_views = n_rendered_views
+        self.multiview_type = multiview_type if n_rendered_views > 1 else "TCO"
+        if self.multiview_type not in ops.MULTIVIEW or ops.MULTIVIEW[self.multiview_type][1] != n_rendered_views:
+            raise ValueError(multiview_type)
+        self.input_depth = input_depth
+        self.render_normals = render_normals
+        self.render_depth = render_depth
+        self.depth_normalization_type = depth_normalization_type
+        if (input_depth or render_depth) and depth_normalization_type not in ops.DEPTH_NORM:
+            raise ValueError(f"Unknown depth_normalization_type = {depth_normalization_type}")
+        self._depth_mode = ops.DEPTH_NORM.get(depth_normalization_type, 0) if (input_depth or render_depth) else 0
+        self.predict_pose_update = predict_pose_update
+        self.predict_rendered_views_logits = predict_rendered_views_logits
+        self.remove_TCO_rendering = remove_TCO_rendering
+        self._n_img = 4 if input_depth else 3
+        self._n_single_render_channels = 3 + (3 if render_normals else 0) + (1 if render_depth else 0)
+        n_inputs = self._n_img + self._n_single_render_channels * n_rendered_views
+        assert backbone.n_inputs == n_inputs, (
+            f"backbone expects {backbone.n_inputs} input channels, configuration needs {n_inputs}")
+        if predict_pose_update:
+            assert backbone.pose_dim == 9
+        if predict_rendered_views_logits:
+            assert backbone.n_logits == n_rendered_views
+        self.timing_dict: Dict[str, float] = defaultdict(float)
+
+    # -- refiner ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor, K: torch.Tensor, labels: Sequence[str], TCO: torch.Tensor,
+                n_iterations: int = 1, random_ambient_light: bool = False,
+                im_ids: Optional[torch.Tensor] = None) -> Dict[str, PosePredictorOutput]:
+        assert not random_ambient_light, "random_ambient_light is a training-time augmentation"
+        bsz = len(labels)
+        assert TCO.shape == (bsz, 4, 4)
+        assert K.dim() == 3 and K.shape[1:] == (3, 3)
+        assert images.dim() == 4 and images.shape[1] >= self._n_img, "images must be [B,C,H,W] with C>=3 (4 if input_depth)"
+        im_ids, obj_ids = self._ids(images, K, labels, im_ids)
+        labels = list(labels)
+        outputs: Dict[str, PosePredictorOutput] = {}
+        TCO_input = TCO.to(self.device, torch.float32)
+        for n in range(n_iterations):
+            prep, x, pose, logits, render_time = self._one_pass(
+                images, K, im_ids, obj_ids, TCO_input, n_img_channels=self._n_img,
+                multiview_type=self.multiview_type, normalize=True, render_normals=self.render_normals,
+                render_depth=self.render_depth, depth_mode=self._depth_mode,
+                want_pose=self.predict_pose_update, want_logits=self.predict_rendered_views_logits)
+            TCO_norm = prep["TCO"]
+            if self.predict_pose_update:
+                TCO_output = ops.pose_update(TCO_norm, prep["K_crop"], pose, prep["tCR"])
+            else:
+                TCO_output = TCO_norm.clone()
+            net_out = {}
+            if pose is not None:
+                net_out["pose"] = pose
+            if logits is not None:
+                net_out["renderings_logits"] = logits
+            images_crop, renders = self._pixels(x, self._n_img, self._n_single_render_channels * self.n_rendered_views)
+            Kb = K[im_ids.long()] if K.shape[0] != bsz else K
+            outputs[f"iteration={n + 1}"] = PosePredictorOutput(
+                renders=renders, images_crop=images_crop, TCO_input=TCO_norm, TCO_output=TCO_output,
+                TCV_O_input=prep["TCV_O"], tCR=prep["tCR"], labels=labels, K=Kb, K_crop=prep["K_crop"][:, 0],
+                KV_crop=prep["K_crop"], network_outputs=net_out, boxes_rend=prep["boxes_rend"],
+                boxes_crop=prep["boxes_crop"],
+                renderings_logits=logits if logits is not None else torch.empty(
+                    bsz, self.n_rendered_views, dtype=torch.float32, device=self.device),
+                timing_dict={"render": render_time})
+            TCO_input = TCO_output
+        return outputs
+
+    __call__ = forward
+
+    # -- coarse / scoring ------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_coarse(self, images: torch.Tensor, K: torch.Tensor, labels: Sequence[str],
+                       TCO_input: torch.Tensor, cuda_timer: bool = False, return_debug_data: bool = False,
+                       im_ids: Optional[torch.Tensor] = None) -> Dict[str, Any]:
+        """``MP/models/pose_rigid.py:708-788``: logits/scores of the rendered view."""
+        assert self.predict_rendered_views_logits, "Method only valid if coarse classification model"
+        bsz = len(labels)
+        assert TCO_input.shape == (bsz, 4, 4)
+        im_ids, obj_ids = self._ids(images, K, labels, im_ids)
+        timer = _Timer(self.device, cuda_timer)
+        timer.start()
+        keep, self.keep_pixels = self.keep_pixels, self.keep_pixels or return_debug_data
+        prep, x, _, logits, render_time = self._one_pass(
+            images, K, im_ids, obj_ids, TCO_input.to(self.device, torch.float32), n_img_channels=self._n_img,
+            multiview_type="TCO", normalize=True, render_normals=self.render_normals,
+            render_depth=self.render_depth, depth_mode=self._depth_mode, want_pose=False, want_logits=True)
+        timer.stop()
+        out = {"logits": logits, "scores": torch.sigmoid(logits), "time": timer.elapsed(),
+               "render_time": render_time, "model_time": timer.elapsed()}
+        if return_debug_data:
+            out["images_crop"], out["renders"] = self._pixels(x, self._n_img, self._n_single_render_channels)
+        self.keep_pixels = keep
+        return out
+
+
+class CosyPosePosePredictor(_RenderAndCompare):
+    """CosyPose predictor, ``CP/models/pose.py:33-199``: one rendered RGB view under white
+    ambient light, 6 input channels, no ``normalize_T``, reference point = object origin
+    (``apply_imagespace_predictions``)."""
+
+    def __init__(self, backbone: ops.Net, renderer: BatchRenderer, mesh_db=None, render_size=(240, 320),
+                 pose_dim: int = 9):
+        self._setup(backbone, renderer, mesh_db, render_size)
+        if pose_dim != 9:
+            raise ValueError(f"pose_dim={pose_dim} not supported")
+        self.pose_dim = pose_dim
+        assert backbone.n_inputs == 6 and backbone.pose_dim == 9
+
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor, K: torch.Tensor, labels: Sequence[str], TCO: torch.Tensor,
+                n_iterations: int = 1, im_ids: Optional[torch.Tensor] = None) -> Dict[str, PosePredictorOutput]:
+        bsz = len(labels)
+        assert images.dim() == 4 and images.shape[1] >= 3
+        assert K.dim() == 3 and K.shape[1:] == (3, 3)
+        assert TCO.shape == (bsz, 4, 4)
+        im_ids, obj_ids = self._ids(images, K, labels, im_ids)
+        labels = list(labels)
+        outputs: Dict[str, PosePredictorOutput] = {}
+        TCO_input = TCO.to(self.device, torch.float32)
+        for n in range(n_iterations):
+            prep, x, pose, _, render_time = self._one_pass(
+                images, K, im_ids, obj_ids, TCO_input, n_img_channels=3, multiview_type="TCO", normalize=False,
+                render_normals=False, render_depth=False, depth_mode=0, want_pose=True, want_logits=False)
+            TCO_output = ops.pose_update(TCO_input, prep["K_crop"], pose, None)
+            images_crop, renders = self._pixels(x, 3, 3)
+            Kb = K[im_ids.long()] if K.shape[0] != bsz else K
+            outputs[f"iteration={n + 1}"] = PosePredictorOutput(
+                renders=renders, images_crop=images_crop, TCO_input=TCO_input, TCO_output=TCO_output,
+                TCV_O_input=prep["TCV_O"], tCR=prep["tCR"], labels=labels, K=Kb, K_crop=prep["K_crop"][:, 0],
+                KV_crop=prep["K_crop"], network_outputs={"pose": pose}, boxes_rend=prep["boxes_rend"],
+                boxes_crop=prep["boxes_crop"], timing_dict={"render": render_time})
+            TCO_input = TCO_output
+        return outputs
+
+    __call__ = forward

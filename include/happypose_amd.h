@@ -133,10 +133,12 @@ int hp_pose_prep(const hp_mesh_store* store, int b, int n_views, int multiview_t
  * (240,320), sampling_ratio=4, aligned=False)  (TB/lib3d/cropping.py:155-197,
  * CP/lib3d/cropping.py:129-134) incl. the RGB-D rule (depth zeroed where the roi-aligned
  * validity mask < 0.99) and, optionally, the depth normalisation of normalize_images.
- * d_images: [Bi][C][H][W] f32 (the reference's ObservationTensor layout).  Output
+ * d_images: [Bi][C][H][W] f32 (the reference's ObservationTensor layout); the first
+ * n_channels (3 = rgb, 4 = rgbd) planes are cropped (a model without input_depth drops the
+ * depth plane of an RGB-D observation, MP/models/pose_rigid.py:557-559).  Output
  * addressing as in hp_rasterize with views_per_item = 1 (s_view unused).
  * ---------------------------------------------------------------------------------- */
-int hp_crop_roi_align(const float* d_images, int Bi, int C, int H, int W,
+int hp_crop_roi_align(const float* d_images, int Bi, int C, int n_channels, int H, int W,
                       const float* d_boxes /* [n][4] */, const int32_t* d_im_ids /* [n] */,
                       int n, int out_h, int out_w, int sampling_ratio, float* d_out,
                       const hp_strides* out_strides, const float* d_depth_norm_z,
@@ -154,13 +156,15 @@ int hp_pose_update(int b, const float* d_TCO, const float* d_K_crop, int k_strid
 
 /* Coarse initialisation.  Replaces TCO_init_from_boxes_autodepth_with_R
  * (TB/lib3d/cosypose_ops.py:184-238; d_R != NULL), TCO_init_from_boxes_zup_autodepth
- * (:241-283; d_R = NULL) over the FULL padded point set of each object.
+ * (:241-283; d_R = NULL).  Extents are taken over the full padded point set of the object
+ * (MegaPose, MP/inference/pose_estimator.py:393-410) or, when d_point_ids is given, over
+ * that deterministic sub-sample (CosyPose, CP/integrated/pose_estimator.py:128-130).
  * Hypothesis i uses box d_boxes[d_box_ids ? d_box_ids[i] : i], intrinsics
  * d_K[d_im_ids[i]], object d_obj_ids[i], rotation d_R[d_rot_ids ? d_rot_ids[i] : i]. */
 int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxes,
                           const int32_t* d_box_ids, const float* d_K, const int32_t* d_im_ids,
                           const int32_t* d_obj_ids, const float* d_R, const int32_t* d_rot_ids,
-                          float* d_TCO_out, void* stream);
+                          const int32_t* d_point_ids, int n_points, float* d_TCO_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Network (backbone + heads).  Replaces PosePredictor.net_forward
