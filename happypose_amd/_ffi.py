@@ -10,7 +10,9 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libhappypose_amd.so"
+import os as _os
+
+_LIB_PATH = Path(_os.environ.get("HAPPYPOSE_AMD_LIB", Path(__file__).resolve().parent / "lib" / "libhappypose_amd.so"))
 _lib = None
 
 c_f32p = C.c_void_p
@@ -60,7 +62,9 @@ _PROTOS = {
     "hp_net_forward": (C.c_int, [C.c_void_p, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "hp_net_flops_per_sample": (C.c_double, [C.c_void_p]),
     "hp_net_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
-    "hp_net_last_conv_ms": (C.c_double, [C.c_void_p]),
+    "hp_conv_occupancy": (C.c_int, [C.c_int]),
+    "hp_net_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_double)]),
     "hp_conv2d_nhwc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                  c_f32p, C.c_void_p]),
@@ -82,6 +86,11 @@ def lib():
                 f"{_LIB_PATH} not found: build it with `python -m happypose_amd.build` "
                 "(__graft_entry__.build()).  happypose_amd has no CPU fallback."
             )
+        # torch owns the device memory and streams we are handed, so the library must bind to
+        # the SAME HIP runtime instance: import torch first (its bundled libamdhip64 is then
+        # the one already loaded when ours resolves its dependency).
+        import torch  # noqa: F401
+
         try:
             handle = C.CDLL(str(_LIB_PATH))
         except OSError as e:  # e.g. libamdhip64 missing

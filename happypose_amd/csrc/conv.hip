@@ -16,24 +16,29 @@
 // (tap offset, kh, kw, channel), which makes the 7x7/5x5 stems (Cin padded to a multiple of
 // 4) and the 3x3/1x1 body convolutions one code path.
 //
-// Mapping to the hardware (wave64, 4 waves per workgroup):
+// Mapping to the hardware (wave64, 4 waves per workgroup, 2 workgroups per CU):
 //   * block tile BM x BN = 128x128 (128x64 for the 64-channel layers), BK = 32; the 4 waves
 //     sit 2x2, each owns a 64x64 (64x32) sub-tile = 2x2 (2x1) MFMA tiles of 32x32 -> 64 (32)
 //     accumulator VGPRs;
-//   * global -> registers -> LDS staging with 16-B loads (one filter tap row of a pixel is a
-//     128-B line shared by 8 adjacent lanes), zero padding by predication, double-buffered
-//     LDS with one barrier per K-tile; the loads of tile t+1 are issued before the MFMAs of
-//     tile t;
-//   * LDS tiles are [rows][32+4] floats: the +4 pad makes both the 16-B staging stores and
-//     the 16-B fragment reads (ds_read_b128: lane -> row = lane&31, k = 4*(lane>>5)..+3)
-//     bank-conflict free.  One ds_read_b128 feeds FOUR k-steps: the order of K inside a
-//     K-tile is permuted (k-step j of a group multiplies k = j and k = 4+j), which is legal
-//     because A and B use the same permutation;
-//   * per K-tile a wave issues 64 MFMAs (4096 matrix-pipe cycles) against 16 ds_read_b128
-//     and ~8 global loads: the kernel is bound by the fp32 matrix pipe (157 TFLOP/s), see
-//     DESIGN.md for the roofline;
+//   * LDS tiles are [rows][32+4] floats, double buffered: the +4 pad makes both the 16-B
+//     staging stores and the 16-B fragment reads (ds_read_b128: lane -> row = lane&31,
+//     k = 4*(lane>>5)..+3) bank-conflict free (SQ_LDS_BANK_CONFLICT = 0 measured).  One
+//     ds_read_b128 feeds FOUR k-steps: the order of K inside a K-tile is permuted (k-step j
+//     of a group multiplies k = j and k = 4+j), legal because A and B use the same order;
+//   * the K loop is software pipelined INSIDE each wave so that the only thing a wave waits
+//     for is the matrix pipe: after the barrier it reads the first fragments, issues the
+//     (branch-free, predicated-by-select) global loads of tile t+1 and the LUT entry of tile
+//     t+2, runs half of its MFMAs, then writes tile t+1 to the other LDS buffer (the loads
+//     have had >= 2000 matrix-pipe cycles to land), runs the other half, and meets the one
+//     barrier of the K-tile.  Fragment reads of group kg+1 are issued under the MFMAs of kg.
+//     An f32 MFMA occupies the pipe for 64 cycles, so all ~200 non-MFMA instructions of a
+//     K-tile fit in the shadows of its 64 MFMAs;
+//   * zero padding and the pre-activation prologue are applied when the staged registers
+//     are written to LDS (not when they are loaded), so no load is ever waited for early;
 //   * workgroup ids are renumbered so that each XCD walks a contiguous range of tiles
 //     (neighbouring tiles share activation rows / weight panels in that XCD's L2).
+// The kernel is bound by the fp32 matrix pipe (157.3 TFLOP/s dense); DESIGN.md has the
+// roofline and the measured fraction.
 // Numerics: exact fp32 FMA chains (the f32 MFMA is bitwise an fmaf chain), K-order differs
 // from the reference's oneDNN/cuDNN kernels, so results agree to fp32 round-off, not bitwise.
 #include "conv.h"
@@ -58,47 +63,121 @@ struct Tile {
   static constexpr int LDS_FLOATS = 2 * (BM + BN) * LDK;
 };
 
+// registers of one staged K-tile
 template <int NA, int NB>
-__device__ __forceinline__ void load_tile(const ConvArgs& a, int t, int kc, const int64_t (&rowoff)[NA],
-                                          const int (&ih0)[NA], const int (&iw0)[NA],
-                                          const float* const (&wrow)[NB], floatx4 (&ra)[NA], floatx4 (&rb)[NB]) {
-  const int4 e = a.lut[t * 8 + kc];  // {offset, kh, kw, channel}; kh < 0 -> K padding
-  floatx4 ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
-  const bool pre = a.pre_scale != nullptr;
-  if (pre && e.y >= 0) {
-    ps = *reinterpret_cast<const floatx4*>(a.pre_scale + e.w);
-    pb = *reinterpret_cast<const floatx4*>(a.pre_shift + e.w);
-  }
+struct Stage {
+  floatx4 ra[NA], rb[NB];
+  floatx4 ps, pb;     // prologue scale / shift of this chunk's 4 channels
+  unsigned ok;        // bit i: A chunk i is inside the image (else it is zero padding)
+};
+
+template <int NA, int NB, bool PRE>
+__device__ __forceinline__ void issue_loads(const ConvArgs& a, int t, const int4 e, const int64_t (&rowoff)[NA],
+                                            const int (&ih0)[NA], const int (&iw0)[NA],
+                                            const float* const (&wrow)[NB], Stage<NA, NB>& s) {
+  // e = {offset, kh, kw, channel}; kh < 0 marks K padding.  Loads are unconditional: an
+  // out-of-image chunk reads a harmless valid address and is zeroed at store time.
+  unsigned ok = 0;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int ih = ih0[i] + e.y, iw = iw0[i] + e.z;
-    const bool ok = (e.y >= 0) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-    floatx4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-      v = *reinterpret_cast<const floatx4*>(a.x + rowoff[i] + e.x);
-      if (pre) {
+    const bool in = (e.y >= 0) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+    const float* p = in ? a.x + rowoff[i] + e.x : a.x;
+    s.ra[i] = *reinterpret_cast<const floatx4*>(p);
+    ok |= (in ? 1u : 0u) << i;
+  }
+  s.ok = ok;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], ps[q], pb[q]), 0.f);
-      }
+  for (int i = 0; i < NB; ++i) s.rb[i] = *reinterpret_cast<const floatx4*>(wrow[i] + t * BK);
+  if (PRE) {
+    const int c = e.y >= 0 ? e.w : 0;
+    s.ps = *reinterpret_cast<const floatx4*>(a.pre_scale + c);
+    s.pb = *reinterpret_cast<const floatx4*>(a.pre_shift + c);
+  }
+}
+
+template <int NA, int NB, bool PRE>
+__device__ __forceinline__ void store_tile(float* Ast, float* Bst, const Stage<NA, NB>& s) {
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    floatx4 v = s.ra[i];
+    if (PRE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], s.ps[q], s.pb[q]), 0.f);
     }
-    ra[i] = v;
+    const bool in = (s.ok >> i) & 1u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = in ? v[q] : 0.f;
+    *reinterpret_cast<floatx4*>(Ast + 32 * i * LDK) = v;
   }
 #pragma unroll
-  for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const floatx4*>(wrow[i] + t * BK);
+  for (int i = 0; i < NB; ++i) *reinterpret_cast<floatx4*>(Bst + 32 * i * LDK) = s.rb[i];
+}
+
+// ---- the same staging work, one chunk at a time (interleaved with the MFMAs) -----------
+template <int NA, int NB>
+__device__ __forceinline__ void load_a_chunk(const ConvArgs& a, const int4 e, int i, int64_t rowoff, int ih0, int iw0,
+                                             Stage<NA, NB>& s) {
+  const int ih = ih0 + e.y, iw = iw0 + e.z;
+  const bool in = (e.y >= 0) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+  const float* p = in ? a.x + rowoff + e.x : a.x;
+  s.ra[i] = *reinterpret_cast<const floatx4*>(p);
+  s.ok |= (in ? 1u : 0u) << i;
+}
+
+template <int NA, int NB, bool PRE>
+__device__ __forceinline__ void load_b_chunks(const ConvArgs& a, int t, const int4 e, const float* const (&wrow)[NB],
+                                              Stage<NA, NB>& s) {
+#pragma unroll
+  for (int i = 0; i < NB; ++i) s.rb[i] = *reinterpret_cast<const floatx4*>(wrow[i] + t * BK);
+  if (PRE) {
+    const int c = e.y >= 0 ? e.w : 0;
+    s.ps = *reinterpret_cast<const floatx4*>(a.pre_scale + c);
+    s.pb = *reinterpret_cast<const floatx4*>(a.pre_shift + c);
+  }
+}
+
+template <int NA, int NB, bool PRE>
+__device__ __forceinline__ void store_a_chunk(float* Aw, int i, const Stage<NA, NB>& s) {
+  floatx4 v = s.ra[i];
+  if (PRE) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], s.ps[q], s.pb[q]), 0.f);
+  }
+  const bool in = (s.ok >> i) & 1u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = in ? v[q] : 0.f;
+  *reinterpret_cast<floatx4*>(Aw + 32 * i * LDK) = v;
 }
 
 template <int NA, int NB>
-__device__ __forceinline__ void store_tile(float* Ast, float* Bst, const floatx4 (&ra)[NA], const floatx4 (&rb)[NB]) {
-#pragma unroll
-  for (int i = 0; i < NA; ++i) *reinterpret_cast<floatx4*>(Ast + 32 * i * LDK) = ra[i];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) *reinterpret_cast<floatx4*>(Bst + 32 * i * LDK) = rb[i];
+__device__ __forceinline__ void store_b_chunk(float* Bw, int i, const Stage<NA, NB>& s) {
+  *reinterpret_cast<floatx4*>(Bw + 32 * i * LDK) = s.rb[i];
 }
 
-template <int BM, int BN>
+template <int MT, int NT>
+__device__ __forceinline__ void read_frags(const float* Ab, const float* Bb, int kg, floatx4 (&fa)[MT], floatx4 (&fb)[NT]) {
+#pragma unroll
+  for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK + kg * 8);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const floatx4*>(Bb + i * 32 * LDK + kg * 8);
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void mfma_group(const floatx4 (&fa)[MT], const floatx4 (&fb)[NT], floatx16 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+}
+
+template <int BM, int BN, bool PRE>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_igemm_f32(ConvArgs a) {
   using TT = Tile<BM, BN>;
-  constexpr int MT = TT::MT, NT = TT::NT;
+  constexpr int MT = TT::MT, NT = TT::NT, NA = TT::A_CHUNKS, NB = TT::B_CHUNKS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                       // [2][BM][LDK]
   float* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
@@ -118,11 +197,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int r0 = tid >> 3;        // first staged row (0..31); rows r0 + 32*i
 
   // ---- per-row (output pixel) constants for the A gather ----
-  int64_t rowoff[TT::A_CHUNKS];
-  int ih0[TT::A_CHUNKS], iw0[TT::A_CHUNKS];
+  int64_t rowoff[NA];
+  int ih0[NA], iw0[NA];
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
-  for (int i = 0; i < TT::A_CHUNKS; ++i) {
+  for (int i = 0; i < NA; ++i) {
     const int64_t m = m0 + r0 + 32 * i;
     if (m < a.M) {
       const int img = (int)(m / HoWo);
@@ -135,11 +214,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
       ih0[i] = -(1 << 28); iw0[i] = 0; rowoff[i] = 0;
     }
   }
-  const float* wrow[TT::B_CHUNKS];
+  const float* wrow[NB];
 #pragma unroll
-  for (int i = 0; i < TT::B_CHUNKS; ++i) wrow[i] = a.w + (int64_t)(n0 + r0 + 32 * i) * a.Kpad + 4 * kc;
+  for (int i = 0; i < NB; ++i) wrow[i] = a.w + (int64_t)(n0 + r0 + 32 * i) * a.Kpad + 4 * kc;
 
-  floatx4 ra[TT::A_CHUNKS], rb[TT::B_CHUNKS];
   float* const Ast = As + r0 * LDK + 4 * kc;  // this thread's staging slot (row r0, chunk kc)
   float* const Bst = Bs + r0 * LDK + 4 * kc;
 
@@ -154,33 +232,81 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int wm = (wave / TT::WAVES_N) * TT::WM;
   const int wn = (wave % TT::WAVES_N) * TT::WN;
   const int frow = lane & 31, fk = 4 * (lane >> 5);
+  const float* const Afr = As + (wm + frow) * LDK + fk;  // this lane's fragment base, buffer 0
+  const float* const Bfr = Bs + (wn + frow) * LDK + fk;
 
-  load_tile(a, 0, kc, rowoff, ih0, iw0, wrow, ra, rb);
-  store_tile(Ast, Bst, ra, rb);
+  Stage<NA, NB> st;
+  // the LUT carries one extra K-tile of padding entries, so t+2 below never reads out of range
+  issue_loads<NA, NB, PRE>(a, 0, a.lut[kc], rowoff, ih0, iw0, wrow, st);
+  int4 e_next = a.lut[8 + kc];
+  store_tile<NA, NB, PRE>(Ast, Bst, st);
   __syncthreads();
 
-  for (int t = 0; t < a.ktiles; ++t) {
+  // One K-tile = 16 "quads" (k-group kg = q/4, k-step j = q%4; a quad is the MT*NT independent
+  // MFMAs of one k-step).  After every quad a small, fixed chunk of the staging work for tile
+  // t+1 is issued, so it executes in the shadow of the quad's 64-cycle MFMAs; sched_barrier
+  // pins this order (left alone, hipcc clusters loads / MFMAs / stores into three phases and
+  // the matrix pipe idles through two of them):
+  //   q0-3   address + global load of A chunk 0..3   (q1: LDS fragments of kg1)
+  //   q4     global loads of the B chunks, prologue scale/shift, LUT entry of tile t+2
+  //   q5     LDS fragments of kg2
+  //   q8-11  zero-pad/prologue + LDS store of A chunk 0..3 (q9: LDS fragments of kg3)
+  //   q12-13 LDS store of the B chunks
+  floatx4 fa[2][MT], fb[2][NT];
+  const int last = a.ktiles - 1;
+  for (int t = 0; t <= last; ++t) {
     const int buf = t & 1;
-    if (t + 1 < a.ktiles) load_tile(a, t + 1, kc, rowoff, ih0, iw0, wrow, ra, rb);
-    const float* Ab = As + buf * BM * LDK + (wm + frow) * LDK + fk;
-    const float* Bb = Bs + buf * BN * LDK + (wn + frow) * LDK + fk;
+    const bool stage = t < last;  // wave-uniform
+    const float* Ab = Afr + buf * BM * LDK;
+    const float* Bb = Bfr + buf * BN * LDK;
+    float* const Aw = Ast + (buf ^ 1) * BM * LDK;
+    float* const Bw = Bst + (buf ^ 1) * BN * LDK;
+    const int4 e = e_next;
+    read_frags<MT, NT>(Ab, Bb, 0, fa[0], fb[0]);
+    if (stage) st.ok = 0;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
-      floatx4 av[MT], bv[NT];
+    for (int q = 0; q < 16; ++q) {
+      const int kg = q >> 2, j = q & 3;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) av[i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK + kg * 8);
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int i = 0; i < NT; ++i) bv[i] = *reinterpret_cast<const floatx4*>(Bb + i * 32 * LDK + kg * 8);
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kg & 1][mi][j], fb[kg & 1][ni][j], acc[mi][ni], 0, 0, 0);
+      // HP_ABL_* are compile-time ablation switches for tools/conv_ablate.sh (which part of the
+      // K loop costs matrix-pipe time); never defined in the product build.
+#ifndef HP_ABL_NO_DSREAD
+      if (q == 1) read_frags<MT, NT>(Ab, Bb, 1, fa[1], fb[1]);
+      if (q == 5) read_frags<MT, NT>(Ab, Bb, 2, fa[0], fb[0]);
+      if (q == 9) read_frags<MT, NT>(Ab, Bb, 3, fa[1], fb[1]);
+#endif
+#ifdef HP_ABL_NO_STAGE
+      if (false) {
+#else
+      if (stage) {
+#endif
+        if (q < 4) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+          for (int i = q; i < NA; i += 4) load_a_chunk<NA, NB>(a, e, i, rowoff[i], ih0[i], iw0[i], st);
+        } else if (q == 4) {
+          load_b_chunks<NA, NB, PRE>(a, t + 1, e, wrow, st);
+          e_next = a.lut[(t + 2) * 8 + kc];
+        } else if (q >= 8 && q < 12) {
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+          for (int i = q - 8; i < NA; i += 4) store_a_chunk<NA, NB, PRE>(Aw, i, st);
+        } else if (q == 12) {
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+          for (int i = 0; i < NB / 2; ++i) store_b_chunk<NA, NB>(Bw, i, st);
+        } else if (q == 13) {
+#pragma unroll
+          for (int i = NB / 2; i < NB; ++i) store_b_chunk<NA, NB>(Bw, i, st);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (t + 1 < a.ktiles) store_tile(Ast + (buf ^ 1) * BM * LDK, Bst + (buf ^ 1) * BN * LDK, ra, rb);
+#ifndef HP_ABL_NO_BARRIER
     __syncthreads();
+#endif
   }
 
   // ---- epilogue: bias, residual, ReLU; NHWC store (32 consecutive channels per half-wave) ----
@@ -204,119 +330,56 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 }
 
-// ---- 3x3 stride-2 pad-1 max pooling, NHWC, 4 channels per lane ------------------------
-__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* x, float* y, int n, int H, int W,
-                                                         int C, int Ho, int Wo) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int C4 = C / 4;
-  const int64_t total = (int64_t)n * Ho * Wo * C4;
-  if (idx >= total) return;
-  const int c4 = (int)(idx % C4);
-  int64_t p = idx / C4;
-  const int ow = (int)(p % Wo); p /= Wo;
-  const int oh = (int)(p % Ho);
-  const int img = (int)(p / Ho);
-  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    const int ih = oh * 2 - 1 + dy;
-    if ((unsigned)ih >= (unsigned)H) continue;
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int iw = ow * 2 - 1 + dx;
-      if ((unsigned)iw >= (unsigned)W) continue;
-      const float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)img * H + ih) * W + iw) * C + 4 * c4);
-      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-    }
-  }
-  *reinterpret_cast<float4*>(y + (((int64_t)img * Ho + oh) * Wo + ow) * C + 4 * c4) = m;
-}
-
-// ---- head: spatial mean -> [fc 512x512 + bias] -> pose / logits linear heads -----------
-// one workgroup per sample; features [HW][C] NHWC.
-__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
-  __shared__ float feat[512];
-  __shared__ float feat2[512];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* x = a.x + (int64_t)b * a.HW * a.C;
-  for (int c = tid; c < a.C; c += 256) {
-    float s = 0.f;
-    for (int p = 0; p < a.HW; ++p) s += x[(int64_t)p * a.C + c];
-    feat[c] = s / (float)a.HW;
-  }
-  __syncthreads();
-  const float* f = feat;
-  if (a.fc_w) {  // torchvision ResNet: avgpool -> fc (MP/models/torchvision_resnet.py:337-341)
-    for (int o = tid; o < a.C; o += 256) {
-      const float* w = a.fc_w + (int64_t)o * a.C;
-      float s = 0.f;
-      for (int c = 0; c < a.C; ++c) s = fmaf(w[c], feat[c], s);
-      feat2[o] = s + a.fc_b[o];
-    }
-    __syncthreads();
-    f = feat2;
-  }
-  if (a.features) for (int c = tid; c < a.C; c += 256) a.features[(int64_t)b * a.C + c] = f[c];
-  // linear heads: one wave per output row, lanes stride the 512 features
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int o = wave; o < a.pose_dim + a.n_logits; o += 4) {
-    const bool is_pose = o < a.pose_dim;
-    const int oo = is_pose ? o : o - a.pose_dim;
-    const float* w = (is_pose ? a.pose_w : a.logit_w) + (int64_t)oo * a.C;
-    float s = 0.f;
-    for (int c = lane; c < a.C; c += 64) s = fmaf(w[c], f[c], s);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) {
-      if (is_pose) { if (a.pose_out) a.pose_out[(int64_t)b * a.pose_dim + oo] = s + a.pose_b[oo]; }
-      else { if (a.logit_out) a.logit_out[(int64_t)b * a.n_logits + oo] = s + a.logit_b[oo]; }
-    }
-  }
-}
-
-int launch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
-  ConvArgs args = a;
-  if (variant == 0) {
-    constexpr int BM = 128, BN = 128;
-    args.tiles_m = (int)((a.M + BM - 1) / BM);
-    args.tiles_n = a.Cout / BN;
-    const int nblk = args.tiles_m * args.tiles_n;
-    const size_t lds = Tile<BM, BN>::LDS_FLOATS * sizeof(float);
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN>), dim3(8 * ((nblk + 7) / 8)), dim3(kThreads), lds, stream, args);
-  } else {
-    constexpr int BM = 128, BN = 64;
-    args.tiles_m = (int)((a.M + BM - 1) / BM);
-    args.tiles_n = a.Cout / BN;
-    const int nblk = args.tiles_m * args.tiles_n;
-    const size_t lds = Tile<BM, BN>::LDS_FLOATS * sizeof(float);
-    hipLaunchKernelGGL((conv_igemm_f32<BM, BN>), dim3(8 * ((nblk + 7) / 8)), dim3(kThreads), lds, stream, args);
-  }
+template <int BM, int BN, bool PRE>
+static int launch_variant(ConvArgs args, hipStream_t stream) {
+  args.tiles_m = (int)((args.M + BM - 1) / BM);
+  args.tiles_n = args.Cout / BN;
+  const int nblk = args.tiles_m * args.tiles_n;
+  const size_t lds = Tile<BM, BN>::LDS_FLOATS * sizeof(float);
+  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, PRE>), dim3(8 * ((nblk + 7) / 8)), dim3(kThreads), lds, stream, args);
   return check_launch("conv_igemm_f32");
 }
 
-int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream) {
-  const int64_t total = (int64_t)n * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(maxpool3x3s2_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, n, H, W, C, Ho, Wo);
-  return check_launch("maxpool3x3s2_nhwc");
+int launch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
+  const bool pre = a.pre_scale != nullptr;
+  if (variant == 0) return pre ? launch_variant<128, 128, true>(a, stream) : launch_variant<128, 128, false>(a, stream);
+  return pre ? launch_variant<128, 64, true>(a, stream) : launch_variant<128, 64, false>(a, stream);
 }
 
-int launch_head(const HeadArgs& a, int batch, hipStream_t stream) {
-  hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(256), 0, stream, a);
-  return check_launch("head_kernel");
+template <int BM, int BN, bool PRE>
+static int opt_in_lds() {
+  // > 64 KB of dynamic LDS needs the opt-in attribute
+  HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, PRE>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(Tile<BM, BN>::LDS_FLOATS * sizeof(float))));
+  return HP_OK;
 }
 
 int conv_setup_once() {
   static bool done = false;
   if (done) return HP_OK;
-  // > 64 KB of dynamic LDS needs the opt-in attribute
-  HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<128, 128>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(Tile<128, 128>::LDS_FLOATS * sizeof(float))));
-  HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<128, 64>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(Tile<128, 64>::LDS_FLOATS * sizeof(float))));
+  int rc;
+  if ((rc = opt_in_lds<128, 128, false>())) return rc;
+  if ((rc = opt_in_lds<128, 128, true>())) return rc;
+  if ((rc = opt_in_lds<128, 64, false>())) return rc;
+  if ((rc = opt_in_lds<128, 64, true>())) return rc;
   done = true;
   return HP_OK;
 }
 
 }  // namespace hp
+
+// diagnostics: resident workgroups per CU the runtime grants a conv variant
+extern "C" int hp_conv_occupancy(int variant) {
+  using namespace hp;
+  if (conv_setup_once() != HP_OK) return HP_ERR_HIP;
+  int nb = 0;
+  if (variant == 0) {
+    HP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_igemm_f32<128, 128, false>, kThreads,
+                                                              Tile<128, 128>::LDS_FLOATS * sizeof(float)));
+  } else {
+    HP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_igemm_f32<128, 64, false>, kThreads,
+                                                              Tile<128, 64>::LDS_FLOATS * sizeof(float)));
+  }
+  return nb;
+}

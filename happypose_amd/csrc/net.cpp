@@ -7,6 +7,7 @@
 // MP/models/wide_resnet.py:120-129 (+ BasicBlock :110-126 / BasicBlockV2 :59-65);
 // heads MP/models/pose_rigid.py:135-149,352-374, CP/models/pose.py:45-47,108-114.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -48,8 +49,9 @@ struct ConvLayer {
   int H, W, Ho, Wo, Kpad;
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
   DevBuf w, bias, lut, pre_scale, pre_shift;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
+
+struct EventPair { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0.0; int conv = -1; };
 
 enum OpKind { OP_CONV, OP_MAXPOOL, OP_HEAD };
 struct Op { OpKind kind; int conv = -1; int in_buf = -1, out_buf = -1; int H = 0, W = 0, C = 0, Ho = 0, Wo = 0; };
@@ -70,8 +72,7 @@ struct Net {
   int feat_H = 0, feat_W = 0;
   double flops_per_sample = 0.0;
   bool profiling = false;
-  double last_conv_ms = 0.0;
-  bool events_pending = false;
+  std::vector<EventPair> ev_pending, ev_pool;  // conv-launch event pairs (profiling only)
 };
 
 namespace {
@@ -210,7 +211,8 @@ int pack_conv(Net& n, ConvLayer& L) {
     if ((rc = L.pre_scale.upload(ps.data(), ps.size() * 4))) return rc;
     if ((rc = L.pre_shift.upload(pb.data(), pb.size() * 4))) return rc;
   }
-  std::vector<int4> lut(L.Kpad / 4);
+  // + 16 padding entries: the kernel prefetches the entries of K-tiles t+1 and t+2
+  std::vector<int4> lut(L.Kpad / 4 + 16, make_int4(0, -1, 0, 0));
   const int kreal = L.kh * L.kw * L.cin;
   for (int q = 0; q < L.Kpad / 4; ++q) {
     const int k = 4 * q;
@@ -244,10 +246,8 @@ extern "C" hp_net* hp_net_create(int arch, int n_inputs, int h, int w) {
 
 extern "C" void hp_net_destroy(hp_net* net) {
   if (!net) return;
-  for (auto& L : net->convs) {
-    if (L->ev0) (void)hipEventDestroy(L->ev0);
-    if (L->ev1) (void)hipEventDestroy(L->ev1);
-  }
+  for (auto& p : net->ev_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+  for (auto& p : net->ev_pool) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
   delete net;
 }
 
@@ -316,12 +316,19 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
       a.M = (int64_t)batch * L.Ho * L.Wo;
       a.H = L.H; a.W = L.W; a.Cin = L.cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.cout;
       a.stride = L.stride; a.pad = L.pad; a.Kpad = L.Kpad; a.ktiles = L.Kpad / 32; a.relu = L.relu;
-      if (net->profiling) {
-        if (!L.ev0) { HP_CHECK_HIP(hipEventCreate(&L.ev0)); HP_CHECK_HIP(hipEventCreate(&L.ev1)); }
-        HP_CHECK_HIP(hipEventRecord(L.ev0, stream));
+      EventPair ev{};
+      if (net->profiling) {  // events are only READ in hp_net_profile_collect: no sync here
+        if (!net->ev_pool.empty()) { ev = net->ev_pool.back(); net->ev_pool.pop_back(); }
+        else { HP_CHECK_HIP(hipEventCreate(&ev.e0)); HP_CHECK_HIP(hipEventCreate(&ev.e1)); }
+        ev.flops = 2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real;
+        ev.conv = op.conv;
+        HP_CHECK_HIP(hipEventRecord(ev.e0, stream));
       }
       if ((rc = launch_conv(a, L.cout == 64 ? 1 : 0, stream))) return rc;
-      if (net->profiling) HP_CHECK_HIP(hipEventRecord(L.ev1, stream));
+      if (net->profiling) {
+        HP_CHECK_HIP(hipEventRecord(ev.e1, stream));
+        net->ev_pending.push_back(ev);
+      }
     } else if (op.kind == OP_MAXPOOL) {
       if ((rc = launch_maxpool((const float*)net->bufs[op.in_buf].p, (float*)net->bufs[op.out_buf].p, batch,
                                op.H, op.W, op.C, op.Ho, op.Wo, stream)))
@@ -350,7 +357,6 @@ extern "C" int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d
   HP_REQUIRE(!d_pose || net->pose_dim > 0, "hp_net_forward: network has no pose head");
   HP_REQUIRE(!d_logits || net->n_logits > 0, "hp_net_forward: network has no logits head");
   hipStream_t st = (hipStream_t)stream;
-  net->last_conv_ms = 0.0;
   const size_t in_stride = (size_t)net->h * net->w * net->c_pad;
   for (int b0 = 0; b0 < batch; b0 += net->max_batch) {
     const int nb = batch - b0 < net->max_batch ? batch - b0 : net->max_batch;
@@ -359,15 +365,38 @@ extern "C" int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d
                            d_logits ? d_logits + (size_t)b0 * net->n_logits : nullptr,
                            d_features ? d_features + (size_t)b0 * 512 : nullptr, st);
     if (rc) return rc;
-    if (net->profiling) {  // events are reused per chunk: drain them now
-      for (auto& L : net->convs) {
-        HP_CHECK_HIP(hipEventSynchronize(L->ev1));
-        float ms = 0.f;
-        HP_CHECK_HIP(hipEventElapsedTime(&ms, L->ev0, L->ev1));
-        net->last_conv_ms += ms;
-      }
+  }
+  return HP_OK;
+}
+
+extern "C" int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, double* conv_flops) {
+  HP_REQUIRE(net, "hp_net_profile_collect: null net");
+  double ms_total = 0.0, fl = 0.0;
+  const bool verbose = std::getenv("HP_PROFILE_LAYERS") != nullptr;
+  std::vector<double> lms(net->convs.size(), 0.0), lfl(net->convs.size(), 0.0);
+  std::vector<int> lcnt(net->convs.size(), 0);
+  for (auto& p : net->ev_pending) {
+    HP_CHECK_HIP(hipEventSynchronize(p.e1));
+    float ms = 0.f;
+    HP_CHECK_HIP(hipEventElapsedTime(&ms, p.e0, p.e1));
+    ms_total += ms;
+    fl += p.flops;
+    if (p.conv >= 0) { lms[p.conv] += ms; lfl[p.conv] += p.flops; lcnt[p.conv]++; }
+    net->ev_pool.push_back(p);
+  }
+  if (verbose) {  // per-layer table (stderr): which convolution shapes lag the roofline
+    for (size_t i = 0; i < net->convs.size(); ++i) {
+      if (!lcnt[i]) continue;
+      const ConvLayer& L = *net->convs[i];
+      std::fprintf(stderr, "[hp conv] %-38s %dx%d s%d %4d->%4d @%3dx%3d  K=%5d  %8.1f us  %6.1f TFLOP/s\n",
+                   L.wname.c_str(), L.kh, L.kw, L.stride, L.cin_real, L.cout, L.Ho, L.Wo, L.Kpad,
+                   1e3 * lms[i] / lcnt[i], lfl[i] / (lms[i] * 1e-3) / 1e12);
     }
   }
+  if (conv_ms) *conv_ms = ms_total;
+  if (n_launches) *n_launches = (int64_t)net->ev_pending.size();
+  if (conv_flops) *conv_flops = fl;
+  net->ev_pending.clear();
   return HP_OK;
 }
 
@@ -379,7 +408,6 @@ extern "C" int hp_net_set_profiling(hp_net* net, int enabled) {
   return HP_OK;
 }
 
-extern "C" double hp_net_last_conv_ms(const hp_net* net) { return net ? net->last_conv_ms : 0.0; }
 
 // ---- single-layer entry for the kernel parity tests ------------------------------------
 extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, const float* d_w, int cout,
@@ -395,7 +423,7 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   if (rc) return rc;
   const int Kreal = kh * kw * cin, Kpad = (Kreal + 31) / 32 * 32;
   HP_REQUIRE(Kreal == Kpad, "hp_conv2d_nhwc: kh*kw*cin must be a multiple of 32 (weights are [cout][kh][kw][cin])");
-  std::vector<int4> lut(Kpad / 4);
+  std::vector<int4> lut(Kpad / 4 + 16, make_int4(0, -1, 0, 0));
   for (int q = 0; q < Kpad / 4; ++q) {
     const int k = 4 * q, seg = k / cin, ch = k % cin, y = seg / kw, x = seg % kw;
     lut[q] = make_int4((y * w + x) * cin + ch, y, x, ch);

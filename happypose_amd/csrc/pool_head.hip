@@ -1,0 +1,91 @@
+// Memory-bound companions of the conv stack: 3x3/2 max pooling (NHWC) and the network head
+// (spatial mean -> optional 512x512 fc -> pose / logits linear heads).
+// Reference: MP/models/torchvision_resnet.py:325-341 (maxpool, avgpool, fc),
+// MP/models/wide_resnet.py:120-129, MP/models/pose_rigid.py:352-374 (heads).
+#include "conv.h"
+
+namespace hp {
+
+// ---- 3x3 stride-2 pad-1 max pooling, NHWC, 4 channels per lane ------------------------
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* x, float* y, int n, int H, int W,
+                                                         int C, int Ho, int Wo) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C4 = C / 4;
+  const int64_t total = (int64_t)n * Ho * Wo * C4;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % C4);
+  int64_t p = idx / C4;
+  const int ow = (int)(p % Wo); p /= Wo;
+  const int oh = (int)(p % Ho);
+  const int img = (int)(p / Ho);
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int ih = oh * 2 - 1 + dy;
+    if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int iw = ow * 2 - 1 + dx;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      const float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)img * H + ih) * W + iw) * C + 4 * c4);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+  }
+  *reinterpret_cast<float4*>(y + (((int64_t)img * Ho + oh) * Wo + ow) * C + 4 * c4) = m;
+}
+
+// ---- head: spatial mean -> [fc 512x512 + bias] -> pose / logits linear heads -----------
+// one workgroup per sample; features [HW][C] NHWC.
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+  __shared__ float feat[512];
+  __shared__ float feat2[512];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* x = a.x + (int64_t)b * a.HW * a.C;
+  for (int c = tid; c < a.C; c += 256) {
+    float s = 0.f;
+    for (int p = 0; p < a.HW; ++p) s += x[(int64_t)p * a.C + c];
+    feat[c] = s / (float)a.HW;
+  }
+  __syncthreads();
+  const float* f = feat;
+  if (a.fc_w) {  // torchvision ResNet: avgpool -> fc (MP/models/torchvision_resnet.py:337-341)
+    for (int o = tid; o < a.C; o += 256) {
+      const float* w = a.fc_w + (int64_t)o * a.C;
+      float s = 0.f;
+      for (int c = 0; c < a.C; ++c) s = fmaf(w[c], feat[c], s);
+      feat2[o] = s + a.fc_b[o];
+    }
+    __syncthreads();
+    f = feat2;
+  }
+  if (a.features) for (int c = tid; c < a.C; c += 256) a.features[(int64_t)b * a.C + c] = f[c];
+  // linear heads: one wave per output row, lanes stride the 512 features
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int o = wave; o < a.pose_dim + a.n_logits; o += 4) {
+    const bool is_pose = o < a.pose_dim;
+    const int oo = is_pose ? o : o - a.pose_dim;
+    const float* w = (is_pose ? a.pose_w : a.logit_w) + (int64_t)oo * a.C;
+    float s = 0.f;
+    for (int c = lane; c < a.C; c += 64) s = fmaf(w[c], f[c], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+      if (is_pose) { if (a.pose_out) a.pose_out[(int64_t)b * a.pose_dim + oo] = s + a.pose_b[oo]; }
+      else { if (a.logit_out) a.logit_out[(int64_t)b * a.n_logits + oo] = s + a.logit_b[oo]; }
+    }
+  }
+}
+
+int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream) {
+  const int64_t total = (int64_t)n * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, n, H, W, C, Ho, Wo);
+  return check_launch("maxpool3x3s2_nhwc");
+}
+
+int launch_head(const HeadArgs& a, int batch, hipStream_t stream) {
+  hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(256), 0, stream, a);
+  return check_launch("head_kernel");
+}
+
+
+}  // namespace hp

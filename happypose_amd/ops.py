@@ -301,8 +301,13 @@ class Net:
     def set_profiling(self, on: bool):
         check(lib().hp_net_set_profiling(self.handle, int(on)), "hp_net_set_profiling")
 
-    def last_conv_ms(self) -> float:
-        return lib().hp_net_last_conv_ms(self.handle)
+    def profile_collect(self):
+        """``(conv_ms, n_launches, conv_flops)`` of the conv launches recorded since the last
+        call (HIP events on the launch stream; waits for them)."""
+        ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+        check(lib().hp_net_profile_collect(self.handle, C.byref(ms), C.byref(n), C.byref(fl)),
+              "hp_net_profile_collect")
+        return ms.value, n.value, fl.value
 
 
 def conv2d_nhwc(x, w_packed, stride, pad, bias=None, residual=None, pre_scale=None, pre_shift=None, relu=False):

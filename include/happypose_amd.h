@@ -196,10 +196,14 @@ int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d_pose, floa
                    float* d_features, void* stream);
 /* total multiply-accumulate FLOPs (2*MAC) of one sample through conv + linear layers */
 double hp_net_flops_per_sample(const hp_net* net);
-/* time (ms, HIP events on `stream`) spent in conv kernels during the last forward when
- * profiling was enabled with hp_net_set_profiling(net, 1); 0 otherwise */
+/* Profiling of the dominant kernel: with hp_net_set_profiling(net, 1) every conv launch is
+ * bracketed by a pair of HIP events recorded on the launch stream (no synchronisation).
+ * hp_net_profile_collect waits for the recorded pairs and returns the summed kernel time
+ * (ms), the number of launches and their algorithmic FLOPs since the previous collect. */
 int hp_net_set_profiling(hp_net* net, int enabled);
-double hp_net_last_conv_ms(const hp_net* net);
+/* diagnostics: workgroups per CU the runtime grants conv tile variant 0 (128x128) / 1 (128x64) */
+int hp_conv_occupancy(int variant);
+int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, double* conv_flops);
 
 /* Single layer entry (used by the parity tests of the conv kernel itself):
  * y[n][ho][wo][cout] = act( conv(x_act, w) + bias + residual ),
