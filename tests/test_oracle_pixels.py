@@ -1,0 +1,200 @@
+"""CPU tests of the pixel-producing parts of the oracle (rasteriser, roi_align, multi-view
+cameras): the reference's own structural renderer asserts on its own test asset, analytic
+known answers, and cross-checks between independent formulations.  These are the parts whose
+third-party definitions (Panda3D, torchvision, NodePath.lookAt) cannot be executed here, so
+they are pinned by construction rather than by golden vectors (see oracle/__init__.py)."""
+
+import numpy as np
+import pytest
+
+from happypose_amd.mesh_io import MeshData
+from happypose_amd.mesh_store import PackedMeshes, RigidObject, RigidObjectDataset
+from oracle import geometry as G
+from oracle import native
+
+
+def test_renderer_structural_asserts_of_the_reference(golden_dir):
+    """tests/test_batch_renderer_panda3d.py:43-69,105-122,166-179 (scene, shapes, dtypes, identical
+    cameras, corner/centre pixels) and test_scene_renderer_panda3d.py:206-214 (mask needs depth)."""
+    ds = RigidObjectDataset([RigidObject("my_favorite_object_label", golden_dir / "obj_000001.npz", mesh_units="mm")])
+    pm = PackedMeshes(ds)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = G.unitquat_to_rotmat(np.array([0.5, 0.5, -0.5, 0.5]))
+    T[:3, 3] = (0, 0, 0.3)
+    K = np.array([[300, 0, 320], [0, 300, 240], [0, 0, 1]], np.float32)
+    Nc = 4
+    r = native.rasterize(pm, np.zeros(Nc, np.int32), np.tile(T, (Nc, 1, 1)), np.tile(K, (Nc, 1, 1)), (480, 640), True, True, True)
+    assert r["rgbs"].shape == (Nc, 3, 480, 640) and r["depths"].shape == (Nc, 1, 480, 640)
+    assert r["normals"].shape == (Nc, 3, 480, 640) and r["binary_masks"].shape == (Nc, 1, 480, 640)
+    assert r["rgbs"].dtype == np.float32 and r["depths"].dtype == np.float32 and r["binary_masks"].dtype == bool
+    for k in ("rgbs", "normals", "depths", "binary_masks"):
+        assert np.array_equal(r[k][0], r[k][1])
+    assert r["rgbs"][0, :, 0, 0].tolist() == [0, 0, 0] and r["depths"][0, 0, 0, 0] == 0
+    assert r["normals"][0, :, 0, 0].tolist() == [0, 0, 0] and not r["binary_masks"][0, 0, 0, 0]
+    assert (r["rgbs"][0, :, 240, 320] > 0).all() and (r["normals"][0, :, 240, 320] > 0).all()
+    assert 0 < r["depths"][0, 0, 240, 320] < 0.3 and r["binary_masks"][0, 0, 240, 320]
+    assert np.array_equal(r["binary_masks"], r["depths"] > 0)
+    with pytest.raises(AssertionError):
+        native.rasterize(pm, [0], T[None], K[None], (480, 640), render_binary_mask=True)
+    # every combination of optional outputs returns None where not requested (:184-242)
+    r2 = native.rasterize(pm, [0], T[None], K[None], (480, 640))
+    assert r2["normals"] is None and r2["depths"] is None and r2["binary_masks"] is None
+
+
+def _quad_store(z_tex=False):
+    """A unit square in the z=0 plane facing -z (towards a camera looking down +z)."""
+    v = np.array([[-0.5, -0.5, 0], [0.5, -0.5, 0], [0.5, 0.5, 0], [-0.5, 0.5, 0]], np.float64)
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    n = np.tile([0, 0, -1.0], (4, 1)).astype(np.float32)
+    uv = np.array([[0, 1], [1, 1], [1, 0], [0, 0]], np.float32)  # v up: top row of the texture at y=-0.5
+    tex = np.zeros((2, 2, 4), np.uint8)
+    tex[0, 0] = (255, 0, 0, 255); tex[0, 1] = (0, 255, 0, 255); tex[1, 0] = (0, 0, 255, 255); tex[1, 1] = (255, 255, 255, 255)
+    return PackedMeshes(RigidObjectDataset([RigidObject("quad", MeshData(v, f, n, uv, texture=tex))]))
+
+
+def test_rasteriser_analytic_known_answers():
+    pm = _quad_store()
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = 2.0  # quad at Z = 2 m, spans u in [160-50, 160+50], v in [120-50, 120+50] for f=200
+    K = np.array([[200, 0, 160], [0, 200, 120], [0, 0, 1]], np.float32)
+    r = native.rasterize(pm, [0], T[None], K[None], (240, 320), True, True, True, quant8=False)
+    m = r["binary_masks"][0, 0]
+    # pixel (i,j) is covered iff its centre (j+.5, i+.5) lies in [110,210]x[70,170]
+    jj, ii = np.meshgrid(np.arange(320) + 0.5, np.arange(240) + 0.5)
+    expect = (jj >= 110) & (jj <= 210) & (ii >= 70) & (ii <= 170)
+    assert np.array_equal(m, expect) and m.sum() == 100 * 100
+    np.testing.assert_allclose(r["depths"][0, 0][m], 2.0, atol=1e-6)  # planar, fronto-parallel
+    # normal (0,0,-1) in the camera frame -> GL eye normal (0,0,+1): code(0)=code(1) wraps
+    nr = r["normals"][0][:, m]
+    assert np.allclose(nr[0], nr[0][0]) and np.allclose(nr[2], nr[2][0])
+    # texture: top-left quadrant of the quad shows texel (0,0)=red near the corner
+    assert r["rgbs"][0, :, 72, 112].argmax() == 0 and r["rgbs"][0, :, 72, 208].argmax() == 1
+    assert r["rgbs"][0, :, 168, 112].argmax() == 2
+    # two-sided: the back face renders too
+    Tb = T.copy(); Tb[:3, :3] = np.diag([1, -1, -1.0])
+    rb = native.rasterize(pm, [0], Tb[None], K[None], (240, 320), render_depth=True)
+    assert (rb["depths"] > 0).sum() == 100 * 100
+    # clip range [0.1, 10] m (TB/renderer/types.py:96-97) and the depth cut at ~9.1 m
+    for z, vis, dep in ((0.05, False, False), (0.2, True, True), (9.5, True, False), (10.5, False, False)):
+        Tz = T.copy(); Tz[2, 3] = z
+        rz = native.rasterize(pm, [0], Tz[None], K[None], (240, 320), render_depth=True)
+        assert (rz["rgbs"].sum() > 0) == vis and (rz["depths"].sum() > 0) == dep, z
+    # non-finite pose -> zero image, no exception (TB/renderer/panda3d_batch_renderer.py:81-111)
+    Tn = T.copy(); Tn[0, 0] = np.inf
+    rn = native.rasterize(pm, [0], Tn[None], K[None], (240, 320), True, True, True)
+    assert rn["rgbs"].sum() == 0 and rn["depths"].sum() == 0 and not rn["binary_masks"].any()
+    # near-plane crossing triangle: no garbage, depth within the clip range
+    c80, s80 = np.cos(np.deg2rad(80)), np.sin(np.deg2rad(80))  # quad spans Z in [-0.19, 0.79] m
+    Tc = np.eye(4, dtype=np.float32); Tc[:3, :3] = np.array([[1, 0, 0], [0, c80, -s80], [0, s80, c80]]); Tc[2, 3] = 0.3
+    Tc[1, 3] = 0.05
+    rc = native.rasterize(pm, [0], Tc[None], K[None], (240, 320), render_depth=True)
+    d = rc["depths"][rc["depths"] > 0]
+    assert d.size > 0 and d.min() >= 0.1 - 1e-6 and d.max() <= 0.8 + 1e-4
+
+
+def test_normal_code_is_the_3d_texture_lookup():
+    """TB/renderer/utils.py:63-79: texel i holds floor(i*255/32); linear filter, repeat wrap."""
+    pm = _quad_store()
+    K = np.array([[200, 0, 160], [0, 200, 120], [0, 0, 1]], np.float32)
+    for ang in (0.0, 0.3, -0.7):
+        c, s = np.cos(ang), np.sin(ang)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+        T[2, 3] = 2.0
+        r = native.rasterize(pm, [0], T[None], K[None], (240, 320), render_normals=True, quant8=False)
+        n_cam = T[:3, :3] @ np.array([0, 0, -1.0])
+        n_gl = np.array([n_cam[0], -n_cam[1], -n_cam[2]])
+        tex = np.floor(np.arange(32) * 255 / 32)
+        exp = []
+        for a in n_gl:
+            x = (a - np.floor(a)) * 32 - 0.5
+            i0 = int(np.floor(x)) % 32
+            f = x - np.floor(x)
+            exp.append((tex[i0] + f * (tex[(i0 + 1) % 32] - tex[i0])) / 255)
+        np.testing.assert_allclose(r["normals"][0, :, 120, 160], exp, atol=2e-6)
+
+
+def _roi_align_definition(img, box, oh, ow, sr=4):
+    """torchvision 0.14.1 roi_align, aligned=False, one ROI -- literal python loops."""
+    C, H, W = img.shape
+    x1, y1, x2, y2 = [np.float32(v) for v in box]
+    rw, rh = max(x2 - x1, np.float32(1)), max(y2 - y1, np.float32(1))
+    bh, bw = rh / np.float32(oh), rw / np.float32(ow)
+    out = np.zeros((C, oh, ow), np.float32)
+    for ph in range(oh):
+        for pw in range(ow):
+            acc = np.zeros(C, np.float32)
+            for iy in range(sr):
+                y = y1 + np.float32(ph) * bh + (np.float32(iy) + np.float32(0.5)) * bh / np.float32(sr)
+                for ix in range(sr):
+                    x = x1 + np.float32(pw) * bw + (np.float32(ix) + np.float32(0.5)) * bw / np.float32(sr)
+                    if y < -1 or y > H or x < -1 or x > W:
+                        continue
+                    yy, xx = max(y, np.float32(0)), max(x, np.float32(0))
+                    yl, xl = int(yy), int(xx)
+                    if yl >= H - 1:
+                        yh = yl = H - 1; yy = np.float32(yl)
+                    else:
+                        yh = yl + 1
+                    if xl >= W - 1:
+                        xh = xl = W - 1; xx = np.float32(xl)
+                    else:
+                        xh = xl + 1
+                    ly, lx = yy - yl, xx - xl
+                    hy, hx = 1 - ly, 1 - lx
+                    acc += hy * hx * img[:, yl, xl] + hy * lx * img[:, yl, xh] + ly * hx * img[:, yh, xl] + ly * lx * img[:, yh, xh]
+            out[:, ph, pw] = acc / np.float32(sr * sr)
+    return out
+
+
+def test_roi_align_against_literal_definition():
+    rs = np.random.RandomState(0)
+    img = rs.rand(1, 3, 24, 32).astype(np.float32)
+    for box in ([3.2, 2.1, 20.7, 15.9], [-4, -3, 10, 9.5], [25, 18, 40, 30], [5, 5, 5.2, 5.1], [0, 0, 32, 24]):
+        got = native.roi_align(img, np.array([box], np.float32), np.zeros(1, np.int32), (6, 8))[0]
+        np.testing.assert_allclose(got, _roi_align_definition(img[0], box, 6, 8), rtol=1e-5, atol=1e-6)
+    # identity: a box covering pixel centres exactly reproduces 2x2-averaged content of a constant image
+    const = np.full((1, 3, 24, 32), 0.25, np.float32)
+    assert np.allclose(native.roi_align(const, np.array([[2, 2, 30, 22]], np.float32), np.zeros(1, np.int32), (5, 7)), 0.25)
+    # RGB-D rule (TB/lib3d/cropping.py:184-195): depth zeroed where validity < 0.99
+    rgbd = np.concatenate([img, np.ones((1, 1, 24, 32), np.float32)], 1)
+    rgbd[0, 3, 10:14, 12:20] = 0
+    c = native.crop_images(rgbd, np.array([[0, 0, 32, 24]], np.float32), np.zeros(1, np.int32), (24, 32))
+    assert (c[0, 3, 10:14, 12:20] == 0).all() and (c[0, 3, :6] == 1).all()
+    assert (c[0, 3, 9, 12:20] == 0).all()  # interpolated border pixels are invalidated too
+
+
+def test_multiview_cameras_properties():
+    """make_TCO_multiview (TB/lib3d/multiview.py:28-92,166-251) restated in closed form: every
+    extra view looks exactly at the reference point, keeps camera-0's up direction as well as
+    possible, and view 0 is the input pose."""
+    rs = np.random.RandomState(0)
+    from happypose_amd.synthetic import random_rotations
+
+    b = 7
+    T = np.tile(np.eye(4, dtype=np.float32), (b, 1, 1))
+    T[:, :3, :3] = random_rotations(rs, b)
+    T[:, :3, 3] = np.stack([rs.uniform(-0.2, 0.2, b), rs.uniform(-0.2, 0.2, b), rs.uniform(0.4, 1.0, b)], -1)
+    tCR = T[:, :3, 3]
+    TCV = G.make_TCO_multiview(T, tCR, "TCO+front_3views", 4)
+    assert TCV.shape == (b, 4, 4, 4) and TCV.dtype == np.float32
+    np.testing.assert_array_equal(TCV[:, 0], T)
+    rho = np.linalg.norm(tCR, axis=1)
+    for v in range(1, 4):
+        Tv = TCV[:, v]
+        R = Tv[:, :3, :3] @ np.swapaxes(T[:, :3, :3], 1, 2)  # = R_CV_C0
+        np.testing.assert_allclose(R @ np.swapaxes(R, 1, 2), np.tile(np.eye(3), (b, 1, 1)), atol=1e-5)
+        np.testing.assert_allclose(np.linalg.det(R), 1, atol=1e-5)
+        # the object origin (reference point) sits on the optical axis
+        np.testing.assert_allclose(Tv[:, :2, 3], 0, atol=1e-5)
+        np.testing.assert_allclose(Tv[:, 2, 3], rho * (1 if v == 1 else np.sqrt(2)), rtol=1e-5)
+    # views 2 and 3 are mirror images about the plane spanned by the up direction and the view axis
+    c2 = -np.einsum("bij,bi->bj", (TCV[:, 2] @ np.linalg.inv(T))[:, :3, :3], (TCV[:, 2] @ np.linalg.inv(T))[:, :3, 3])
+    c3 = -np.einsum("bij,bi->bj", (TCV[:, 3] @ np.linalg.inv(T))[:, :3, :3], (TCV[:, 3] @ np.linalg.inv(T))[:, :3, 3])
+    np.testing.assert_allclose(c2 + c3, 0, atol=1e-5)  # +/- radius * right, in camera-0 coordinates
+    np.testing.assert_allclose(np.linalg.norm(c2, axis=1), rho, rtol=1e-5)
+    # single view and the non-finite fallback
+    np.testing.assert_array_equal(G.make_TCO_multiview(T, tCR, "TCO", 1)[:, 0], T)
+    Tn = T.copy(); Tn[0, 0, 0] = np.nan
+    out = G.make_TCO_multiview(Tn, tCR, "TCO+front_3views", 4)
+    assert np.isfinite(out[1:]).all()
