@@ -1,6 +1,7 @@
 // C-ABI glue: error reporting, device queries and the device-resident mesh store.
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -76,9 +77,22 @@ extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float
   hp_mesh_store* s = new hp_mesh_store();
   s->n_obj = n_obj;
   s->n_pad = h_points ? n_pad : 0;
+  for (int o = 0; o < n_obj; ++o) {
+    if (h_obj[8 * o + 1] > s->max_verts) s->max_verts = h_obj[8 * o + 1];
+    if (h_obj[8 * o + 3] > s->max_faces) s->max_faces = h_obj[8 * o + 3];
+  }
   int rc = 0;
   rc |= upload(&s->verts, h_verts, (size_t)n_verts_total * 3);
   rc |= upload(&s->normals, h_normals, (size_t)n_verts_total * 3);
+  {
+    std::vector<float4> v4((size_t)n_verts_total), n4((size_t)n_verts_total);
+    for (int64_t i = 0; i < n_verts_total; ++i) {
+      v4[i] = make_float4(h_verts[3 * i], h_verts[3 * i + 1], h_verts[3 * i + 2], 0.f);
+      n4[i] = make_float4(h_normals[3 * i], h_normals[3 * i + 1], h_normals[3 * i + 2], 0.f);
+    }
+    rc |= upload(&s->verts4, v4.data(), v4.size());
+    rc |= upload(&s->normals4, n4.data(), n4.size());
+  }
   rc |= upload(&s->uvs, h_uvs, (size_t)n_verts_total * 2);
   rc |= upload(&s->colors, h_colors, (size_t)n_verts_total * 4);
   rc |= upload(&s->faces, h_faces, (size_t)n_faces_total * 3);
@@ -96,6 +110,8 @@ extern "C" void hp_mesh_store_destroy(hp_mesh_store* s) {
   if (!s) return;
   (void)hipFree(s->verts); (void)hipFree(s->normals); (void)hipFree(s->uvs); (void)hipFree(s->colors);
   (void)hipFree(s->faces); (void)hipFree(s->tex); (void)hipFree(s->obj); (void)hipFree(s->points);
+  (void)hipFree(s->bin_list); (void)hipFree(s->bin_count);
+  (void)hipFree(s->verts4); (void)hipFree(s->normals4);
   delete s;
 }
 

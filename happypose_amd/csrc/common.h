@@ -41,14 +41,19 @@ inline int check_launch(const char* what) {
 struct MeshStore {
   float* verts = nullptr;
   float* normals = nullptr;
+  float4* verts4 = nullptr;    // the same, padded to 16 B (one gather per vertex in the rasteriser)
+  float4* normals4 = nullptr;
   float* uvs = nullptr;
   uint8_t* colors = nullptr;
   int32_t* faces = nullptr;
   uint8_t* tex = nullptr;
   int64_t* obj = nullptr;  // [n_obj][8]
   float* points = nullptr; // [n_obj][n_pad][3]
-  float4* scratch_sv = nullptr;  // per-view transformed vertices (grown on demand)
-  size_t scratch_sv_elems = 0;
+  // rasteriser scratch: per-(view, band) triangle lists (grown on demand, see raster.hip)
+  int32_t* bin_list = nullptr;
+  size_t bin_list_bytes = 0;
+  int32_t* bin_count = nullptr;
+  size_t bin_count_bytes = 0;
   int n_obj = 0;
   int n_pad = 0;
   int64_t max_verts = 0;  // max vertices of a single object

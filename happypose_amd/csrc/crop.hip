@@ -6,9 +6,16 @@
 //
 // Gather kernel, HBM/L2 bound: every hypothesis reads the SAME 640x480 frame (3.7-4.9 MB,
 // L2/MALL resident), so the traffic that reaches HBM is the output.  One lane = one output
-// pixel for all channels: the 16 bilinear sample positions/weights are computed once and
-// reused per channel; consecutive lanes take consecutive output columns, so source reads
+// pixel for all channels; consecutive lanes take consecutive output columns, so source reads
 // of a wave fall into a few adjacent cache lines and NCHW stores are coalesced.
+//
+// The 4x4 bilinear samples of an output pixel are SEPARABLE: sample (iy, ix) contributes
+// (wy_lo[iy] I[y_lo] + wy_hi[iy] I[y_hi]) x (wx_lo[ix] I[x_lo] + wx_hi[ix] I[x_hi]), so the
+// pixel is sum_r sum_c Wy[r] Wx[c] I[r][c] over the DISTINCT rows/columns the samples touch.
+// Crops up-sample or mildly down-sample the frame (bin <= ~2.5 px), so that is 2-5 rows x 2-5
+// columns = 4-25 loads per channel instead of 64.  Pixels whose samples span more than 5
+// rows or columns (bin > 2.67 px: crop boxes wider than ~850 px) take the literal 16-sample
+// path.  The factorisation only re-associates the fp32 sum (<= 1e-6 relative).
 #include "common.h"
 
 namespace hp {
@@ -23,6 +30,85 @@ struct CropArgs {
 };
 
 constexpr int kMaxSR = 4;
+constexpr int kSpan = 5;  // distinct rows / columns handled by the separable path
+
+struct Axis {
+  int lo[kMaxSR], hi[kMaxSR];
+  float w0[kMaxSR], w1[kMaxSR];
+  bool valid[kMaxSR];
+};
+
+// torchvision's sample placement + boundary rules along one axis (size = H or W)
+__device__ __forceinline__ void make_axis(float start, int p, float bin, int g, int size, Axis& ax) {
+#pragma unroll
+  for (int s = 0; s < kMaxSR; ++s) {
+    if (s < g) {
+      float y = start + (float)p * bin + ((float)s + 0.5f) * bin / (float)g;
+      ax.valid[s] = !(y < -1.0f || y > (float)size);
+      if (y <= 0.0f) y = 0.0f;
+      int y_low = (int)y, y_high;
+      if (y_low >= size - 1) { y_high = y_low = size - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+      const float l = y - (float)y_low;
+      ax.lo[s] = y_low; ax.hi[s] = y_high; ax.w1[s] = l; ax.w0[s] = 1.0f - l;
+    } else {
+      ax.valid[s] = false; ax.lo[s] = ax.hi[s] = 0; ax.w0[s] = ax.w1[s] = 0.0f;
+    }
+  }
+}
+
+// first index touched by the valid samples, number of indices, and the per-index summed weights
+__device__ __forceinline__ void fold_axis(const Axis& ax, int g, int& first, int& span, float (&wsum)[kSpan]) {
+  first = 1 << 30;
+  int last = -1;
+#pragma unroll
+  for (int s = 0; s < kMaxSR; ++s)
+    if (s < g && ax.valid[s]) { first = min(first, ax.lo[s]); last = max(last, ax.hi[s]); }
+  span = last >= first ? last - first + 1 : 0;
+  if (span == 0) first = 0;
+#pragma unroll
+  for (int k = 0; k < kSpan; ++k) {
+    float w = 0.0f;
+#pragma unroll
+    for (int s = 0; s < kMaxSR; ++s) {
+      if (s < g && ax.valid[s]) {
+        w += (ax.lo[s] - first == k) ? ax.w0[s] : 0.0f;
+        w += (ax.hi[s] - first == k) ? ax.w1[s] : 0.0f;
+      }
+    }
+    wsum[k] = w;
+  }
+}
+
+// Literal 16-sample evaluation (torchvision's loop) for strongly down-sampling crops; rolled
+// loops and no inlining so that it does not cost the common path registers.
+__device__ __noinline__ void slow_pixel(const float* plane, int H, int W, float y1, float x1, int ph, int pw,
+                                        float bin_h, float bin_w, int g, bool want_valid, float& acc, float& vacc) {
+#pragma unroll 1
+  for (int iy = 0; iy < g; ++iy) {
+    float y = y1 + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)g;
+    if (y < -1.0f || y > (float)H) continue;
+    if (y <= 0.0f) y = 0.0f;
+    int yl = (int)y, yh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
+    const float ly = y - (float)yl, hy = 1.0f - ly;
+#pragma unroll 1
+    for (int ix = 0; ix < g; ++ix) {
+      float x = x1 + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)g;
+      if (x < -1.0f || x > (float)W) continue;
+      if (x <= 0.0f) x = 0.0f;
+      int xl = (int)x, xh;
+      if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
+      const float lx = x - (float)xl, hx = 1.0f - lx;
+      const float v00 = plane[yl * W + xl], v01 = plane[yl * W + xh];
+      const float v10 = plane[yh * W + xl], v11 = plane[yh * W + xh];
+      const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+      acc += w1 * v00 + w2 * v01 + w3 * v10 + w4 * v11;
+      if (want_valid)  // validity mask (depth > 0) through the same interpolation
+        vacc += w1 * (v00 > 0.0f ? 1.0f : 0.0f) + w2 * (v01 > 0.0f ? 1.0f : 0.0f) +
+                w3 * (v10 > 0.0f ? 1.0f : 0.0f) + w4 * (v11 > 0.0f ? 1.0f : 0.0f);
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
   const int r = blockIdx.y;
@@ -39,56 +125,49 @@ __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
   const float count = (float)(g * g);
   const int H = a.H, W = a.W;
 
-  // sample positions: separable in y and x
-  int yl[kMaxSR], yh[kMaxSR], xl[kMaxSR], xh[kMaxSR];
-  float wy0[kMaxSR], wy1[kMaxSR], wx0[kMaxSR], wx1[kMaxSR];
-  bool vy[kMaxSR], vx[kMaxSR];
-#pragma unroll
-  for (int s = 0; s < kMaxSR; ++s) {
-    if (s < g) {
-      float y = y1 + (float)ph * bin_h + ((float)s + 0.5f) * bin_h / (float)g;
-      float x = x1 + (float)pw * bin_w + ((float)s + 0.5f) * bin_w / (float)g;
-      vy[s] = !(y < -1.0f || y > (float)H);
-      vx[s] = !(x < -1.0f || x > (float)W);
-      if (y <= 0.0f) y = 0.0f;
-      if (x <= 0.0f) x = 0.0f;
-      int y_low = (int)y, x_low = (int)x, y_high, x_high;
-      if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
-      if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
-      float ly = y - (float)y_low, lx = x - (float)x_low;
-      yl[s] = y_low; yh[s] = y_high; xl[s] = x_low; xh[s] = x_high;
-      wy1[s] = ly; wy0[s] = 1.0f - ly; wx1[s] = lx; wx0[s] = 1.0f - lx;
-    } else {
-      vy[s] = vx[s] = false; yl[s] = yh[s] = xl[s] = xh[s] = 0;
-      wy0[s] = wy1[s] = wx0[s] = wx1[s] = 0.0f;
-    }
+  // The folded weights are all the separable path keeps live (14 registers); the per-sample
+  // tables die here, which keeps the kernel at high occupancy -- it is latency bound.
+  int r0, c0, nr, nc;
+  float wy[kSpan], wx[kSpan];
+  {
+    Axis t;
+    make_axis(y1, ph, bin_h, g, H, t);
+    fold_axis(t, g, r0, nr, wy);
+    make_axis(x1, pw, bin_w, g, W, t);
+    fold_axis(t, g, c0, nc, wx);
   }
+  const bool separable = nr <= kSpan && nc <= kSpan;
+
   const float* img = a.images + (int64_t)a.im_ids[r] * a.C * H * W;
   const int64_t obase = (int64_t)r * a.os.s_item + (int64_t)ph * a.os.s_row + (int64_t)pw * a.os.s_col;
-  float valid_acc = 0.0f;
+#pragma unroll 1
   for (int c = 0; c < a.NC; ++c) {
     const float* plane = img + (int64_t)c * H * W;
     float acc = 0.0f, vacc = 0.0f;
+    if (separable) {
 #pragma unroll
-    for (int iy = 0; iy < kMaxSR; ++iy) {
+      for (int i = 0; i < kSpan; ++i) {
+        if (i < nr) {
+          const float* row = plane + (int64_t)(r0 + i) * W + c0;
+          float racc = 0.0f, rv = 0.0f;
 #pragma unroll
-      for (int ix = 0; ix < kMaxSR; ++ix) {
-        if (iy < g && ix < g && vy[iy] && vx[ix]) {
-          const float v00 = plane[yl[iy] * W + xl[ix]], v01 = plane[yl[iy] * W + xh[ix]];
-          const float v10 = plane[yh[iy] * W + xl[ix]], v11 = plane[yh[iy] * W + xh[ix]];
-          const float w1 = wy0[iy] * wx0[ix], w2 = wy0[iy] * wx1[ix];
-          const float w3 = wy1[iy] * wx0[ix], w4 = wy1[iy] * wx1[ix];
-          acc += w1 * v00 + w2 * v01 + w3 * v10 + w4 * v11;
-          if (c == 3)  // validity mask (depth > 0) through the same interpolation
-            vacc += w1 * (v00 > 0.0f ? 1.0f : 0.0f) + w2 * (v01 > 0.0f ? 1.0f : 0.0f) +
-                    w3 * (v10 > 0.0f ? 1.0f : 0.0f) + w4 * (v11 > 0.0f ? 1.0f : 0.0f);
+          for (int j = 0; j < kSpan; ++j) {
+            if (j < nc) {
+              const float v = row[j];
+              racc += wx[j] * v;
+              if (c == 3) rv += wx[j] * (v > 0.0f ? 1.0f : 0.0f);
+            }
+          }
+          acc += wy[i] * racc;
+          vacc += wy[i] * rv;
         }
       }
+    } else {
+      slow_pixel(plane, H, W, y1, x1, ph, pw, bin_h, bin_w, g, c == 3, acc, vacc);
     }
     float val = acc / count;
     if (c == 3) {
-      valid_acc = vacc / count;
-      if (valid_acc < 0.99f) val = 0.0f;  // TB/lib3d/cropping.py:184-195
+      if (vacc / count < 0.99f) val = 0.0f;  // TB/lib3d/cropping.py:184-195
       if (a.depth_norm_mode != 0) {
         const float zn = a.depth_norm_z[r];
         if (a.depth_norm_mode == 1) val = val / zn;

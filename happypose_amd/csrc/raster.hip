@@ -34,11 +34,13 @@ constexpr unsigned long long kKeyEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kBandPixels = 9600;  // 76.8 KB of LDS z-buffer
 constexpr int kBigQueue = 1024;
 constexpr int kBigArea = 128;  // bbox pixels above which a triangle is walked cooperatively
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;    // band kernel: 16 waves per workgroup, 2 workgroups per CU = full occupancy
+constexpr int kBinThreads = 1024;  // binning kernel
+constexpr int kMaxBands = 128;
 
 struct RasterArgs {
-  const float* verts;
-  const float* normals;
+  const float4* verts4;   // xyz + pad
+  const float4* normals4;
   const float* uvs;
   const uint8_t* colors;
   const int32_t* faces;
@@ -59,6 +61,10 @@ struct RasterArgs {
   int n, views_per_item, n_lights, h, w, flags, depth_norm_mode;
   int band_rows, n_bands;
   float depth_max;
+  // per-(view, band) triangle lists built by raster_bin_kernel
+  int32_t* bin_count;   // [chunk views][n_bands]
+  int32_t* bin_list;    // [chunk views][n_bands][bin_cap]
+  int bin_cap, view0, max_faces;
 };
 
 __device__ __forceinline__ void edge_fn(const float* P0, int i0, const float* P1, int i1, float* e) {
@@ -71,10 +77,11 @@ __device__ __forceinline__ void edge_fn(const float* P0, int i0, const float* P1
   e[2] = sgn * fmaf(P[0], Q[1], -(P[1] * Q[0]));
 }
 
-__device__ __forceinline__ void xform_vertex(const float* T, const float* Kv, const float* p, float* o) {
-  float cx = fmaf(T[0], p[0], fmaf(T[1], p[1], fmaf(T[2], p[2], T[3])));
-  float cy = fmaf(T[4], p[0], fmaf(T[5], p[1], fmaf(T[6], p[2], T[7])));
-  float cz = fmaf(T[8], p[0], fmaf(T[9], p[1], fmaf(T[10], p[2], T[11])));
+// vertices are stored as float4 (xyz + pad): one 16-B gather per vertex
+__device__ __forceinline__ void xform_vertex(const float* T, const float* Kv, const float4 p, float* o) {
+  float cx = fmaf(T[0], p.x, fmaf(T[1], p.y, fmaf(T[2], p.z, T[3])));
+  float cy = fmaf(T[4], p.x, fmaf(T[5], p.y, fmaf(T[6], p.z, T[7])));
+  float cz = fmaf(T[8], p.x, fmaf(T[9], p.y, fmaf(T[10], p.z, T[11])));
   o[0] = fmaf(Kv[0], cx, fmaf(Kv[1], cy, Kv[2] * cz));
   o[1] = fmaf(Kv[4], cy, Kv[5] * cz);
   o[2] = cz;
@@ -127,17 +134,17 @@ struct TriSetup {
   int x0, x1, y0, y1;  // inclusive pixel bbox clipped to the band; empty if x0 > x1
 };
 
-// Returns false when the triangle cannot touch rows [row0, row1] of this view.
-__device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const float* T, const float* Kv,
-                                               const float* vbase, const int32_t* tri, int row0,
-                                               int row1, TriSetup& s) {
-  float V0[3], V1[3], V2[3];
-  xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[0], V0);
-  xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[1], V1);
-  xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[2], V2);
+// Screen-space vertices + inclusive pixel bbox (clipped to the image).  Returns false when the
+// triangle is outside the clip range or the image.
+__device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const float* T, const float* Kv, const float4* vbase,
+                                         const int32_t* tri, float (&V0)[3], float (&V1)[3], float (&V2)[3],
+                                         int& x0, int& x1, int& y0, int& y1) {
+  xform_vertex(T, Kv, vbase[tri[0]], V0);
+  xform_vertex(T, Kv, vbase[tri[1]], V1);
+  xform_vertex(T, Kv, vbase[tri[2]], V2);
   float zmin = fminf(V0[2], fminf(V1[2], V2[2])), zmax = fmaxf(V0[2], fmaxf(V1[2], V2[2]));
   if (!(zmax >= kZNear) || !(zmin <= kZFar)) return false;
-  s.x0 = 0; s.x1 = a.w - 1; s.y0 = 0; s.y1 = a.h - 1;
+  x0 = 0; x1 = a.w - 1; y0 = 0; y1 = a.h - 1;
   if (zmin > 1e-6f) {
     float u0 = V0[0] / V0[2], u1 = V1[0] / V1[2], u2 = V2[0] / V2[2];
     float v0 = V0[1] / V0[2], v1 = V1[1] / V1[2], v2 = V2[1] / V2[2];
@@ -146,12 +153,21 @@ __device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const float*
     if (!(umax >= 0.0f) || !(umin <= (float)a.w) || !(vmax >= 0.0f) || !(vmin <= (float)a.h)) return false;
     float xa = ceilf(umin - 0.5f), xb = floorf(umax - 0.5f);
     float ya = ceilf(vmin - 0.5f), yb = floorf(vmax - 0.5f);
-    s.x0 = xa < 0.0f ? 0 : (int)xa; s.x1 = xb > (float)(a.w - 1) ? a.w - 1 : (int)xb;
-    s.y0 = ya < 0.0f ? 0 : (int)ya; s.y1 = yb > (float)(a.h - 1) ? a.h - 1 : (int)yb;
+    x0 = xa < 0.0f ? 0 : (int)xa; x1 = xb > (float)(a.w - 1) ? a.w - 1 : (int)xb;
+    y0 = ya < 0.0f ? 0 : (int)ya; y1 = yb > (float)(a.h - 1) ? a.h - 1 : (int)yb;
   }
+  return y0 <= y1 && x0 <= x1;
+}
+
+// Returns false when the triangle cannot touch rows [row0, row1] of this view.
+__device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const float* T, const float* Kv,
+                                               const float4* vbase, const int32_t* tri, int row0,
+                                               int row1, TriSetup& s) {
+  float V0[3], V1[3], V2[3];
+  if (!tri_bbox(a, T, Kv, vbase, tri, V0, V1, V2, s.x0, s.x1, s.y0, s.y1)) return false;
   if (s.y0 < row0) s.y0 = row0;
   if (s.y1 > row1) s.y1 = row1;
-  if (s.y0 > s.y1 || s.x0 > s.x1) return false;
+  if (s.y0 > s.y1) return false;
   edge_fn(V1, tri[1], V2, tri[2], s.e0);
   edge_fn(V2, tri[2], V0, tri[0], s.e1);
   edge_fn(V0, tri[0], V1, tri[1], s.e2);
@@ -176,17 +192,85 @@ __device__ __forceinline__ void shade_pixel(const TriSetup& s, int i, int j, uin
   atomicMin(&zb[(i - row0) * w + j], key);
 }
 
+struct ViewXform { float T[12], Kv[9]; bool finite; };
+
+__device__ __forceinline__ ViewXform load_view(const RasterArgs& a, int view) {
+  ViewXform x;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) x.T[k] = a.TCO[16 * (int64_t)view + k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) x.Kv[k] = a.K[9 * (int64_t)view + k];
+  bool finite = true;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) finite &= isfinite(x.T[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) finite &= isfinite(a.TCO[16 * (int64_t)view + 12 + k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) finite &= isfinite(x.Kv[k]);
+  x.finite = finite;
+  return x;
+}
+
+// Pass 1: one lane per (view, triangle) -> append the triangle to the list of every band its
+// bounding box touches.  Appends are aggregated per wave (one atomic per band per wave).
+__global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
+  const int lv = blockIdx.y;               // view within the chunk
+  const int view = a.view0 + lv;
+  const int f = blockIdx.x * kBinThreads + threadIdx.x;
+  const ViewXform x = load_view(a, view);
+  const int item = view / a.views_per_item;
+  const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
+  const int nf = x.finite ? (int)ob[3] : 0;
+  int b0 = 1, b1 = 0;  // empty band range
+  if (f < nf) {
+    const int32_t* fbase = a.faces + 3 * ob[2];
+    int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
+    float V0[3], V1[3], V2[3];
+    int x0, x1, y0, y1;
+    if (tri_bbox(a, x.T, x.Kv, a.verts4 + ob[0], tri, V0, V1, V2, x0, x1, y0, y1)) {
+      b0 = y0 / a.band_rows;
+      b1 = y1 / a.band_rows;
+    }
+  }
+  // Appends are aggregated twice: lanes -> wave (ballot) -> workgroup (LDS counters), so only
+  // one global atomic per band per workgroup reaches L2 (same-address L2 atomics serialise).
+  __shared__ int wg_cnt[kMaxBands], wg_base[kMaxBands];
+  __shared__ int wave_base[kBinThreads / 64][kMaxBands];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = tid; b < a.n_bands; b += kBinThreads) wg_cnt[b] = 0;
+  __syncthreads();
+  int lo = b0 <= b1 ? b0 : a.n_bands, hi = b0 <= b1 ? b1 : -1;  // bands touched by this wave
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+  for (int b = lo; b <= hi; ++b) {
+    const unsigned long long m = __ballot(b0 <= b && b <= b1);
+    if (m != 0 && lane == 0) wave_base[wave][b] = atomicAdd(&wg_cnt[b], __popcll(m));
+  }
+  __syncthreads();
+  for (int b = tid; b < a.n_bands; b += kBinThreads)
+    if (wg_cnt[b] > 0) wg_base[b] = atomicAdd(&a.bin_count[lv * a.n_bands + b], wg_cnt[b]);
+  __syncthreads();
+  for (int b = lo; b <= hi; ++b) {
+    const bool mine = b0 <= b && b <= b1;
+    const unsigned long long m = __ballot(mine);
+    if (mine) {
+      const int slot = wg_base[b] + wave_base[wave][b] + __popcll(m & ((1ull << lane) - 1ull));
+      if (slot < a.bin_cap) a.bin_list[((int64_t)lv * a.n_bands + b) * a.bin_cap + slot] = f;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   __shared__ unsigned long long zb[kBandPixels];
   __shared__ int big_q[kBigQueue];
   __shared__ int big_n;
 
   // XCD-aware renumbering: dispatch order b -> XCD b % 8; give each XCD a contiguous range.
-  const int total = a.n * a.n_bands;
+  const int total = a.n * a.n_bands;  // a.n = views of this chunk
   const int per_xcd = (total + 7) / 8;
   const int lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (lin >= total) return;
-  const int view = lin / a.n_bands;
+  const int view = a.view0 + lin / a.n_bands;
   const int band = lin % a.n_bands;
   const int row0 = band * a.band_rows;
   const int row1 = min(a.h, row0 + a.band_rows) - 1;
@@ -211,15 +295,18 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   const int64_t voff = ob[0], foff = ob[2], toff = ob[4];
   const int nf = finite ? (int)ob[3] : 0;
   const int tw = (int)ob[5], th = (int)ob[6];
-  const float* vbase = a.verts + 3 * voff;
+  const float4* vbase = a.verts4 + voff;
   const int32_t* fbase = a.faces + 3 * foff;
 
   for (int p = tid; p < npix; p += kThreads) zb[p] = kKeyEmpty;
   if (tid == 0) big_n = 0;
   __syncthreads();
 
-  // ---- coverage + depth ----
-  for (int f = tid; f < nf; f += kThreads) {
+  // ---- coverage + depth: only the triangles binned to this band ----
+  const int cnt = nf > 0 ? min(a.bin_count[lin], a.bin_cap) : 0;
+  const int32_t* list = a.bin_list + (int64_t)lin * a.bin_cap;
+  for (int k = tid; k < cnt; k += kThreads) {
+    const int f = list[k];
     int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
     TriSetup s;
     if (!setup_triangle(a, T, Kv, vbase, tri, row0, row1, s)) continue;
@@ -261,9 +348,9 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
       const int f = (int)(key & 0xFFFFFFFFull);
       int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
       float V0[3], V1[3], V2[3], e0[3], e1[3], e2[3];
-      xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[0], V0);
-      xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[1], V1);
-      xform_vertex(T, Kv, vbase + 3 * (int64_t)tri[2], V2);
+      xform_vertex(T, Kv, vbase[tri[0]], V0);
+      xform_vertex(T, Kv, vbase[tri[1]], V1);
+      xform_vertex(T, Kv, vbase[tri[2]], V2);
       edge_fn(V1, tri[1], V2, tri[2], e0);
       edge_fn(V2, tri[2], V0, tri[0], e1);
       edge_fn(V0, tri[0], V1, tri[1], e2);
@@ -290,9 +377,10 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
                         fmaf(b1, (float)a.colors[4 * g1 + c], b2 * (float)a.colors[4 * g2 + c])) / 255.0f;
       }
       float no[3], nc[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        no[c] = fmaf(b0, a.normals[3 * g0 + c], fmaf(b1, a.normals[3 * g1 + c], b2 * a.normals[3 * g2 + c]));
+      const float4 n0 = a.normals4[g0], n1 = a.normals4[g1], n2 = a.normals4[g2];
+      no[0] = fmaf(b0, n0.x, fmaf(b1, n1.x, b2 * n2.x));
+      no[1] = fmaf(b0, n0.y, fmaf(b1, n1.y, b2 * n2.y));
+      no[2] = fmaf(b0, n0.z, fmaf(b1, n1.z, b2 * n2.z));
       nc[0] = fmaf(T[0], no[0], fmaf(T[1], no[1], T[2] * no[2]));
       nc[1] = fmaf(T[4], no[0], fmaf(T[5], no[1], T[6] * no[2]));
       nc[2] = fmaf(T[8], no[0], fmaf(T[9], no[1], T[10] * no[2]));
@@ -356,7 +444,8 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   HP_REQUIRE(store != nullptr, "hp_rasterize: null mesh store");
   HP_REQUIRE(n >= 0 && views_per_item >= 1 && n % views_per_item == 0,
              "hp_rasterize: n must be a multiple of views_per_item");
-  HP_REQUIRE(h > 0 && w > 0 && w <= kBandPixels, "hp_rasterize: unsupported resolution");
+  HP_REQUIRE(h > 0 && w > 0 && w <= kBandPixels && (h + kBandPixels / w - 1) / (kBandPixels / w) <= kMaxBands,
+             "hp_rasterize: unsupported resolution");
   HP_REQUIRE(!d_mask || d_depth, "Binary mask can only be rendered if depth is rendered");
   if (n == 0) return HP_OK;
   HP_REQUIRE(d_TCO && d_K && d_obj_ids, "hp_rasterize: null pose/intrinsics/object ids");
@@ -367,7 +456,7 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   HP_REQUIRE(depth_norm_mode >= 0 && depth_norm_mode <= 3, "hp_rasterize: bad depth_norm_mode");
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_rasterize: depth_norm_z missing");
   RasterArgs a{};
-  a.verts = store->verts; a.normals = store->normals; a.uvs = store->uvs; a.colors = store->colors;
+  a.verts4 = store->verts4; a.normals4 = store->normals4; a.uvs = store->uvs; a.colors = store->colors;
   a.faces = store->faces; a.tex = store->tex; a.obj = store->obj;
   a.obj_ids = d_obj_ids; a.TCO = d_TCO; a.K = d_K; a.ambient = d_ambient;
   a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
@@ -379,8 +468,41 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   a.band_rows = kBandPixels / w;
   a.n_bands = (h + a.band_rows - 1) / a.band_rows;
   a.depth_max = kZNear / (1.0f - (1.0f - 1e-3f) * (kZFar - kZNear) / kZFar);
-  const int total = n * a.n_bands;
-  const int grid = 8 * ((total + 7) / 8);
-  hipLaunchKernelGGL(raster_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+  // Views are processed in chunks so that the per-(view, band) triangle lists stay within a
+  // fixed scratch budget; the scratch (owned by the store) only grows on the first call of
+  // a given size -- callers sharing one store must be stream-ordered.
+  hp::MeshStore* ms = const_cast<hp_mesh_store*>(store);
+  a.max_faces = (int)store->max_faces;
+  a.bin_cap = a.max_faces;
+  const size_t per_view = (size_t)a.n_bands * a.bin_cap * sizeof(int32_t);
+  const size_t budget = (size_t)512 << 20;
+  int chunk = (int)(budget / per_view);
+  if (chunk < 1) chunk = 1;
+  if (chunk > n) chunk = n;
+  const size_t need_list = (size_t)chunk * per_view, need_cnt = (size_t)chunk * a.n_bands * sizeof(int32_t);
+  if (ms->bin_list_bytes < need_list) {
+    if (ms->bin_list) (void)hipFree(ms->bin_list);
+    ms->bin_list = nullptr; ms->bin_list_bytes = 0;
+    HP_CHECK_HIP(hipMalloc((void**)&ms->bin_list, need_list));
+    ms->bin_list_bytes = need_list;
+  }
+  if (ms->bin_count_bytes < need_cnt) {
+    if (ms->bin_count) (void)hipFree(ms->bin_count);
+    ms->bin_count = nullptr; ms->bin_count_bytes = 0;
+    HP_CHECK_HIP(hipMalloc((void**)&ms->bin_count, need_cnt));
+    ms->bin_count_bytes = need_cnt;
+  }
+  a.bin_list = ms->bin_list;
+  a.bin_count = ms->bin_count;
+  hipStream_t st = (hipStream_t)stream;
+  for (int v0 = 0; v0 < n; v0 += chunk) {
+    const int nv = n - v0 < chunk ? n - v0 : chunk;
+    a.view0 = v0;
+    a.n = nv;
+    HP_CHECK_HIP(hipMemsetAsync(ms->bin_count, 0, (size_t)nv * a.n_bands * sizeof(int32_t), st));
+    hipLaunchKernelGGL(raster_bin_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
+    const int total = nv * a.n_bands;
+    hipLaunchKernelGGL(raster_kernel, dim3(8 * ((total + 7) / 8)), dim3(kThreads), 0, st, a);
+  }
   return check_launch("raster_kernel");
 }
