@@ -17,6 +17,10 @@ struct ConvArgs {
   int64_t M;               // n * Ho * Wo
   int H, W, Cin, Ho, Wo, Cout, stride, pad, Kpad, ktiles, relu;
   int tiles_m, tiles_n;    // filled by launch_conv
+  // tail split-K of the patch kernel (filled by launch_conv_patch)
+  int sk_regular, sk_S, sk_tail_items;
+  float* sk_slabs;
+  int* sk_counters;
 };
 
 struct HeadArgs {
@@ -30,6 +34,9 @@ struct HeadArgs {
 
 // variant 0: 128x128 block tile, variant 1: 128x64 (Cout == 64)
 int launch_conv(const ConvArgs& a, int variant, hipStream_t stream);
+// 3x3 / stride 1 / pad 1 / Cin % 32 == 0: input staged once per channel chunk (conv_patch.hip)
+bool conv_patch_applicable(const ConvArgs& a, int kh, int kw);
+int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream);
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream);
 int conv_setup_once();

@@ -42,6 +42,7 @@
 // Numerics: exact fp32 FMA chains (the f32 MFMA is bitwise an fmaf chain), K-order differs
 // from the reference's oneDNN/cuDNN kernels, so results agree to fp32 round-off, not bitwise.
 #include "conv.h"
+#include "conv_epilogue.h"
 
 namespace hp {
 
@@ -309,25 +310,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 #endif
   }
 
-  // ---- epilogue: bias, residual, ReLU; NHWC store (32 consecutive channels per half-wave) ----
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + wn + nt * 32 + (lane & 31);
-      const float bias = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < a.M) {
-          float v = acc[mt][nt][r] + bias;
-          if (a.residual) v += a.residual[m * a.Cout + n];
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.y[m * a.Cout + n] = v;
-        }
-      }
-    }
-  }
+  // ---- epilogue: bias, residual, ReLU through an LDS transpose (conv_epilogue.h) ----
+  conv_epilogue<BM, BN, MT, NT, kThreads>(a, lds, acc, m0, n0, wm, wn);
 }
 
 template <int BM, int BN, bool PRE>

@@ -1,0 +1,61 @@
+// Shared epilogue of the MFMA conv kernels: bias (folded BN), residual add, ReLU, NHWC store.
+//
+// The 32x32 MFMA accumulator layout gives a lane 16 values of ONE output channel (column) in
+// 16 different pixels (rows), so a direct store is 4 bytes per lane per instruction and the
+// residual read likewise.  Instead the block tile is transposed through LDS (free at this
+// point): accumulators -> LDS [row][BN+4] with ds_write_b32 (conflict free: a half-wave writes
+// 32 consecutive columns of a row), then every thread moves 16-B pieces: ds_read_b128, float4
+// bias, float4 residual load, ReLU, float4 global store -- 4x fewer and fully coalesced
+// vector-memory instructions (a 128-channel row = 512 contiguous bytes per 32 lanes).
+#pragma once
+
+#include "conv.h"
+
+namespace hp {
+
+typedef float epi_floatx16 __attribute__((ext_vector_type(16)));
+typedef float epi_floatx4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN>
+constexpr int epilogue_lds_floats() { return BM * (BN + 4); }
+
+template <int BM, int BN, int MT, int NT, int THREADS>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* lds, epi_floatx16 (&acc)[MT][NT],
+                                              int64_t m0, int n0, int wm, int wn) {
+  constexpr int LDC = BN + 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  __syncthreads();  // every wave is done reading the operand tiles
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        lds[row * LDC + wn + nt * 32 + (lane & 31)] = acc[mt][nt][r];
+      }
+  __syncthreads();
+  constexpr int C4 = BN / 4;                       // 16-B pieces per row
+  constexpr int ITERS = BM * C4 / THREADS;
+  const int c4 = tid % C4;
+  const int n = n0 + 4 * c4;
+  epi_floatx4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias = *reinterpret_cast<const epi_floatx4*>(a.bias + n);
+#pragma unroll
+  for (int k = 0; k < ITERS; ++k) {
+    const int row = tid / C4 + k * (THREADS / C4);
+    const int64_t m = m0 + row;
+    if (m < a.M) {
+      epi_floatx4 v = *reinterpret_cast<const epi_floatx4*>(lds + row * LDC + 4 * c4);
+      v += bias;
+      if (a.residual) v += *reinterpret_cast<const epi_floatx4*>(a.residual + m * a.Cout + n);
+      if (a.relu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+      }
+      *reinterpret_cast<epi_floatx4*>(a.y + m * a.Cout + n) = v;
+    }
+  }
+}
+
+}  // namespace hp

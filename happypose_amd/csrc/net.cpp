@@ -324,7 +324,10 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
         ev.conv = op.conv;
         HP_CHECK_HIP(hipEventRecord(ev.e0, stream));
       }
-      if ((rc = launch_conv(a, L.cout == 64 ? 1 : 0, stream))) return rc;
+      static const bool no_patch = std::getenv("HP_CONV_NO_PATCH") != nullptr;
+      if (!no_patch && conv_patch_applicable(a, L.kh, L.kw)) rc = launch_conv_patch(a, L.cout == 64 ? 1 : 0, stream);
+      else rc = launch_conv(a, L.cout == 64 ? 1 : 0, stream);
+      if (rc) return rc;
       if (net->profiling) {
         HP_CHECK_HIP(hipEventRecord(ev.e1, stream));
         net->ev_pending.push_back(ev);
@@ -447,5 +450,7 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   a.H = h; a.W = w; a.Cin = cin; a.Ho = (h + 2 * pad - kh) / stride + 1; a.Wo = (w + 2 * pad - kw) / stride + 1;
   a.Cout = cout; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.ktiles = Kpad / 32; a.relu = relu;
   a.M = (int64_t)n * a.Ho * a.Wo;
+  if (std::getenv("HP_CONV_NO_PATCH") == nullptr && conv_patch_applicable(a, kh, kw))
+    return launch_conv_patch(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
   return launch_conv(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
 }
