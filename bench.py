@@ -30,6 +30,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_HBM_BPS = 8.0e12        # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 N_DET, N_HYP, N_ITERS = 8, 16, 5
 
@@ -93,14 +94,16 @@ def effective_cpu_count() -> int:
     return max(1, n)
 
 
-def cpu_baseline(ds_store, scene, weights, arch, budget_s=15.0):
+def cpu_baseline(ds_store, scene, weights, arch, budget_s=15.0, cores=None):
     """The oracle port of the reference algorithm (torch-CPU conv stack, C rasteriser and
     roi_align, reference batching bsz_objects=8) timed on the host cores on a bounded
-    sample of the same workload."""
-    cores = effective_cpu_count()
-    os.environ["OMP_NUM_THREADS"] = str(cores)  # the C oracle's OpenMP pool (read at load time)
+    sample of the same workload.  cores=None: every core the box grants; cores=1: the setting the
+    reference itself forces at import (OMP_NUM_THREADS=MKL_NUM_THREADS=1, MP/__init__.py:35-36)."""
+    cores = cores or effective_cpu_count()
+    from oracle import native as oracle_native
     from oracle.pipeline import OraclePredictor
 
+    oracle_native.set_threads(cores)
     torch.set_num_threads(cores)
     ora = OraclePredictor(weights, ds_store.packed, ds_store.mesh_db.points, arch=arch, cosypose=True)
 
@@ -119,6 +122,47 @@ def cpu_baseline(ds_store, scene, weights, arch, budget_s=15.0):
                       f"(oracle/pipeline.py: torch-CPU unfused conv stack + C rasteriser/roi_align), {t:.1f} s"}
 
 
+def stage_rates(store, scene, images, K, TCO0, im_ids, device, reps=20):
+    """Rasteriser and crop kernels on the C2 inputs in the product layout (NHWC slices of the
+    network input), timed with events on the stream they are launched on (torch's current
+    stream).  Bytes are the ALGORITHMIC bytes of SURVEY.md 8(d): per view V*32 + F*12 + h*w*4*C_out
+    + 4 B of texture per covered pixel (rasteriser); output bytes (crop)."""
+    from happypose_amd import ops
+
+    B = TCO0.shape[0]
+    obj = torch.as_tensor(scene["hyp_obj_ids"], device=device)
+    prep = ops.pose_prep(store, TCO0, K, im_ids, obj, (480, 640))
+    Kc = prep["K_crop"][:, 0].contiguous()
+    x = torch.zeros((B, 240, 320, 8), device=device)
+    depth = ops.rasterize(store, obj, TCO0, Kc, (240, 320), render_depth=True)[2]
+    covered = float((depth > 0).sum().item())
+    rows = store.packed.obj[np.asarray(scene["hyp_obj_ids"])]  # (voff, nv, foff, nf, ...)
+    nv, nf = rows[:, 1].astype(np.float64), rows[:, 3].astype(np.float64)
+    raster_bytes = float((nv * 32 + nf * 12).sum()) + B * 76800 * 3 * 4 + covered * 4
+    crop_bytes = float(B * 76800 * 3 * 4)
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    t_r = timeit(lambda: ops.rasterize_into(store, x, 3, obj, TCO0[:, None], Kc[:, None], False, False))
+    t_c = timeit(lambda: ops.crop_roi_align(images, prep["boxes_crop"], im_ids, out=x))
+    return {
+        "rasterize": {"views": B, "us": t_r * 1e6, "algorithmic_MB": raster_bytes / 1e6,
+                      "GB/s": raster_bytes / t_r / 1e9, "frac_hbm_peak": raster_bytes / t_r / PEAK_HBM_BPS,
+                      "coverage": covered / (B * 76800)},
+        "crop_roi_align": {"crops": B, "us": t_c * 1e6, "algorithmic_MB": crop_bytes / 1e6,
+                           "GB/s": crop_bytes / t_c / 1e9, "frac_hbm_peak": crop_bytes / t_c / PEAK_HBM_BPS},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +170,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--arch", default="resnet34", choices=["resnet34", "resnet18"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-1thread", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -188,16 +233,19 @@ def main():
                                    f"hypotheses = {B} hypotheses/GPU, {N_ITERS} iterations, {args.arch} "
                                    "(WideResNet) on 6x240x320, 8 objects of 8.2k vertices / 16.1k faces, 1024^2 textures",
                        "hypotheses_per_gpu": B, "iterations": N_ITERS, "parallelism": f"hypothesis-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_f32 + conv_igemm_f32 (fp32 MFMA implicit-GEMM conv, all 36 conv launches of a forward)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }
+        line["stages"] = stage_rates(store, scene, images, K, TCO0, im_ids, device)
         if not args.no_cpu_baseline:
             base = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds)
             line["cpu_baseline"] = base
             line["speedup_vs_cpu"] = line["value"] / base["value"]
+            if not args.no_cpu_1thread:
+                line["cpu_baseline_1thread"] = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds / 2, cores=1)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

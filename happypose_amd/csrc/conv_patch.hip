@@ -259,7 +259,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     __syncthreads();
     if (ticket_s != a.sk_S - 1) return;  // not the last slice of this tile
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      a.sk_counters[tail_tile] = 0;  // every slice has taken its ticket: re-arm for the next launch
+    }
     __syncthreads();
     // sum ALL slices in slice order (own one re-read from its slab) so that the result does
     // not depend on which slice happened to arrive last: bitwise run-to-run reproducible
@@ -289,8 +292,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // Decide how the tiles of the last partial round are split (see the kernel), provide the
-// slab / counter workspace (grown on demand, reused by every launch on the device) and zero
-// the counters on the launch stream.
+// slab / counter workspace (grown on demand, reused by every launch; launches that split are
+// therefore expected on ONE stream per process, which is how net.cpp issues them).  Counters are
+// zeroed when allocated and re-armed by the reducing block.
 struct SplitWorkspace { float* slabs = nullptr; size_t slab_bytes = 0; int* counters = nullptr; size_t counter_bytes = 0; int slots = 0; };
 
 double rounds_cost(double r) {  // time of r rounds' worth of equal items; a partial round runs faster
@@ -336,9 +340,9 @@ int plan_split(ConvArgs& a, int T, size_t lds_bytes, hipStream_t stream) {
       if (ws.counters) (void)hipFree(ws.counters);
       ws.counters = nullptr; ws.counter_bytes = 0;
       HP_CHECK_HIP(hipMalloc((void**)&ws.counters, need_cnt));
+      HP_CHECK_HIP(hipMemsetAsync(ws.counters, 0, need_cnt, stream));  // kernels leave them at zero
       ws.counter_bytes = need_cnt;
     }
-    HP_CHECK_HIP(hipMemsetAsync(ws.counters, 0, need_cnt, stream));
     a.sk_slabs = ws.slabs;
     a.sk_counters = ws.counters;
   }

@@ -29,6 +29,15 @@
 #include <omp.h>
 #endif
 
+/* thread count of the OpenMP loops below (bench.py times the port at 1 thread and at all cores) */
+void hp_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* roi_align                                                                            */
 /* ------------------------------------------------------------------------------------ */

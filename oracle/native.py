@@ -48,6 +48,11 @@ def lib():
     return _lib
 
 
+def set_threads(n: int) -> None:
+    """Thread count of the C oracle's OpenMP loops."""
+    lib().hp_oracle_set_threads(int(n))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
