@@ -1,0 +1,415 @@
+// 3x3 / stride-1 / pad-1 convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+// 85 % of the backbone FLOPs are 3x3 stride-1 convolutions and the direct kernels
+// (conv_patch.hip) already sit at ~90 % of what the fp32 MFMA pipe sustains, so the remaining
+// lever is the amount of matrix work itself: Y = A^T [ (G g G^T) . (B^T d B) ] A produces a 2x2
+// output tile from a 4x4 input tile with 16 multiplies per (cin, cout) instead of 36 -- 2.25x
+// fewer MFMA FLOPs for the same result up to fp32 round-off (the transform constants are 0, +-1,
+// +-1/2, so the error stays within ~2x of the direct kernel's; tests/test_gpu_kernels.py).
+//
+// GEMM view: 16 independent products, one per transform position p = (xi, nu):
+//   M_p[tile][cout] = sum_cin V_p[tile][cin] * U_p[cin][cout]
+// Everything is fused in ONE kernel -- no transformed tensor ever touches HBM:
+//   * a wave owns 16 consecutive output tiles (linear index over batch x tile-rows x tile-cols,
+//     so any feature-map size fills the tile exactly) x 32 output channels x ALL 16 positions,
+//     with v_mfma_f32_16x16x4_f32: the accumulators of a lane are then the 16 positions of the
+//     same (tile, cout) -> the output transform A^T M A is pure register arithmetic;
+//   * the block (4 waves = 64 tiles) stages the pixel range its tiles touch -- a contiguous
+//     range of the pixel-linear NHWC index, whole image rows -- for 16 input channels at a time
+//     in LDS with coalesced 16-B loads (a first version let every lane fetch its own 4x4 pixels
+//     from global memory: 64 separate 16-B accesses per wave instruction, far slower).  The
+//     pre-activation BN+ReLU prologue is applied on the way into LDS.  Lane (tile = lane & 15,
+//     kg = lane >> 4) then reads the 4x4 pixels of its tile for channels 4kg..4kg+3
+//     (16 ds_read_b128; padding pixels read a row of zeros) and forms B^T d B with 32 packed
+//     float4 adds; the float4 feeds 4 MFMA k-steps (k-step j multiplies channel 4 kg + j; A and
+//     B use the same order, so the permutation is free);
+//   * transformed weights U (device pre-pass, BN folded) are packed so that the [16 positions]
+//     [4 kg][32 couts] float4 image of one (chunk, cout block) is copied to LDS verbatim
+//     (double buffered) and shared by the 4 waves of the block;
+//   * LDS layouts are chosen for the lane groups of ds_read_b128 ({0-3,12-15,20-27}, ... :
+//     MI355X_MICROARCH.md, LDS): weights [pos][kg][cout] float4 -> the 16 lanes of a group hit
+//     16 different 16-B slots whatever their kg; pixels as 4 channel-quad planes [kg][P'] float4
+//     with P' odd, so the stride-2-pixel reads of neighbouring tiles in two kg planes interleave;
+//   * ~400 VGPRs+AGPRs (128 accumulators): one wave per SIMD, one block per CU, so latency must be
+//     hidden inside the wave: the stage (item, chunk) two ahead is in flight from global memory
+//     while the one after the current is written to LDS after three quarters of the current
+//     chunk's 128 MFMAs; its LDS reads fly under the last quarter.  The staging code is branch
+//     free (clamped addresses, a dump row) so that the compiler can interleave it with the MFMAs.
+//     Blocks are PERSISTENT (one per CU, static round-robin over the work items of its XCD), the
+//     load cursor simply runs on into the next item, so fill latency hides behind the epilogue.
+// Item = 64 tiles (256 output pixels) x 32 couts; an XCD walks a contiguous item range with
+// the couts fastest, so the blocks that re-read the same input share an L2.
+#include <algorithm>
+#include <cstdlib>
+
+#include "conv.h"
+
+namespace hp {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int CK = 16;        // channels per chunk
+constexpr int BN = 32;        // output channels per item
+constexpr int TPB = 64;       // tiles per item (16 per wave)
+constexpr int U_BUF = 16 * 4 * BN * 4;  // floats per weight buffer: [pos][kg][cout] float4
+
+// pixel-linear range [lo, lo + P) that the tiles of item row bm touch (whole image rows)
+__host__ __device__ inline void item_range(int bm, int T, int TH, int TW, int H, int W, int& lo, int& P) {
+  const int per = TH * TW;
+  const int t0 = bm * TPB, t1 = (t0 + TPB - 1 < T - 1) ? t0 + TPB - 1 : T - 1;
+  const int i0 = t0 / per, th0 = (t0 - i0 * per) / TW;
+  const int i1 = t1 / per, th1 = (t1 - i1 * per) / TW;
+  const int r0 = 2 * th0 - 1 > 0 ? 2 * th0 - 1 : 0;
+  const int r1 = 2 * th1 + 2 < H - 1 ? 2 * th1 + 2 : H - 1;
+  lo = (i0 * H + r0) * W;
+  P = (i1 * H + r1) * W + W - lo;
+}
+
+// plane length (float4 slots) for a staged range of up to Pmax pixels: + zero row + dump row,
+// odd and = 3 (mod 8) (read and write bank spread, see the header)
+__host__ __device__ inline int plane_len(int Pmax) {
+  int n = Pmax + 2;
+  while (n % 8 != 3) ++n;
+  return n;
+}
+
+// a - b on the packed-f32 pipe (hipcc packs float adds but not subtractions)
+__device__ __forceinline__ floatx4 sub4(floatx4 a, floatx4 b) {
+  floatx2 lo, hi;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(a.xy), "v"(b.xy));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(a.zw), "v"(b.zw));
+  return floatx4{lo.x, lo.y, hi.x, hi.y};
+}
+
+template <bool PRE, int NLD>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino_f32(
+    ConvArgs a, int TH, int TW, int T, int tiles_n, int n_items, int Pmax) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int Pp = plane_len(Pmax);
+  float* const rawl = lds;               // [4 kg][Pp] float4; slot Pmax = zeros, slot Pmax+1 = dump
+  float* const ul = lds + 4 * Pp * 4;    // [2][16 pos][4 kg][BN] float4
+
+  const int nslot = gridDim.x / 8;
+  const int ipx = (n_items + 7) / 8;
+  const int item_begin = (blockIdx.x % 8) * ipx;
+  const int item_end = item_begin + ipx < n_items ? item_begin + ipx : n_items;
+  int item = item_begin + blockIdx.x / 8;
+  if (item >= item_end) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = lane >> 4;
+  const int H = a.H, W = a.W, Cin = a.Cin;
+  const int nchunks = Cin / CK;
+  const int c4 = tid & 3, srow = tid >> 2;  // channel quad / first pixel row this thread stages
+  if (tid < 16) rawl[((tid >> 2) * Pp + Pmax) * 4 + (tid & 3)] = 0.f;
+
+  // ---- weights: the [16][4][32] float4 image of a (chunk, cout block) is 16 segments of 2 KB
+  const int64_t u_pos_stride = (int64_t)(a.Cout / BN) * (4 * BN * 4);  // floats between positions
+  const int64_t u_chunk_stride = 16 * u_pos_stride;
+  const float* const usrc = a.w + (int64_t)(tid >> 7) * u_pos_stride + (tid & 127) * 4;  // + nb*512, + 2 i pos
+  float* const udst = ul + tid * 4;                                                       // + 1024 i floats
+  const float* const ufr = ul + (kg * BN + (lane & 15)) * 4;                              // + (pos*128 + nt*16) * 4
+  float* const rdst = rawl + (c4 * Pp) * 4;
+
+  // ---- the load cursor runs two stages (item, chunk) ahead of the compute cursor; past the
+  //      last stage it keeps re-reading it (harmless, keeps the loop branch free)
+  floatx4 rs[NLD], us[8];
+  floatx4 ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};  // prologue of the chunk held in rs
+  int l_item = item, l_c = 0, l_lo, l_P;
+  int held_P = 0;
+  item_range(l_item / tiles_n, T, TH, TW, H, W, l_lo, l_P);
+  auto issue_loads = [&]() {
+    const float* xs = a.x + (int64_t)l_lo * Cin + l_c * CK + 4 * c4;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int row = srow + 64 * k;
+      const float* q = row < l_P ? xs + (int64_t)row * Cin : a.x;
+      rs[k] = *reinterpret_cast<const floatx4*>(q);
+    }
+    const float* s = usrc + (int64_t)(l_item % tiles_n) * (4 * BN * 4) + (int64_t)l_c * u_chunk_stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) us[i] = *reinterpret_cast<const floatx4*>(s + 2 * i * u_pos_stride);
+    if (PRE) {
+      ps = *reinterpret_cast<const floatx4*>(a.pre_scale + l_c * CK + 4 * c4);
+      pb = *reinterpret_cast<const floatx4*>(a.pre_shift + l_c * CK + 4 * c4);
+    }
+    held_P = l_P;
+    const bool wrap = l_c + 1 == nchunks;
+    const bool more = !wrap || l_item + nslot < item_end;
+    if (more) {
+      l_c = wrap ? 0 : l_c + 1;
+      if (wrap) {
+        l_item += nslot;
+        item_range(l_item / tiles_n, T, TH, TW, H, W, l_lo, l_P);
+      }
+    }
+  };
+  auto store_held = [&](int ubuf) {  // rs/us -> LDS (pixels: the single buffer; weights: buffer ubuf)
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int row = srow + 64 * k;
+      floatx4 v = rs[k];
+      if (PRE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], ps[q], pb[q]), 0.f);
+      }
+      *reinterpret_cast<floatx4*>(rdst + (row < held_P ? row : Pmax + 1) * 4) = v;
+    }
+    float* d = udst + ubuf * U_BUF;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<floatx4*>(d + 1024 * i) = us[i];
+  };
+
+  int ubuf = 0;  // weight buffer holding the chunk about to be consumed
+  issue_loads();
+  store_held(ubuf);
+  __syncthreads();
+  issue_loads();
+
+  for (;;) {
+    const int bm = item / tiles_n, n0 = (item % tiles_n) * BN;
+    int lo, P;
+    item_range(bm, T, TH, TW, H, W, lo, P);
+
+    // ---- the lane's input tile: LDS offsets of its 4x4 pixels (padding -> the zero slot)
+    int doff[16];
+    {
+      const int g = bm * TPB + wave * 16 + (lane & 15);
+      const int gg = g < T ? g : 0;
+      const int img = gg / (TH * TW), r = gg - img * (TH * TW);
+      const int th = r / TW, tw = r - th * TW;
+      const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
+      const int prow = (img * H + ih0) * W + iw0 - lo;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const bool ok = (g < T) & ((unsigned)(ih0 + p / 4) < (unsigned)H) & ((unsigned)(iw0 + p % 4) < (unsigned)W);
+        doff[p] = (kg * Pp + (ok ? prow + (p / 4) * W + (p % 4) : Pmax)) * 4;
+      }
+    }
+    floatx4 d[16];
+    auto read_d = [&]() {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) d[p] = *reinterpret_cast<const floatx4*>(rawl + doff[p]);
+    };
+    read_d();
+
+    floatx4 acc[16][2];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[p][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();  // every wave holds its pixels of chunk 0: the pixel buffer may be refilled
+
+    for (int c = 0; c < nchunks; ++c) {
+      const bool last = c + 1 == nchunks;
+      // ---- input transform of chunk c, V = B^T d B
+      floatx4 V[16];
+      {
+        floatx4 t[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t[0 + j] = sub4(d[0 + j], d[8 + j]);
+          t[4 + j] = d[4 + j] + d[8 + j];
+          t[8 + j] = sub4(d[8 + j], d[4 + j]);
+          t[12 + j] = sub4(d[4 + j], d[12 + j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          V[4 * i + 0] = sub4(t[4 * i + 0], t[4 * i + 2]);
+          V[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
+          V[4 * i + 2] = sub4(t[4 * i + 2], t[4 * i + 1]);
+          V[4 * i + 3] = sub4(t[4 * i + 1], t[4 * i + 3]);
+        }
+      }
+      // ---- 16 positions x 2 cout tiles x 4 k-steps, in 4 groups of 4 positions
+      const float* ub = ufr + ubuf * U_BUF;
+      auto mfma_group = [&](int pg) {
+        floatx4 bf[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            bf[q][nt] = *reinterpret_cast<const floatx4*>(ub + ((4 * pg + q) * 128 + nt * 16) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[4 * pg + q][nt] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * pg + q][j], bf[q][nt][j], acc[4 * pg + q][nt], 0, 0, 0);
+      };
+      mfma_group(0);
+      mfma_group(1);
+      mfma_group(2);
+      // ---- the stage after (item, c) goes into LDS (pixels: single buffer, free since the
+      //      barrier that followed the reads of chunk c; weights: the other buffer), and the
+      //      loads of the stage after that are issued: a whole chunk of MFMAs ahead of their use
+      store_held(ubuf ^ 1);
+      __syncthreads();
+      issue_loads();
+      if (!last) read_d();  // flies under the last quarter of the MFMAs
+      mfma_group(3);
+      ubuf ^= 1;
+      if (!last) __syncthreads();  // every wave holds its pixels of chunk c+1
+    }
+
+    // ---- output transform Y = A^T M A per (tile row i of the lane, cout tile), epilogue
+    const int ncol = n0 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int go = bm * TPB + wave * 16 + 4 * kg + i;
+      if (go >= T) continue;
+      const int img = go / (TH * TW), r = go - img * (TH * TW);
+      const int th = r / TW, tw = r - th * TW;
+      const int oh = 2 * th, ow = 2 * tw;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t0[j] = acc[0 + j][nt][i] + acc[4 + j][nt][i] + acc[8 + j][nt][i];
+          t1[j] = acc[4 + j][nt][i] - acc[8 + j][nt][i] - acc[12 + j][nt][i];
+        }
+        float y[2][2];
+        y[0][0] = t0[0] + t0[1] + t0[2];
+        y[0][1] = t0[1] - t0[2] - t0[3];
+        y[1][0] = t1[0] + t1[1] + t1[2];
+        y[1][1] = t1[1] - t1[2] - t1[3];
+        const int n = ncol + nt * 16;
+        const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss) {
+            if (oh + rr < a.Ho && ow + ss < a.Wo) {
+              const int64_t o = (((int64_t)img * a.Ho + oh + rr) * a.Wo + ow + ss) * a.Cout + n;
+              float v = y[rr][ss] + bias;
+              if (a.residual) v += a.residual[o];
+              if (a.relu) v = fmaxf(v, 0.f);
+              a.y[o] = v;
+            }
+          }
+      }
+    }
+    item += nslot;
+    if (item >= item_end) break;
+  }
+}
+
+// w [Cout][Kpad] with K ordered (kh, kw, c) (BN already folded)  ->
+// U [Cin/16][16 positions][Cout/32][4 kg][32 couts][4 channels],  U = G g G^T,
+// G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ void wino_weight_transform(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Kpad) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)Cout * Cin) return;
+  const int o = (int)(idx / Cin), ci = (int)(idx % Cin);
+  float g[3][3];
+  for (int y = 0; y < 3; ++y)
+    for (int x = 0; x < 3; ++x) g[y][x] = w[(int64_t)o * Kpad + (y * 3 + x) * Cin + ci];
+  float tg[4][3];
+  for (int x = 0; x < 3; ++x) {
+    tg[0][x] = g[0][x];
+    tg[1][x] = 0.5f * (g[0][x] + g[1][x] + g[2][x]);
+    tg[2][x] = 0.5f * (g[0][x] - g[1][x] + g[2][x]);
+    tg[3][x] = g[2][x];
+  }
+  const int chunk = ci / CK, kgi = (ci % CK) / 4, j4 = ci % 4, nb = o / BN, n = o % BN;
+  for (int i = 0; i < 4; ++i) {
+    const float u[4] = {tg[i][0], 0.5f * (tg[i][0] + tg[i][1] + tg[i][2]), 0.5f * (tg[i][0] - tg[i][1] + tg[i][2]), tg[i][2]};
+    for (int j = 0; j < 4; ++j)
+      U[(((((int64_t)chunk * 16 + (4 * i + j)) * (Cout / BN) + nb) * 4 + kgi) * BN + n) * 4 + j4] = u[j];
+  }
+}
+
+struct WinoGeom { int TH, TW, T, Pmax; bool ok; };
+
+// tile counts and the largest staged pixel range of any item (the pattern of item starts
+// repeats after TH*TW items, so that many, plus the ragged last one, are enough to look at)
+WinoGeom wino_geom(int H, int W, int64_t n_img) {
+  WinoGeom g{};
+  g.TH = (H + 1) / 2; g.TW = (W + 1) / 2;
+  const int64_t T64 = n_img * g.TH * g.TW;
+  g.ok = T64 > 0 && T64 < (1 << 30) && n_img * H * W < (1ll << 30);
+  if (!g.ok) return g;
+  g.T = (int)T64;
+  const int tiles_m = (g.T + TPB - 1) / TPB;
+  const int look = std::min(tiles_m, g.TH * g.TW + 1);
+  int lo, P;
+  for (int bm = 0; bm < look; ++bm) {
+    item_range(bm, g.T, g.TH, g.TW, H, W, lo, P);
+    g.Pmax = std::max(g.Pmax, P);
+  }
+  item_range(tiles_m - 1, g.T, g.TH, g.TW, H, W, lo, P);
+  g.Pmax = std::max(g.Pmax, P);
+  return g;
+}
+
+constexpr int kMaxNld = 12;  // staged pixel range <= 768 pixels
+size_t wino_lds_bytes(int Pmax) { return ((size_t)4 * plane_len(Pmax) * 4 + 2 * (size_t)U_BUF) * sizeof(float); }
+
+template <bool PRE, int NLD>
+int launch(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
+  static bool opted = false;
+  static int cus = 0;
+  if (!opted) {
+    int dev = 0;
+    HP_CHECK_HIP(hipGetDevice(&dev));
+    HP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<PRE, NLD>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    opted = true;
+  }
+  const int tiles_m = (g.T + TPB - 1) / TPB, tiles_n = a.Cout / BN;
+  const int n_items = tiles_m * tiles_n;
+  // one persistent block per CU, an equal number per XCD
+  const int ipx = (n_items + 7) / 8;
+  const int slots = std::max(1, std::min(ipx, cus / 8));
+  hipLaunchKernelGGL((conv3x3_wino_f32<PRE, NLD>), dim3(8 * slots), dim3(kThreads), wino_lds_bytes(g.Pmax), stream, a,
+                     g.TH, g.TW, g.T, tiles_n, n_items, g.Pmax);
+  return check_launch("conv3x3_wino_f32");
+}
+
+template <bool PRE>
+int launch_nld(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
+  const int nld = (g.Pmax * 4 + kThreads - 1) / kThreads;
+  if (nld <= 4) return launch<PRE, 4>(a, g, stream);
+  if (nld <= 6) return launch<PRE, 6>(a, g, stream);
+  if (nld <= 8) return launch<PRE, 8>(a, g, stream);
+  if (nld <= 10) return launch<PRE, 10>(a, g, stream);
+  return launch<PRE, 12>(a, g, stream);
+}
+
+}  // namespace
+
+bool conv_wino_applicable(const ConvArgs& a, int kh, int kw) {
+  static const bool off = std::getenv("HP_CONV_NO_WINOGRAD") != nullptr;
+  if (off || kh != 3 || kw != 3 || a.stride != 1 || a.pad != 1 || a.Cin % CK != 0 || a.Cout % BN != 0) return false;
+  if (a.H < 2 || a.W < 2 || a.Ho != a.H || a.Wo != a.W) return false;
+  // the staged pixel range of 64 consecutive tiles must fit LDS next to the weight buffers
+  // (batch independent once there are a few images: look at a long virtual batch)
+  const WinoGeom g = wino_geom(a.H, a.W, 64);
+  return g.ok && g.Pmax <= kMaxNld * 64 && wino_lds_bytes(g.Pmax) <= 160 * 1024;
+}
+
+size_t conv_wino_weight_floats(int cout, int cin) { return (size_t)16 * cout * cin; }
+
+int conv_wino_transform_weights(const float* d_w, float* d_U, int cout, int cin, int Kpad, hipStream_t stream) {
+  const int64_t n = (int64_t)cout * cin;
+  hipLaunchKernelGGL(wino_weight_transform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_w, d_U, cout, cin, Kpad);
+  return check_launch("wino_weight_transform");
+}
+
+// a.w must point at the transformed weights U
+int launch_conv_wino(const ConvArgs& a, hipStream_t stream) {
+  const WinoGeom g = wino_geom(a.H, a.W, a.M / ((int64_t)a.Ho * a.Wo));
+  if (!g.ok || g.Pmax > kMaxNld * 64 || wino_lds_bytes(g.Pmax) > 160 * 1024)
+    return fail(HP_ERR_ARG, "conv3x3_wino_f32: geometry not supported (check conv_wino_applicable)");
+  return a.pre_scale ? launch_nld<true>(a, g, stream) : launch_nld<false>(a, g, stream);
+}
+
+}  // namespace hp

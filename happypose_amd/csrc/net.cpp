@@ -48,7 +48,7 @@ struct ConvLayer {
   int cin_real, cin, cout, kh, kw, stride, pad, relu;
   int H, W, Ho, Wo, Kpad;
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
-  DevBuf w, bias, lut, pre_scale, pre_shift;
+  DevBuf w, w_wino, bias, lut, pre_scale, pre_shift;  // w_wino: Winograd-transformed weights (3x3 s1 layers)
 };
 
 struct EventPair { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0.0; int conv = -1; };
@@ -203,6 +203,16 @@ int pack_conv(Net& n, ConvLayer& L) {
               (*w)[(((size_t)o * L.cin_real + ci) * L.kh + y) * L.kw + x] * s;
   }
   if ((rc = L.w.upload(packed.data(), packed.size() * 4))) return rc;
+  {
+    ConvArgs probe{};
+    probe.stride = L.stride; probe.pad = L.pad; probe.Cin = L.cin; probe.Cout = L.cout;
+    probe.H = L.H; probe.W = L.W; probe.Ho = L.Ho; probe.Wo = L.Wo;
+    if (conv_wino_applicable(probe, L.kh, L.kw)) {
+      if ((rc = L.w_wino.alloc(conv_wino_weight_floats(L.cout, L.cin) * 4))) return rc;
+      if ((rc = conv_wino_transform_weights((const float*)L.w.p, (float*)L.w_wino.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
+      HP_CHECK_HIP(hipStreamSynchronize(nullptr));
+    }
+  }
   if (!shift.empty() && (rc = L.bias.upload(shift.data(), shift.size() * 4))) return rc;
   if (!L.bn_before.empty()) {
     std::vector<float> ps, pb;
@@ -325,7 +335,8 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
         HP_CHECK_HIP(hipEventRecord(ev.e0, stream));
       }
       static const bool no_patch = std::getenv("HP_CONV_NO_PATCH") != nullptr;
-      if (!no_patch && conv_patch_applicable(a, L.kh, L.kw)) rc = launch_conv_patch(a, L.cout == 64 ? 1 : 0, stream);
+      if (L.w_wino.p) { a.w = (const float*)L.w_wino.p; rc = launch_conv_wino(a, stream); }
+      else if (!no_patch && conv_patch_applicable(a, L.kh, L.kw)) rc = launch_conv_patch(a, L.cout == 64 ? 1 : 0, stream);
       else rc = launch_conv(a, L.cout == 64 ? 1 : 0, stream);
       if (rc) return rc;
       if (net->profiling) {
@@ -450,6 +461,21 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   a.H = h; a.W = w; a.Cin = cin; a.Ho = (h + 2 * pad - kh) / stride + 1; a.Wo = (w + 2 * pad - kw) / stride + 1;
   a.Cout = cout; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.ktiles = Kpad / 32; a.relu = relu;
   a.M = (int64_t)n * a.Ho * a.Wo;
+  if (conv_wino_applicable(a, kh, kw)) {
+    // test entry: the weights are transformed on every call into a per-process scratch buffer
+    static float* d_U = nullptr;
+    static size_t U_floats = 0;
+    const size_t need_floats = conv_wino_weight_floats(cout, cin);
+    if (U_floats < need_floats) {
+      if (d_U) (void)hipFree(d_U);
+      d_U = nullptr; U_floats = 0;
+      HP_CHECK_HIP(hipMalloc((void**)&d_U, need_floats * sizeof(float)));
+      U_floats = need_floats;
+    }
+    if ((rc = conv_wino_transform_weights(d_w, d_U, cout, cin, Kpad, (hipStream_t)stream))) return rc;
+    a.w = d_U;
+    return launch_conv_wino(a, (hipStream_t)stream);
+  }
   if (std::getenv("HP_CONV_NO_PATCH") == nullptr && conv_patch_applicable(a, kh, kw))
     return launch_conv_patch(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
   return launch_conv(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
