@@ -40,6 +40,7 @@ int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream);
 // 3x3 / stride 1 / pad 1 / Cin % 16 == 0 / Cout % 32 == 0: Winograd F(2x2,3x3) (conv_wino.hip);
 // a.w must point at weights transformed by conv_wino_transform_weights
 bool conv_wino_applicable(const ConvArgs& a, int kh, int kw);
+bool conv_wino_launchable(const ConvArgs& a);  // per launch: batch-dependent limits
 size_t conv_wino_weight_floats(int cout, int cin);
 int conv_wino_transform_weights(const float* d_w, float* d_U, int cout, int cin, int Kpad, hipStream_t stream);
 int launch_conv_wino(const ConvArgs& a, hipStream_t stream);

@@ -107,12 +107,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   const int c4 = tid & 3, srow = tid >> 2;  // channel quad / first pixel row this thread stages
   if (tid < 16) rawl[((tid >> 2) * Pp + Pmax) * 4 + (tid & 3)] = 0.f;
 
-  // ---- weights: the [16][4][32] float4 image of a (chunk, cout block) is 16 segments of 2 KB
-  const int64_t u_pos_stride = (int64_t)(a.Cout / BN) * (4 * BN * 4);  // floats between positions
-  const int64_t u_chunk_stride = 16 * u_pos_stride;
-  const float* const usrc = a.w + (int64_t)(tid >> 7) * u_pos_stride + (tid & 127) * 4;  // + nb*512, + 2 i pos
-  float* const udst = ul + tid * 4;                                                       // + 1024 i floats
-  const float* const ufr = ul + (kg * BN + (lane & 15)) * 4;                              // + (pos*128 + nt*16) * 4
+  // ---- global loads go through buffer descriptors: the per-lane byte offset is a constant, the
+  //      stage-dependent part is wave-uniform (soffset), so a load costs no vector ALU work; rows
+  //      past the end of the tensor read as zero instead of faulting
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((int64_t)a.M / ((int64_t)a.Ho * a.Wo) * H * W * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ursrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 16 * a.Cout * Cin * 4, 0x00020000);
+  const int x_voff = (srow * Cin + 4 * c4) * 4;
+  const int x_kstride = 64 * Cin * 4;  // bytes between the rows a thread stages
+  // weights: the [16][4][32] float4 image of a (chunk, cout block) is 16 segments of 2 KB
+  const int u_pos_stride = (a.Cout / BN) * (4 * BN * 16);  // bytes between positions
+  const int u_chunk_stride = 16 * u_pos_stride;
+  const int u_voff = (tid >> 7) * u_pos_stride + (tid & 127) * 16;  // + nb*2048 + 2 i pos
+  float* const udst = ul + tid * 4;                                  // + 1024 i floats
+  const float* const ufr = ul + (kg * BN + (lane & 15)) * 4;         // + (pos*128 + nt*16) * 4
   float* const rdst = rawl + (c4 * Pp) * 4;
 
   // ---- the load cursor runs two stages (item, chunk) ahead of the compute cursor; past the
@@ -123,16 +132,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   int held_P = 0;
   item_range(l_item / tiles_n, T, TH, TW, H, W, l_lo, l_P);
   auto issue_loads = [&]() {
-    const float* xs = a.x + (int64_t)l_lo * Cin + l_c * CK + 4 * c4;
+    const int xs = (l_lo * Cin + l_c * CK) * 4;
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-      const int row = srow + 64 * k;
-      const float* q = row < l_P ? xs + (int64_t)row * Cin : a.x;
-      rs[k] = *reinterpret_cast<const floatx4*>(q);
-    }
-    const float* s = usrc + (int64_t)(l_item % tiles_n) * (4 * BN * 4) + (int64_t)l_c * u_chunk_stride;
+    for (int k = 0; k < NLD; ++k)
+      rs[k] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, x_voff, xs + k * x_kstride, 0));
+    const int s = (l_item % tiles_n) * (4 * BN * 16) + l_c * u_chunk_stride;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) us[i] = *reinterpret_cast<const floatx4*>(s + 2 * i * u_pos_stride);
+    for (int i = 0; i < 8; ++i)
+      us[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, u_voff, s + 2 * i * u_pos_stride, 0));
     if (PRE) {
       ps = *reinterpret_cast<const floatx4*>(a.pre_scale + l_c * CK + 4 * c4);
       pb = *reinterpret_cast<const floatx4*>(a.pre_shift + l_c * CK + 4 * c4);
@@ -148,9 +155,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       }
     }
   };
-  auto store_held = [&](int ubuf) {  // rs/us -> LDS (pixels: the single buffer; weights: buffer ubuf)
+  // rs/us -> LDS (pixels: the single buffer; weights: buffer ubuf), in three parts
+  auto store_held = [&](int ubuf, int part) {
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
+      if (k % 3 != part) continue;
       const int row = srow + 64 * k;
       floatx4 v = rs[k];
       if (PRE) {
@@ -161,12 +170,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     float* d = udst + ubuf * U_BUF;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<floatx4*>(d + 1024 * i) = us[i];
+    for (int i = 0; i < 8; ++i)
+      if (i % 3 == part) *reinterpret_cast<floatx4*>(d + 1024 * i) = us[i];
   };
 
   int ubuf = 0;  // weight buffer holding the chunk about to be consumed
   issue_loads();
-  store_held(ubuf);
+  store_held(ubuf, 0); store_held(ubuf, 1); store_held(ubuf, 2);
   __syncthreads();
   issue_loads();
 
@@ -190,12 +200,27 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         doff[p] = (kg * Pp + (ok ? prow + (p / 4) * W + (p % 4) : Pmax)) * 4;
       }
     }
-    floatx4 d[16];
-    auto read_d = [&]() {
+    floatx4 d[16], V[16];
+    auto read_d_rows = [&](int r0, int r1) {  // pixel rows r0 and r1 of the 4x4 patch
 #pragma unroll
-      for (int p = 0; p < 16; ++p) d[p] = *reinterpret_cast<const floatx4*>(rawl + doff[p]);
+      for (int j = 0; j < 4; ++j) {
+        d[4 * r0 + j] = *reinterpret_cast<const floatx4*>(rawl + doff[4 * r0 + j]);
+        d[4 * r1 + j] = *reinterpret_cast<const floatx4*>(rawl + doff[4 * r1 + j]);
+      }
     };
-    read_d();
+    // V row i = (B^T d) row i times B
+    auto xform_row = [&](int i) {
+      floatx4 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        t[j] = i == 0 ? sub4(d[0 + j], d[8 + j]) : i == 1 ? d[4 + j] + d[8 + j] : i == 2 ? sub4(d[8 + j], d[4 + j]) : sub4(d[4 + j], d[12 + j]);
+      V[4 * i + 0] = sub4(t[0], t[2]);
+      V[4 * i + 1] = t[1] + t[2];
+      V[4 * i + 2] = sub4(t[2], t[1]);
+      V[4 * i + 3] = sub4(t[1], t[3]);
+    };
+    read_d_rows(0, 2);
+    read_d_rows(1, 3);
 
     floatx4 acc[16][2];
 #pragma unroll
@@ -206,67 +231,62 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 
     for (int c = 0; c < nchunks; ++c) {
       const bool last = c + 1 == nchunks;
-      // ---- input transform of chunk c, V = B^T d B
-      floatx4 V[16];
-      {
-        floatx4 t[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          t[0 + j] = sub4(d[0 + j], d[8 + j]);
-          t[4 + j] = d[4 + j] + d[8 + j];
-          t[8 + j] = sub4(d[8 + j], d[4 + j]);
-          t[12 + j] = sub4(d[4 + j], d[12 + j]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          V[4 * i + 0] = sub4(t[4 * i + 0], t[4 * i + 2]);
-          V[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
-          V[4 * i + 2] = sub4(t[4 * i + 2], t[4 * i + 1]);
-          V[4 * i + 3] = sub4(t[4 * i + 1], t[4 * i + 3]);
-        }
-      }
-      // ---- 16 positions x 2 cout tiles x 4 k-steps, in 4 groups of 4 positions
+      // One chunk = 16 steps (one transform position each: 2 weight fragment reads for the next
+      // step, 8 MFMAs), with the rest of the work dealt out between them so that the matrix pipe
+      // never waits: input transform rows 1-3 under steps 0/4/8, the next stage's LDS stores under
+      // steps 9-11 (pixel buffer free since the barrier after the previous chunk's reads, weights
+      // go to the other buffer), the loads of the stage after that at step 12, the next chunk's
+      // pixel reads under steps 12-13.
       const float* ub = ufr + ubuf * U_BUF;
-      auto mfma_group = [&](int pg) {
-        floatx4 bf[4][2];
+      floatx4 bf[2][2];
+      xform_row(0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+      for (int nt = 0; nt < 2; ++nt) bf[0][nt] = *reinterpret_cast<const floatx4*>(ub + nt * 16 * 4);
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        if (p + 1 < 16) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
-            bf[q][nt] = *reinterpret_cast<const floatx4*>(ub + ((4 * pg + q) * 128 + nt * 16) * 4);
+            bf[(p + 1) & 1][nt] = *reinterpret_cast<const floatx4*>(ub + ((p + 1) * 128 + nt * 16) * 4);
+        }
+        if (p == 0) xform_row(1);
+        if (p == 4) xform_row(2);
+        if (p == 8) xform_row(3);
+        if (p == 9) store_held(ubuf ^ 1, 0);
+        if (p == 10) store_held(ubuf ^ 1, 1);
+        if (p == 11) store_held(ubuf ^ 1, 2);
+        if (p == 12) {
+          __syncthreads();  // the next stage is in LDS
+          issue_loads();
+          if (!last) read_d_rows(0, 2);
+        }
+        if (p == 13 && !last) read_d_rows(1, 3);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-              acc[4 * pg + q][nt] =
-                  __builtin_amdgcn_mfma_f32_16x16x4f32(V[4 * pg + q][j], bf[q][nt][j], acc[4 * pg + q][nt], 0, 0, 0);
-      };
-      mfma_group(0);
-      mfma_group(1);
-      mfma_group(2);
-      // ---- the stage after (item, c) goes into LDS (pixels: single buffer, free since the
-      //      barrier that followed the reads of chunk c; weights: the other buffer), and the
-      //      loads of the stage after that are issued: a whole chunk of MFMAs ahead of their use
-      store_held(ubuf ^ 1);
-      __syncthreads();
-      issue_loads();
-      if (!last) read_d();  // flies under the last quarter of the MFMAs
-      mfma_group(3);
+          for (int nt = 0; nt < 2; ++nt)
+            acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p][j], bf[p & 1][nt][j], acc[p][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       ubuf ^= 1;
       if (!last) __syncthreads();  // every wave holds its pixels of chunk c+1
     }
 
-    // ---- output transform Y = A^T M A per (tile row i of the lane, cout tile), epilogue
-    const int ncol = n0 + (lane & 15);
+    // ---- output transform Y = A^T M A per (tile row i of the lane, cout tile), epilogue.
+    //      A lane holds the 2x2 pixels of ONE cout; a 4x4 transpose inside each lane quad (two
+    //      DPP butterfly stages) turns that into 4 consecutive couts of ONE pixel, so bias,
+    //      residual and store are 16-B accesses instead of 4-B ones.
+    const int lq = lane & 3;                       // after the transpose: the pixel this lane stores
+    const int ncol = n0 + ((lane & 15) & ~3);      // first of its 4 couts (+ nt * 16)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int go = bm * TPB + wave * 16 + 4 * kg + i;
-      if (go >= T) continue;
-      const int img = go / (TH * TW), r = go - img * (TH * TW);
+      const int go = bm * TPB + wave * 16 + 4 * kg + i;   // uniform over the 16 lanes of a kg group
+      const int gc = go < T ? go : 0;
+      const int img = gc / (TH * TW), r = gc - img * (TH * TW);
       const int th = r / TW, tw = r - th * TW;
-      const int oh = 2 * th, ow = 2 * tw;
+      const int oh = 2 * th + (lq >> 1), ow = 2 * tw + (lq & 1);
+      const bool ok = (go < T) & (oh < a.Ho) & (ow < a.Wo);
+      const int64_t obase = (((int64_t)img * a.Ho + oh) * a.Wo + ow) * a.Cout + ncol;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         float t0[4], t1[4];
@@ -275,25 +295,38 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
           t0[j] = acc[0 + j][nt][i] + acc[4 + j][nt][i] + acc[8 + j][nt][i];
           t1[j] = acc[4 + j][nt][i] - acc[8 + j][nt][i] - acc[12 + j][nt][i];
         }
-        float y[2][2];
-        y[0][0] = t0[0] + t0[1] + t0[2];
-        y[0][1] = t0[1] - t0[2] - t0[3];
-        y[1][0] = t1[0] + t1[1] + t1[2];
-        y[1][1] = t1[1] - t1[2] - t1[3];
-        const int n = ncol + nt * 16;
-        const float bias = a.bias ? a.bias[n] : 0.f;
+        float y[4];  // pixels (0,0) (0,1) (1,0) (1,1) of this lane's cout
+        y[0] = t0[0] + t0[1] + t0[2];
+        y[1] = t0[1] - t0[2] - t0[3];
+        y[2] = t1[0] + t1[1] + t1[2];
+        y[3] = t1[1] - t1[2] - t1[3];
+        // stage 1: lanes l, l^1 swap the off-diagonal of each 2x2 block
+        {
+          const bool odd = lq & 1;
+          const float s0 = odd ? y[0] : y[1], s1 = odd ? y[2] : y[3];
+          const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+          const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+          if (odd) { y[0] = x0; y[2] = x1; } else { y[1] = x0; y[3] = x1; }
+        }
+        // stage 2: lanes l, l^2 swap the off-diagonal 2x2 blocks
+        {
+          const bool hi = lq & 2;
+          const float s0 = hi ? y[0] : y[2], s1 = hi ? y[1] : y[3];
+          const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));
+          const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
+          if (hi) { y[0] = x0; y[1] = x1; } else { y[2] = x0; y[3] = x1; }
+        }
+        // y[c] = pixel lq, cout ncol + nt*16 + c
+        if (ok) {
+          floatx4 v = {y[0], y[1], y[2], y[3]};
+          if (a.bias) v += *reinterpret_cast<const floatx4*>(a.bias + ncol + nt * 16);
+          if (a.residual) v += *reinterpret_cast<const floatx4*>(a.residual + obase + nt * 16);
+          if (a.relu) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-          for (int ss = 0; ss < 2; ++ss) {
-            if (oh + rr < a.Ho && ow + ss < a.Wo) {
-              const int64_t o = (((int64_t)img * a.Ho + oh + rr) * a.Wo + ow + ss) * a.Cout + n;
-              float v = y[rr][ss] + bias;
-              if (a.residual) v += a.residual[o];
-              if (a.relu) v = fmaxf(v, 0.f);
-              a.y[o] = v;
-            }
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
           }
+          *reinterpret_cast<floatx4*>(a.y + obase + nt * 16) = v;
+        }
       }
     }
     item += nslot;
@@ -404,11 +437,31 @@ int conv_wino_transform_weights(const float* d_w, float* d_U, int cout, int cin,
   return check_launch("wino_weight_transform");
 }
 
+// geometry of the last few (H, W, batch) seen: the look-ahead loop of wino_geom is not free
+const WinoGeom& cached_geom(int H, int W, int64_t n_img) {
+  struct Entry { int H, W; int64_t n; WinoGeom g; };
+  static Entry cache[16];
+  static int used = 0, next = 0;
+  for (int i = 0; i < used; ++i)
+    if (cache[i].H == H && cache[i].W == W && cache[i].n == n_img) return cache[i].g;
+  const int slot = used < 16 ? used++ : (next++ % 16);
+  cache[slot] = Entry{H, W, n_img, wino_geom(H, W, n_img)};
+  return cache[slot].g;
+}
+
+// batch-dependent part of the applicability test: 32-bit buffer offsets, staged range fits
+bool conv_wino_launchable(const ConvArgs& a) {
+  const int64_t n_img = a.M / ((int64_t)a.Ho * a.Wo);
+  if (n_img * a.H * a.W * a.Cin * 4 >= (1ll << 31)) return false;
+  const WinoGeom& g = cached_geom(a.H, a.W, n_img);
+  return g.ok && g.Pmax <= kMaxNld * 64 && wino_lds_bytes(g.Pmax) <= 160 * 1024;
+}
+
 // a.w must point at the transformed weights U
 int launch_conv_wino(const ConvArgs& a, hipStream_t stream) {
-  const WinoGeom g = wino_geom(a.H, a.W, a.M / ((int64_t)a.Ho * a.Wo));
-  if (!g.ok || g.Pmax > kMaxNld * 64 || wino_lds_bytes(g.Pmax) > 160 * 1024)
-    return fail(HP_ERR_ARG, "conv3x3_wino_f32: geometry not supported (check conv_wino_applicable)");
+  if (!conv_wino_launchable(a))
+    return fail(HP_ERR_ARG, "conv3x3_wino_f32: geometry not supported (check conv_wino_launchable)");
+  const WinoGeom& g = cached_geom(a.H, a.W, a.M / ((int64_t)a.Ho * a.Wo));
   return a.pre_scale ? launch_nld<true>(a, g, stream) : launch_nld<false>(a, g, stream);
 }
 

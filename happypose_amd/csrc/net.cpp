@@ -335,7 +335,7 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
         HP_CHECK_HIP(hipEventRecord(ev.e0, stream));
       }
       static const bool no_patch = std::getenv("HP_CONV_NO_PATCH") != nullptr;
-      if (L.w_wino.p) { a.w = (const float*)L.w_wino.p; rc = launch_conv_wino(a, stream); }
+      if (L.w_wino.p && conv_wino_launchable(a)) { a.w = (const float*)L.w_wino.p; rc = launch_conv_wino(a, stream); }
       else if (!no_patch && conv_patch_applicable(a, L.kh, L.kw)) rc = launch_conv_patch(a, L.cout == 64 ? 1 : 0, stream);
       else rc = launch_conv(a, L.cout == 64 ? 1 : 0, stream);
       if (rc) return rc;
@@ -461,7 +461,7 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   a.H = h; a.W = w; a.Cin = cin; a.Ho = (h + 2 * pad - kh) / stride + 1; a.Wo = (w + 2 * pad - kw) / stride + 1;
   a.Cout = cout; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.ktiles = Kpad / 32; a.relu = relu;
   a.M = (int64_t)n * a.Ho * a.Wo;
-  if (conv_wino_applicable(a, kh, kw)) {
+  if (conv_wino_applicable(a, kh, kw) && conv_wino_launchable(a)) {
     // test entry: the weights are transformed on every call into a per-process scratch buffer
     static float* d_U = nullptr;
     static size_t U_floats = 0;
