@@ -212,7 +212,7 @@ def main():
         poses = step()
     fence()
     elapsed = time.perf_counter() - t0
-    conv_ms, n_launch, conv_flops = model.backbone.profile_collect()
+    conv_ms, n_launch, conv_flops, mfma_flops = model.backbone.profile_collect()
     model.backbone.set_profiling(False)
     assert torch.isfinite(poses).all()
 
@@ -233,9 +233,16 @@ def main():
                                    f"hypotheses = {B} hypotheses/GPU, {N_ITERS} iterations, {args.arch} "
                                    "(WideResNet) on 6x240x320, 8 objects of 8.2k vertices / 16.1k faces, 1024^2 textures",
                        "hypotheses_per_gpu": B, "iterations": N_ITERS, "parallelism": f"hypothesis-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_patch_f32 + conv_igemm_f32 (fp32 MFMA implicit-GEMM conv, all 36 conv launches of a forward)",
+            # achieved = ALGORITHMIC FLOPs (direct-convolution 2*MAC) / kernel time.  30 of
+            # the 36 convs run as Winograd F(2x2,3x3) and execute 2.25x fewer MFMA FLOPs than that, so
+            # the fraction of the pipe actually busy is reported separately (mfma_executed_*).
+            "roofline": {"bound": "mfma",
+                         "kernel": "conv3x3_wino_f32 + conv_igemm_f32 (+ conv3x3_patch_f32 when Winograd does not apply): "
+                                   "fp32 MFMA conv kernels, all 36 conv launches of a forward",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "mfma_executed_tflops": mfma_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+                         "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if conv_ms > 0 else 0.0,
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }

@@ -47,5 +47,7 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t stream);
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream);
 int conv_setup_once();
+// HP_CONV_ALGO_* currently selected (hp_conv_select_algo / HP_CONV_NO_WINOGRAD, HP_CONV_NO_PATCH)
+int conv_algo();
 
 }  // namespace hp

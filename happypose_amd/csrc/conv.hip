@@ -41,6 +41,8 @@
 // roofline and the measured fraction.
 // Numerics: exact fp32 FMA chains (the f32 MFMA is bitwise an fmaf chain), K-order differs
 // from the reference's oneDNN/cuDNN kernels, so results agree to fp32 round-off, not bitwise.
+#include <cstdlib>
+
 #include "conv.h"
 #include "conv_epilogue.h"
 
@@ -354,6 +356,27 @@ int conv_setup_once() {
 }  // namespace hp
 
 // diagnostics: resident workgroups per CU the runtime grants a conv variant
+// ---- which kernel families the dispatchers may use (process-wide diagnostic switch) ----------
+namespace hp {
+namespace {
+int g_conv_algo = -1;  // -1: not initialised (environment), else HP_CONV_ALGO_*
+}
+int conv_algo() {
+  if (g_conv_algo < 0) {
+    g_conv_algo = HP_CONV_ALGO_AUTO;
+    if (std::getenv("HP_CONV_NO_WINOGRAD")) g_conv_algo = HP_CONV_ALGO_DIRECT;
+    if (std::getenv("HP_CONV_NO_WINOGRAD") && std::getenv("HP_CONV_NO_PATCH")) g_conv_algo = HP_CONV_ALGO_IGEMM;
+  }
+  return g_conv_algo;
+}
+}  // namespace hp
+
+extern "C" int hp_conv_select_algo(int algo) {
+  HP_REQUIRE(algo >= HP_CONV_ALGO_AUTO && algo <= HP_CONV_ALGO_IGEMM, "hp_conv_select_algo: unknown algorithm");
+  hp::g_conv_algo = algo;
+  return HP_OK;
+}
+
 extern "C" int hp_conv_occupancy(int variant) {
   using namespace hp;
   if (conv_setup_once() != HP_OK) return HP_ERR_HIP;

@@ -420,8 +420,7 @@ int launch_nld(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
 }  // namespace
 
 bool conv_wino_applicable(const ConvArgs& a, int kh, int kw) {
-  static const bool off = std::getenv("HP_CONV_NO_WINOGRAD") != nullptr;
-  if (off || kh != 3 || kw != 3 || a.stride != 1 || a.pad != 1 || a.Cin % CK != 0 || a.Cout % BN != 0) return false;
+  if (kh != 3 || kw != 3 || a.stride != 1 || a.pad != 1 || a.Cin % CK != 0 || a.Cout % BN != 0) return false;
   if (a.H < 2 || a.W < 2 || a.Ho != a.H || a.Wo != a.W) return false;
   // the staged pixel range of 64 consecutive tiles must fit LDS next to the weight buffers
   // (batch independent once there are a few images: look at a long virtual batch)

@@ -51,7 +51,7 @@ struct ConvLayer {
   DevBuf w, w_wino, bias, lut, pre_scale, pre_shift;  // w_wino: Winograd-transformed weights (3x3 s1 layers)
 };
 
-struct EventPair { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0.0; int conv = -1; };
+struct EventPair { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0.0, mfma_flops = 0.0; int conv = -1; };
 
 enum OpKind { OP_CONV, OP_MAXPOOL, OP_HEAD };
 struct Op { OpKind kind; int conv = -1; int in_buf = -1, out_buf = -1; int H = 0, W = 0, C = 0, Ho = 0, Wo = 0; };
@@ -334,10 +334,18 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
         ev.conv = op.conv;
         HP_CHECK_HIP(hipEventRecord(ev.e0, stream));
       }
-      static const bool no_patch = std::getenv("HP_CONV_NO_PATCH") != nullptr;
-      if (L.w_wino.p && conv_wino_launchable(a)) { a.w = (const float*)L.w_wino.p; rc = launch_conv_wino(a, stream); }
-      else if (!no_patch && conv_patch_applicable(a, L.kh, L.kw)) rc = launch_conv_patch(a, L.cout == 64 ? 1 : 0, stream);
-      else rc = launch_conv(a, L.cout == 64 ? 1 : 0, stream);
+      const int algo = conv_algo();
+      // FLOPs the matrix cores actually execute (padded tiles / K included): 16 multiplies per
+      // 2x2 output tile, cin and cout for the Winograd layers, M x Cout x Kpad otherwise
+      if (algo == HP_CONV_ALGO_AUTO && L.w_wino.p && conv_wino_launchable(a)) {
+        a.w = (const float*)L.w_wino.p;
+        rc = launch_conv_wino(a, stream);
+        ev.mfma_flops = 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout;
+      } else {
+        if (algo != HP_CONV_ALGO_IGEMM && conv_patch_applicable(a, L.kh, L.kw)) rc = launch_conv_patch(a, L.cout == 64 ? 1 : 0, stream);
+        else rc = launch_conv(a, L.cout == 64 ? 1 : 0, stream);
+        ev.mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout * L.Kpad;
+      }
       if (rc) return rc;
       if (net->profiling) {
         HP_CHECK_HIP(hipEventRecord(ev.e1, stream));
@@ -383,9 +391,10 @@ extern "C" int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d
   return HP_OK;
 }
 
-extern "C" int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, double* conv_flops) {
+extern "C" int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, double* conv_flops,
+                                      double* mfma_flops) {
   HP_REQUIRE(net, "hp_net_profile_collect: null net");
-  double ms_total = 0.0, fl = 0.0;
+  double ms_total = 0.0, fl = 0.0, mfl = 0.0;
   const bool verbose = std::getenv("HP_PROFILE_LAYERS") != nullptr;
   std::vector<double> lms(net->convs.size(), 0.0), lfl(net->convs.size(), 0.0);
   std::vector<int> lcnt(net->convs.size(), 0);
@@ -395,6 +404,7 @@ extern "C" int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_l
     HP_CHECK_HIP(hipEventElapsedTime(&ms, p.e0, p.e1));
     ms_total += ms;
     fl += p.flops;
+    mfl += p.mfma_flops;
     if (p.conv >= 0) { lms[p.conv] += ms; lfl[p.conv] += p.flops; lcnt[p.conv]++; }
     net->ev_pool.push_back(p);
   }
@@ -410,6 +420,7 @@ extern "C" int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_l
   if (conv_ms) *conv_ms = ms_total;
   if (n_launches) *n_launches = (int64_t)net->ev_pending.size();
   if (conv_flops) *conv_flops = fl;
+  if (mfma_flops) *mfma_flops = mfl;
   net->ev_pending.clear();
   return HP_OK;
 }
@@ -461,7 +472,8 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   a.H = h; a.W = w; a.Cin = cin; a.Ho = (h + 2 * pad - kh) / stride + 1; a.Wo = (w + 2 * pad - kw) / stride + 1;
   a.Cout = cout; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.ktiles = Kpad / 32; a.relu = relu;
   a.M = (int64_t)n * a.Ho * a.Wo;
-  if (conv_wino_applicable(a, kh, kw) && conv_wino_launchable(a)) {
+  const int algo = conv_algo();
+  if (algo == HP_CONV_ALGO_AUTO && conv_wino_applicable(a, kh, kw) && conv_wino_launchable(a)) {
     // test entry: the weights are transformed on every call into a per-process scratch buffer
     static float* d_U = nullptr;
     static size_t U_floats = 0;
@@ -476,7 +488,7 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
     a.w = d_U;
     return launch_conv_wino(a, (hipStream_t)stream);
   }
-  if (std::getenv("HP_CONV_NO_PATCH") == nullptr && conv_patch_applicable(a, kh, kw))
+  if (algo != HP_CONV_ALGO_IGEMM && conv_patch_applicable(a, kh, kw))
     return launch_conv_patch(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
   return launch_conv(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
 }

@@ -302,12 +302,24 @@ class Net:
         check(lib().hp_net_set_profiling(self.handle, int(on)), "hp_net_set_profiling")
 
     def profile_collect(self):
-        """``(conv_ms, n_launches, conv_flops)`` of the conv launches recorded since the last
-        call (HIP events on the launch stream; waits for them)."""
-        ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
-        check(lib().hp_net_profile_collect(self.handle, C.byref(ms), C.byref(n), C.byref(fl)),
+        """``(conv_ms, n_launches, conv_flops, mfma_flops)`` of the conv launches recorded since
+        the last call (HIP events on the launch stream; waits for them): algorithmic FLOPs of the
+        direct convolutions and FLOPs the matrix cores executed (Winograd layers execute 2.25x
+        fewer, padded tiles more)."""
+        ms, n, fl, mfl = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
+        check(lib().hp_net_profile_collect(self.handle, C.byref(ms), C.byref(n), C.byref(fl), C.byref(mfl)),
               "hp_net_profile_collect")
-        return ms.value, n.value, fl.value
+        return ms.value, n.value, fl.value, mfl.value
+
+
+CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2}
+
+
+def select_conv_algo(name: str = "auto") -> None:
+    """Restrict the conv kernels the library may pick (process wide; parity tests / diagnostics):
+    ``auto`` = Winograd F(2x2,3x3) where it applies, ``direct`` = no Winograd, ``igemm`` = the
+    generic implicit-GEMM kernel only (``hp_conv_select_algo``)."""
+    check(lib().hp_conv_select_algo(CONV_ALGOS[name]), "hp_conv_select_algo")
 
 
 def conv2d_nhwc(x, w_packed, stride, pad, bias=None, residual=None, pre_scale=None, pre_shift=None, relu=False):

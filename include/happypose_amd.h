@@ -199,11 +199,22 @@ double hp_net_flops_per_sample(const hp_net* net);
 /* Profiling of the dominant kernel: with hp_net_set_profiling(net, 1) every conv launch is
  * bracketed by a pair of HIP events recorded on the launch stream (no synchronisation).
  * hp_net_profile_collect waits for the recorded pairs and returns the summed kernel time
- * (ms), the number of launches and their algorithmic FLOPs since the previous collect. */
+ * (ms), the number of launches, their ALGORITHMIC FLOPs (2 x M x Cout x kh x kw x Cin of the
+ * direct convolution) and the FLOPs the matrix cores actually executed (less for the Winograd
+ * layers, more where tiles / K are padded) since the previous collect. */
 int hp_net_set_profiling(hp_net* net, int enabled);
+/* Diagnostics / parity tests: restrict the convolution kernels the dispatchers may pick
+ * (process wide).  AUTO = Winograd F(2x2,3x3) for 3x3 stride-1 layers, else the patch-staged
+ * direct kernel, else the generic implicit GEMM; DIRECT = no Winograd; IGEMM = generic kernel only.
+ * Environment equivalents read at first use: HP_CONV_NO_WINOGRAD, HP_CONV_NO_PATCH. */
+#define HP_CONV_ALGO_AUTO 0
+#define HP_CONV_ALGO_DIRECT 1
+#define HP_CONV_ALGO_IGEMM 2
+int hp_conv_select_algo(int algo);
 /* diagnostics: workgroups per CU the runtime grants conv tile variant 0 (128x128) / 1 (128x64) */
 int hp_conv_occupancy(int variant);
-int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, double* conv_flops);
+int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, double* conv_flops,
+                           double* mfma_flops);
 
 /* Single layer entry (used by the parity tests of the conv kernel itself):
  * y[n][ho][wo][cout] = act( conv(x_act, w) + bias + residual ),

@@ -324,6 +324,32 @@ def _conv_ref(x_nhwc, w_oihw, stride, pad, bias, residual, pre, relu):
     dict(n=2, h=31, w=23, cin=8, cout=64, k=2, s=1, p=0, bias=False, res=False, pre=False, relu=False),
 ])
 def test_conv2d_vs_fp64(dev, case):
+    _check_conv(dev, case)
+
+
+# the three kernel families behind 3x3 / stride-1 layers must agree with fp64: Winograd F(2x2,3x3)
+# ("auto"), the patch-staged direct kernel ("direct") and the generic implicit GEMM ("igemm")
+@pytest.mark.parametrize("algo", ["auto", "direct", "igemm"])
+@pytest.mark.parametrize("case", [
+    dict(n=3, h=30, w=40, cin=128, cout=128, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=True),
+    dict(n=7, h=15, w=20, cin=256, cout=256, k=3, s=1, p=1, bias=False, res=True, pre=True, relu=False),  # odd H
+    dict(n=9, h=8, w=10, cin=512, cout=512, k=3, s=1, p=1, bias=True, res=False, pre=False, relu=True),    # tiles span images
+    dict(n=5, h=9, w=7, cin=32, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=False),        # odd H and W, ragged
+    dict(n=1, h=2, w=2, cin=32, cout=64, k=3, s=1, p=1, bias=False, res=False, pre=False, relu=False),     # a single tile
+    dict(n=130, h=8, w=10, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=False, relu=True),     # > 1 item per block
+])
+def test_conv3x3_kernel_families(dev, case, algo):
+    from happypose_amd import ops
+
+    ops.select_conv_algo(algo)
+    try:
+        # Winograd's transforms cost about one extra bit of round-off
+        _check_conv(dev, case, tol=4e-5 if algo == "auto" else 2e-5)
+    finally:
+        ops.select_conv_algo("auto")
+
+
+def _check_conv(dev, case, tol=2e-5):
     from happypose_amd import ops
 
     rs = np.random.RandomState(3)
@@ -340,7 +366,7 @@ def test_conv2d_vs_fp64(dev, case):
     y = ops.conv2d_nhwc(t(x), t(wp), c["s"], c["p"], t(bias), t(res), t(pre[0]) if pre else None,
                         t(pre[1]) if pre else None, c["relu"])
     err = np.abs(y.cpu().numpy() - ref).max()
-    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
+    assert err <= tol * max(1.0, np.abs(ref).max()), err
 
 
 @pytest.mark.parametrize("arch,cin,tag", [("vanilla_resnet34", 27, "vanilla_resnet34_27"),
