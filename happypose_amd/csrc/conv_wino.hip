@@ -41,6 +41,7 @@
 // the couts fastest, so the blocks that re-read the same input share an L2.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv.h"
 
@@ -124,42 +125,61 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   const float* const ufr = ul + (kg * BN + (lane & 15)) * 4;         // + (pos*128 + nt*16) * 4
   float* const rdst = rawl + (c4 * Pp) * 4;
 
-  // ---- the load cursor runs two stages (item, chunk) ahead of the compute cursor; past the
-  //      last stage it keeps re-reading it (harmless, keeps the loop branch free)
-  floatx4 rs[NLD], us[8];
-  floatx4 ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};  // prologue of the chunk held in rs
-  int l_item = item, l_c = 0, l_lo, l_P;
-  int held_P = 0;
-  item_range(l_item / tiles_n, T, TH, TW, H, W, l_lo, l_P);
-  auto issue_loads = [&]() {
-    const int xs = (l_lo * Cin + l_c * CK) * 4;
-#pragma unroll
-    for (int k = 0; k < NLD; ++k)
-      rs[k] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, x_voff, xs + k * x_kstride, 0));
-    const int s = (l_item % tiles_n) * (4 * BN * 16) + l_c * u_chunk_stride;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      us[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, u_voff, s + 2 * i * u_pos_stride, 0));
-    if (PRE) {
-      ps = *reinterpret_cast<const floatx4*>(a.pre_scale + l_c * CK + 4 * c4);
-      pb = *reinterpret_cast<const floatx4*>(a.pre_shift + l_c * CK + 4 * c4);
-    }
-    held_P = l_P;
-    const bool wrap = l_c + 1 == nchunks;
-    const bool more = !wrap || l_item + nslot < item_end;
+  // ---- two load cursors run ahead of the compute cursor over the stages (item, chunk): the
+  //      pixel cursor three stages (two register sets, alternating with the parity of the chunk:
+  //      pixel data comes from HBM / the far L2 and needs more than one chunk of MFMAs to arrive),
+  //      the weight cursor two (L2 resident).  Past the last stage they keep re-reading it
+  //      (harmless, keeps the loop branch free).
+  struct Cursor { int item, c, lo, P; };
+  auto advance = [&](Cursor& k) {
+    const bool wrap = k.c + 1 == nchunks;
+    const bool more = !wrap || k.item + nslot < item_end;
     if (more) {
-      l_c = wrap ? 0 : l_c + 1;
+      k.c = wrap ? 0 : k.c + 1;
       if (wrap) {
-        l_item += nslot;
-        item_range(l_item / tiles_n, T, TH, TW, H, W, l_lo, l_P);
+        k.item += nslot;
+        item_range(k.item / tiles_n, T, TH, TW, H, W, k.lo, k.P);
       }
     }
   };
-  // rs/us -> LDS (pixels: the single buffer; weights: buffer ubuf), in three parts
-  auto store_held = [&](int ubuf, int part) {
+  Cursor rc{item, 0, 0, 0}, uc{item, 0, 0, 0};
+  item_range(item / tiles_n, T, TH, TW, H, W, rc.lo, rc.P);
+  floatx4 rsA[NLD], rsB[NLD], us[8];
+  floatx4 psA = {1.f, 1.f, 1.f, 1.f}, pbA = {0.f, 0.f, 0.f, 0.f}, psB = psA, pbB = pbA;  // prologue of the held chunks
+  int heldA = 0, heldB = 0;  // P of the stage held in each set
+  // the loads of a stage are issued in 8 parts (one per step): a burst of 4 waves x 14-18 loads
+  // backs up the texture-address FIFO and the waves stall at issue with the matrix pipe idle
+  auto issue_raw = [&](auto set, int part) {
+    floatx4(&rs)[NLD] = decltype(set)::value ? rsB : rsA;
+    const int xs = (rc.lo * Cin + rc.c * CK) * 4;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (part < 0 || k % 8 == part)
+        rs[k] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, x_voff, xs + k * x_kstride, 0));
+    if (part >= 0 && part < 7) return;
+    if (PRE) {
+      (decltype(set)::value ? psB : psA) = *reinterpret_cast<const floatx4*>(a.pre_scale + rc.c * CK + 4 * c4);
+      (decltype(set)::value ? pbB : pbA) = *reinterpret_cast<const floatx4*>(a.pre_shift + rc.c * CK + 4 * c4);
+    }
+    (decltype(set)::value ? heldB : heldA) = rc.P;
+    advance(rc);
+  };
+  auto issue_u = [&](int part) {
+    const int s = (uc.item % tiles_n) * (4 * BN * 16) + uc.c * u_chunk_stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (part < 0 || i == part)
+        us[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, u_voff, s + 2 * i * u_pos_stride, 0));
+    if (part < 0 || part == 7) advance(uc);
+  };
+  // held stage -> LDS (pixels: the single buffer; weights: buffer ubuf), in eight parts (or all: -1)
+  auto store_held = [&](auto set, int ubuf, int part) {
+    floatx4(&rs)[NLD] = decltype(set)::value ? rsB : rsA;
+    const floatx4 ps = decltype(set)::value ? psB : psA, pb = decltype(set)::value ? pbB : pbA;
+    const int held_P = decltype(set)::value ? heldB : heldA;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-      if (k % 3 != part) continue;
+      if (part >= 0 && k % 8 != part) continue;
       const int row = srow + 64 * k;
       floatx4 v = rs[k];
       if (PRE) {
@@ -171,14 +191,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     float* d = udst + ubuf * U_BUF;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (i % 3 == part) *reinterpret_cast<floatx4*>(d + 1024 * i) = us[i];
+      if (part < 0 || i == part) *reinterpret_cast<floatx4*>(d + 1024 * i) = us[i];
   };
+  constexpr std::integral_constant<int, 0> SET_A{};
+  constexpr std::integral_constant<int, 1> SET_B{};
 
   int ubuf = 0;  // weight buffer holding the chunk about to be consumed
-  issue_loads();
-  store_held(ubuf, 0); store_held(ubuf, 1); store_held(ubuf, 2);
+  issue_raw(SET_A, -1);  // stage 0
+  issue_u(-1);
+  store_held(SET_A, ubuf, -1);
   __syncthreads();
-  issue_loads();
+  issue_raw(SET_B, -1);  // stage 1: stored during chunk 0
+  issue_raw(SET_A, -1);  // stage 2: stored during chunk 1
+  issue_u(-1);           // stage 1
 
   for (;;) {
     const int bm = item / tiles_n, n0 = (item % tiles_n) * BN;
@@ -201,11 +226,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       }
     }
     floatx4 d[16], V[16];
-    auto read_d_rows = [&](int r0, int r1) {  // pixel rows r0 and r1 of the 4x4 patch
+    auto read_d_rows = [&](const float* rb, int r0, int r1) {  // pixel rows r0 and r1 of the 4x4 patch
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        d[4 * r0 + j] = *reinterpret_cast<const floatx4*>(rawl + doff[4 * r0 + j]);
-        d[4 * r1 + j] = *reinterpret_cast<const floatx4*>(rawl + doff[4 * r1 + j]);
+        d[4 * r0 + j] = *reinterpret_cast<const floatx4*>(rb + doff[4 * r0 + j]);
+        if (r1 != r0) d[4 * r1 + j] = *reinterpret_cast<const floatx4*>(rb + doff[4 * r1 + j]);
       }
     };
     // V row i = (B^T d) row i times B
@@ -214,13 +239,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         t[j] = i == 0 ? sub4(d[0 + j], d[8 + j]) : i == 1 ? d[4 + j] + d[8 + j] : i == 2 ? sub4(d[8 + j], d[4 + j]) : sub4(d[4 + j], d[12 + j]);
+#ifdef HP_WABL_NO_XFORM
+      V[4 * i + 0] = d[4 * i + 0]; V[4 * i + 1] = d[4 * i + 1]; V[4 * i + 2] = d[4 * i + 2]; V[4 * i + 3] = d[4 * i + 3];
+#else
       V[4 * i + 0] = sub4(t[0], t[2]);
       V[4 * i + 1] = t[1] + t[2];
       V[4 * i + 2] = sub4(t[2], t[1]);
       V[4 * i + 3] = sub4(t[1], t[3]);
+#endif
     };
-    read_d_rows(0, 2);
-    read_d_rows(1, 3);
+    read_d_rows(rawl, 0, 2);
+    read_d_rows(rawl, 1, 3);
 
     floatx4 acc[16][2];
 #pragma unroll
@@ -229,7 +258,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       for (int nt = 0; nt < 2; ++nt) acc[p][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();  // every wave holds its pixels of chunk 0: the pixel buffer may be refilled
 
-    for (int c = 0; c < nchunks; ++c) {
+    // one chunk; `odd` = parity of the chunk = register set of the stage two ahead (the set of
+    // the next stage is the other one)
+    auto chunk = [&](int c, auto odd) {
+      constexpr std::integral_constant<int, 1 - decltype(odd)::value> nxt{};
       const bool last = c + 1 == nchunks;
       // One chunk = 16 steps (one transform position each: 2 weight fragment reads for the next
       // step, 8 MFMAs), with the rest of the work dealt out between them so that the matrix pipe
@@ -252,24 +284,47 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
         if (p == 0) xform_row(1);
         if (p == 4) xform_row(2);
         if (p == 8) xform_row(3);
-        if (p == 9) store_held(ubuf ^ 1, 0);
-        if (p == 10) store_held(ubuf ^ 1, 1);
-        if (p == 11) store_held(ubuf ^ 1, 2);
-        if (p == 12) {
-          __syncthreads();  // the next stage is in LDS
-          issue_loads();
-          if (!last) read_d_rows(0, 2);
+#if !defined(HP_WABL_NO_STAGE) && !defined(HP_WABL_NO_LSTORE)
+        if (p < 8) store_held(nxt, ubuf ^ 1, p);
+#endif
+#if !defined(HP_WABL_NO_STAGE) && !defined(HP_WABL_NO_GLOAD)
+        if (p >= 8) {  // registers of the stage just stored are free: stage + 3 pixels, stage + 2 weights
+          issue_raw(nxt, p - 8);
+          issue_u(p - 8);
         }
-        if (p == 13 && !last) read_d_rows(1, 3);
+#endif
+        if (p == 12) {
+#ifndef HP_WABL_NO_BARRIER
+          __syncthreads();  // the next stage is in LDS
+#endif
+
+        }
+#ifndef HP_WABL_NO_READD
+        if (p == 12 && !last) read_d_rows(rawl, 0, 0);
+        if (p == 13 && !last) read_d_rows(rawl, 2, 2);
+        if (p == 14 && !last) read_d_rows(rawl, 1, 1);
+        if (p == 15 && !last) read_d_rows(rawl, 3, 3);
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
             acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p][j], bf[p & 1][nt][j], acc[p][nt], 0, 0, 0);
+#ifndef HP_WABL_NO_PIN
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       ubuf ^= 1;
-      if (!last) __syncthreads();  // every wave holds its pixels of chunk c+1
+#ifndef HP_WABL_NO_BARRIER
+      // every wave holds its pixels of chunk c+1 and is done with this chunk's weights: both
+      // buffers may be refilled (a third weight buffer + a second pixel buffer would save this
+      // barrier, but the 60x80 layers have no LDS left for them)
+      if (!last) __syncthreads();
+#endif
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+      chunk(c, SET_A);
+      chunk(c + 1, SET_B);
     }
 
     // ---- output transform Y = A^T M A per (tile row i of the lane, cout tile), epilogue.
@@ -317,7 +372,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
           if (hi) { y[0] = x0; y[1] = x1; } else { y[2] = x0; y[3] = x1; }
         }
         // y[c] = pixel lq, cout ncol + nt*16 + c
+#ifdef HP_WABL_NO_EPI
+        if (ok && y[0] == 123.456f) {
+#else
         if (ok) {
+#endif
           floatx4 v = {y[0], y[1], y[2], y[3]};
           if (a.bias) v += *reinterpret_cast<const floatx4*>(a.bias + ncol + nt * 16);
           if (a.residual) v += *reinterpret_cast<const floatx4*>(a.residual + obase + nt * 16);
@@ -420,7 +479,7 @@ int launch_nld(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
 }  // namespace
 
 bool conv_wino_applicable(const ConvArgs& a, int kh, int kw) {
-  if (kh != 3 || kw != 3 || a.stride != 1 || a.pad != 1 || a.Cin % CK != 0 || a.Cout % BN != 0) return false;
+  if (kh != 3 || kw != 3 || a.stride != 1 || a.pad != 1 || a.Cin % (2 * CK) != 0 || a.Cout % BN != 0) return false;
   if (a.H < 2 || a.W < 2 || a.Ho != a.H || a.Wo != a.W) return false;
   // the staged pixel range of 64 consecutive tiles must fit LDS next to the weight buffers
   // (batch independent once there are a few images: look at a long virtual batch)
