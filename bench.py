@@ -35,49 +35,46 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dens
 N_DET, N_HYP, N_ITERS = 8, 16, 5
 
 
-def build_world(device, arch="resnet34", seed=0):
-    from happypose_amd.models import create_pose_model_cosypose
+WORKLOADS = ("C2", "C3", "C5")
+
+
+def build_world(device, arch="resnet34", seed=0, workload="C2"):
+    """Synthetic world of SURVEY.md 8(d) for a BASELINE.json config:
+    C2 CosyPose refiner (8 det x 16 hyp, WideResNet-34 on 6 channels, 1 RGB view);
+    C3 MegaPose RGB-D refiner (64 hypotheses, 4 views x (RGB + normals + depth), ResNet-34 on 32 ch);
+    C5 MegaPose coarse scoring (8 objects x 576 SO(3)-grid poses, 1 view RGB + normals, ResNet-34 on 9 ch)."""
+    from happypose_amd.models import create_model_pose, create_pose_model_cosypose, pose_model_param_shapes
     from happypose_amd.renderer import BatchRenderer
     from happypose_amd.synthetic import make_object_dataset, make_scene, predictor_weights
-    from happypose_amd.ops import ARCH  # noqa: F401
 
     ds = make_object_dataset(8, seed=1, tex_size=1024)
     renderer = BatchRenderer(ds, device=device)
-    scene = make_scene(n_detections=N_DET, n_hypotheses=N_HYP, n_objects=8, seed=2 + seed)
-    shapes = _predictor_shapes(arch, 6)
-    weights = predictor_weights(shapes, seed=0)
-    model = create_pose_model_cosypose(dict(backbone_str=arch), renderer, state_dict=weights,
-                                       max_batch=N_DET * N_HYP)
+    if workload == "C2":
+        scene = make_scene(n_detections=N_DET, n_hypotheses=N_HYP, n_objects=8, seed=2 + seed)
+        weights = predictor_weights(pose_model_param_shapes(arch, 6), seed=0)
+        model = create_pose_model_cosypose(dict(backbone_str=arch), renderer, state_dict=weights,
+                                           max_batch=N_DET * N_HYP)
+    elif workload == "C3":
+        scene = make_scene(n_detections=8, n_hypotheses=8, n_objects=8, seed=2 + seed, with_depth=True)
+        weights = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 32), seed=0)
+        cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views",
+                   render_normals=True, render_depth=True, input_depth=True, predict_pose_update=True,
+                   depth_augmentation=False, depth_normalization_type="tCR_scale_clamp_center")
+        model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=64)
+    else:
+        from happypose_amd.pose_estimator import load_SO3_grid
+
+        scene = make_scene(n_detections=8, n_hypotheses=1, n_objects=8, seed=2 + seed)
+        grid = load_SO3_grid(576).numpy()
+        T = np.repeat(scene["TCO_det"], 576, axis=0)
+        T[:, :3, :3] = np.tile(grid, (8, 1, 1))
+        scene["TCO_hyp"] = T.astype(np.float32)
+        scene["hyp_obj_ids"] = np.repeat(scene["det_obj_ids"], 576).astype(np.int32)
+        weights = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 9, pose_dim=0, n_views_logits=1), seed=0)
+        cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
+                   predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
+        model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=576)
     return ds, renderer, scene, weights, model
-
-
-def _predictor_shapes(arch, n_in):
-    """state-dict key -> shape of the predictor (same table the tests use; kept here so the
-    product side of the bench does not import the oracle)."""
-    planes, layers = [64, 128, 256, 512], {"resnet34": [3, 4, 6, 3], "resnet18": [2, 2, 2, 2]}[arch]
-    s = {}
-
-    def bn(p, c):
-        for k in ("weight", "bias", "running_mean", "running_var"):
-            s[f"{p}.{k}"] = (c,)
-
-    s["backbone.conv1.weight"] = (64, n_in, 5, 5)
-    bn("backbone.bn1", 64)
-    inpl = 64
-    for li, (pl, nb) in enumerate(zip(planes, layers), start=1):
-        for b in range(nb):
-            stride = 2 if (b == 0 and li > 1) else 1
-            p = f"backbone.layer{li}.{b}"
-            bn(f"{p}.bn1", inpl)
-            s[f"{p}.conv1.weight"] = (pl, inpl, 3, 3)
-            bn(f"{p}.bn2", pl)
-            s[f"{p}.conv2.weight"] = (pl, pl, 3, 3)
-            if stride != 1 or inpl != pl:
-                s[f"{p}.downsample.weight"] = (pl, inpl, 1, 1)
-            inpl = pl
-    s["pose_fc.weight"] = (9, 512)
-    s["pose_fc.bias"] = (9,)
-    return s
 
 
 def effective_cpu_count() -> int:
@@ -169,6 +166,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--arch", default="resnet34", choices=["resnet34", "resnet18"])
+    ap.add_argument("--workload", default="C2", choices=list(WORKLOADS),
+                    help="BASELINE.json config (default C2 = the one the headline metric is quoted on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-1thread", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -182,9 +181,9 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
-    ds, renderer, scene, weights, model = build_world(device, args.arch, seed=rank)
+    ds, renderer, scene, weights, model = build_world(device, args.arch, seed=rank, workload=args.workload)
     store = renderer.store
-    B = N_DET * N_HYP
+    B = len(scene["TCO_hyp"])
     images = torch.as_tensor(scene["images"], device=device)  # inputs resident in HBM
     K = torch.as_tensor(scene["K"], device=device)
     TCO0 = torch.as_tensor(scene["TCO_hyp"], device=device)
@@ -192,10 +191,15 @@ def main():
     im_ids = torch.zeros(B, dtype=torch.int32, device=device)
 
     def step():
-        out = model.forward(images, K, labels, TCO0, n_iterations=N_ITERS, im_ids=im_ids)
-        poses = out[f"iteration={N_ITERS}"].TCO_output
+        if args.workload == "C5":  # coarse scoring, one object (576 grid poses) per chunk as in 8(e)
+            scores = [model.forward_coarse(images, K, labels[i:i + 576], TCO0[i:i + 576], im_ids=im_ids[i:i + 576])["logits"]
+                      for i in range(0, B, 576)]
+            poses, logits = TCO0, torch.cat(scores).reshape(-1)
+        else:
+            out = model.forward(images, K, labels, TCO0, n_iterations=N_ITERS, im_ids=im_ids)
+            poses, logits = out[f"iteration={N_ITERS}"].TCO_output, None
         if world > 1:
-            poses, _ = D.gather_poses(poses, None, rank * B, world * B)
+            poses, _ = D.gather_poses(poses, logits, rank * B, world * B)
         return poses
 
     def fence():
@@ -224,15 +228,23 @@ def main():
     if rank == 0:
         total = world * B * args.steps
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        desc = {
+            "C2": f"C2: CosyPose refiner, one 640x480 frame per GPU, {N_DET} detections x {N_HYP} hypotheses = {B} "
+                  f"hypotheses/GPU, {N_ITERS} iterations, {args.arch} (WideResNet) on 6x240x320",
+            "C3": f"C3: MegaPose RGB-D refiner, one 640x480 RGB-D frame per GPU, {B} hypotheses/GPU, {N_ITERS} iterations, "
+                  "4 views x (RGB + normals + depth), vanilla_resnet34 on 32x240x320",
+            "C5": f"C5 (fp32; the fp16 variant is not built yet): MegaPose coarse scoring, 8 objects x 576 SO(3)-grid "
+                  f"poses = {B} views/GPU, RGB + normals, vanilla_resnet34 on 9x240x320",
+        }[args.workload] + ", 8 objects of 8.2k vertices / 16.1k faces, 1024^2 textures"
         line = {
-            "metric": "refined poses/sec (640x480, 16 hyp/det, 5 refiner iters)",
-            "value": total / elapsed, "unit": "refined poses/s", "n_gpus": world, "steps": args.steps,
+            "metric": "refined poses/sec (640x480, 16 hyp/det, 5 refiner iters)" if args.workload != "C5"
+                      else "coarse-scoring views/sec (640x480, 576 SO(3)-grid poses / object)",
+            "value": total / elapsed, "unit": "refined poses/s" if args.workload != "C5" else "views/s",
+            "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2: CosyPose refiner, one 640x480 frame per GPU, {N_DET} detections x {N_HYP} "
-                                   f"hypotheses = {B} hypotheses/GPU, {N_ITERS} iterations, {args.arch} "
-                                   "(WideResNet) on 6x240x320, 8 objects of 8.2k vertices / 16.1k faces, 1024^2 textures",
-                       "hypotheses_per_gpu": B, "iterations": N_ITERS, "parallelism": f"hypothesis-shard x{world}"},
+            "config": {"workload": desc, "hypotheses_per_gpu": B, "iterations": N_ITERS if args.workload != "C5" else 1,
+                       "parallelism": f"hypothesis-shard x{world}"},
             # achieved = ALGORITHMIC FLOPs (direct-convolution 2*MAC) / kernel time.  30 of
             # the 36 convs run as Winograd F(2x2,3x3) and execute 2.25x fewer MFMA FLOPs than that, so
             # the fraction of the pipe actually busy is reported separately (mfma_executed_*).
@@ -246,8 +258,9 @@ def main():
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }
-        line["stages"] = stage_rates(store, scene, images, K, TCO0, im_ids, device)
-        if not args.no_cpu_baseline:
+        if args.workload == "C2":
+            line["stages"] = stage_rates(store, scene, images, K, TCO0, im_ids, device)
+        if not args.no_cpu_baseline and args.workload == "C2":
             base = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds)
             line["cpu_baseline"] = base
             line["speedup_vs_cpu"] = line["value"] / base["value"]

@@ -85,6 +85,60 @@ def _arch(backbone_str: str) -> str:
     raise ValueError("Unknown backbone", backbone_str)  # e.g. efficientnet-b3: SURVEY.md section 8f
 
 
+def pose_model_param_shapes(backbone_str: str, n_inputs: int, pose_dim: int = 9,
+                            n_views_logits: int = 0) -> Dict[str, tuple]:
+    """state-dict key -> shape of a pose model, in the reference's registration order:
+    ``vanilla_resnet34`` = ``MP/models/torchvision_resnet.py:191-344`` (7x7 stem, BasicBlock,
+    BN after the 1x1 downsample, fc 512->512); ``resnet34`` / ``resnet18`` = the WideResNet of
+    ``MP/models/wide_resnet.py:68-154`` (5x5 stem, pre-activation BasicBlockV2, conv-only
+    downsample); heads ``MP/models/pose_rigid.py:135-149``."""
+    s: Dict[str, tuple] = {}
+
+    def bn(p, c):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{p}.{k}"] = (c,)
+        s[f"{p}.num_batches_tracked"] = ()
+
+    planes = [64, 128, 256, 512]
+    vanilla = backbone_str == "vanilla_resnet34"
+    layers = [2, 2, 2, 2] if backbone_str == "resnet18" else [3, 4, 6, 3]
+    assert backbone_str in ("vanilla_resnet34", "resnet34", "resnet18"), backbone_str
+    k1 = 7 if vanilla else 5
+    s["backbone.conv1.weight"] = (64, n_inputs, k1, k1)
+    bn("backbone.bn1", 64)
+    inpl = 64
+    for li, (pl, nb) in enumerate(zip(planes, layers), start=1):
+        for b in range(nb):
+            stride = 2 if (b == 0 and li > 1) else 1
+            p = f"backbone.layer{li}.{b}"
+            if vanilla:
+                s[f"{p}.conv1.weight"] = (pl, inpl, 3, 3)
+                bn(f"{p}.bn1", pl)
+                s[f"{p}.conv2.weight"] = (pl, pl, 3, 3)
+                bn(f"{p}.bn2", pl)
+                if stride != 1 or inpl != pl:
+                    s[f"{p}.downsample.0.weight"] = (pl, inpl, 1, 1)
+                    bn(f"{p}.downsample.1", pl)
+            else:
+                bn(f"{p}.bn1", inpl)
+                s[f"{p}.conv1.weight"] = (pl, inpl, 3, 3)
+                bn(f"{p}.bn2", pl)
+                s[f"{p}.conv2.weight"] = (pl, pl, 3, 3)
+                if stride != 1 or inpl != pl:
+                    s[f"{p}.downsample.weight"] = (pl, inpl, 1, 1)
+            inpl = pl
+    if vanilla:
+        s["backbone.fc.weight"] = (512, 512)
+        s["backbone.fc.bias"] = (512,)
+    if pose_dim:
+        s["pose_fc.weight"] = (pose_dim, 512)
+        s["pose_fc.bias"] = (pose_dim,)
+    if n_views_logits:
+        s["views_logits_head.weight"] = (n_views_logits, 512)
+        s["views_logits_head.bias"] = (n_views_logits,)
+    return s
+
+
 def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Optional[Dict] = None,
                       max_batch: int = 128) -> PosePredictor:
     """MegaPose predictor (``MP/training/pose_models_cfg.py:89-142``).  ``state_dict`` holds the
