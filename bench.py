@@ -32,13 +32,14 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_BPS = 8.0e12        # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2516.6  # dense fp16 MFMA: 16x the fp32 rate (same table)
 N_DET, N_HYP, N_ITERS = 8, 16, 5
 
 
 WORKLOADS = ("C2", "C3", "C5")
 
 
-def build_world(device, arch="resnet34", seed=0, workload="C2"):
+def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32"):
     """Synthetic world of SURVEY.md 8(d) for a BASELINE.json config:
     C2 CosyPose refiner (8 det x 16 hyp, WideResNet-34 on 6 channels, 1 RGB view);
     C3 MegaPose RGB-D refiner (64 hypotheses, 4 views x (RGB + normals + depth), ResNet-34 on 32 ch);
@@ -53,14 +54,14 @@ def build_world(device, arch="resnet34", seed=0, workload="C2"):
         scene = make_scene(n_detections=N_DET, n_hypotheses=N_HYP, n_objects=8, seed=2 + seed)
         weights = predictor_weights(pose_model_param_shapes(arch, 6), seed=0)
         model = create_pose_model_cosypose(dict(backbone_str=arch), renderer, state_dict=weights,
-                                           max_batch=N_DET * N_HYP)
+                                           max_batch=N_DET * N_HYP, precision=precision)
     elif workload == "C3":
         scene = make_scene(n_detections=8, n_hypotheses=8, n_objects=8, seed=2 + seed, with_depth=True)
         weights = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 32), seed=0)
         cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views",
                    render_normals=True, render_depth=True, input_depth=True, predict_pose_update=True,
                    depth_augmentation=False, depth_normalization_type="tCR_scale_clamp_center")
-        model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=64)
+        model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=64, precision=precision)
     else:
         from happypose_amd.pose_estimator import load_SO3_grid
 
@@ -73,7 +74,7 @@ def build_world(device, arch="resnet34", seed=0, workload="C2"):
         weights = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 9, pose_dim=0, n_views_logits=1), seed=0)
         cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
                    predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
-        model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=576)
+        model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=576, precision=precision)
     return ds, renderer, scene, weights, model
 
 
@@ -168,6 +169,8 @@ def main():
     ap.add_argument("--arch", default="resnet34", choices=["resnet34", "resnet18"])
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS),
                     help="BASELINE.json config (default C2 = the one the headline metric is quoted on)")
+    ap.add_argument("--precision", default=None, choices=["f32", "f16"],
+                    help="conv arithmetic (default: f32, the reference's; f16 for C5 as BASELINE.json names it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-1thread", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -181,7 +184,10 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
-    ds, renderer, scene, weights, model = build_world(device, args.arch, seed=rank, workload=args.workload)
+    precision = args.precision or ("f16" if args.workload == "C5" else "f32")
+    peak = PEAK_F16_MFMA_TFLOPS if precision == "f16" else PEAK_F32_MFMA_TFLOPS
+    ds, renderer, scene, weights, model = build_world(device, args.arch, seed=rank, workload=args.workload,
+                                                      precision=precision)
     store = renderer.store
     B = len(scene["TCO_hyp"])
     images = torch.as_tensor(scene["images"], device=device)  # inputs resident in HBM
@@ -233,7 +239,7 @@ def main():
                   f"hypotheses/GPU, {N_ITERS} iterations, {args.arch} (WideResNet) on 6x240x320",
             "C3": f"C3: MegaPose RGB-D refiner, one 640x480 RGB-D frame per GPU, {B} hypotheses/GPU, {N_ITERS} iterations, "
                   "4 views x (RGB + normals + depth), vanilla_resnet34 on 32x240x320",
-            "C5": f"C5 (fp32; the fp16 variant is not built yet): MegaPose coarse scoring, 8 objects x 576 SO(3)-grid "
+            "C5": f"C5: MegaPose coarse scoring, 8 objects x 576 SO(3)-grid "
                   f"poses = {B} views/GPU, RGB + normals, vanilla_resnet34 on 9x240x320",
         }[args.workload] + ", 8 objects of 8.2k vertices / 16.1k faces, 1024^2 textures"
         line = {
@@ -242,19 +248,20 @@ def main():
             "value": total / elapsed, "unit": "refined poses/s" if args.workload != "C5" else "views/s",
             "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
             "config": {"workload": desc, "hypotheses_per_gpu": B, "iterations": N_ITERS if args.workload != "C5" else 1,
                        "parallelism": f"hypothesis-shard x{world}"},
             # achieved = ALGORITHMIC FLOPs (direct-convolution 2*MAC) / kernel time.  30 of
             # the 36 convs run as Winograd F(2x2,3x3) and execute 2.25x fewer MFMA FLOPs than that, so
             # the fraction of the pipe actually busy is reported separately (mfma_executed_*).
             "roofline": {"bound": "mfma",
-                         "kernel": "conv3x3_wino_f32 + conv_igemm_f32 (+ conv3x3_patch_f32 when Winograd does not apply): "
-                                   "fp32 MFMA conv kernels, all 36 conv launches of a forward",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": ("conv3x3_wino_f32 + conv_igemm_f32 (+ conv3x3_patch_f32 when Winograd does not apply): "
+                                    "fp32 MFMA conv kernels" if precision == "f32" else
+                                    "conv_igemm_f16: fp16 MFMA implicit-GEMM conv (fp32 accumulate)") + ", all conv launches of a forward",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
                          "mfma_executed_tflops": mfma_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
-                         "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if conv_ms > 0 else 0.0,
+                         "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else 0.0,
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }

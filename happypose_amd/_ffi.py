@@ -58,6 +58,8 @@ _PROTOS = {
     "hp_net_destroy": (None, [C.c_void_p]),
     "hp_net_input_channels_padded": (C.c_int, [C.c_void_p]),
     "hp_net_set_param": (C.c_int, [C.c_void_p, C.c_char_p, c_f32p, C.c_int64]),
+    "hp_net_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "hp_net_precision": (C.c_int, [C.c_void_p]),
     "hp_net_finalize": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_net_forward": (C.c_int, [C.c_void_p, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "hp_net_flops_per_sample": (C.c_double, [C.c_void_p]),
@@ -66,6 +68,9 @@ _PROTOS = {
     "hp_conv_select_algo": (C.c_int, [C.c_int]),
     "hp_net_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "hp_conv2d_nhwc_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
     "hp_conv2d_nhwc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                  c_f32p, C.c_void_p]),

@@ -23,8 +23,24 @@ struct ConvArgs {
   int* sk_counters;
 };
 
+// fp16 path (conv_f16.hip): activations / weights / prologue vectors are halves, bias is fp32
+struct ConvArgsH {
+  const _Float16* x;          // NHWC [n][H][W][Cin], Cin % 8 == 0
+  const _Float16* w;          // packed [Cout][Kpad], Kpad % 64 == 0
+  const float* bias;          // [Cout] or null
+  const _Float16* residual;   // NHWC [n][Ho][Wo][Cout] or null
+  const _Float16* pre_scale;  // [Cin] or null  (x_act = relu(x * scale + shift), packed fp16)
+  const _Float16* pre_shift;
+  const int4* lut;            // [Kpad/8] {offset (halves), kh, kw, channel}; kh < 0 marks K padding
+  _Float16* y;
+  int64_t M, x_bytes, w_bytes;
+  int H, W, Cin, Ho, Wo, Cout, stride, pad, Kpad, ktiles, relu;
+  int tiles_m, tiles_n;       // filled by the launcher
+};
+
 struct HeadArgs {
-  const float* x;  // NHWC [b][HW][C]
+  int x_is_half;   // features are fp16 (fp16 plan) instead of fp32
+  const void* x;   // NHWC [b][HW][C]
   int HW, C;
   const float* fc_w; const float* fc_b;        // optional 512x512 fc (torchvision ResNet)
   const float* pose_w; const float* pose_b; int pose_dim;
@@ -46,6 +62,9 @@ int conv_wino_transform_weights(const float* d_w, float* d_U, int cout, int cin,
 int launch_conv_wino(const ConvArgs& a, hipStream_t stream);
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream);
+int launch_conv_f16(const ConvArgsH& a, hipStream_t stream);
+int launch_cast_pad_f16(const float* x, void* y, int64_t pixels, int c_in, int c_out, hipStream_t stream);
+int launch_maxpool_f16(const void* x, void* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
 int conv_setup_once();
 // HP_CONV_ALGO_* currently selected (hp_conv_select_algo / HP_CONV_NO_WINOGRAD, HP_CONV_NO_PATCH)
 int conv_algo();

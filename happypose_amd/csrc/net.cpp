@@ -49,6 +49,9 @@ struct ConvLayer {
   int H, W, Ho, Wo, Kpad;
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
   DevBuf w, w_wino, bias, lut, pre_scale, pre_shift;  // w_wino: Winograd-transformed weights (3x3 s1 layers)
+  // fp16 plan: cin rounded to 8, K to 64; packed halves, LUT per 8-half chunk, prologue in halves
+  int cin16 = 0, Kpad16 = 0;
+  DevBuf w16, lut16, pre_scale16, pre_shift16;
 };
 
 struct EventPair { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0.0, mfma_flops = 0.0; int conv = -1; };
@@ -61,6 +64,8 @@ struct Op { OpKind kind; int conv = -1; int in_buf = -1, out_buf = -1; int H = 0
 struct Net {
   int arch, n_inputs, c_pad, h, w;
   bool finalized = false;
+  int precision = HP_PRECISION_F32;
+  DevBuf x16;  // fp16 plan: the network input converted to fp16 NHWC [max_batch][h][w][cin16 of the stem]
   int max_batch = 0;
   std::map<std::string, std::vector<float>> params;
   std::vector<std::unique_ptr<ConvLayer>> convs;
@@ -236,6 +241,47 @@ int pack_conv(Net& n, ConvLayer& L) {
   return L.lut.upload(lut.data(), lut.size() * sizeof(int4));
 }
 
+// fp16 plan: BN folded in fp32, then rounded once to fp16; K order (kh, kw, c) with c padded to 8
+int pack_conv_f16(Net& n, ConvLayer& L) {
+  const std::vector<float>* w;
+  const size_t numel = (size_t)L.cout * L.cin_real * L.kh * L.kw;
+  int rc = need(n, L.wname, numel, &w);
+  if (rc) return rc;
+  std::vector<float> scale, shift;
+  if (!L.bn_after.empty() && (rc = bn_affine(n, L.bn_after, L.cout, scale, shift))) return rc;
+  L.cin16 = (L.cin_real + 7) / 8 * 8;
+  L.Kpad16 = (L.kh * L.kw * L.cin16 + 63) / 64 * 64;
+  std::vector<_Float16> packed((size_t)L.cout * L.Kpad16, (_Float16)0.f);
+  for (int o = 0; o < L.cout; ++o) {
+    const float s = scale.empty() ? 1.f : scale[o];
+    for (int ci = 0; ci < L.cin_real; ++ci)
+      for (int y = 0; y < L.kh; ++y)
+        for (int x = 0; x < L.kw; ++x)
+          packed[(size_t)o * L.Kpad16 + (size_t)(y * L.kw + x) * L.cin16 + ci] =
+              (_Float16)((*w)[(((size_t)o * L.cin_real + ci) * L.kh + y) * L.kw + x] * s);
+  }
+  if ((rc = L.w16.upload(packed.data(), packed.size() * 2))) return rc;
+  if (!shift.empty() && (rc = L.bias.upload(shift.data(), shift.size() * 4))) return rc;
+  if (!L.bn_before.empty()) {
+    std::vector<float> ps, pb;
+    if ((rc = bn_affine(n, L.bn_before, L.cin_real, ps, pb))) return rc;
+    std::vector<_Float16> hs(L.cin16, (_Float16)0.f), hb(L.cin16, (_Float16)0.f);
+    for (int i = 0; i < L.cin_real; ++i) { hs[i] = (_Float16)ps[i]; hb[i] = (_Float16)pb[i]; }
+    if ((rc = L.pre_scale16.upload(hs.data(), hs.size() * 2))) return rc;
+    if ((rc = L.pre_shift16.upload(hb.data(), hb.size() * 2))) return rc;
+  }
+  std::vector<int4> lut(L.Kpad16 / 8, make_int4(0, -1, 0, 0));
+  const int kreal = L.kh * L.kw * L.cin16;
+  for (int q = 0; q < L.Kpad16 / 8; ++q) {
+    const int k = 8 * q;
+    if (k < kreal) {
+      const int seg = k / L.cin16, ch = k % L.cin16, y = seg / L.kw, x = seg % L.kw;
+      lut[q] = make_int4((y * L.W + x) * L.cin16 + ch, y, x, ch);
+    }
+  }
+  return L.lut16.upload(lut.data(), lut.size() * sizeof(int4));
+}
+
 }  // namespace
 }  // namespace hp
 
@@ -270,12 +316,23 @@ extern "C" int hp_net_set_param(hp_net* net, const char* name, const float* h_da
   return HP_OK;
 }
 
+extern "C" int hp_net_set_precision(hp_net* net, int precision) {
+  HP_REQUIRE(net, "hp_net_set_precision: null net");
+  HP_REQUIRE(!net->finalized, "hp_net_set_precision: network already finalized");
+  HP_REQUIRE(precision == HP_PRECISION_F32 || precision == HP_PRECISION_F16, "hp_net_set_precision: unknown precision");
+  net->precision = precision;
+  return HP_OK;
+}
+
+extern "C" int hp_net_precision(const hp_net* net) { return net ? net->precision : HP_ERR_ARG; }
+
 extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   HP_REQUIRE(net && max_batch >= 1, "hp_net_finalize: bad argument");
   int rc = conv_setup_once();
   if (rc) return rc;
+  const bool f16 = net->precision == HP_PRECISION_F16;
   for (auto& L : net->convs)
-    if ((rc = pack_conv(*net, *L))) return rc;
+    if ((rc = f16 ? pack_conv_f16(*net, *L) : pack_conv(*net, *L))) return rc;
   const std::vector<float>* v;
   if (net->arch == HP_ARCH_VANILLA_RESNET34) {
     if ((rc = need(*net, "backbone.fc.weight", 512 * 512, &v))) return rc;
@@ -301,7 +358,8 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   net->bufs.clear();
   net->bufs.resize(net->buf_floats_per_sample.size());
   for (size_t s = 0; s < net->bufs.size(); ++s)
-    if ((rc = net->bufs[s].alloc(net->buf_floats_per_sample[s] * (size_t)max_batch * 4))) return rc;
+    if ((rc = net->bufs[s].alloc(net->buf_floats_per_sample[s] * (size_t)max_batch * (f16 ? 2 : 4)))) return rc;
+  if (f16 && (rc = net->x16.alloc((size_t)max_batch * net->h * net->w * net->convs[0]->cin16 * 2))) return rc;
   net->max_batch = max_batch;
   net->params.clear();  // host copies are no longer needed
   net->finalized = true;
@@ -311,8 +369,42 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
 static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose, float* d_logits,
                          float* d_features, hipStream_t stream) {
   int rc;
+  const bool f16 = net->precision == HP_PRECISION_F16;
+  if (f16 && (rc = launch_cast_pad_f16(d_x, net->x16.p, (int64_t)batch * net->h * net->w, net->c_pad,
+                                       net->convs[0]->cin16, stream)))
+    return rc;
   for (const Op& op : net->ops) {
-    if (op.kind == OP_CONV) {
+    if (op.kind == OP_CONV && f16) {
+      ConvLayer& L = *net->convs[op.conv];
+      ConvArgsH a{};
+      a.x = (const _Float16*)(L.in_buf < 0 ? net->x16.p : net->bufs[L.in_buf].p);
+      a.w = (const _Float16*)L.w16.p;
+      a.bias = (const float*)L.bias.p;
+      a.residual = L.res_buf < 0 ? nullptr : (const _Float16*)net->bufs[L.res_buf].p;
+      a.pre_scale = (const _Float16*)L.pre_scale16.p;
+      a.pre_shift = (const _Float16*)L.pre_shift16.p;
+      a.lut = (const int4*)L.lut16.p;
+      a.y = (_Float16*)net->bufs[L.out_buf].p;
+      a.M = (int64_t)batch * L.Ho * L.Wo;
+      a.H = L.H; a.W = L.W; a.Cin = L.cin16; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.cout;
+      a.stride = L.stride; a.pad = L.pad; a.Kpad = L.Kpad16; a.ktiles = L.Kpad16 / 64; a.relu = L.relu;
+      a.x_bytes = (int64_t)batch * L.H * L.W * L.cin16 * 2;
+      a.w_bytes = (int64_t)L.cout * L.Kpad16 * 2;
+      EventPair ev{};
+      if (net->profiling) {
+        if (!net->ev_pool.empty()) { ev = net->ev_pool.back(); net->ev_pool.pop_back(); }
+        else { HP_CHECK_HIP(hipEventCreate(&ev.e0)); HP_CHECK_HIP(hipEventCreate(&ev.e1)); }
+        ev.flops = 2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real;
+        ev.mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout * L.Kpad16;
+        ev.conv = op.conv;
+        HP_CHECK_HIP(hipEventRecord(ev.e0, stream));
+      }
+      if ((rc = launch_conv_f16(a, stream))) return rc;
+      if (net->profiling) {
+        HP_CHECK_HIP(hipEventRecord(ev.e1, stream));
+        net->ev_pending.push_back(ev);
+      }
+    } else if (op.kind == OP_CONV) {
       ConvLayer& L = *net->convs[op.conv];
       ConvArgs a{};
       a.x = L.in_buf < 0 ? d_x : (const float*)net->bufs[L.in_buf].p;
@@ -351,13 +443,17 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
         HP_CHECK_HIP(hipEventRecord(ev.e1, stream));
         net->ev_pending.push_back(ev);
       }
+    } else if (op.kind == OP_MAXPOOL && f16) {
+      if ((rc = launch_maxpool_f16(net->bufs[op.in_buf].p, net->bufs[op.out_buf].p, batch, op.H, op.W, op.C, op.Ho,
+                                   op.Wo, stream)))
+        return rc;
     } else if (op.kind == OP_MAXPOOL) {
       if ((rc = launch_maxpool((const float*)net->bufs[op.in_buf].p, (float*)net->bufs[op.out_buf].p, batch,
                                op.H, op.W, op.C, op.Ho, op.Wo, stream)))
         return rc;
     } else {
       HeadArgs h{};
-      h.x = (const float*)net->bufs[op.in_buf].p; h.HW = op.H * op.W; h.C = op.C;
+      h.x = net->bufs[op.in_buf].p; h.x_is_half = f16 ? 1 : 0; h.HW = op.H * op.W; h.C = op.C;
       h.fc_w = (const float*)net->fc_w.p; h.fc_b = (const float*)net->fc_b.p;
       h.pose_w = (const float*)net->pose_w.p; h.pose_b = (const float*)net->pose_b.p;
       h.pose_dim = d_pose ? net->pose_dim : 0;
@@ -491,4 +587,44 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   if (algo != HP_CONV_ALGO_IGEMM && conv_patch_applicable(a, kh, kw))
     return launch_conv_patch(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
   return launch_conv(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
+}
+
+// ---- single-layer entry of the fp16 kernel for the parity tests (all tensors fp16 except bias) ----
+extern "C" int hp_conv2d_nhwc_f16(const void* d_x, int n, int h, int w, int cin, const void* d_w, int cout, int kh,
+                                  int kw, int stride, int pad, const float* d_bias, const void* d_residual,
+                                  const void* d_pre_scale, const void* d_pre_shift, int relu, void* d_y,
+                                  void* stream) {
+  HP_REQUIRE(d_x && d_w && d_y, "hp_conv2d_nhwc_f16: null pointer");
+  HP_REQUIRE(cin % 8 == 0 && cin > 0, "hp_conv2d_nhwc_f16: cin must be a multiple of 8");
+  HP_REQUIRE(cout % 64 == 0 && cout > 0, "hp_conv2d_nhwc_f16: cout must be a multiple of 64");
+  HP_REQUIRE(kh == kw && kh >= 1 && (stride == 1 || stride == 2) && pad >= 0, "hp_conv2d_nhwc_f16: unsupported geometry");
+  HP_REQUIRE((d_pre_scale == nullptr) == (d_pre_shift == nullptr), "hp_conv2d_nhwc_f16: pre_scale/pre_shift must come together");
+  const int Kreal = kh * kw * cin, Kpad = (Kreal + 63) / 64 * 64;
+  HP_REQUIRE(Kreal == Kpad, "hp_conv2d_nhwc_f16: kh*kw*cin must be a multiple of 64 (weights are [cout][kh][kw][cin])");
+  std::vector<int4> lut(Kpad / 8);
+  for (int q = 0; q < Kpad / 8; ++q) {
+    const int k = 8 * q, seg = k / cin, ch = k % cin, y = seg / kw, x = seg % kw;
+    lut[q] = make_int4((y * w + x) * cin + ch, y, x, ch);
+  }
+  static std::map<std::string, int4*> cache;
+  const std::string key = std::to_string(w) + "_" + std::to_string(cin) + "_" + std::to_string(kh);
+  int4* d_lut = nullptr;
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    HP_CHECK_HIP(hipMalloc((void**)&d_lut, lut.size() * sizeof(int4)));
+    HP_CHECK_HIP(hipMemcpy(d_lut, lut.data(), lut.size() * sizeof(int4), hipMemcpyHostToDevice));
+    cache[key] = d_lut;
+  } else {
+    d_lut = it->second;
+  }
+  ConvArgsH a{};
+  a.x = (const _Float16*)d_x; a.w = (const _Float16*)d_w; a.bias = d_bias; a.residual = (const _Float16*)d_residual;
+  a.pre_scale = (const _Float16*)d_pre_scale; a.pre_shift = (const _Float16*)d_pre_shift; a.lut = d_lut;
+  a.y = (_Float16*)d_y;
+  a.H = h; a.W = w; a.Cin = cin; a.Ho = (h + 2 * pad - kh) / stride + 1; a.Wo = (w + 2 * pad - kw) / stride + 1;
+  a.Cout = cout; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.ktiles = Kpad / 64; a.relu = relu;
+  a.M = (int64_t)n * a.Ho * a.Wo;
+  a.x_bytes = (int64_t)n * h * w * cin * 2;
+  a.w_bytes = (int64_t)cout * Kpad * 2;
+  return launch_conv_f16(a, (hipStream_t)stream);
 }

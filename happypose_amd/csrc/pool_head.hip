@@ -36,14 +36,15 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* x, float* 
 
 // ---- head: spatial mean -> [fc 512x512 + bias] -> pose / logits linear heads -----------
 // one workgroup per sample; features [HW][C] NHWC.
+template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   __shared__ float feat[512];
   __shared__ float feat2[512];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const float* x = a.x + (int64_t)b * a.HW * a.C;
+  const T* x = reinterpret_cast<const T*>(a.x) + (int64_t)b * a.HW * a.C;
   for (int c = tid; c < a.C; c += 256) {
     float s = 0.f;
-    for (int p = 0; p < a.HW; ++p) s += x[(int64_t)p * a.C + c];
+    for (int p = 0; p < a.HW; ++p) s += (float)x[(int64_t)p * a.C + c];
     feat[c] = s / (float)a.HW;
   }
   __syncthreads();
@@ -83,7 +84,8 @@ int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho,
 }
 
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream) {
-  hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(256), 0, stream, a);
+  if (a.x_is_half) hipLaunchKernelGGL(head_kernel<_Float16>, dim3(batch), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(head_kernel<float>, dim3(batch), dim3(256), 0, stream, a);
   return check_launch("head_kernel");
 }
 

@@ -140,13 +140,14 @@ def pose_model_param_shapes(backbone_str: str, n_inputs: int, pose_dim: int = 9,
 
 
 def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Optional[Dict] = None,
-                      max_batch: int = 128) -> PosePredictor:
+                      max_batch: int = 128, precision: str = "f32") -> PosePredictor:
     """MegaPose predictor (``MP/training/pose_models_cfg.py:89-142``).  ``state_dict`` holds the
     reference's keys (``backbone.*``, ``pose_fc.*``, ``views_logits_head.*``)."""
     cfg = check_update_config(cfg)
     assert state_dict is not None, "weights are required (no training path here)"
     sd = change_keys_of_older_models(state_dict)
-    net = ops.Net(_arch(cfg.backbone_str), n_input_channels(cfg), sd, max_batch=max_batch, device=renderer.device)
+    net = ops.Net(_arch(cfg.backbone_str), n_input_channels(cfg), sd, max_batch=max_batch, device=renderer.device,
+                  precision=precision)
     # the coarse compat model renders exactly the TCO view
     mv = cfg.multiview_type if cfg.n_rendered_views > 1 else "TCO"
     model = PosePredictor(
@@ -161,14 +162,14 @@ def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Op
 
 
 def create_pose_model_cosypose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Optional[Dict] = None,
-                               max_batch: int = 128) -> CosyPosePosePredictor:
+                               max_batch: int = 128, precision: str = "f32") -> CosyPosePosePredictor:
     """``CP/training/pose_models_cfg.py:30-53`` (6 input channels; ``n_pose_dims`` = 9)."""
     d = dict(cfg) if isinstance(cfg, dict) else dict(vars(cfg))
     d.setdefault("init_method", "v0")  # check_update_config, :24-27
     d.setdefault("n_pose_dims", 9)
     cfg = SimpleNamespace(**d)
     assert state_dict is not None
-    net = ops.Net(_arch(cfg.backbone_str), 6, state_dict, max_batch=max_batch, device=renderer.device)
+    net = ops.Net(_arch(cfg.backbone_str), 6, state_dict, max_batch=max_batch, device=renderer.device, precision=precision)
     model = CosyPosePosePredictor(backbone=net, renderer=renderer, mesh_db=mesh_db, render_size=(240, 320),
                                   pose_dim=cfg.n_pose_dims)
     model.cfg = model.config = cfg

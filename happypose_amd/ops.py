@@ -249,9 +249,12 @@ class Net:
     """``hp_net``: backbone + heads with BN folded, on one device."""
 
     def __init__(self, arch: str, n_inputs: int, state_dict: Dict[str, "np.ndarray | torch.Tensor"],
-                 max_batch: int = 128, device="cuda", h: int = 240, w: int = 320):
+                 max_batch: int = 128, device="cuda", h: int = 240, w: int = 320, precision: str = "f32"):
+        """``precision``: ``"f32"`` (the reference's arithmetic) or ``"f16"`` (fp16 weights and
+        activations, fp32 accumulation: configuration C5; inputs / outputs stay fp32)."""
         self.device = torch.device(device)
         self.arch, self.n_inputs, self.h, self.w = arch, n_inputs, h, w
+        self.precision = precision
         with torch.cuda.device(self.device):
             self._h = lib().hp_net_create(ARCH[arch], n_inputs, h, w)
             if not self._h:
@@ -263,6 +266,7 @@ class Net:
                 arr = np.ascontiguousarray(arr, dtype=np.float32)
                 check(lib().hp_net_set_param(self.handle, name.encode(), _np_ptr(arr), arr.size),
                       f"hp_net_set_param({name})")
+            check(lib().hp_net_set_precision(self.handle, {"f32": 0, "f16": 1}[precision]), "hp_net_set_precision")
             check(lib().hp_net_finalize(self.handle, max_batch), "hp_net_finalize")
         self.c_pad = lib().hp_net_input_channels_padded(self.handle)
         self.pose_dim = state_dict["pose_fc.weight"].shape[0] if "pose_fc.weight" in state_dict else 0
@@ -334,4 +338,23 @@ def conv2d_nhwc(x, w_packed, stride, pad, bias=None, residual=None, pre_scale=No
         check(lib().hp_conv2d_nhwc(ptr(x), n, h, w, cin, ptr(w_packed), cout, kh, kw, stride, pad, ptr(bias),
                                    ptr(residual), ptr(pre_scale), ptr(pre_shift), int(relu), ptr(y),
                                    stream_ptr(dev)), "hp_conv2d_nhwc")
+    return y
+
+
+def conv2d_nhwc_f16(x, w_packed, stride, pad, bias=None, residual=None, pre_scale=None, pre_shift=None, relu=False):
+    """Single conv layer of the fp16 kernel (parity tests): ``x [n,h,w,cin]`` and ``w_packed
+    [cout,kh,kw,cin]`` (and residual / pre_scale / pre_shift) fp16, bias fp32; returns fp16."""
+    dev = x.device
+    n, h, w, cin = x.shape
+    cout, kh, kw, cin2 = w_packed.shape
+    assert cin == cin2 and x.dtype == torch.float16 and w_packed.dtype == torch.float16
+    for t in (residual, pre_scale, pre_shift):
+        assert t is None or t.dtype == torch.float16
+    assert bias is None or bias.dtype == torch.float32
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().hp_conv2d_nhwc_f16(ptr(x), n, h, w, cin, ptr(w_packed), cout, kh, kw, stride, pad, ptr(bias),
+                                       ptr(residual), ptr(pre_scale), ptr(pre_shift), int(relu), ptr(y),
+                                       stream_ptr(dev)), "hp_conv2d_nhwc_f16")
     return y

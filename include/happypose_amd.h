@@ -191,6 +191,15 @@ hp_net* hp_net_create(int arch, int n_inputs, int h, int w);
 void hp_net_destroy(hp_net* net);
 int hp_net_input_channels_padded(const hp_net* net);
 int hp_net_set_param(hp_net* net, const char* name, const float* h_data, int64_t numel);
+/* Arithmetic of the conv stack, to be chosen before hp_net_finalize:
+ *   HP_PRECISION_F32 (default): fp32 MFMA, the reference's precision;
+ *   HP_PRECISION_F16: weights / activations rounded to fp16 once per layer, fp32 accumulation
+ *     (v_mfma_f32_32x32x16_f16) -- configuration C5 of SURVEY.md 8; the reference has no fp16
+ *     path, the tolerance is stated in DESIGN.md.  hp_net_forward still takes / returns fp32. */
+#define HP_PRECISION_F32 0
+#define HP_PRECISION_F16 1
+int hp_net_set_precision(hp_net* net, int precision);
+int hp_net_precision(const hp_net* net);
 int hp_net_finalize(hp_net* net, int max_batch);
 int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d_pose, float* d_logits,
                    float* d_features, void* stream);
@@ -224,6 +233,12 @@ int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, const float* 
                    int kh, int kw, int stride, int pad, const float* d_bias,
                    const float* d_residual, const float* d_pre_scale, const float* d_pre_shift,
                    int relu, float* d_y, void* stream);
+/* the same for the fp16 kernel: x, w, residual, pre_scale / pre_shift and y are fp16 device
+ * arrays (bias stays fp32); cin % 8 == 0, kh*kw*cin % 64 == 0, cout % 64 == 0 */
+int hp_conv2d_nhwc_f16(const void* d_x, int n, int h, int w, int cin, const void* d_w, int cout, int kh,
+                       int kw, int stride, int pad, const float* d_bias, const void* d_residual,
+                       const void* d_pre_scale, const void* d_pre_shift, int relu, void* d_y,
+                       void* stream);
 
 #ifdef __cplusplus
 }

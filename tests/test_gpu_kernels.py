@@ -369,6 +369,65 @@ def _check_conv(dev, case, tol=2e-5):
     assert err <= tol * max(1.0, np.abs(ref).max()), err
 
 
+# fp16 kernel (configuration C5): operands rounded to fp16, fp32 accumulation, one rounding of the
+# result -> compare with fp64 on the SAME fp16-rounded operands; the only error left is the
+# accumulation order and the final rounding to fp16 (2^-11 relative)
+@pytest.mark.parametrize("case", [
+    dict(n=3, h=60, w=80, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=False, relu=True),
+    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),
+    dict(n=2, h=30, w=40, cin=128, cout=256, k=1, s=2, p=0, bias=False, res=False, pre=True, relu=False),
+    dict(n=2, h=15, w=20, cin=256, cout=512, k=3, s=1, p=1, bias=False, res=True, pre=False, relu=False),
+    dict(n=5, h=9, w=7, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=False, pre=False, relu=False),   # ragged M
+    dict(n=2, h=31, w=23, cin=16, cout=64, k=2, s=1, p=0, bias=False, res=False, pre=False, relu=False),  # one K-tile
+    dict(n=1, h=24, w=32, cin=8, cout=64, k=4, s=2, p=1, bias=True, res=False, pre=False, relu=True),    # 2 K-tiles, odd taps
+])
+def test_conv2d_f16_vs_fp64(dev, case):
+    from happypose_amd import ops
+
+    rs = np.random.RandomState(5)
+    c = case
+    h16 = lambda a: a.astype(np.float16)  # noqa: E731
+    x = h16(rs.normal(size=(c["n"], c["h"], c["w"], c["cin"])))
+    w = h16(rs.normal(size=(c["cout"], c["cin"], c["k"], c["k"])) / np.sqrt(c["cin"] * c["k"] ** 2))
+    ho, wo = (c["h"] + 2 * c["p"] - c["k"]) // c["s"] + 1, (c["w"] + 2 * c["p"] - c["k"]) // c["s"] + 1
+    bias = rs.normal(size=c["cout"]).astype(np.float32) if c["bias"] else None
+    res = h16(rs.normal(size=(c["n"], ho, wo, c["cout"]))) if c["res"] else None
+    pre = (h16(rs.uniform(0.5, 1.5, c["cin"])), h16(rs.normal(size=c["cin"]))) if c["pre"] else None
+    xin = x.astype(np.float64)
+    if pre is not None:  # the prologue itself is evaluated in fp16 (fma, relu): restate that rounding
+        xin = np.maximum((x.astype(np.float32) * pre[0].astype(np.float32) + pre[1].astype(np.float32)).astype(np.float16), 0).astype(np.float64)
+    ref = _conv_ref(xin, w.astype(np.float64), c["s"], c["p"], bias, None if res is None else res.astype(np.float64), None, c["relu"])
+    t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+    wp = np.ascontiguousarray(w.transpose(0, 2, 3, 1))
+    y = ops.conv2d_nhwc_f16(t(x), t(wp), c["s"], c["p"], t(bias), t(res), t(pre[0]) if pre else None,
+                            t(pre[1]) if pre else None, c["relu"])
+    err = np.abs(y.float().cpu().numpy() - ref).max()
+    assert err <= 1.5e-3 * max(1.0, np.abs(ref).max()), err
+
+
+@pytest.mark.parametrize("arch,cin", [("vanilla_resnet34", 9), ("resnet34", 6)])
+def test_backbone_f16_vs_f32(dev, arch, cin):
+    """The fp16 plan of a whole backbone against the fp32 plan on the same weights and input:
+    features agree to the fp16 tolerance stated in DESIGN.md (2e-2 of the feature scale)."""
+    from happypose_amd import ops
+    from happypose_amd.models import pose_model_param_shapes
+    from happypose_amd.synthetic import predictor_weights
+
+    w = predictor_weights(pose_model_param_shapes(arch, cin, pose_dim=9, n_views_logits=1), seed=4)
+    x = np.random.RandomState(7).uniform(-1, 1, size=(3, 240, 320, cin)).astype(np.float32)
+    outs = {}
+    for prec in ("f32", "f16"):
+        net = ops.Net(arch, cin, w, max_batch=2, device=dev, precision=prec)  # 3 samples -> chunks 2 + 1
+        xin = net.new_input(3)
+        xin[..., :cin] = torch.as_tensor(x, device=dev)
+        pose, logits, feats = net.forward(xin, want_pose=True, want_logits=True, want_features=True)
+        outs[prec] = [t.cpu().numpy() for t in (pose, logits, feats)]
+    scale = np.abs(outs["f32"][2]).max()
+    assert np.abs(outs["f16"][2] - outs["f32"][2]).max() <= 2e-2 * scale
+    np.testing.assert_allclose(outs["f16"][0], outs["f32"][0], atol=2e-2 * max(1.0, np.abs(outs["f32"][0]).max()))
+    np.testing.assert_allclose(outs["f16"][1], outs["f32"][1], atol=2e-2 * max(1.0, np.abs(outs["f32"][1]).max()))
+
+
 @pytest.mark.parametrize("arch,cin,tag", [("vanilla_resnet34", 27, "vanilla_resnet34_27"),
                                           ("vanilla_resnet34", 9, "vanilla_resnet34_9"),
                                           ("resnet34", 6, "resnet34_6"), ("resnet18", 6, "resnet18_6")])
