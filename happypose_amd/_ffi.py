@@ -68,6 +68,9 @@ _PROTOS = {
     "hp_conv_select_algo": (C.c_int, [C.c_int]),
     "hp_net_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "hp_icp_refine": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                c_f32p, c_f32p, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p, C.c_void_p, c_f32p,
+                                C.c_void_p]),
     "hp_conv2d_nhwc_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p]),

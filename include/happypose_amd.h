@@ -225,6 +225,23 @@ int hp_conv_occupancy(int variant);
 int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, double* conv_flops,
                            double* mfma_flops);
 
+/* ------------------------------------------------------------------------------------
+ * Depth refinement (run_depth_refiner=True): point-to-plane ICP between the depth rendered at
+ * the predicted pose and the measured depth.  Replaces icp_refinement / ICPRefiner.refine_poses
+ * (MP/inference/icp_refiner.py:135-303, masks of MP/inference/refiner_utils.py:27-53); the
+ * registration itself is OpenCV's ppf_match_3d_ICP there and a projective point-to-plane ICP here
+ * (parity unpinned, see csrc/icp.hip).  d_depth_rendered [n][H][W] (hp_rasterize at d_TCO),
+ * d_depth_measured [B][H][W] metres, d_masks [B][H][W] u8 or NULL (= the "threshold" mask with
+ * depth_delta_thresh), im_ids on device and host, d_K [n][9].  Outputs: d_TCO_out [n][16]
+ * (= input pose where the registration is rejected), d_retval [n] (0 / -1), d_residual [n]
+ * (RMS point-to-plane distance of the inliers, metres); the last two may be NULL.
+ * ---------------------------------------------------------------------------------- */
+int hp_icp_refine(int n, int B, int H, int W, const float* d_depth_rendered, const float* d_depth_measured,
+                  const uint8_t* d_masks, const int32_t* d_im_ids, const int32_t* h_im_ids, const float* d_K,
+                  const float* d_TCO, int n_iterations, int n_min_points, float tolerance,
+                  float depth_delta_thresh, float* d_TCO_out, int32_t* d_retval, float* d_residual,
+                  void* stream);
+
 /* Single layer entry (used by the parity tests of the conv kernel itself):
  * y[n][ho][wo][cout] = act( conv(x_act, w) + bias + residual ),
  * x_act = pre_scale ? relu(x * pre_scale[c] + pre_shift[c]) : x   (zero padding AFTER it).

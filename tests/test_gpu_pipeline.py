@@ -246,3 +246,81 @@ def test_cosypose_pipeline(dev, world):
     direct = refiner.forward(obs.images, obs.K, _labels(world, sc["hyp_obj_ids"]), torch.as_tensor(sc["TCO_hyp"]),
                              n_iterations=2, im_ids=torch.zeros(12, dtype=torch.int32))
     np.testing.assert_allclose(f2.poses.cpu().numpy(), direct["iteration=2"].TCO_output.cpu().numpy(), atol=1e-6)
+
+
+def test_load_pose_models_from_run_dirs(dev, world, tmp_path):
+    """<models_root>/<run_id>/{config.yaml, checkpoint.pth.tar} -> predictors.  The
+    checkpoints are written in the reference's layout (incl. the legacy key names) and the loaded
+    models must behave exactly like ones built from the same weights directly."""
+    from happypose_amd.load_model import load_pose_models
+    from happypose_amd.models import create_model_pose
+
+    sc = world["scene"]
+    wc = _weights("vanilla_resnet34", 9, pose=False, logits=1, seed=3, scale=0.05)
+    wr = _weights("vanilla_resnet34", 27, seed=2)
+    legacy = {("backbone.backbone." + k[len("backbone."):] if k.startswith("backbone.") else
+               k.replace("views_logits_head.", "backbone.head.0.")): torch.as_tensor(v) for k, v in wc.items()}
+    for run, sd, cfg in (
+        ("coarse-x", legacy, "!!python/object:argparse.Namespace\nbackbone_str: vanilla_resnet34\n"
+                             "input_strategy: input=obs+one_render\nrender_normals: true\nrenderer: panda3d\n"),
+        ("refiner-x", {k: torch.as_tensor(v) for k, v in wr.items()},
+         "!!python/object:argparse.Namespace\nbackbone_str: vanilla_resnet34\nn_views: 4\n"
+         "multiview_type: front_3views\nrender_normals: true\nrenderer: panda3d\n"),
+    ):
+        (tmp_path / run).mkdir()
+        (tmp_path / run / "config.yaml").write_text(cfg)
+        torch.save({"state_dict": sd, "epoch": 1}, tmp_path / run / "checkpoint.pth.tar")
+    coarse, refiner, mesh_db = load_pose_models("coarse-x", "refiner-x", world["ds"], models_root=tmp_path, device=dev,
+                                                max_batch=8)
+    assert coarse.predict_rendered_views_logits and not coarse.predict_pose_update and refiner.n_rendered_views == 4
+    assert len(mesh_db.batched().labels) == 3
+    images = torch.as_tensor(sc["images"][:, :3].copy(), device=dev)
+    K = torch.as_tensor(sc["K"], device=dev)
+    sel = np.array([0, 5, 9])
+    labels, T, ids = _labels(world, sc["hyp_obj_ids"][sel]), torch.as_tensor(sc["TCO_hyp"][sel]), torch.zeros(3, dtype=torch.int32)
+    ref_c = create_model_pose(dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
+                                   predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False),
+                              world["renderer"], state_dict=wc, max_batch=8)
+    assert torch.equal(coarse.forward_coarse(images, K, labels, T, im_ids=ids)["logits"],
+                       ref_c.forward_coarse(images, K, labels, T, im_ids=ids)["logits"])
+    ref_r = create_model_pose(dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views",
+                                   render_normals=True), world["renderer"], state_dict=wr, max_batch=8)
+    a = refiner.forward(images, K, labels, T, n_iterations=1, im_ids=ids)["iteration=1"].TCO_output
+    b = ref_r.forward(images, K, labels, T, n_iterations=1, im_ids=ids)["iteration=1"].TCO_output
+    assert torch.equal(a, b)
+    c2, r2, _ = load_pose_models(None, "refiner-x", world["ds"], models_root=tmp_path, device=dev, max_batch=8)
+    assert c2 is None and r2 is not None
+
+
+def test_pipeline_with_depth_refiner(dev, world):
+    """run_depth_refiner=True (MP/inference/pose_estimator.py:404-410): the ICP refiner runs on the
+    top-1 estimates and its output becomes the final prediction."""
+    from happypose_amd.icp_refiner import ICPRefiner
+    from happypose_amd.models import create_model_pose
+    from happypose_amd.pose_estimator import ObservationTensor, PoseEstimator, make_detections_from_object_data
+    from oracle import geometry as G
+
+    sc, store = world["scene"], world["store"]
+    ccfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
+                predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
+    rcfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+                depth_augmentation=False)
+    coarse = create_model_pose(ccfg, world["renderer"], state_dict=_weights("vanilla_resnet34", 9, pose=False, logits=1, seed=3, scale=0.05), max_batch=32)
+    refiner = create_model_pose(rcfg, world["renderer"], state_dict=_weights("vanilla_resnet34", 27, seed=2), max_batch=8)
+    obs = ObservationTensor(torch.as_tensor(sc["images"].copy(), device=dev), torch.as_tensor(sc["K"], device=dev))
+    assert obs.depth is not None
+    pts = store.mesh_db.points[sc["det_obj_ids"]]
+    boxes = G.boxes_from_uv(G.project_points(pts, np.repeat(sc["K"], 3, 0), sc["TCO_det"]))
+    det = make_detections_from_object_data(_labels(world, sc["det_obj_ids"]), boxes)
+    est = PoseEstimator(refiner_model=refiner, coarse_model=coarse, depth_refiner=ICPRefiner(store.mesh_db, world["renderer"]),
+                        bsz_objects=8, bsz_images=64, SO3_grid_size=72)
+    final, extra = est.run_inference_pipeline(obs, detections=det.to(dev), n_refiner_iterations=1, n_pose_hypotheses=1,
+                                              run_depth_refiner=True)
+    assert "depth_refiner" in extra and len(extra["depth_refiner"]["preds"]) == 3
+    assert final.poses.shape == (3, 4, 4) and torch.isfinite(final.poses).all()
+    # the synthetic depth is noise in [0.3, 0.7] m, unrelated to the objects: registrations are rejected
+    # (or accepted with a finite pose); poses_input always holds the refiner's output
+    assert torch.equal(final.poses_input.cpu(), extra["refiner"]["preds"].poses.cpu())
+    with pytest.raises(AssertionError):
+        PoseEstimator(refiner_model=refiner, coarse_model=coarse).run_inference_pipeline(
+            obs, detections=det.to(dev), n_refiner_iterations=1, run_depth_refiner=True)

@@ -202,3 +202,34 @@ def test_synthetic_scene_is_seeded_and_in_view():
     w1 = named_weights({"a.weight": (4, 3, 3, 3), "bn.running_var": (4,)}, seed=0)
     w2 = named_weights({"bn.running_var": (4,), "a.weight": (4, 3, 3, 3)}, seed=0)
     assert np.array_equal(w1["a.weight"], w2["a.weight"]) and (w1["bn.running_var"] > 0).all()
+
+
+def test_load_cfg_restricted_yaml_and_named_models(tmp_path):
+    """config.yaml files of the reference are dumps of argparse.Namespace objects (read there with
+    yaml.UnsafeLoader): the restricted loader maps those tags to attribute bags and refuses to
+    construct anything else."""
+    import yaml
+
+    from happypose_amd import load_model as LM
+    from happypose_amd.models import check_update_config, n_input_channels
+
+    f = tmp_path / "config.yaml"
+    f.write_text("!!python/object:argparse.Namespace\nbackbone_str: vanilla_resnet34\nn_views: 4\n"
+                 "multiview_type: front_3views\nrender_normals: true\ninput_resize: !!python/tuple [540, 720]\n"
+                 "renderer: panda3d\n")
+    cfg = LM.load_cfg(f)
+    assert cfg.backbone_str == "vanilla_resnet34" and cfg.input_resize == (540, 720)
+    upd = check_update_config(cfg)
+    assert upd.multiview_type == "TCO+front_3views" and n_input_channels(upd) == 27
+    f.write_text("a: 1\nb: [2, 3]\n")  # plain mapping (OmegaConf-style configs)
+    assert LM.load_cfg(f).b == [2, 3]
+    f.write_text("x: !!python/object/apply:os.system ['echo pwned']\n")
+    with pytest.raises(yaml.YAMLError):
+        LM.load_cfg(f)
+    m = LM.NAMED_MODELS
+    assert set(m) == {"megapose-1.0-RGB", "megapose-1.0-RGBD", "megapose-1.0-RGB-multi-hypothesis",
+                      "megapose-1.0-RGB-multi-hypothesis-icp"}
+    assert m["megapose-1.0-RGBD"]["requires_depth"] and m["megapose-1.0-RGBD"]["refiner_run_id"] == "refiner-rgbd-288182519"
+    assert m["megapose-1.0-RGB-multi-hypothesis-icp"]["inference_parameters"] == {
+        "n_refiner_iterations": 5, "n_pose_hypotheses": 5, "run_depth_refiner": True}
+    assert m["megapose-1.0-RGB"]["inference_parameters"] == {"n_refiner_iterations": 5, "n_pose_hypotheses": 1}
