@@ -161,6 +161,16 @@ def stage_rates(store, scene, images, K, TCO0, im_ids, device, reps=20):
     }
 
 
+def measured_traffic(workload, precision):
+    """HBM bytes per conv launch from the committed PMC summary (rocprofv3 FETCH_SIZE / WRITE_SIZE
+    passes of this bench command, tools/pmc_traffic.py); None when no summary matches the run."""
+    path = os.path.join(ROOT, "profiles", "r01c_conv_hbm_traffic.json")
+    if workload != "C2" or precision != "f32" or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return float(json.load(fh)["hbm_bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,7 +269,9 @@ def main():
                                     "fp32 MFMA conv kernels" if precision == "f32" else
                                     "conv_igemm_f16: fp16 MFMA implicit-GEMM conv (fp32 accumulate)") + ", all conv launches of a forward",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": measured_traffic(args.workload, precision),
+                         "traffic_note": "HBM bytes per conv launch (incl. Infinity-Cache hits), PMC passes of this command: "
+                                         "profiles/r01c_conv_hbm_traffic.json; the kernels are MFMA-bound",
                          "mfma_executed_tflops": mfma_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else 0.0,
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
