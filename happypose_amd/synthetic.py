@@ -157,6 +157,8 @@ def named_weights(shapes: Dict[str, Tuple[int, ...]], seed: int = 0,
                 w = w * head_scale
             if name.endswith("conv2.weight"):
                 w = w * 0.25  # keeps the residual stream O(1) through 16 blocks
+            if name.endswith("_project_conv.weight"):
+                w = w * 0.3  # same for the 26 MBConv blocks of EfficientNet-b3
             out[name] = w.astype(np.float32)
     return out
 

@@ -132,6 +132,106 @@ def wide_resnet_forward(x: torch.Tensor, sd, depth: int = 34, prefix: str = "") 
     return x
 
 
+# --------------------------------------------------------------------------- EfficientNet-b3
+# CP/models/efficientnet.py:20-331 + efficientnet_utils.py (the backbone of the released
+# CosyPose checkpoints, selected at CP/training/pose_models_cfg.py:33-35).  Pinned by golden G9
+# (tests/golden/g9_efficientnet.npz: output of the reference module on name-keyed weights).
+_EFF_BASE = [  # repeats, kernel, stride, expand, in, out  (efficientnet_utils.py:345-353; se_ratio 0.25)
+    (1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+    (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+_EFF_B3 = dict(width=1.2, depth=1.4, image_size=300, bn_eps=1e-3, divisor=8)  # :248, :357-367
+
+
+def _eff_round_filters(f, width=1.2, divisor=8):
+    f = f * width
+    new = max(divisor, int(f + divisor / 2) // divisor * divisor)
+    if new < 0.9 * f:
+        new += divisor
+    return int(new)
+
+
+def efficientnet_b3_blocks():
+    """[(kernel, stride, expand, in, out, se_channels)] of the 26 MBConv blocks."""
+    import math
+
+    blocks = []
+    for r, k, s, e, i, o in _EFF_BASE:
+        i, o = _eff_round_filters(i), _eff_round_filters(o)
+        for j in range(int(math.ceil(_EFF_B3["depth"] * r))):
+            cin, stride = (i, s) if j == 0 else (o, 1)
+            blocks.append((k, stride, e, cin, o, max(1, int(cin * 0.25))))
+    return blocks
+
+
+def efficientnet_b3_param_shapes(n_inputs: int) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    stem = _eff_round_filters(32)
+    s["_conv_stem.weight"] = (stem, n_inputs, 3, 3)
+    s.update(_bn_shapes("_bn0", stem))
+    for bi, (k, _st, e, cin, cout, cse) in enumerate(efficientnet_b3_blocks()):
+        p, mid = f"_blocks.{bi}", cin * e
+        if e != 1:
+            s[f"{p}._expand_conv.weight"] = (mid, cin, 1, 1)
+            s.update(_bn_shapes(f"{p}._bn0", mid))
+        s[f"{p}._depthwise_conv.weight"] = (mid, 1, k, k)
+        s.update(_bn_shapes(f"{p}._bn1", mid))
+        s[f"{p}._se_reduce.weight"] = (cse, mid, 1, 1)
+        s[f"{p}._se_reduce.bias"] = (cse,)
+        s[f"{p}._se_expand.weight"] = (mid, cse, 1, 1)
+        s[f"{p}._se_expand.bias"] = (mid,)
+        s[f"{p}._project_conv.weight"] = (cout, mid, 1, 1)
+        s.update(_bn_shapes(f"{p}._bn2", cout))
+    head = _eff_round_filters(1280)
+    s["_conv_head.weight"] = (head, efficientnet_b3_blocks()[-1][4], 1, 1)
+    s.update(_bn_shapes("_bn1", head))
+    return s
+
+
+def _same_pad_static(k: int, stride: int, image_size: int = 300):
+    """Conv2dStaticSamePadding (efficientnet_utils.py:183-212): the padding is computed ONCE for
+    ``image_size`` (300 for b3), not for the actual feature map: (left/top, right/bottom)."""
+    import math
+
+    o = math.ceil(image_size / stride)
+    pad = max((o - 1) * stride + (k - 1) + 1 - image_size, 0)
+    return pad // 2, pad - pad // 2
+
+
+def efficientnet_b3_forward(x: torch.Tensor, sd, prefix: str = "") -> torch.Tensor:
+    """``EfficientNet.extract_features`` (CP/models/efficientnet.py:265-277) in eval mode (no drop
+    connect); returns ``[B,1536,h',w']`` ([.,.,7,10] for a 240x320 input)."""
+    sdp = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)} if prefix else sd
+    eps = _EFF_B3["bn_eps"]
+
+    def conv(x, name, k, stride, groups=1, bias=None):
+        lo, hi = _same_pad_static(k, stride)
+        if lo or hi:
+            x = F.pad(x, (lo, hi, lo, hi))
+        return F.conv2d(x, _t(sdp, name), None if bias is None else _t(sdp, bias), stride=stride, groups=groups)
+
+    def bn(x, p):
+        return F.batch_norm(x, _t(sdp, f"{p}.running_mean"), _t(sdp, f"{p}.running_var"), _t(sdp, f"{p}.weight"),
+                            _t(sdp, f"{p}.bias"), False, 0.0, eps)
+
+    def swish(x):
+        return x * torch.sigmoid(x)
+
+    x = swish(bn(conv(x, "_conv_stem.weight", 3, 2), "_bn0"))
+    for bi, (k, stride, e, cin, cout, _cse) in enumerate(efficientnet_b3_blocks()):
+        p, inp = f"_blocks.{bi}", x
+        if e != 1:
+            x = swish(bn(conv(x, f"{p}._expand_conv.weight", 1, 1), f"{p}._bn0"))
+        x = swish(bn(conv(x, f"{p}._depthwise_conv.weight", k, stride, groups=x.shape[1]), f"{p}._bn1"))
+        sq = F.adaptive_avg_pool2d(x, 1)
+        sq = conv(swish(conv(sq, f"{p}._se_reduce.weight", 1, 1, bias=f"{p}._se_reduce.bias")),
+                  f"{p}._se_expand.weight", 1, 1, bias=f"{p}._se_expand.bias")
+        x = torch.sigmoid(sq) * x
+        x = bn(conv(x, f"{p}._project_conv.weight", 1, 1), f"{p}._bn2")
+        if stride == 1 and cin == cout:
+            x = x + inp
+    return swish(bn(conv(x, "_conv_head.weight", 1, 1), "_bn1"))
+
+
 def net_forward(x: torch.Tensor, sd, arch: str, heads=("pose",)) -> Dict[str, torch.Tensor]:
     """``PosePredictor.net_forward`` (MP/models/pose_rigid.py:352-374,
     CP/models/pose.py:108-114): backbone -> (spatial mean if 4-D) -> linear heads.
@@ -139,6 +239,8 @@ def net_forward(x: torch.Tensor, sd, arch: str, heads=("pose",)) -> Dict[str, to
     ``views_logits_head.*``."""
     if arch == "vanilla_resnet34":
         f = resnet34_forward(x, sd, "backbone.")
+    elif arch == "efficientnet-b3":
+        f = efficientnet_b3_forward(x, sd, "backbone.").flatten(2).mean(dim=-1)
     else:
         f = wide_resnet_forward(x, sd, 34 if arch == "resnet34" else 18, "backbone.")
         f = f.flatten(2).mean(dim=-1)

@@ -145,3 +145,25 @@ def test_so3_grid():
     s = np.sqrt(0.5)
     np.testing.assert_allclose(G.unitquat_to_rotmat(np.array([0, 0, s, s])),
                                np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]]), atol=1e-7)
+
+
+def test_g9_efficientnet_b3_restatement(golden_dir):
+    """oracle.backbones.efficientnet_b3_forward vs the reference module's own output (G9):
+    key list, shapes and features must match the module exactly."""
+    import torch
+
+    from happypose_amd.synthetic import named_weights
+    from oracle import backbones as ob
+
+    g = np.load(golden_dir / "g9_efficientnet.npz")
+    shapes = ob.efficientnet_b3_param_shapes(6)
+    assert list(shapes.keys()) == list(g["keys"]) and [str(v) for v in shapes.values()] == list(g["shapes"])
+    assert len(ob.efficientnet_b3_blocks()) == 26
+    w = named_weights(shapes, seed=0)
+    x = np.random.RandomState(106).uniform(-1, 1, size=(2, 6, 240, 320)).astype(np.float32)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        y = ob.efficientnet_b3_forward(torch.as_tensor(x), w)
+    assert tuple(y.shape) == tuple(g["out_shape"]) == (2, 1536, 7, 10)
+    np.testing.assert_allclose(y.mean(dim=(2, 3)).numpy(), g["out_mean"], atol=1e-6)
+    np.testing.assert_allclose(y.flatten()[::211].numpy(), g["out_sample"], atol=1e-6)
