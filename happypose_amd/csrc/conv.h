@@ -5,12 +5,16 @@
 
 namespace hp {
 
+// activation applied by the conv epilogues (ConvArgs::relu)
+enum { HP_ACT_NONE = 0, HP_ACT_RELU = 1, HP_ACT_SWISH = 2 };
+
 struct ConvArgs {
   const float* x;          // NHWC [n][H][W][Cin]
   const float* w;          // packed [Cout][Kpad]
   const float* bias;       // [Cout] or null
   const float* residual;   // NHWC [n][Ho][Wo][Cout] or null
-  const float* pre_scale;  // [Cin] or null  (x_act = relu(x * scale + shift))
+  const float* pre_scale;  // [Cin] or null  (x_act = relu(x * scale + shift)); with pre_shift == null:
+                           // [n_img][Cin] squeeze-excitation gate, x_act = x * scale[img] (generic kernel only)
   const float* pre_shift;
   const int4* lut;         // [Kpad/4] {offset, kh, kw, channel}; kh < 0 marks K padding
   float* y;                // NHWC [n][Ho][Wo][Cout]

@@ -70,13 +70,17 @@ struct Tile {
 template <int NA, int NB>
 struct Stage {
   floatx4 ra[NA], rb[NB];
-  floatx4 ps, pb;     // prologue scale / shift of this chunk's 4 channels
+  floatx4 ps, pb;     // prologue scale / shift of this chunk's 4 channels (PRE == 1)
+  floatx4 se[NA];     // per-sample channel scale of each staged row (PRE == 2: squeeze-excitation)
   unsigned ok;        // bit i: A chunk i is inside the image (else it is zero padding)
 };
 
-template <int NA, int NB, bool PRE>
+// PRE: 0 = none, 1 = per-channel scale / shift / ReLU (pre-activation BN), 2 = per-(sample, channel)
+// scale (the squeeze-excitation gate of an MBConv block, applied where the projection reads it)
+
+template <int NA, int NB, int PRE>
 __device__ __forceinline__ void issue_loads(const ConvArgs& a, int t, const int4 e, const int64_t (&rowoff)[NA],
-                                            const int (&ih0)[NA], const int (&iw0)[NA],
+                                            const int (&ih0)[NA], const int (&iw0)[NA], const int (&imgoff)[NA],
                                             const float* const (&wrow)[NB], Stage<NA, NB>& s) {
   // e = {offset, kh, kw, channel}; kh < 0 marks K padding.  Loads are unconditional: an
   // out-of-image chunk reads a harmless valid address and is zeroed at store time.
@@ -88,26 +92,28 @@ __device__ __forceinline__ void issue_loads(const ConvArgs& a, int t, const int4
     const float* p = in ? a.x + rowoff[i] + e.x : a.x;
     s.ra[i] = *reinterpret_cast<const floatx4*>(p);
     ok |= (in ? 1u : 0u) << i;
+    if (PRE == 2) s.se[i] = *reinterpret_cast<const floatx4*>(a.pre_scale + (in ? imgoff[i] + e.w : 0));
   }
   s.ok = ok;
 #pragma unroll
   for (int i = 0; i < NB; ++i) s.rb[i] = *reinterpret_cast<const floatx4*>(wrow[i] + t * BK);
-  if (PRE) {
+  if (PRE == 1) {
     const int c = e.y >= 0 ? e.w : 0;
     s.ps = *reinterpret_cast<const floatx4*>(a.pre_scale + c);
     s.pb = *reinterpret_cast<const floatx4*>(a.pre_shift + c);
   }
 }
 
-template <int NA, int NB, bool PRE>
+template <int NA, int NB, int PRE>
 __device__ __forceinline__ void store_tile(float* Ast, float* Bst, const Stage<NA, NB>& s) {
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     floatx4 v = s.ra[i];
-    if (PRE) {
+    if (PRE == 1) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], s.ps[q], s.pb[q]), 0.f);
     }
+    if (PRE == 2) v *= s.se[i];
     const bool in = (s.ok >> i) & 1u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = in ? v[q] : 0.f;
@@ -118,35 +124,37 @@ __device__ __forceinline__ void store_tile(float* Ast, float* Bst, const Stage<N
 }
 
 // ---- the same staging work, one chunk at a time (interleaved with the MFMAs) -----------
-template <int NA, int NB>
+template <int NA, int NB, int PRE>
 __device__ __forceinline__ void load_a_chunk(const ConvArgs& a, const int4 e, int i, int64_t rowoff, int ih0, int iw0,
-                                             Stage<NA, NB>& s) {
+                                             int imgoff, Stage<NA, NB>& s) {
   const int ih = ih0 + e.y, iw = iw0 + e.z;
   const bool in = (e.y >= 0) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
   const float* p = in ? a.x + rowoff + e.x : a.x;
   s.ra[i] = *reinterpret_cast<const floatx4*>(p);
   s.ok |= (in ? 1u : 0u) << i;
+  if (PRE == 2) s.se[i] = *reinterpret_cast<const floatx4*>(a.pre_scale + (in ? imgoff + e.w : 0));
 }
 
-template <int NA, int NB, bool PRE>
+template <int NA, int NB, int PRE>
 __device__ __forceinline__ void load_b_chunks(const ConvArgs& a, int t, const int4 e, const float* const (&wrow)[NB],
                                               Stage<NA, NB>& s) {
 #pragma unroll
   for (int i = 0; i < NB; ++i) s.rb[i] = *reinterpret_cast<const floatx4*>(wrow[i] + t * BK);
-  if (PRE) {
+  if (PRE == 1) {
     const int c = e.y >= 0 ? e.w : 0;
     s.ps = *reinterpret_cast<const floatx4*>(a.pre_scale + c);
     s.pb = *reinterpret_cast<const floatx4*>(a.pre_shift + c);
   }
 }
 
-template <int NA, int NB, bool PRE>
+template <int NA, int NB, int PRE>
 __device__ __forceinline__ void store_a_chunk(float* Aw, int i, const Stage<NA, NB>& s) {
   floatx4 v = s.ra[i];
-  if (PRE) {
+  if (PRE == 1) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], s.ps[q], s.pb[q]), 0.f);
   }
+  if (PRE == 2) v *= s.se[i];
   const bool in = (s.ok >> i) & 1u;
 #pragma unroll
   for (int q = 0; q < 4; ++q) v[q] = in ? v[q] : 0.f;
@@ -177,7 +185,7 @@ __device__ __forceinline__ void mfma_group(const floatx4 (&fa)[MT], const floatx
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
 }
 
-template <int BM, int BN, bool PRE>
+template <int BM, int BN, int PRE>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_igemm_f32(ConvArgs a) {
   using TT = Tile<BM, BN>;
   constexpr int MT = TT::MT, NT = TT::NT, NA = TT::A_CHUNKS, NB = TT::B_CHUNKS;
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   // ---- per-row (output pixel) constants for the A gather ----
   int64_t rowoff[NA];
-  int ih0[NA], iw0[NA];
+  int ih0[NA], iw0[NA], imgoff[NA];
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -213,8 +221,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
       ih0[i] = oh * a.stride - a.pad;
       iw0[i] = ow * a.stride - a.pad;
       rowoff[i] = (((int64_t)img * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
+      imgoff[i] = img * a.Cin;
     } else {
-      ih0[i] = -(1 << 28); iw0[i] = 0; rowoff[i] = 0;
+      ih0[i] = -(1 << 28); iw0[i] = 0; rowoff[i] = 0; imgoff[i] = 0;
     }
   }
   const float* wrow[NB];
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   Stage<NA, NB> st;
   // the LUT carries one extra K-tile of padding entries, so t+2 below never reads out of range
-  issue_loads<NA, NB, PRE>(a, 0, a.lut[kc], rowoff, ih0, iw0, wrow, st);
+  issue_loads<NA, NB, PRE>(a, 0, a.lut[kc], rowoff, ih0, iw0, imgoff, wrow, st);
   int4 e_next = a.lut[8 + kc];
   store_tile<NA, NB, PRE>(Ast, Bst, st);
   __syncthreads();
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 #endif
         if (q < 4) {
 #pragma unroll
-          for (int i = q; i < NA; i += 4) load_a_chunk<NA, NB>(a, e, i, rowoff[i], ih0[i], iw0[i], st);
+          for (int i = q; i < NA; i += 4) load_a_chunk<NA, NB, PRE>(a, e, i, rowoff[i], ih0[i], iw0[i], imgoff[i], st);
         } else if (q == 4) {
           load_b_chunks<NA, NB, PRE>(a, t + 1, e, wrow, st);
           e_next = a.lut[(t + 2) * 8 + kc];
@@ -316,10 +325,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   conv_epilogue<BM, BN, MT, NT, kThreads>(a, lds, acc, m0, n0, wm, wn);
 }
 
-template <int BM, int BN, bool PRE>
+template <int BM, int BN, int PRE>
 static int launch_variant(ConvArgs args, hipStream_t stream) {
   args.tiles_m = (int)((args.M + BM - 1) / BM);
-  args.tiles_n = args.Cout / BN;
+  args.tiles_n = (args.Cout + BN - 1) / BN;  // weights / bias are padded to whole tiles; stores are not
   const int nblk = args.tiles_m * args.tiles_n;
   const size_t lds = Tile<BM, BN>::LDS_FLOATS * sizeof(float);
   hipLaunchKernelGGL((conv_igemm_f32<BM, BN, PRE>), dim3(8 * ((nblk + 7) / 8)), dim3(kThreads), lds, stream, args);
@@ -327,12 +336,16 @@ static int launch_variant(ConvArgs args, hipStream_t stream) {
 }
 
 int launch_conv(const ConvArgs& a, int variant, hipStream_t stream) {
-  const bool pre = a.pre_scale != nullptr;
-  if (variant == 0) return pre ? launch_variant<128, 128, true>(a, stream) : launch_variant<128, 128, false>(a, stream);
-  return pre ? launch_variant<128, 64, true>(a, stream) : launch_variant<128, 64, false>(a, stream);
+  const int pre = a.pre_scale == nullptr ? 0 : (a.pre_shift != nullptr ? 1 : 2);
+  if (variant == 0) {
+    if (pre == 2) return launch_variant<128, 128, 2>(a, stream);
+    return pre ? launch_variant<128, 128, 1>(a, stream) : launch_variant<128, 128, 0>(a, stream);
+  }
+  if (pre == 2) return launch_variant<128, 64, 2>(a, stream);
+  return pre ? launch_variant<128, 64, 1>(a, stream) : launch_variant<128, 64, 0>(a, stream);
 }
 
-template <int BM, int BN, bool PRE>
+template <int BM, int BN, int PRE>
 static int opt_in_lds() {
   // > 64 KB of dynamic LDS needs the opt-in attribute
   HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<BM, BN, PRE>),
@@ -345,10 +358,12 @@ int conv_setup_once() {
   static bool done = false;
   if (done) return HP_OK;
   int rc;
-  if ((rc = opt_in_lds<128, 128, false>())) return rc;
-  if ((rc = opt_in_lds<128, 128, true>())) return rc;
-  if ((rc = opt_in_lds<128, 64, false>())) return rc;
-  if ((rc = opt_in_lds<128, 64, true>())) return rc;
+  if ((rc = opt_in_lds<128, 128, 0>())) return rc;
+  if ((rc = opt_in_lds<128, 128, 1>())) return rc;
+  if ((rc = opt_in_lds<128, 128, 2>())) return rc;
+  if ((rc = opt_in_lds<128, 64, 0>())) return rc;
+  if ((rc = opt_in_lds<128, 64, 1>())) return rc;
+  if ((rc = opt_in_lds<128, 64, 2>())) return rc;
   done = true;
   return HP_OK;
 }
@@ -382,10 +397,10 @@ extern "C" int hp_conv_occupancy(int variant) {
   if (conv_setup_once() != HP_OK) return HP_ERR_HIP;
   int nb = 0;
   if (variant == 0) {
-    HP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_igemm_f32<128, 128, false>, kThreads,
+    HP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_igemm_f32<128, 128, 0>, kThreads,
                                                               Tile<128, 128>::LDS_FLOATS * sizeof(float)));
   } else {
-    HP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_igemm_f32<128, 64, false>, kThreads,
+    HP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_igemm_f32<128, 64, 0>, kThreads,
                                                               Tile<128, 64>::LDS_FLOATS * sizeof(float)));
   }
   return nb;

@@ -40,18 +40,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* lds, epi
   const int c4 = tid % C4;
   const int n = n0 + 4 * c4;
   epi_floatx4 bias = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias) bias = *reinterpret_cast<const epi_floatx4*>(a.bias + n);
+  if (a.bias) bias = *reinterpret_cast<const epi_floatx4*>(a.bias + n);  // padded to whole tiles by the planner
+  const bool n_ok = n < a.Cout;  // the last tile of a layer whose Cout is not a multiple of BN
 #pragma unroll
   for (int k = 0; k < ITERS; ++k) {
     const int row = tid / C4 + k * (THREADS / C4);
     const int64_t m = m0 + row;
-    if (m < a.M) {
+    if (m < a.M && n_ok) {
       epi_floatx4 v = *reinterpret_cast<const epi_floatx4*>(lds + row * LDC + 4 * c4);
       v += bias;
       if (a.residual) v += *reinterpret_cast<const epi_floatx4*>(a.residual + m * a.Cout + n);
-      if (a.relu) {
+      if (a.relu == HP_ACT_RELU) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+      } else if (a.relu == HP_ACT_SWISH) {  // x * sigmoid(x)  (MemoryEfficientSwish, CP/models/efficientnet_utils.py)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + __expf(-v[q]));
       }
       *reinterpret_cast<epi_floatx4*>(a.y + m * a.Cout + n) = v;
     }

@@ -374,7 +374,7 @@ int launch(ConvArgs args, hipStream_t stream, bool* opted) {
 }  // namespace
 
 bool conv_patch_applicable(const ConvArgs& a, int kh, int kw) {
-  if (kh != 3 || kw != 3 || a.stride != 1 || a.pad != 1 || a.Cin % BK != 0) return false;
+  if (kh != 3 || kw != 3 || a.stride != 1 || a.pad != 1 || a.Cin % BK != 0 || a.Cout % 64 != 0) return false;
   const int P = BM + 2 * a.W + 2;
   if ((P * 8 + kThreads - 1) / kThreads > kMaxPatchChunks) return false;
   // patch + double-buffered 128-wide weight tile must fit the 160 KB of LDS

@@ -537,17 +537,39 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
                               const float* d_pre_shift, int relu, float* d_y, void* stream) {
   HP_REQUIRE(d_x && d_w && d_y, "hp_conv2d_nhwc: null pointer");
   HP_REQUIRE(cin % 4 == 0 && cin > 0, "hp_conv2d_nhwc: cin must be a multiple of 4");
-  HP_REQUIRE(cout % 64 == 0 && cout > 0, "hp_conv2d_nhwc: cout must be a multiple of 64");
+  HP_REQUIRE(cout % 4 == 0 && cout > 0, "hp_conv2d_nhwc: cout must be a multiple of 4");
   HP_REQUIRE(kh == kw && kh >= 1 && (stride == 1 || stride == 2) && pad >= 0, "hp_conv2d_nhwc: unsupported geometry");
-  HP_REQUIRE((d_pre_scale == nullptr) == (d_pre_shift == nullptr), "hp_conv2d_nhwc: pre_scale/pre_shift must come together");
+  HP_REQUIRE(d_pre_scale || !d_pre_shift, "hp_conv2d_nhwc: pre_shift without pre_scale");
+  HP_REQUIRE(relu >= HP_ACT_NONE && relu <= HP_ACT_SWISH, "hp_conv2d_nhwc: unknown activation");
   int rc = conv_setup_once();
   if (rc) return rc;
   const int Kreal = kh * kw * cin, Kpad = (Kreal + 31) / 32 * 32;
-  HP_REQUIRE(Kreal == Kpad, "hp_conv2d_nhwc: kh*kw*cin must be a multiple of 32 (weights are [cout][kh][kw][cin])");
   std::vector<int4> lut(Kpad / 4 + 16, make_int4(0, -1, 0, 0));
-  for (int q = 0; q < Kpad / 4; ++q) {
+  for (int q = 0; q < Kreal / 4; ++q) {
     const int k = 4 * q, seg = k / cin, ch = k % cin, y = seg / kw, x = seg % kw;
     lut[q] = make_int4((y * w + x) * cin + ch, y, x, ch);
+  }
+  // weights / bias padded to whole 64-wide tiles and to a multiple of 32 in K (the planner does
+  // this once at load time; this test entry on every call, into per-process scratch buffers)
+  const int cout_pad = (cout + 63) / 64 * 64;
+  const bool padded = cout_pad != cout || Kpad != Kreal;
+  if (padded) {
+    static float* d_wp = nullptr;
+    static size_t wp_floats = 0;
+    const size_t need = (size_t)cout_pad * Kpad + cout_pad;
+    if (wp_floats < need) {
+      if (d_wp) (void)hipFree(d_wp);
+      d_wp = nullptr; wp_floats = 0;
+      HP_CHECK_HIP(hipMalloc((void**)&d_wp, need * sizeof(float)));
+      wp_floats = need;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HP_CHECK_HIP(hipMemsetAsync(d_wp, 0, need * sizeof(float), st));
+    HP_CHECK_HIP(hipMemcpy2DAsync(d_wp, (size_t)Kpad * 4, d_w, (size_t)Kreal * 4, (size_t)Kreal * 4, cout,
+                                  hipMemcpyDeviceToDevice, st));
+    if (d_bias) HP_CHECK_HIP(hipMemcpyAsync(d_wp + (size_t)cout_pad * Kpad, d_bias, (size_t)cout * 4, hipMemcpyDeviceToDevice, st));
+    d_w = d_wp;
+    if (d_bias) d_bias = d_wp + (size_t)cout_pad * Kpad;
   }
   // the LUT lives until the stream has consumed it: allocate, async copy, free after sync is
   // avoided by keeping a small per-process cache keyed on the geometry.
@@ -568,7 +590,8 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   a.H = h; a.W = w; a.Cin = cin; a.Ho = (h + 2 * pad - kh) / stride + 1; a.Wo = (w + 2 * pad - kw) / stride + 1;
   a.Cout = cout; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.ktiles = Kpad / 32; a.relu = relu;
   a.M = (int64_t)n * a.Ho * a.Wo;
-  const int algo = conv_algo();
+  const bool classic = !padded && relu != HP_ACT_SWISH && (d_pre_shift || !d_pre_scale);  // what the 3x3 kernels support
+  const int algo = classic ? conv_algo() : HP_CONV_ALGO_IGEMM;
   if (algo == HP_CONV_ALGO_AUTO && conv_wino_applicable(a, kh, kw) && conv_wino_launchable(a)) {
     // test entry: the weights are transformed on every call into a per-process scratch buffer
     static float* d_U = nullptr;
@@ -586,7 +609,7 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   }
   if (algo != HP_CONV_ALGO_IGEMM && conv_patch_applicable(a, kh, kw))
     return launch_conv_patch(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
-  return launch_conv(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
+  return launch_conv(a, cout_pad % 128 == 0 ? 0 : 1, (hipStream_t)stream);
 }
 
 // ---- single-layer entry of the fp16 kernel for the parity tests (all tensors fp16 except bias) ----

@@ -327,7 +327,9 @@ def select_conv_algo(name: str = "auto") -> None:
 
 
 def conv2d_nhwc(x, w_packed, stride, pad, bias=None, residual=None, pre_scale=None, pre_shift=None, relu=False):
-    """Single conv layer (parity tests).  ``x [n,h,w,cin]``, ``w_packed [cout,kh,kw,cin]``."""
+    """Single conv layer (parity tests).  ``x [n,h,w,cin]``, ``w_packed [cout,kh,kw,cin]``.
+    ``relu``: False/0 none, True/1 ReLU, 2 swish.  ``pre_scale [cin]`` + ``pre_shift [cin]`` = the
+    BN+ReLU prologue; ``pre_scale [n,cin]`` alone = a squeeze-excitation gate on the input."""
     dev = x.device
     n, h, w, cin = x.shape
     cout, kh, kw, cin2 = w_packed.shape

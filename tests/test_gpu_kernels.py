@@ -349,6 +349,38 @@ def test_conv3x3_kernel_families(dev, case, algo):
         ops.select_conv_algo("auto")
 
 
+# what the MBConv blocks of EfficientNet-b3 need from the generic kernel: channel counts that are not
+# multiples of 64 (weights padded to whole tiles, stores not), K = Cin not a multiple of 32, swish,
+# the squeeze-excitation gate on the input of the projection
+@pytest.mark.parametrize("case", [
+    dict(n=2, h=30, w=40, cin=8, cout=40, k=3, s=2, p=1, bias=True, res=False, act=2, se=False),     # stem-like
+    dict(n=3, h=30, w=40, cin=24, cout=144, k=1, s=1, p=0, bias=True, res=False, act=2, se=False),   # expand
+    dict(n=3, h=15, w=20, cin=144, cout=24, k=1, s=1, p=0, bias=True, res=True, act=0, se=True),     # project + skip
+    dict(n=2, h=7, w=10, cin=232, cout=136, k=1, s=1, p=0, bias=False, res=False, act=0, se=True),
+    dict(n=2, h=7, w=10, cin=384, cout=1536, k=1, s=1, p=0, bias=True, res=False, act=2, se=False),  # head
+])
+def test_conv2d_mbconv_features(dev, case):
+    from happypose_amd import ops
+
+    rs = np.random.RandomState(11)
+    c = case
+    x = rs.normal(size=(c["n"], c["h"], c["w"], c["cin"])).astype(np.float32)
+    w = (rs.normal(size=(c["cout"], c["cin"], c["k"], c["k"])) / np.sqrt(c["cin"] * c["k"] ** 2)).astype(np.float32)
+    ho, wo = (c["h"] + 2 * c["p"] - c["k"]) // c["s"] + 1, (c["w"] + 2 * c["p"] - c["k"]) // c["s"] + 1
+    bias = rs.normal(size=c["cout"]).astype(np.float32) if c["bias"] else None
+    res = rs.normal(size=(c["n"], ho, wo, c["cout"])).astype(np.float32) if c["res"] else None
+    gate = rs.uniform(0.1, 1.0, size=(c["n"], c["cin"])).astype(np.float32) if c["se"] else None
+    xin = x.astype(np.float64) * (gate[:, None, None, :] if gate is not None else 1.0)
+    ref = _conv_ref(xin, w, c["s"], c["p"], bias, res, None, False)
+    if c["act"] == 2:
+        ref = ref / (1.0 + np.exp(-ref))
+    t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+    y = ops.conv2d_nhwc(t(x), t(np.ascontiguousarray(w.transpose(0, 2, 3, 1))), c["s"], c["p"], t(bias), t(res), t(gate), None, c["act"])
+    assert y.shape == (c["n"], ho, wo, c["cout"])
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
+
+
 def _check_conv(dev, case, tol=2e-5):
     from happypose_amd import ops
 
