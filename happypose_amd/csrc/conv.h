@@ -42,6 +42,12 @@ struct ConvArgsH {
   int tiles_m, tiles_n;       // filled by the launcher
 };
 
+// depthwise k x k conv + folded BN + swish (mbconv.hip)
+struct DwArgs {
+  const float* x; const float* w /* [k*k][C], BN scale folded */; const float* bias /* [C] BN shift */; float* y;
+  int n, H, W, C, Ho, Wo, k, stride, pad_t, pad_l;
+};
+
 struct HeadArgs {
   int x_is_half;   // features are fp16 (fp16 plan) instead of fp32
   const void* x;   // NHWC [b][HW][C]
@@ -66,6 +72,10 @@ int conv_wino_transform_weights(const float* d_w, float* d_U, int cout, int cin,
 int launch_conv_wino(const ConvArgs& a, hipStream_t stream);
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream);
+int launch_dwconv(const DwArgs& a, hipStream_t stream);
+// squeeze-excitation: pooled [n][C] = mean over HW of y; gate [n][C] = sigmoid(W2 swish(W1 pooled + b1) + b2)
+int launch_se(const float* y, float* pooled, float* gate, const float* w1, const float* b1, const float* w2, const float* b2,
+              int n, int HW, int C, int Cse, hipStream_t stream);
 int launch_conv_f16(const ConvArgsH& a, hipStream_t stream);
 int launch_cast_pad_f16(const float* x, void* y, int64_t pixels, int c_in, int c_out, hipStream_t stream);
 int launch_maxpool_f16(const void* x, void* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);

@@ -1,0 +1,116 @@
+// Memory-bound pieces of the MBConv block of EfficientNet (CP/models/efficientnet.py:20-150,
+// the backbone of the released CosyPose checkpoints -- SURVEY.md 8f-1): depthwise k x k
+// convolution + folded BatchNorm + swish, and squeeze-excitation (global mean -> 1x1 reduce ->
+// swish -> 1x1 expand -> sigmoid).  The 1x1 expansion / projection convolutions are GEMMs and
+// run on the generic MFMA kernel (conv.hip), which also applies the excitation gate while it
+// stages the projection's input, so the gated tensor never exists in memory.
+//
+// All tensors NHWC fp32 with C % 4 == 0 (every EfficientNet width is a multiple of 8).
+// "Same" padding follows Conv2dStaticSamePadding (efficientnet_utils.py:183-212): the pad
+// (top/left, bottom/right) is fixed per layer by the planner; bottom/right padding is implicit
+// in the bounds test.
+#include "conv.h"
+
+namespace hp {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ floatx4 swish4(floatx4 v) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + __expf(-v[q]));
+  return v;
+}
+
+// one lane = 4 channels of one output pixel; consecutive lanes = consecutive channel quads, so a
+// wave reads / writes contiguous 1-KB runs; the k*k taps of neighbouring pixels are L1/L2 hits
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_swish_nhwc(DwArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C4 = a.C / 4;
+  if (idx >= (int64_t)a.n * a.Ho * a.Wo * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  int64_t p = idx / C4;
+  const int ow = (int)(p % a.Wo); p /= a.Wo;
+  const int oh = (int)(p % a.Ho);
+  const int img = (int)(p / a.Ho);
+  floatx4 acc = *reinterpret_cast<const floatx4*>(a.bias + c);
+  const int ih0 = oh * a.stride - a.pad_t, iw0 = ow * a.stride - a.pad_l;
+#pragma unroll
+  for (int dy = 0; dy < K; ++dy) {
+    const int ih = ih0 + dy;
+    if ((unsigned)ih >= (unsigned)a.H) continue;
+#pragma unroll
+    for (int dx = 0; dx < K; ++dx) {
+      const int iw = iw0 + dx;
+      if ((unsigned)iw >= (unsigned)a.W) continue;
+      const floatx4 xv = *reinterpret_cast<const floatx4*>(a.x + (((int64_t)img * a.H + ih) * a.W + iw) * a.C + c);
+      const floatx4 wv = *reinterpret_cast<const floatx4*>(a.w + (dy * K + dx) * a.C + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = fmaf(xv[q], wv[q], acc[q]);
+    }
+  }
+  *reinterpret_cast<floatx4*>(a.y + (((int64_t)img * a.Ho + oh) * a.Wo + ow) * a.C + c) = swish4(acc);
+}
+
+// global mean over the pixels of each (image, channel): block = 64 channels x 4 pixel lanes, fixed
+// summation order (pixel lanes stride the map, then a 4-way LDS sum) -> bitwise reproducible
+__global__ __launch_bounds__(256) void se_pool_kernel(const float* y, float* pooled, int HW, int C) {
+  __shared__ float part[4][64];
+  const int img = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C) {
+    const float* base = y + (int64_t)img * HW * C + c;
+    for (int p = pl; p < HW; p += 4) s += base[(int64_t)p * C];
+  }
+  part[pl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (pl == 0 && c < C) pooled[(int64_t)img * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)HW;
+}
+
+// gate = sigmoid(W2 swish(W1 pooled + b1) + b2): one block per image (Cse <= 128, C <= 4096)
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* pooled, const float* w1, const float* b1, const float* w2,
+                                                      const float* b2, float* gate, int C, int Cse) {
+  __shared__ float sq[128];
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* pv = pooled + (int64_t)img * C;
+  for (int j = wave; j < Cse; j += 4) {
+    const float* w = w1 + (int64_t)j * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(w[c], pv[c], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) { s += b1[j]; sq[j] = s / (1.f + __expf(-s)); }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const float* w = w2 + (int64_t)c * Cse;
+    float s = b2[c];
+    for (int j = 0; j < Cse; ++j) s = fmaf(w[j], sq[j], s);
+    gate[(int64_t)img * C + c] = 1.f / (1.f + __expf(-s));
+  }
+}
+
+}  // namespace
+
+int launch_dwconv(const DwArgs& a, hipStream_t stream) {
+  const int64_t total = (int64_t)a.n * a.Ho * a.Wo * (a.C / 4);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (a.k == 3) hipLaunchKernelGGL(dwconv_swish_nhwc<3>, grid, dim3(256), 0, stream, a);
+  else if (a.k == 5) hipLaunchKernelGGL(dwconv_swish_nhwc<5>, grid, dim3(256), 0, stream, a);
+  else return fail(HP_ERR_ARG, "dwconv_swish_nhwc: kernel size must be 3 or 5");
+  return check_launch("dwconv_swish_nhwc");
+}
+
+int launch_se(const float* y, float* pooled, float* gate, const float* w1, const float* b1, const float* w2, const float* b2,
+              int n, int HW, int C, int Cse, hipStream_t stream) {
+  if (Cse > 128) return fail(HP_ERR_ARG, "se_gate_kernel: more than 128 squeezed channels");
+  hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, n), dim3(256), 0, stream, y, pooled, HW, C);
+  int rc = check_launch("se_pool_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(se_gate_kernel, dim3(n), dim3(256), 0, stream, pooled, w1, b1, w2, b2, gate, C, Cse);
+  return check_launch("se_gate_kernel");
+}
+
+}  // namespace hp

@@ -20,7 +20,6 @@ namespace hp {
 
 namespace {
 
-constexpr float kBnEps = 1e-5f;  // nn.BatchNorm2d default, all reference BNs
 const int kLayers34[4] = {3, 4, 6, 3};
 const int kLayers18[4] = {2, 2, 2, 2};
 const int kPlanes[4] = {64, 128, 256, 512};
@@ -49,6 +48,8 @@ struct ConvLayer {
   int H, W, Ho, Wo, Kpad;
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
   DevBuf w, w_wino, bias, lut, pre_scale, pre_shift;  // w_wino: Winograd-transformed weights (3x3 s1 layers)
+  int cout_pad = 0;        // weight rows / bias padded to whole 64-wide tiles
+  int se = 0;              // the input is gated by the squeeze-excitation vector of this block (1x1 projections)
   // fp16 plan: cin rounded to 8, K to 64; packed halves, LUT per 8-half chunk, prologue in halves
   int cin16 = 0, Kpad16 = 0;
   DevBuf w16, lut16, pre_scale16, pre_shift16;
@@ -56,7 +57,19 @@ struct ConvLayer {
 
 struct EventPair { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0.0, mfma_flops = 0.0; int conv = -1; };
 
-enum OpKind { OP_CONV, OP_MAXPOOL, OP_HEAD };
+// MBConv pieces (EfficientNet): depthwise conv + BN + swish, squeeze-excitation
+struct DwLayer {
+  std::string wname, bn;
+  int C, k, stride, pad, H, W, Ho, Wo, in_buf, out_buf;
+  DevBuf w, bias;
+};
+struct SeLayer {
+  std::string prefix;  // "<block>._se_reduce" / "._se_expand"
+  int C, Cse, HW, in_buf;
+  DevBuf w1, b1, w2, b2;
+};
+
+enum OpKind { OP_CONV, OP_MAXPOOL, OP_HEAD, OP_DW, OP_SE };
 struct Op { OpKind kind; int conv = -1; int in_buf = -1, out_buf = -1; int H = 0, W = 0, C = 0, Ho = 0, Wo = 0; };
 
 }  // namespace
@@ -69,6 +82,12 @@ struct Net {
   int max_batch = 0;
   std::map<std::string, std::vector<float>> params;
   std::vector<std::unique_ptr<ConvLayer>> convs;
+  std::vector<std::unique_ptr<DwLayer>> dws;
+  std::vector<std::unique_ptr<SeLayer>> ses;
+  DevBuf se_pooled, se_gate;  // [max_batch][max expanded channels]
+  int se_max_c = 0;
+  float bn_eps = 1e-5f;       // nn.BatchNorm2d default (ResNets); 1e-3 for EfficientNet
+  int n_features = 512;
   std::vector<Op> ops;
   std::vector<size_t> buf_floats_per_sample;  // arena slot sizes
   std::vector<DevBuf> bufs;
@@ -106,7 +125,7 @@ int bn_affine(const Net& n, const std::string& p, int c, std::vector<float>& sca
   if ((rc = need(n, p + ".running_var", c, &v))) return rc;
   scale.resize(c); shift.resize(c);
   for (int i = 0; i < c; ++i) {
-    const float s = (*g)[i] / std::sqrt((*v)[i] + kBnEps);
+    const float s = (*g)[i] / std::sqrt((*v)[i] + n.bn_eps);
     scale[i] = s;
     shift[i] = (*b)[i] - (*m)[i] * s;
   }
@@ -115,13 +134,15 @@ int bn_affine(const Net& n, const std::string& p, int c, std::vector<float>& sca
 
 int add_conv(Net& n, const std::string& wname, const std::string& bn_after, const std::string& bn_before,
              int cin_real, int cout, int k, int stride, int pad, int relu, int H, int W, int in_buf,
-             int out_buf, int res_buf) {
+             int out_buf, int res_buf, int Ho = -1, int Wo = -1) {
   auto L = std::make_unique<ConvLayer>();
   L->wname = wname; L->bn_after = bn_after; L->bn_before = bn_before;
   L->cin_real = cin_real; L->cin = (cin_real + 3) / 4 * 4; L->cout = cout; L->kh = L->kw = k;
   L->stride = stride; L->pad = pad; L->relu = relu; L->H = H; L->W = W;
-  L->Ho = (H + 2 * pad - k) / stride + 1; L->Wo = (W + 2 * pad - k) / stride + 1;
+  L->Ho = Ho > 0 ? Ho : (H + 2 * pad - k) / stride + 1;  // explicit for asymmetric "same" padding
+  L->Wo = Wo > 0 ? Wo : (W + 2 * pad - k) / stride + 1;
   L->Kpad = (k * k * L->cin + 31) / 32 * 32;
+  L->cout_pad = (cout + 63) / 64 * 64;
   L->in_buf = in_buf; L->out_buf = out_buf; L->res_buf = res_buf;
   n.flops_per_sample += 2.0 * L->Ho * L->Wo * cout * k * k * cin_real;
   Op op; op.kind = OP_CONV; op.conv = (int)n.convs.size();
@@ -191,6 +212,84 @@ int build_graph(Net& n) {
   return HP_OK;
 }
 
+// ---- EfficientNet-b3 (CP/models/efficientnet.py; width 1.2, depth 1.4, static "same" padding
+//      computed for image_size 300: efficientnet_utils.py:183-212,241-256,339-367) -----------------
+int eff_round_filters(int f) {  // round_filters: width 1.2, divisor 8
+  const double x = f * 1.2;
+  int nf = std::max(8, (int)(x + 4) / 8 * 8);
+  if (nf < 0.9 * x) nf += 8;
+  return nf;
+}
+
+void eff_same_pad(int k, int stride, int* lo, int* total) {  // padding fixed for a 300-pixel image
+  const int o = (300 + stride - 1) / stride;
+  *total = std::max((o - 1) * stride + k - 300, 0);
+  *lo = *total / 2;
+}
+
+int build_graph_efficientnet(Net& n) {
+  n.convs.clear(); n.dws.clear(); n.ses.clear(); n.ops.clear(); n.buf_floats_per_sample.clear();
+  n.flops_per_sample = 0.0; n.bn_eps = 1e-3f; n.se_max_c = 0;
+  const std::string bb = "backbone.";
+  static const int base[7][6] = {{1, 3, 1, 1, 32, 16}, {2, 3, 2, 6, 16, 24}, {2, 5, 2, 6, 24, 40}, {3, 3, 2, 6, 40, 80},
+                                 {3, 5, 1, 6, 80, 112}, {4, 5, 2, 6, 112, 192}, {1, 3, 1, 6, 192, 320}};
+  // arena slots: 0 / 1 = block input / output (ping-pong), 2 = expanded, 3 = depthwise output
+  int lo, tot;
+  eff_same_pad(3, 2, &lo, &tot);
+  int H = (n.h + tot - 3) / 2 + 1, W = (n.w + tot - 3) / 2 + 1;
+  const int stem = eff_round_filters(32);
+  add_conv(n, bb + "_conv_stem.weight", bb + "_bn0", "", n.n_inputs, stem, 3, 2, lo, HP_ACT_SWISH, n.h, n.w, -1, 0, -1, H, W);
+  want(n, 0, (size_t)H * W * stem);
+  int cur = 0, bi = 0, inpl = stem;
+  for (const auto& st : base) {
+    const int reps = (int)std::ceil(1.4 * st[0]), k = st[1], e = st[3];
+    const int out_f = eff_round_filters(st[5]);
+    for (int j = 0; j < reps; ++j, ++bi) {
+      const int stride = j == 0 ? st[2] : 1;
+      const int cin = j == 0 ? eff_round_filters(st[4]) : out_f;
+      if (cin != inpl) return fail(HP_ERR_STATE, "efficientnet plan: channel mismatch");
+      const int mid = cin * e, cse = std::max(1, (int)(cin * 0.25));
+      const std::string p = bb + "_blocks." + std::to_string(bi);
+      int src = cur;
+      if (e != 1) {
+        add_conv(n, p + "._expand_conv.weight", p + "._bn0", "", cin, mid, 1, 1, 0, HP_ACT_SWISH, H, W, cur, 2, -1);
+        want(n, 2, (size_t)H * W * mid);
+        src = 2;
+      }
+      eff_same_pad(k, stride, &lo, &tot);
+      const int Ho = (H + tot - k) / stride + 1, Wo = (W + tot - k) / stride + 1;
+      auto D = std::make_unique<DwLayer>();
+      D->wname = p + "._depthwise_conv.weight"; D->bn = p + "._bn1";
+      D->C = mid; D->k = k; D->stride = stride; D->pad = lo; D->H = H; D->W = W; D->Ho = Ho; D->Wo = Wo;
+      D->in_buf = src; D->out_buf = 3;
+      want(n, 3, (size_t)Ho * Wo * mid);
+      n.flops_per_sample += 2.0 * Ho * Wo * mid * k * k;
+      Op od; od.kind = OP_DW; od.conv = (int)n.dws.size();
+      n.dws.push_back(std::move(D)); n.ops.push_back(od);
+      auto S = std::make_unique<SeLayer>();
+      S->prefix = p; S->C = mid; S->Cse = cse; S->HW = Ho * Wo; S->in_buf = 3;
+      n.se_max_c = std::max(n.se_max_c, mid);
+      n.flops_per_sample += 2.0 * 2.0 * mid * cse;
+      Op os; os.kind = OP_SE; os.conv = (int)n.ses.size();
+      n.ses.push_back(std::move(S)); n.ops.push_back(os);
+      const bool skip = stride == 1 && cin == out_f;
+      const int dst = 1 - cur;
+      const int c = add_conv(n, p + "._project_conv.weight", p + "._bn2", "", mid, out_f, 1, 1, 0, HP_ACT_NONE, Ho, Wo, 3, dst,
+                             skip ? cur : -1);
+      n.convs[c]->se = 1;
+      want(n, dst, (size_t)Ho * Wo * out_f);
+      cur = dst; H = Ho; W = Wo; inpl = out_f;
+    }
+  }
+  const int head = eff_round_filters(1280);
+  add_conv(n, bb + "_conv_head.weight", bb + "_bn1", "", inpl, head, 1, 1, 0, HP_ACT_SWISH, H, W, cur, 2, -1);
+  want(n, 2, (size_t)H * W * head);
+  Op hd; hd.kind = OP_HEAD; hd.in_buf = 2; hd.H = H; hd.W = W; hd.C = head;
+  n.ops.push_back(hd);
+  n.feat_H = H; n.feat_W = W; n.n_features = head;
+  return HP_OK;
+}
+
 int pack_conv(Net& n, ConvLayer& L) {
   const std::vector<float>* w;
   const size_t numel = (size_t)L.cout * L.cin_real * L.kh * L.kw;
@@ -198,7 +297,7 @@ int pack_conv(Net& n, ConvLayer& L) {
   if (rc) return rc;
   std::vector<float> scale, shift;
   if (!L.bn_after.empty() && (rc = bn_affine(n, L.bn_after, L.cout, scale, shift))) return rc;
-  std::vector<float> packed((size_t)L.cout * L.Kpad, 0.f);
+  std::vector<float> packed((size_t)L.cout_pad * L.Kpad, 0.f);  // rows padded to whole 64-wide tiles
   for (int o = 0; o < L.cout; ++o) {
     const float s = scale.empty() ? 1.f : scale[o];
     for (int ci = 0; ci < L.cin_real; ++ci)
@@ -218,7 +317,10 @@ int pack_conv(Net& n, ConvLayer& L) {
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
     }
   }
-  if (!shift.empty() && (rc = L.bias.upload(shift.data(), shift.size() * 4))) return rc;
+  if (!shift.empty()) {
+    shift.resize(L.cout_pad, 0.f);  // read by whole tiles
+    if ((rc = L.bias.upload(shift.data(), shift.size() * 4))) return rc;
+  }
   if (!L.bn_before.empty()) {
     std::vector<float> ps, pb;
     if ((rc = bn_affine(n, L.bn_before, L.cin_real, ps, pb))) return rc;
@@ -239,6 +341,32 @@ int pack_conv(Net& n, ConvLayer& L) {
     }
   }
   return L.lut.upload(lut.data(), lut.size() * sizeof(int4));
+}
+
+int pack_dw(Net& n, DwLayer& D) {
+  const std::vector<float>* w;
+  int rc = need(n, D.wname, (size_t)D.C * D.k * D.k, &w);  // [C][1][k][k]
+  if (rc) return rc;
+  std::vector<float> scale, shift;
+  if ((rc = bn_affine(n, D.bn, D.C, scale, shift))) return rc;
+  std::vector<float> packed((size_t)D.k * D.k * D.C);
+  for (int c = 0; c < D.C; ++c)
+    for (int t = 0; t < D.k * D.k; ++t) packed[(size_t)t * D.C + c] = (*w)[(size_t)c * D.k * D.k + t] * scale[c];
+  if ((rc = D.w.upload(packed.data(), packed.size() * 4))) return rc;
+  return D.bias.upload(shift.data(), shift.size() * 4);
+}
+
+int pack_se(Net& n, SeLayer& S) {
+  const std::vector<float>* v;
+  int rc;
+  if ((rc = need(n, S.prefix + "._se_reduce.weight", (size_t)S.Cse * S.C, &v))) return rc;
+  if ((rc = S.w1.upload(v->data(), v->size() * 4))) return rc;
+  if ((rc = need(n, S.prefix + "._se_reduce.bias", S.Cse, &v))) return rc;
+  if ((rc = S.b1.upload(v->data(), v->size() * 4))) return rc;
+  if ((rc = need(n, S.prefix + "._se_expand.weight", (size_t)S.C * S.Cse, &v))) return rc;
+  if ((rc = S.w2.upload(v->data(), v->size() * 4))) return rc;
+  if ((rc = need(n, S.prefix + "._se_expand.bias", S.C, &v))) return rc;
+  return S.b2.upload(v->data(), v->size() * 4);
 }
 
 // fp16 plan: BN folded in fp32, then rounded once to fp16; K order (kh, kw, c) with c padded to 8
@@ -290,13 +418,16 @@ struct hp_net : hp::Net {};
 using namespace hp;
 
 extern "C" hp_net* hp_net_create(int arch, int n_inputs, int h, int w) {
-  if (arch < 0 || arch > 2 || n_inputs < 1 || h < 32 || w < 32) {
+  if (arch < 0 || arch > HP_ARCH_EFFICIENTNET_B3 || n_inputs < 1 || h < 32 || w < 32) {
     set_error("hp_net_create: bad architecture / input shape");
     return nullptr;
   }
   hp_net* n = new hp_net();
   n->arch = arch; n->n_inputs = n_inputs; n->c_pad = (n_inputs + 3) / 4 * 4; n->h = h; n->w = w;
-  build_graph(*n);
+  if ((arch == HP_ARCH_EFFICIENTNET_B3 ? build_graph_efficientnet(*n) : build_graph(*n)) != HP_OK) {
+    delete n;
+    return nullptr;
+  }
   return n;
 }
 
@@ -331,6 +462,15 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   int rc = conv_setup_once();
   if (rc) return rc;
   const bool f16 = net->precision == HP_PRECISION_F16;
+  HP_REQUIRE(!(f16 && net->arch == HP_ARCH_EFFICIENTNET_B3), "hp_net_finalize: no fp16 plan for EfficientNet");
+  for (auto& D : net->dws)
+    if ((rc = pack_dw(*net, *D))) return rc;
+  for (auto& S : net->ses)
+    if ((rc = pack_se(*net, *S))) return rc;
+  if (net->se_max_c > 0) {
+    if ((rc = net->se_pooled.alloc((size_t)max_batch * net->se_max_c * 4))) return rc;
+    if ((rc = net->se_gate.alloc((size_t)max_batch * net->se_max_c * 4))) return rc;
+  }
   for (auto& L : net->convs)
     if ((rc = f16 ? pack_conv_f16(*net, *L) : pack_conv(*net, *L))) return rc;
   const std::vector<float>* v;
@@ -342,15 +482,15 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   }
   net->pose_dim = net->n_logits = 0;
   if ((v = find(*net, "pose_fc.weight"))) {
-    HP_REQUIRE(v->size() % 512 == 0 && !v->empty(), "pose_fc.weight must be [pose_dim, 512]");
-    net->pose_dim = (int)(v->size() / 512);
+    HP_REQUIRE(v->size() % net->n_features == 0 && !v->empty(), "pose_fc.weight must be [pose_dim, n_features]");
+    net->pose_dim = (int)(v->size() / net->n_features);
     if ((rc = net->pose_w.upload(v->data(), v->size() * 4))) return rc;
     if ((rc = need(*net, "pose_fc.bias", net->pose_dim, &v))) return rc;
     if ((rc = net->pose_b.upload(v->data(), v->size() * 4))) return rc;
   }
   if ((v = find(*net, "views_logits_head.weight"))) {
-    HP_REQUIRE(v->size() % 512 == 0 && !v->empty(), "views_logits_head.weight must be [n_views, 512]");
-    net->n_logits = (int)(v->size() / 512);
+    HP_REQUIRE(v->size() % net->n_features == 0 && !v->empty(), "views_logits_head.weight must be [n_views, n_features]");
+    net->n_logits = (int)(v->size() / net->n_features);
     if ((rc = net->logit_w.upload(v->data(), v->size() * 4))) return rc;
     if ((rc = need(*net, "views_logits_head.bias", net->n_logits, &v))) return rc;
     if ((rc = net->logit_b.upload(v->data(), v->size() * 4))) return rc;
@@ -373,7 +513,14 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
   if (f16 && (rc = launch_cast_pad_f16(d_x, net->x16.p, (int64_t)batch * net->h * net->w, net->c_pad,
                                        net->convs[0]->cin16, stream)))
     return rc;
+  static const bool sync_ops = std::getenv("HP_NET_SYNC") != nullptr;  // diagnostics: fault isolation
+  int op_index = 0;
   for (const Op& op : net->ops) {
+    if (sync_ops) {
+      HP_CHECK_HIP(hipDeviceSynchronize());
+      std::fprintf(stderr, "[hp net] op %d kind %d conv %d (everything before it has completed)\n", op_index, (int)op.kind, op.conv);
+    }
+    ++op_index;
     if (op.kind == OP_CONV && f16) {
       ConvLayer& L = *net->convs[op.conv];
       ConvArgsH a{};
@@ -418,6 +565,12 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
       a.M = (int64_t)batch * L.Ho * L.Wo;
       a.H = L.H; a.W = L.W; a.Cin = L.cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.cout;
       a.stride = L.stride; a.pad = L.pad; a.Kpad = L.Kpad; a.ktiles = L.Kpad / 32; a.relu = L.relu;
+      if (L.se) { a.pre_scale = (const float*)net->se_gate.p; a.pre_shift = nullptr; }  // gate [batch][Cin]
+      const int variant = L.cout_pad % 128 == 0 ? 0 : 1;  // 128x128 tiles, or 128x64
+      if (sync_ops)
+        std::fprintf(stderr, "[hp net]   conv %s M=%lld H=%d W=%d Cin=%d Ho=%d Wo=%d Cout=%d pad=%d Kpad=%d act=%d se=%d in=%d out=%d res=%d x=%p y=%p r=%p\n",
+                     L.wname.c_str(), (long long)a.M, a.H, a.W, a.Cin, a.Ho, a.Wo, a.Cout, a.pad, a.Kpad, a.relu, L.se, L.in_buf,
+                     L.out_buf, L.res_buf, (const void*)a.x, (void*)a.y, (const void*)a.residual);
       EventPair ev{};
       if (net->profiling) {  // events are only READ in hp_net_profile_collect: no sync here
         if (!net->ev_pool.empty()) { ev = net->ev_pool.back(); net->ev_pool.pop_back(); }
@@ -434,15 +587,30 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
         rc = launch_conv_wino(a, stream);
         ev.mfma_flops = 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout;
       } else {
-        if (algo != HP_CONV_ALGO_IGEMM && conv_patch_applicable(a, L.kh, L.kw)) rc = launch_conv_patch(a, L.cout == 64 ? 1 : 0, stream);
-        else rc = launch_conv(a, L.cout == 64 ? 1 : 0, stream);
-        ev.mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout * L.Kpad;
+        if (algo != HP_CONV_ALGO_IGEMM && a.relu != HP_ACT_SWISH && !L.se && conv_patch_applicable(a, L.kh, L.kw))
+          rc = launch_conv_patch(a, variant, stream);
+        else rc = launch_conv(a, variant, stream);
+        ev.mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout_pad * L.Kpad;
       }
       if (rc) return rc;
       if (net->profiling) {
         HP_CHECK_HIP(hipEventRecord(ev.e1, stream));
         net->ev_pending.push_back(ev);
       }
+    } else if (op.kind == OP_DW) {
+      const DwLayer& D = *net->dws[op.conv];
+      DwArgs d{};
+      d.x = (const float*)net->bufs[D.in_buf].p; d.w = (const float*)D.w.p; d.bias = (const float*)D.bias.p;
+      d.y = (float*)net->bufs[D.out_buf].p;
+      d.n = batch; d.H = D.H; d.W = D.W; d.C = D.C; d.Ho = D.Ho; d.Wo = D.Wo; d.k = D.k; d.stride = D.stride;
+      d.pad_t = d.pad_l = D.pad;
+      if ((rc = launch_dwconv(d, stream))) return rc;
+    } else if (op.kind == OP_SE) {
+      const SeLayer& S = *net->ses[op.conv];
+      if ((rc = launch_se((const float*)net->bufs[S.in_buf].p, (float*)net->se_pooled.p, (float*)net->se_gate.p,
+                          (const float*)S.w1.p, (const float*)S.b1.p, (const float*)S.w2.p, (const float*)S.b2.p, batch, S.HW,
+                          S.C, S.Cse, stream)))
+        return rc;
     } else if (op.kind == OP_MAXPOOL && f16) {
       if ((rc = launch_maxpool_f16(net->bufs[op.in_buf].p, net->bufs[op.out_buf].p, batch, op.H, op.W, op.C, op.Ho,
                                    op.Wo, stream)))
@@ -481,7 +649,7 @@ extern "C" int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d
     int rc = forward_chunk(net, d_x + (size_t)b0 * in_stride, nb,
                            d_pose ? d_pose + (size_t)b0 * net->pose_dim : nullptr,
                            d_logits ? d_logits + (size_t)b0 * net->n_logits : nullptr,
-                           d_features ? d_features + (size_t)b0 * 512 : nullptr, st);
+                           d_features ? d_features + (size_t)b0 * net->n_features : nullptr, st);
     if (rc) return rc;
   }
   return HP_OK;

@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* x, float* 
 // one workgroup per sample; features [HW][C] NHWC.
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
-  __shared__ float feat[512];
-  __shared__ float feat2[512];
+  __shared__ float feat[2048];   // C <= 2048 (512 ResNets, 1536 EfficientNet-b3)
+  __shared__ float feat2[512];   // fc output (torchvision ResNet only, C = 512)
   const int b = blockIdx.x, tid = threadIdx.x;
   const T* x = reinterpret_cast<const T*>(a.x) + (int64_t)b * a.HW * a.C;
   for (int c = tid; c < a.C; c += 256) {

@@ -82,7 +82,9 @@ def _arch(backbone_str: str) -> str:
         return "resnet34"
     if "resnet18" in backbone_str:
         return "resnet18"
-    raise ValueError("Unknown backbone", backbone_str)  # e.g. efficientnet-b3: SURVEY.md section 8f
+    if backbone_str == "efficientnet-b3":  # CP/training/pose_models_cfg.py:33-35 (the released CosyPose checkpoints)
+        return "efficientnet-b3"
+    raise ValueError("Unknown backbone", backbone_str)
 
 
 def pose_model_param_shapes(backbone_str: str, n_inputs: int, pose_dim: int = 9,
@@ -99,6 +101,8 @@ def pose_model_param_shapes(backbone_str: str, n_inputs: int, pose_dim: int = 9,
             s[f"{p}.{k}"] = (c,)
         s[f"{p}.num_batches_tracked"] = ()
 
+    if backbone_str == "efficientnet-b3":
+        return _efficientnet_b3_param_shapes(n_inputs, pose_dim, n_views_logits)
     planes = [64, 128, 256, 512]
     vanilla = backbone_str == "vanilla_resnet34"
     layers = [2, 2, 2, 2] if backbone_str == "resnet18" else [3, 4, 6, 3]
@@ -135,6 +139,64 @@ def pose_model_param_shapes(backbone_str: str, n_inputs: int, pose_dim: int = 9,
         s["pose_fc.bias"] = (pose_dim,)
     if n_views_logits:
         s["views_logits_head.weight"] = (n_views_logits, 512)
+        s["views_logits_head.bias"] = (n_views_logits,)
+    return s
+
+
+def efficientnet_b3_blocks():
+    """``[(kernel, stride, expand, in, out, se_channels)]`` of the 26 MBConv blocks of EfficientNet-b3
+    (``CP/models/efficientnet_utils.py:241-256,339-367``: width 1.2, depth 1.4, filters rounded to 8)."""
+    import math
+
+    def rf(f):
+        f = f * 1.2
+        new = max(8, int(f + 4) // 8 * 8)
+        return int(new + 8 if new < 0.9 * f else new)
+
+    base = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+            (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+    blocks = []
+    for r, k, s, e, i, o in base:
+        i, o = rf(i), rf(o)
+        for j in range(int(math.ceil(1.4 * r))):
+            cin, stride = (i, s) if j == 0 else (o, 1)
+            blocks.append((k, stride, e, cin, o, max(1, int(cin * 0.25))))
+    return blocks
+
+
+def _efficientnet_b3_param_shapes(n_inputs: int, pose_dim: int, n_views_logits: int) -> Dict[str, tuple]:
+    """Registration order of ``CP/models/efficientnet.py:165-233`` under ``backbone.``; the heads see
+    1536 features (``CP/training/pose_models_cfg.py:33-35``)."""
+    s: Dict[str, tuple] = {}
+
+    def bn(p, c):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{p}.{k}"] = (c,)
+        s[f"{p}.num_batches_tracked"] = ()
+
+    blocks = efficientnet_b3_blocks()
+    s["backbone._conv_stem.weight"] = (40, n_inputs, 3, 3)
+    bn("backbone._bn0", 40)
+    for bi, (k, _stride, e, cin, cout, cse) in enumerate(blocks):
+        p, mid = f"backbone._blocks.{bi}", cin * e
+        if e != 1:
+            s[f"{p}._expand_conv.weight"] = (mid, cin, 1, 1)
+            bn(f"{p}._bn0", mid)
+        s[f"{p}._depthwise_conv.weight"] = (mid, 1, k, k)
+        bn(f"{p}._bn1", mid)
+        s[f"{p}._se_reduce.weight"] = (cse, mid, 1, 1)
+        s[f"{p}._se_reduce.bias"] = (cse,)
+        s[f"{p}._se_expand.weight"] = (mid, cse, 1, 1)
+        s[f"{p}._se_expand.bias"] = (mid,)
+        s[f"{p}._project_conv.weight"] = (cout, mid, 1, 1)
+        bn(f"{p}._bn2", cout)
+    s["backbone._conv_head.weight"] = (1536, blocks[-1][4], 1, 1)
+    bn("backbone._bn1", 1536)
+    if pose_dim:
+        s["pose_fc.weight"] = (pose_dim, 1536)
+        s["pose_fc.bias"] = (pose_dim,)
+    if n_views_logits:
+        s["views_logits_head.weight"] = (n_views_logits, 1536)
         s["views_logits_head.bias"] = (n_views_logits,)
     return s
 

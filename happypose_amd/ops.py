@@ -20,7 +20,8 @@ from .mesh_store import MeshDataBase, PackedMeshes, RigidObjectDataset, sample_p
 DEPTH_NORM = {None: 0, "none": 0, "tCR_scale": 1, "tCR_scale_clamp_center": 2, "tCR_center_clamp": 3}
 MULTIVIEW = {"TCO": (0, 1), "1view_TCO": (0, 1), "TCO+front_1view": (1, 2),
              "TCO+front_3views": (3, 4), "TCO+front_5views": (5, 6)}
-ARCH = {"vanilla_resnet34": 0, "resnet34": 1, "resnet18": 2}
+ARCH = {"vanilla_resnet34": 0, "resnet34": 1, "resnet18": 2, "efficientnet-b3": 3}
+N_FEATURES = {"vanilla_resnet34": 512, "resnet34": 512, "resnet18": 512, "efficientnet-b3": 1536}
 
 
 def _np_ptr(a):
@@ -255,6 +256,7 @@ class Net:
         self.device = torch.device(device)
         self.arch, self.n_inputs, self.h, self.w = arch, n_inputs, h, w
         self.precision = precision
+        self.n_features = N_FEATURES[arch]
         with torch.cuda.device(self.device):
             self._h = lib().hp_net_create(ARCH[arch], n_inputs, h, w)
             if not self._h:
@@ -296,7 +298,7 @@ class Net:
         f = dict(dtype=torch.float32, device=self.device)
         pose = torch.empty((b, self.pose_dim), **f) if (want_pose and self.pose_dim) else None
         logits = torch.empty((b, self.n_logits), **f) if (want_logits and self.n_logits) else None
-        feats = torch.empty((b, 512), **f) if want_features else None
+        feats = torch.empty((b, self.n_features), **f) if want_features else None
         with torch.cuda.device(self.device):
             check(lib().hp_net_forward(self.handle, ptr(x), b, ptr(pose), ptr(logits), ptr(feats),
                                        stream_ptr(self.device)), "hp_net_forward")

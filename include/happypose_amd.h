@@ -172,6 +172,8 @@ int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxe
  * MP/training/pose_models_cfg.py:106-122 / CP/training/pose_models_cfg.py:39-42:
  *   HP_ARCH_VANILLA_RESNET34  MP/models/torchvision_resnet.py:191-344 (num_classes=512)
  *   HP_ARCH_WIDE_RESNET34/18  MP/models/wide_resnet.py:68-154 == CP/models/wide_resnet.py
+ *   HP_ARCH_EFFICIENTNET_B3   CP/models/efficientnet.py:153-277 (extract_features; BN eps 1e-3,
+ *                             static "same" padding for image_size 300), features [batch][1536]
  * Parameters are handed over by their reference state_dict names ("backbone.conv1.weight",
  * "backbone.layer1.0.bn1.running_var", "pose_fc.weight", "views_logits_head.bias", ...;
  * legacy names of TB/utils/models_compat.py are translated by the host side), fp32 host
@@ -179,11 +181,12 @@ int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxe
  * BatchNorm (eps 1e-5) and repacks to the kernels' layout.
  * Input: d_x NHWC [batch][h][w][c_pad], c_pad = hp_net_input_channels_padded(), pad
  * channels zero.  Outputs (each may be NULL): d_pose [batch][pose_dim],
- * d_logits [batch][n_logits], d_features [batch][512].
+ * d_logits [batch][n_logits], d_features [batch][512] (1536 for EfficientNet-b3).
  * ---------------------------------------------------------------------------------- */
 #define HP_ARCH_VANILLA_RESNET34 0
 #define HP_ARCH_WIDE_RESNET34 1
 #define HP_ARCH_WIDE_RESNET18 2
+#define HP_ARCH_EFFICIENTNET_B3 3 /* CP/models/efficientnet.py (CosyPose's released checkpoints): features [b,1536] */
 
 typedef struct hp_net hp_net;
 

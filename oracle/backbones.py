@@ -254,11 +254,13 @@ def net_forward(x: torch.Tensor, sd, arch: str, heads=("pose",)) -> Dict[str, to
 
 
 def predictor_param_shapes(arch: str, n_inputs: int, pose_dim: int = 9, n_views_logits: int = 0):
-    s = {f"backbone.{k}": v for k, v in param_shapes(arch, n_inputs).items()}
+    eff = arch == "efficientnet-b3"
+    nf = 1536 if eff else 512  # backbone.n_features (CP/training/pose_models_cfg.py:35,42)
+    s = {f"backbone.{k}": v for k, v in (efficientnet_b3_param_shapes(n_inputs) if eff else param_shapes(arch, n_inputs)).items()}
     if pose_dim:
-        s["pose_fc.weight"] = (pose_dim, 512)
+        s["pose_fc.weight"] = (pose_dim, nf)
         s["pose_fc.bias"] = (pose_dim,)
     if n_views_logits:
-        s["views_logits_head.weight"] = (n_views_logits, 512)
+        s["views_logits_head.weight"] = (n_views_logits, nf)
         s["views_logits_head.bias"] = (n_views_logits,)
     return s

@@ -502,3 +502,36 @@ def test_net_heads_and_batch_chunking(dev):
         ref = ob.net_forward(torch.as_tensor(x), w, "resnet18", heads=("pose", "renderings_logits"))
     np.testing.assert_allclose(pose.cpu().numpy(), ref["pose"].numpy(), rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(logits.cpu().numpy(), ref["renderings_logits"].numpy(), rtol=1e-3, atol=2e-4)
+
+
+def test_efficientnet_b3_backbone_golden_g9(dev, golden_dir):
+    """EfficientNet-b3 (the backbone of the released CosyPose checkpoints) against the
+    reference module's own output (G9), and the pose head against the CPU restatement."""
+    from happypose_amd import ops
+    from happypose_amd.models import pose_model_param_shapes
+    from happypose_amd.synthetic import named_weights
+    from oracle import backbones as ob
+
+    g = np.load(golden_dir / "g9_efficientnet.npz")
+    # the golden weights are keyed by the backbone's own parameter names (no "backbone." prefix)
+    w = {f"backbone.{k}": v for k, v in named_weights(ob.efficientnet_b3_param_shapes(6), seed=0).items()}
+    w.update(named_weights({"pose_fc.weight": (9, 1536), "pose_fc.bias": (9,)}, seed=0))
+    assert list(w) == list(pose_model_param_shapes("efficientnet-b3", 6, pose_dim=9))
+    net = ops.Net("efficientnet-b3", 6, w, max_batch=2, device=dev)
+    assert net.n_features == 1536 and abs(net.flops_per_sample / 1e9 - 2.91) < 0.1
+    x = np.random.RandomState(106).uniform(-1, 1, size=(2, 6, 240, 320)).astype(np.float32)
+    xin = net.new_input(2)
+    xin[..., :6] = torch.as_tensor(x, device=dev).permute(0, 2, 3, 1)
+    pose, _, feats = net.forward(xin, want_pose=True, want_features=True)
+    ref = g["out_mean"]  # spatial mean of the [2,1536,7,10] feature map
+    err = np.abs(feats.cpu().numpy() - ref).max()
+    assert err <= 2e-4 * np.abs(ref).max(), (err, np.abs(ref).max())
+    with torch.no_grad():
+        rp = ob.net_forward(torch.as_tensor(x), w, "efficientnet-b3", heads=("pose",))["pose"].numpy()
+    np.testing.assert_allclose(pose.cpu().numpy(), rp, rtol=1e-3, atol=2e-4)
+    # batch chunking (3 samples through max_batch 2) gives the same rows
+    x3 = np.concatenate([x, x[:1]], 0)
+    xin3 = net.new_input(3)
+    xin3[..., :6] = torch.as_tensor(x3, device=dev).permute(0, 2, 3, 1)
+    _, _, f3 = net.forward(xin3, want_pose=False, want_features=True)
+    assert torch.equal(f3[:2], feats) and torch.equal(f3[2], feats[0])

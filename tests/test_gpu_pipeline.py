@@ -83,6 +83,29 @@ def test_cosypose_refiner_vs_oracle(dev, world):
     assert torch.equal(out2["iteration=1"].TCO_output, out["iteration=1"].TCO_output)
 
 
+def test_cosypose_efficientnet_refiner_vs_oracle(dev, world):
+    """CosyPose with the EfficientNet-b3 backbone of its released checkpoints (SURVEY.md 8f-1,
+    CP/training/pose_models_cfg.py:33-35): two refiner iterations against the CPU restatement."""
+    from happypose_amd.models import create_pose_model_cosypose
+    from oracle.pipeline import OraclePredictor
+
+    sc, store = world["scene"], world["store"]
+    w = _weights("efficientnet-b3", 6, seed=1, scale=0.01)
+    model = create_pose_model_cosypose(dict(backbone_str="efficientnet-b3"), world["renderer"], state_dict=w, max_batch=8)
+    images = torch.as_tensor(sc["images"][:, :3].copy(), device=dev)
+    K = torch.as_tensor(sc["K"], device=dev)
+    sel = np.arange(0, 12, 2)
+    im_ids = torch.zeros(len(sel), dtype=torch.int32)
+    out = model.forward(images, K, _labels(world, sc["hyp_obj_ids"][sel]), torch.as_tensor(sc["TCO_hyp"][sel]), n_iterations=2,
+                        im_ids=im_ids)
+    ora = OraclePredictor(w, store.packed, store.mesh_db.points, arch="efficientnet-b3", cosypose=True)
+    ref = ora.forward(sc["images"][:, :3], sc["K"], np.zeros(len(sel), np.int32), sc["hyp_obj_ids"][sel], sc["TCO_hyp"][sel], 2)
+    for n in range(2):
+        dt, dr = _pose_err(out[f"iteration={n + 1}"].TCO_output.cpu().numpy(), ref[n]["TCO_output"])
+        assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
+    assert _pose_err(out["iteration=2"].TCO_output.cpu().numpy(), sc["TCO_hyp"][sel])[1] > 1e-4
+
+
 @pytest.mark.parametrize("rgbd", [False, True])
 def test_megapose_refiner_vs_oracle(dev, world, rgbd):
     from happypose_amd.models import create_model_pose

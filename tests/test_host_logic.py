@@ -176,8 +176,10 @@ def test_model_config_defaults_and_key_renames():
     assert models.n_input_channels(old) == 9
     sd = models.change_keys_of_older_models({"backbone.backbone.conv1.weight": 1, "backbone.head.0.weight": 2, "pose_fc.bias": 3})
     assert sd == {"backbone.conv1.weight": 1, "views_logits_head.weight": 2, "pose_fc.bias": 3}
+    assert models._arch("efficientnet-b3") == "efficientnet-b3"
     with pytest.raises(ValueError):
-        models._arch("efficientnet-b3")
+        models._arch("efficientnet-b7")
+    assert len(models.efficientnet_b3_blocks()) == 26 and len(models.pose_model_param_shapes("efficientnet-b3", 6)) == 574
 
 
 def test_lights_and_render_argument_checks():
