@@ -176,7 +176,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--arch", default="resnet34", choices=["resnet34", "resnet18"])
+    ap.add_argument("--arch", default="resnet34", choices=["resnet34", "resnet18", "efficientnet-b3"],
+                    help="CosyPose backbone for C2: resnet34 = the WideResNet-34 BASELINE.json quotes; efficientnet-b3 = the released checkpoints' architecture")
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS),
                     help="BASELINE.json config (default C2 = the one the headline metric is quoted on)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16"],
@@ -246,7 +247,7 @@ def main():
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         desc = {
             "C2": f"C2: CosyPose refiner, one 640x480 frame per GPU, {N_DET} detections x {N_HYP} hypotheses = {B} "
-                  f"hypotheses/GPU, {N_ITERS} iterations, {args.arch} (WideResNet) on 6x240x320",
+                  f"hypotheses/GPU, {N_ITERS} iterations, {args.arch}{' (WideResNet)' if 'resnet' in args.arch else ''} on 6x240x320",
             "C3": f"C3: MegaPose RGB-D refiner, one 640x480 RGB-D frame per GPU, {B} hypotheses/GPU, {N_ITERS} iterations, "
                   "4 views x (RGB + normals + depth), vanilla_resnet34 on 32x240x320",
             "C5": f"C5: MegaPose coarse scoring, 8 objects x 576 SO(3)-grid "

@@ -54,27 +54,40 @@ __global__ __launch_bounds__(256) void dwconv_swish_nhwc(DwArgs a) {
   *reinterpret_cast<floatx4*>(a.y + (((int64_t)img * a.Ho + oh) * a.Wo + ow) * a.C + c) = swish4(acc);
 }
 
-// global mean over the pixels of each (image, channel): block = 64 channels x 4 pixel lanes, fixed
-// summation order (pixel lanes stride the map, then a 4-way LDS sum) -> bitwise reproducible
-__global__ __launch_bounds__(256) void se_pool_kernel(const float* y, float* pooled, int HW, int C) {
+// sums over the pixels of each (image, channel) in kSeStrips strips: block = 64 channels x 4 pixel
+// lanes of one strip, fixed summation order (pixel lanes stride the strip, then a 4-way LDS sum; the
+// strips are added in order by se_gate_kernel) -> bitwise reproducible, and enough blocks to fill
+// the chip on the 120x160 maps
+constexpr int kSeStrips = 32;
+
+__global__ __launch_bounds__(256) void se_pool_kernel(const float* y, float* partial, int HW, int C) {
   __shared__ float part[4][64];
-  const int img = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const int img = blockIdx.y, strip = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const int per = (HW + kSeStrips - 1) / kSeStrips;
+  const int p0 = strip * per, p1 = p0 + per < HW ? p0 + per : HW;
   float s = 0.f;
   if (c < C) {
     const float* base = y + (int64_t)img * HW * C + c;
-    for (int p = pl; p < HW; p += 4) s += base[(int64_t)p * C];
+    for (int p = p0 + pl; p < p1; p += 4) s += base[(int64_t)p * C];
   }
   part[pl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (pl == 0 && c < C) pooled[(int64_t)img * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)HW;
+  if (pl == 0 && c < C)
+    partial[((int64_t)img * kSeStrips + strip) * C + c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
-// gate = sigmoid(W2 swish(W1 pooled + b1) + b2): one block per image (Cse <= 128, C <= 4096)
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* pooled, const float* w1, const float* b1, const float* w2,
-                                                      const float* b2, float* gate, int C, int Cse) {
+// gate = sigmoid(W2 swish(W1 mean + b1) + b2): one block per image (Cse <= 128, C <= 4096)
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* partial, float* pooled, const float* w1, const float* b1,
+                                                      const float* w2, const float* b2, float* gate, int HW, int C, int Cse) {
   __shared__ float sq[128];
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* pv = pooled + (int64_t)img * C;
+  float* pv = pooled + (int64_t)img * C;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int st = 0; st < kSeStrips; ++st) s += partial[((int64_t)img * kSeStrips + st) * C + c];
+    pv[c] = s / (float)HW;
+  }
+  __syncthreads();
   for (int j = wave; j < Cse; j += 4) {
     const float* w = w1 + (int64_t)j * C;
     float s = 0.f;
@@ -103,13 +116,15 @@ int launch_dwconv(const DwArgs& a, hipStream_t stream) {
   return check_launch("dwconv_swish_nhwc");
 }
 
-int launch_se(const float* y, float* pooled, float* gate, const float* w1, const float* b1, const float* w2, const float* b2,
-              int n, int HW, int C, int Cse, hipStream_t stream) {
+int se_partial_floats(int n, int C) { return n * kSeStrips * C; }
+
+int launch_se(const float* y, float* partial, float* pooled, float* gate, const float* w1, const float* b1, const float* w2,
+              const float* b2, int n, int HW, int C, int Cse, hipStream_t stream) {
   if (Cse > 128) return fail(HP_ERR_ARG, "se_gate_kernel: more than 128 squeezed channels");
-  hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, n), dim3(256), 0, stream, y, pooled, HW, C);
+  hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, n, kSeStrips), dim3(256), 0, stream, y, partial, HW, C);
   int rc = check_launch("se_pool_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(se_gate_kernel, dim3(n), dim3(256), 0, stream, pooled, w1, b1, w2, b2, gate, C, Cse);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(n), dim3(256), 0, stream, partial, pooled, w1, b1, w2, b2, gate, HW, C, Cse);
   return check_launch("se_gate_kernel");
 }
 

@@ -84,7 +84,7 @@ struct Net {
   std::vector<std::unique_ptr<ConvLayer>> convs;
   std::vector<std::unique_ptr<DwLayer>> dws;
   std::vector<std::unique_ptr<SeLayer>> ses;
-  DevBuf se_pooled, se_gate;  // [max_batch][max expanded channels]
+  DevBuf se_pooled, se_gate, se_partial;  // [max_batch][max expanded channels] (+ strip partial sums)
   int se_max_c = 0;
   float bn_eps = 1e-5f;       // nn.BatchNorm2d default (ResNets); 1e-3 for EfficientNet
   int n_features = 512;
@@ -470,6 +470,7 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   if (net->se_max_c > 0) {
     if ((rc = net->se_pooled.alloc((size_t)max_batch * net->se_max_c * 4))) return rc;
     if ((rc = net->se_gate.alloc((size_t)max_batch * net->se_max_c * 4))) return rc;
+    if ((rc = net->se_partial.alloc((size_t)se_partial_floats(max_batch, net->se_max_c) * 4))) return rc;
   }
   for (auto& L : net->convs)
     if ((rc = f16 ? pack_conv_f16(*net, *L) : pack_conv(*net, *L))) return rc;
@@ -607,7 +608,7 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
       if ((rc = launch_dwconv(d, stream))) return rc;
     } else if (op.kind == OP_SE) {
       const SeLayer& S = *net->ses[op.conv];
-      if ((rc = launch_se((const float*)net->bufs[S.in_buf].p, (float*)net->se_pooled.p, (float*)net->se_gate.p,
+      if ((rc = launch_se((const float*)net->bufs[S.in_buf].p, (float*)net->se_partial.p, (float*)net->se_pooled.p, (float*)net->se_gate.p,
                           (const float*)S.w1.p, (const float*)S.b1.p, (const float*)S.w2.p, (const float*)S.b2.p, batch, S.HW,
                           S.C, S.Cse, stream)))
         return rc;
