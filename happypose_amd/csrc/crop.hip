@@ -6,8 +6,8 @@
 //
 // Gather kernel, HBM/L2 bound: every hypothesis reads the SAME 640x480 frame (3.7-4.9 MB,
 // L2/MALL resident), so the traffic that reaches HBM is the output.  One lane = one output
-// pixel for all channels; consecutive lanes take consecutive output columns, so source reads
-// of a wave fall into a few adjacent cache lines and NCHW stores are coalesced.
+// pixel for all channels; a workgroup is a 16 x 16 pixel tile, a wave 4 rows of 16 columns, so
+// source reads of a wave fall into a few adjacent cache lines.
 //
 // The 4x4 bilinear samples of an output pixel are SEPARABLE: sample (iy, ix) contributes
 // (wy_lo[iy] I[y_lo] + wy_hi[iy] I[y_hi]) x (wx_lo[ix] I[x_lo] + wx_hi[ix] I[x_hi]), so the
@@ -110,11 +110,18 @@ __device__ __noinline__ void slow_pixel(const float* plane, int H, int W, float 
   }
 }
 
+// folded weights of one output row (or column): shared by the 16 pixels of the tile that lie on it
+struct Fold { int first, span; float w[kSpan]; };
+
+// One workgroup = a 16 x 16 tile of output pixels of one crop.  The sample placement depends only
+// on the output row (y axis) or column (x axis), so 32 lanes build the 16 + 16 folded weight sets
+// once and the tile shares them through LDS (building them per pixel made the kernel VALU bound:
+// ~250 of its ~330 vector instructions per pixel).
 __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
-  const int r = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.oh * a.ow) return;
-  const int ph = p / a.ow, pw = p % a.ow;
+  __shared__ Fold folds[2][16];
+  const int r = blockIdx.z;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int ph = blockIdx.y * 16 + ty, pw = blockIdx.x * 16 + tx;
   const float* box = a.boxes + 4 * (int64_t)r;
   const float x1 = box[0], y1 = box[1];
   float roi_w = box[2] - x1, roi_h = box[3] - y1;
@@ -125,47 +132,70 @@ __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
   const float count = (float)(g * g);
   const int H = a.H, W = a.W;
 
-  // The folded weights are all the separable path keeps live (14 registers); the per-sample
-  // tables die here, which keeps the kernel at high occupancy -- it is latency bound.
-  int r0, c0, nr, nc;
-  float wy[kSpan], wx[kSpan];
-  {
+  if (threadIdx.x < 32) {  // lanes 0-15: the tile's rows, lanes 16-31: its columns
+    const bool is_x = threadIdx.x >= 16;
+    const int k = threadIdx.x & 15;
     Axis t;
-    make_axis(y1, ph, bin_h, g, H, t);
-    fold_axis(t, g, r0, nr, wy);
-    make_axis(x1, pw, bin_w, g, W, t);
-    fold_axis(t, g, c0, nc, wx);
+    Fold f;
+    if (is_x) make_axis(x1, blockIdx.x * 16 + k, bin_w, g, W, t);
+    else make_axis(y1, blockIdx.y * 16 + k, bin_h, g, H, t);
+    fold_axis(t, g, f.first, f.span, f.w);
+    folds[is_x ? 1 : 0][k] = f;
   }
+  __syncthreads();
+  if (ph >= a.oh || pw >= a.ow) return;
+  const Fold fy = folds[0][ty], fx = folds[1][tx];
+  const int r0 = fy.first, nr = fy.span, c0 = fx.first, nc = fx.span;
+  const float (&wy)[kSpan] = fy.w;
+  const float (&wx)[kSpan] = fx.w;
   const bool separable = nr <= kSpan && nc <= kSpan;
 
   const float* img = a.images + (int64_t)a.im_ids[r] * a.C * H * W;
   const int64_t obase = (int64_t)r * a.os.s_item + (int64_t)ph * a.os.s_row + (int64_t)pw * a.os.s_col;
-#pragma unroll 1
-  for (int c = 0; c < a.NC; ++c) {
-    const float* plane = img + (int64_t)c * H * W;
-    float acc = 0.0f, vacc = 0.0f;
-    if (separable) {
+  const int HW = H * W;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float vacc = 0.0f;
+  if (separable) {
+    // taps outermost, channels innermost: one 32-bit offset per tap serves every plane (the plane
+    // bases are wave-uniform), so a tap costs one load + one FMA per channel
+    const int off0 = r0 * W + c0;
 #pragma unroll
-      for (int i = 0; i < kSpan; ++i) {
-        if (i < nr) {
-          const float* row = plane + (int64_t)(r0 + i) * W + c0;
-          float racc = 0.0f, rv = 0.0f;
+    for (int i = 0; i < kSpan; ++i) {
+      if (i < nr) {
+        const int off = off0 + i * W;
+        float racc[4] = {0.f, 0.f, 0.f, 0.f};
+        float rv = 0.0f;
 #pragma unroll
-          for (int j = 0; j < kSpan; ++j) {
-            if (j < nc) {
-              const float v = row[j];
-              racc += wx[j] * v;
-              if (c == 3) rv += wx[j] * (v > 0.0f ? 1.0f : 0.0f);
+        for (int j = 0; j < kSpan; ++j) {
+          if (j < nc) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (c < a.NC) {
+                const float v = img[c * HW + off + j];
+                racc[c] += wx[j] * v;
+                if (c == 3) rv += wx[j] * (v > 0.0f ? 1.0f : 0.0f);
+              }
             }
           }
-          acc += wy[i] * racc;
-          vacc += wy[i] * rv;
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += wy[i] * racc[c];
+        vacc += wy[i] * rv;
       }
-    } else {
-      slow_pixel(plane, H, W, y1, x1, ph, pw, bin_h, bin_w, g, c == 3, acc, vacc);
     }
-    float val = acc / count;
+  } else {
+#pragma unroll 1
+    for (int c = 0; c < a.NC; ++c) {
+      float s = 0.0f, sv = 0.0f;
+      slow_pixel(img + (int64_t)c * HW, H, W, y1, x1, ph, pw, bin_h, bin_w, g, c == 3, s, sv);
+      acc[c] = s;
+      if (c == 3) vacc = sv;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c >= a.NC) break;
+    float val = acc[c] / count;
     if (c == 3) {
       if (vacc / count < 0.99f) val = 0.0f;  // TB/lib3d/cropping.py:184-195
       if (a.depth_norm_mode != 0) {
@@ -198,7 +228,7 @@ extern "C" int hp_crop_roi_align(const float* d_images, int Bi, int C, int n_cha
   HP_REQUIRE(d_boxes && d_im_ids && d_out, "hp_crop_roi_align: null pointer");
   CropArgs a{d_images, Bi, C, n_channels, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio,
              d_out, *out_strides, d_depth_norm_z, depth_norm_mode};
-  dim3 grid((out_h * out_w + 255) / 256, n);
+  dim3 grid((out_w + 15) / 16, (out_h + 15) / 16, n);
   hipLaunchKernelGGL(crop_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("crop_kernel");
 }
