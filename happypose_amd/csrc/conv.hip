@@ -45,6 +45,7 @@
 
 #include "conv.h"
 #include "conv_epilogue.h"
+#include "conv_splitk.h"
 
 namespace hp {
 
@@ -193,11 +194,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   float* As = lds;                       // [2][BM][LDK]
   float* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
 
-  // XCD-aware tile order (dispatch puts block b on XCD b % 8)
-  const int nblk = a.tiles_m * a.tiles_n;
-  const int per_xcd = (nblk + 7) / 8;
-  const int lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  if (lin >= nblk) return;
+  // XCD-aware work-item order; the tiles of the last partial round are split along K (conv_splitk.h:
+  // the stride-2 3x3 layers have 320 / 600 / 1200 tiles for 512 slots)
+  int lin, slice;
+  bool split;
+  if (!splitk_decode(a, lin, slice, split)) return;
   const int tile_m = lin / a.tiles_n, tile_n = lin % a.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
@@ -248,9 +249,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const float* const Bfr = Bs + (wn + frow) * LDK + fk;
 
   Stage<NA, NB> st;
+  // K-tile range of this work item
+  const int t_begin = split ? slice * a.ktiles / a.sk_S : 0;
+  const int t_end = split ? (slice + 1) * a.ktiles / a.sk_S : a.ktiles;
   // the LUT carries one extra K-tile of padding entries, so t+2 below never reads out of range
-  issue_loads<NA, NB, PRE>(a, 0, a.lut[kc], rowoff, ih0, iw0, imgoff, wrow, st);
-  int4 e_next = a.lut[8 + kc];
+  issue_loads<NA, NB, PRE>(a, t_begin, a.lut[t_begin * 8 + kc], rowoff, ih0, iw0, imgoff, wrow, st);
+  int4 e_next = a.lut[(t_begin + 1) * 8 + kc];
   store_tile<NA, NB, PRE>(Ast, Bst, st);
   __syncthreads();
 
@@ -265,9 +269,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   //   q8-11  zero-pad/prologue + LDS store of A chunk 0..3 (q9: LDS fragments of kg3)
   //   q12-13 LDS store of the B chunks
   floatx4 fa[2][MT], fb[2][NT];
-  const int last = a.ktiles - 1;
-  for (int t = 0; t <= last; ++t) {
-    const int buf = t & 1;
+  const int last = t_end - 1;
+  for (int t = t_begin; t <= last; ++t) {
+    const int buf = (t - t_begin) & 1;
     const bool stage = t < last;  // wave-uniform
     const float* Ab = Afr + buf * BM * LDK;
     const float* Bb = Bfr + buf * BN * LDK;
@@ -321,6 +325,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 #endif
   }
 
+  if (split && !splitk_reduce<BM, BN, MT, NT, kThreads>(a, acc, lin - a.sk_regular, slice)) return;
+
   // ---- epilogue: bias, residual, ReLU through an LDS transpose (conv_epilogue.h) ----
   conv_epilogue<BM, BN, MT, NT, kThreads>(a, lds, acc, m0, n0, wm, wn);
 }
@@ -331,7 +337,10 @@ static int launch_variant(ConvArgs args, hipStream_t stream) {
   args.tiles_n = (args.Cout + BN - 1) / BN;  // weights / bias are padded to whole tiles; stores are not
   const int nblk = args.tiles_m * args.tiles_n;
   const size_t lds = Tile<BM, BN>::LDS_FLOATS * sizeof(float);
-  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, PRE>), dim3(8 * ((nblk + 7) / 8)), dim3(kThreads), lds, stream, args);
+  int rc = conv_plan_split(args, nblk, lds, args.ktiles, 1, stream);
+  if (rc) return rc;
+  const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
+  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, PRE>), dim3(8 * per_xcd), dim3(kThreads), lds, stream, args);
   return check_launch("conv_igemm_f32");
 }
 

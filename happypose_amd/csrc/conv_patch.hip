@@ -22,6 +22,7 @@
 
 #include "conv.h"
 #include "conv_epilogue.h"
+#include "conv_splitk.h"
 
 namespace hp {
 
@@ -50,24 +51,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   float* patch = lds;                 // [P][LDK]
   float* Bs = lds + P * LDK;          // [2][BN][LDK]
 
-  // Work items, per XCD (dispatch puts block b on XCD b % 8): first its share of the
-  // "regular" tiles (whole K), then its share of the tail items.  The tail = the tiles of the
-  // last, partially filled round of the grid; each is split into sk_S slices of the channel-
-  // chunk loop so that the round fills the machine (tile quantisation cost 20-40 % on the
-  // 15x20 / 8x10 layers).  Slices meet through the "last arriver reduces" protocol below.
-  const int rpx = a.sk_regular / 8, tpx = (a.sk_tail_items + 7) / 8;
-  const int xcd = blockIdx.x % 8, li = blockIdx.x / 8;
-  int tile, slice = 0;
-  bool split = false;
-  if (li < rpx) {
-    tile = xcd * rpx + li;
-  } else {
-    const int ti = xcd * tpx + (li - rpx);
-    if (li - rpx >= tpx || ti >= a.sk_tail_items) return;
-    tile = a.sk_regular + ti / a.sk_S;
-    slice = ti % a.sk_S;
-    split = a.sk_S > 1;
-  }
+  // work item = a regular tile (whole K) or a (tile, slice) of the tail round (conv_splitk.h):
+  // tile quantisation cost 20-40 % on the 15x20 / 8x10 layers
+  int tile, slice;
+  bool split;
+  if (!splitk_decode(a, tile, slice, split)) return;
   const int tile_m = tile / a.tiles_n, tile_n = tile % a.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
@@ -235,57 +223,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 
   // ---- split tiles: park the partial sums, the last slice to arrive adds the others
-  if (split) {
-    __shared__ int ticket_s;
-    const int tail_tile = tile - a.sk_regular;
-    float* const slab = a.sk_slabs + ((size_t)tail_tile * a.sk_S + slice) * (BM * BN);
-    // register layout -> [mt][nt][r4][thread][4]: every store is a coalesced 16 B per lane
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          floatx4 v = {acc[mt][nt][4 * r4], acc[mt][nt][4 * r4 + 1], acc[mt][nt][4 * r4 + 2], acc[mt][nt][4 * r4 + 3]};
-          *reinterpret_cast<floatx4*>(slab + ((((mt * NT + nt) * 4 + r4) * kThreads) + tid) * 4) = v;
-        }
-    // publish: stores drained -> agent-scope release -> ticket (cdna_hip_programming.md G16)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ticket_s = __hip_atomic_fetch_add(a.sk_counters + tail_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (ticket_s != a.sk_S - 1) return;  // not the last slice of this tile
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      a.sk_counters[tail_tile] = 0;  // every slice has taken its ticket: re-arm for the next launch
-    }
-    __syncthreads();
-    // sum ALL slices in slice order (own one re-read from its slab) so that the result does
-    // not depend on which slice happened to arrive last: bitwise run-to-run reproducible
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int s2 = 0; s2 < a.sk_S; ++s2) {
-      const float* other = a.sk_slabs + ((size_t)tail_tile * a.sk_S + s2) * (BM * BN);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const floatx4 v = *reinterpret_cast<const floatx4*>(other + ((((mt * NT + nt) * 4 + r4) * kThreads) + tid) * 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[mt][nt][4 * r4 + q] += v[q];
-          }
-    }
-  }
+  if (split && !splitk_reduce<BM, BN, MT, NT, kThreads>(a, acc, tile - a.sk_regular, slice)) return;
 
   // ---- epilogue: bias, residual, ReLU through an LDS transpose (conv_epilogue.h) ----
   conv_epilogue<BM, BN, MT, NT, kThreads>(a, lds, acc, m0, n0, wm, wn);
@@ -302,7 +240,9 @@ double rounds_cost(double r) {  // time of r rounds' worth of equal items; a par
   return full + (frac > 0 ? 0.55 + 0.45 * frac : 0.0);
 }
 
-int plan_split(ConvArgs& a, int T, size_t lds_bytes, hipStream_t stream) {
+}  // namespace
+
+int conv_plan_split(ConvArgs& a, int T, size_t lds_bytes, int k_units, int ktiles_per_unit, hipStream_t stream) {
   static SplitWorkspace ws;
   if (ws.slots == 0) {
     int dev = 0, cus = 256;
@@ -311,16 +251,18 @@ int plan_split(ConvArgs& a, int T, size_t lds_bytes, hipStream_t stream) {
     ws.slots = 2 * cus;  // two workgroups per CU
   }
   const int slots = lds_bytes * 2 <= 160 * 1024 ? ws.slots : ws.slots / 2;
-  const int ncc = a.Cin / BK;
+  const int ncc = k_units;
   static const bool no_split = std::getenv("HP_CONV_NO_SPLITK") != nullptr;
   int regular = (T / slots) * slots, tail = T - regular, S = 1;
   regular -= regular % 8;  // the kernel deals regular tiles to the 8 XCDs evenly
   tail = T - regular;
   if (tail > 0 && ncc > 1 && !no_split) {
     double best = rounds_cost((double)tail / slots);
-    for (int s = 2; s <= ncc && s <= 16; ++s) {
+    // a slice must stay long (>= 12 K-tiles of 32): parking and re-reading a 64-KB slab costs about
+    // as much as 2-3 K-tiles, so splitting short tiles loses (measured on the 64->128 stride-2 layer)
+    for (int s = 2; s <= ncc && s <= 16 && (ncc * ktiles_per_unit) / s >= 12; ++s) {
       const double c = rounds_cost((double)tail * s / slots) / s + 0.015 * s;  // + slab traffic / item start-up
-      if (c < best - 1e-9) { best = c; S = s; }
+      if (c < 0.9 * best) { best = c; S = s; }
     }
   }
   a.sk_regular = regular;
@@ -349,6 +291,8 @@ int plan_split(ConvArgs& a, int T, size_t lds_bytes, hipStream_t stream) {
   return HP_OK;
 }
 
+namespace {
+
 template <int BN, bool PRE>
 int launch(ConvArgs args, hipStream_t stream, bool* opted) {
   const int P = BM + 2 * args.W + 2;
@@ -364,7 +308,7 @@ int launch(ConvArgs args, hipStream_t stream, bool* opted) {
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = args.Cout / BN;
   const int T = args.tiles_m * args.tiles_n;
-  int rc = plan_split(args, T, lds, stream);
+  int rc = conv_plan_split(args, T, lds, args.Cin / BK, 9, stream);
   if (rc) return rc;
   const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
   hipLaunchKernelGGL((conv3x3_patch_f32<BN, PRE>), dim3(8 * per_xcd), dim3(kThreads), lds, stream, args, P, npc);
