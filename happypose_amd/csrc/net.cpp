@@ -50,6 +50,7 @@ struct ConvLayer {
   DevBuf w, w_wino, bias, lut, pre_scale, pre_shift;  // w_wino: Winograd-transformed weights (3x3 s1 layers)
   int cout_pad = 0;        // weight rows / bias padded to whole 64-wide tiles
   int se = 0;              // the input is gated by the squeeze-excitation vector of this block (1x1 projections)
+  int run_mode = 0;        // stem with K ordered (kh, [kw x cin run]) over an UNPADDED 6-channel input, see pack_conv
   // fp16 plan: cin rounded to 8, K to 64; packed halves, LUT per 8-half chunk, prologue in halves
   int cin16 = 0, Kpad16 = 0;
   DevBuf w16, lut16, pre_scale16, pre_shift16;
@@ -164,6 +165,17 @@ int build_graph(Net& n) {
   const std::string bb = "backbone.";
   const int k1 = vanilla ? 7 : 5;
   int c = add_conv(n, bb + "conv1.weight", bb + "bn1", "", n.n_inputs, 64, k1, 2, k1 / 2, 1, n.h, n.w, -1, 0, -1);
+  if (!vanilla && n.n_inputs == 6 && n.w % 2 == 0) {
+    // CosyPose stem (5x5, stride 2, 6 channels): the 5 taps x 6 channels of a filter row are 30
+    // CONTIGUOUS floats of an unpadded NHWC input, so K = 5 rows x 32 = 160 instead of 25 taps x 8
+    // padded channels = 200 (-> 224): 29 % less matrix work in the largest launch of a forward.
+    // 16-B chunk alignment holds because a pixel is 24 B and tap offsets are even; a chunk covers
+    // taps {0}, {0,1}, {1}, {2}, {2,3}, {3}, {4}, {4,pad} and the taps that fall outside the image
+    // at the left / right border ({0,1} / {4}) cover whole chunks, so validity stays per chunk.
+    ConvLayer& S = *n.convs[c];
+    S.run_mode = 1; S.cin = 6; S.Kpad = 5 * 32;
+    n.c_pad = 6;
+  }
   int H = n.convs[c]->Ho, W = n.convs[c]->Wo;
   want(n, 0, (size_t)H * W * 64);
   Op mp; mp.kind = OP_MAXPOOL; mp.in_buf = 0; mp.out_buf = 1; mp.H = H; mp.W = W; mp.C = 64;
@@ -298,13 +310,15 @@ int pack_conv(Net& n, ConvLayer& L) {
   std::vector<float> scale, shift;
   if (!L.bn_after.empty() && (rc = bn_affine(n, L.bn_after, L.cout, scale, shift))) return rc;
   std::vector<float> packed((size_t)L.cout_pad * L.Kpad, 0.f);  // rows padded to whole 64-wide tiles
+  const int run = (L.kw * L.cin + 3) / 4 * 4;  // run mode: floats per filter row (30 -> 32)
   for (int o = 0; o < L.cout; ++o) {
     const float s = scale.empty() ? 1.f : scale[o];
     for (int ci = 0; ci < L.cin_real; ++ci)
       for (int y = 0; y < L.kh; ++y)
-        for (int x = 0; x < L.kw; ++x)
-          packed[(size_t)o * L.Kpad + (size_t)(y * L.kw + x) * L.cin + ci] =
-              (*w)[(((size_t)o * L.cin_real + ci) * L.kh + y) * L.kw + x] * s;
+        for (int x = 0; x < L.kw; ++x) {
+          const size_t k = L.run_mode ? (size_t)y * run + (size_t)x * L.cin + ci : (size_t)(y * L.kw + x) * L.cin + ci;
+          packed[(size_t)o * L.Kpad + k] = (*w)[(((size_t)o * L.cin_real + ci) * L.kh + y) * L.kw + x] * s;
+        }
   }
   if ((rc = L.w.upload(packed.data(), packed.size() * 4))) return rc;
   {
@@ -330,14 +344,18 @@ int pack_conv(Net& n, ConvLayer& L) {
   }
   // + 16 padding entries: the kernel prefetches the entries of K-tiles t+1 and t+2
   std::vector<int4> lut(L.Kpad / 4 + 16, make_int4(0, -1, 0, 0));
-  const int kreal = L.kh * L.kw * L.cin;
+  const int kreal = L.run_mode ? L.kh * run : L.kh * L.kw * L.cin;
   for (int q = 0; q < L.Kpad / 4; ++q) {
     const int k = 4 * q;
-    if (k < kreal) {
+    if (k >= kreal) {
+      lut[q] = make_int4(0, -1, 0, 0);
+    } else if (L.run_mode) {
+      // chunk j of filter row y starts at float 4j of the run; validity follows its FIRST tap
+      const int y = k / run, j4 = k % run;
+      lut[q] = make_int4(y * L.W * L.cin + j4, y, j4 / L.cin, 0);
+    } else {
       const int seg = k / L.cin, ch = k % L.cin, y = seg / L.kw, x = seg % L.kw;
       lut[q] = make_int4((y * L.W + x) * L.cin + ch, y, x, ch);
-    } else {
-      lut[q] = make_int4(0, -1, 0, 0);
     }
   }
   return L.lut.upload(lut.data(), lut.size() * sizeof(int4));
