@@ -39,6 +39,7 @@ struct ConvArgsH {
   _Float16* y;
   int64_t M, x_bytes, w_bytes;
   int H, W, Cin, Ho, Wo, Cout, stride, pad, Kpad, ktiles, relu;
+  int kh, kw;                 // filter size (selects the patch-staged 3x3 kernel)
   int tiles_m, tiles_n;       // filled by the launcher
 };
 

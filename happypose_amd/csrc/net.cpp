@@ -554,6 +554,7 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
       a.M = (int64_t)batch * L.Ho * L.Wo;
       a.H = L.H; a.W = L.W; a.Cin = L.cin16; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.cout;
       a.stride = L.stride; a.pad = L.pad; a.Kpad = L.Kpad16; a.ktiles = L.Kpad16 / 64; a.relu = L.relu;
+      a.kh = L.kh; a.kw = L.kw;
       a.x_bytes = (int64_t)batch * L.H * L.W * L.cin16 * 2;
       a.w_bytes = (int64_t)L.cout * L.Kpad16 * 2;
       EventPair ev{};
@@ -833,6 +834,7 @@ extern "C" int hp_conv2d_nhwc_f16(const void* d_x, int n, int h, int w, int cin,
   a.y = (_Float16*)d_y;
   a.H = h; a.W = w; a.Cin = cin; a.Ho = (h + 2 * pad - kh) / stride + 1; a.Wo = (w + 2 * pad - kw) / stride + 1;
   a.Cout = cout; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.ktiles = Kpad / 64; a.relu = relu;
+  a.kh = kh; a.kw = kw;
   a.M = (int64_t)n * a.Ho * a.Wo;
   a.x_bytes = (int64_t)n * h * w * cin * 2;
   a.w_bytes = (int64_t)cout * Kpad * 2;
