@@ -305,7 +305,11 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   // ---- coverage + depth: only the triangles binned to this band ----
   const int cnt = nf > 0 ? min(a.bin_count[lin], a.bin_cap) : 0;
   const int32_t* list = a.bin_list + (int64_t)lin * a.bin_cap;
+#ifdef HP_RABL_NO_COVER
+  for (int k = tid; k < 0; k += kThreads) {
+#else
   for (int k = tid; k < cnt; k += kThreads) {
+#endif
     const int f = list[k];
     int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
     TriSetup s;
@@ -344,7 +348,11 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
     const int i = row0 + p / a.w, j = p % a.w;
     const unsigned long long key = zb[p];
     float o_rgb[3] = {0.f, 0.f, 0.f}, o_n[3] = {0.f, 0.f, 0.f}, o_d = 0.0f;
+#ifdef HP_RABL_NO_SHADE
+    if (key != kKeyEmpty && a.w < 0) {
+#else
     if (key != kKeyEmpty) {
+#endif
       const int f = (int)(key & 0xFFFFFFFFull);
       int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
       float V0[3], V1[3], V2[3], e0[3], e1[3], e2[3];

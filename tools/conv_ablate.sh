@@ -7,7 +7,7 @@
 # Results of round 1 are in DESIGN.md ("conv kernel: where the time goes").
 set -e
 cd "$(dirname "$0")/.."
-SRC="api.cpp net.cpp raster.hip geometry.hip crop.hip conv.hip conv_patch.hip pool_head.hip"
+SRC=$(python3 -c "from happypose_amd.build import SOURCES; print(' '.join(SOURCES))")
 mkdir -p gpurun_out/abl
 for v in "FULL:" "NO_BARRIER:-DHP_ABL_NO_BARRIER" "NO_STAGE:-DHP_ABL_NO_STAGE" \
          "MFMA_ONLY:-DHP_ABL_NO_STAGE -DHP_ABL_NO_BARRIER -DHP_ABL_NO_DSREAD"; do

@@ -2,7 +2,7 @@
 # Ablation of the Winograd conv loop (run on the GPU box); see tools/conv_ablate.sh.
 set -e
 cd "$(dirname "$0")/.."
-SRC="api.cpp net.cpp raster.hip geometry.hip crop.hip conv.hip conv_patch.hip conv_wino.hip pool_head.hip"
+SRC=$(python3 -c "from happypose_amd.build import SOURCES; print(' '.join(SOURCES))")
 mkdir -p gpurun_out/abl
 for v in ${VARIANTS:-"FULL:" "NO_GLOAD:-DHP_WABL_NO_GLOAD" "NO_GLOAD_RAW:-DHP_WABL_NO_GLOAD_RAW" "NO_GLOAD_U:-DHP_WABL_NO_GLOAD_U" "NO_LSTORE:-DHP_WABL_NO_LSTORE" "NO_STAGE:-DHP_WABL_NO_STAGE"}; do
   name=${v%%:*}; flags=${v#*:}
