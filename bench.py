@@ -164,7 +164,7 @@ def stage_rates(store, scene, images, K, TCO0, im_ids, device, reps=20):
 def measured_traffic(workload, precision):
     """HBM bytes per conv launch from the committed PMC summary (rocprofv3 FETCH_SIZE / WRITE_SIZE
     passes of this bench command, tools/pmc_traffic.py); None when no summary matches the run."""
-    path = os.path.join(ROOT, "profiles", "r01c_conv_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01e_conv_hbm_traffic.json")
     if workload != "C2" or precision != "f32" or not os.path.exists(path):
         return None
     with open(path) as fh:
@@ -272,7 +272,9 @@ def main():
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": measured_traffic(args.workload, precision),
                          "traffic_note": "HBM bytes per conv launch (incl. Infinity-Cache hits), PMC passes of this command: "
-                                         "profiles/r01c_conv_hbm_traffic.json; the kernels are MFMA-bound",
+                                         "profiles/r01e_conv_hbm_traffic.json; the kernels are MFMA-bound",
+                         "frac_note": "achieved counts the ALGORITHMIC FLOPs of the direct convolution (SURVEY.md 8d); the Winograd F(2x2,3x3) "
+                                      "layers execute 2.25x fewer, so frac can exceed 1 -- mfma_executed_frac is the busy fraction of the matrix pipe",
                          "mfma_executed_tflops": mfma_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else 0.0,
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
