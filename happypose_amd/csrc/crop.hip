@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
       if (c == 3) vacc = sv;
     }
   }
+  float outv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if (c >= a.NC) break;
@@ -205,7 +206,16 @@ __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
         else val = fminf(fmaxf(val - zn, -2.0f), 2.0f);
       }
     }
-    a.out[obase + (int64_t)c * a.os.s_chan] = val;
+    outv[c] = val;
+  }
+  // channel-interleaved destination (NHWC slice of the network input): one 12-B store per pixel
+  typedef float float3v __attribute__((ext_vector_type(3)));
+  if (a.os.s_chan == 1 && a.NC == 3) {
+    *reinterpret_cast<float3v*>(a.out + obase) = float3v{outv[0], outv[1], outv[2]};
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < a.NC) a.out[obase + (int64_t)c * a.os.s_chan] = outv[c];
   }
 }
 

@@ -420,13 +420,22 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
       o_d = Z > a.depth_max ? 0.0f : Z;
     }
     const int64_t co = cbase + (int64_t)i * a.cs.s_row + (int64_t)j * a.cs.s_col;
+    // channel-interleaved destinations (NHWC slices of the network input): one 12-B store per pixel
+    // instead of three 4-B ones (the slice is 4-B aligned only, so no wider)
+    typedef float float3v __attribute__((ext_vector_type(3)));
     if (a.rgb) {
+      if (a.cs.s_chan == 1) *reinterpret_cast<float3v*>(a.rgb + co) = float3v{o_rgb[0], o_rgb[1], o_rgb[2]};
+      else {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a.rgb[co + c * a.cs.s_chan] = o_rgb[c];
+        for (int c = 0; c < 3; ++c) a.rgb[co + c * a.cs.s_chan] = o_rgb[c];
+      }
     }
     if (a.nrm) {
+      if (a.cs.s_chan == 1) *reinterpret_cast<float3v*>(a.nrm + co) = float3v{o_n[0], o_n[1], o_n[2]};
+      else {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a.nrm[co + c * a.cs.s_chan] = o_n[c];
+        for (int c = 0; c < 3; ++c) a.nrm[co + c * a.cs.s_chan] = o_n[c];
+      }
     }
     if (a.mask) a.mask[((int64_t)view * a.h + i) * a.w + j] = o_d > 0.0f ? 1 : 0;
     if (a.depth) {
