@@ -271,15 +271,16 @@ def main():
                                     "conv_igemm_f16: fp16 MFMA implicit-GEMM conv (fp32 accumulate)") + ", all conv launches of a forward",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": measured_traffic(args.workload, precision),
-                         "traffic_note": "HBM bytes per conv launch (incl. Infinity-Cache hits), PMC passes of this command: "
-                                         "profiles/r01e_conv_hbm_traffic.json; the kernels are MFMA-bound",
-                         "frac_note": "achieved counts the ALGORITHMIC FLOPs of the direct convolution (SURVEY.md 8d); the Winograd F(2x2,3x3) "
-                                      "layers execute 2.25x fewer, so frac can exceed 1 -- mfma_executed_frac is the busy fraction of the matrix pipe",
-                         "mfma_executed_tflops": mfma_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
-                         "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else 0.0,
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }
+        if precision == "f32":
+            line["roofline"]["frac_note"] = ("achieved counts the ALGORITHMIC FLOPs of the direct convolution (SURVEY.md 8d); the Winograd "
+                                             "F(2x2,3x3) layers execute 2.25x fewer, so frac can exceed 1 -- mfma_executed_frac is the busy "
+                                             "fraction of the matrix pipe")
+            if line["roofline"]["traffic"] is not None:
+                line["roofline"]["traffic_note"] = ("HBM bytes per conv launch (incl. Infinity-Cache hits), PMC passes of this command: "
+                                                    "profiles/r01e_conv_hbm_traffic.json; the kernels are MFMA-bound")
         if args.workload == "C2":
             line["stages"] = stage_rates(store, scene, images, K, TCO0, im_ids, device)
         if not args.no_cpu_baseline and args.workload == "C2":
