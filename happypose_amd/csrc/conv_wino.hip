@@ -333,12 +333,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     //      residual and store are 16-B accesses instead of 4-B ones.
     const int lq = lane & 3;                       // after the transpose: the pixel this lane stores
     const int ncol = n0 + ((lane & 15) & ~3);      // first of its 4 couts (+ nt * 16)
+    // tile of accumulator row i = 0 decoded once, then stepped (integer divisions cost ~25 VALU each)
+    const int go0 = bm * TPB + wave * 16 + 4 * kg;  // uniform over the 16 lanes of a kg group
+    int e_img, e_th, e_tw;
+    {
+      const int gc = go0 < T ? go0 : 0;
+      e_img = gc / (TH * TW);
+      const int r = gc - e_img * (TH * TW);
+      e_th = r / TW;
+      e_tw = r - e_th * TW;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int go = bm * TPB + wave * 16 + 4 * kg + i;   // uniform over the 16 lanes of a kg group
-      const int gc = go < T ? go : 0;
-      const int img = gc / (TH * TW), r = gc - img * (TH * TW);
-      const int th = r / TW, tw = r - th * TW;
+      const int go = go0 + i;
+      const int img = e_img, th = e_th, tw = e_tw;
+      if (++e_tw == TW) { e_tw = 0; if (++e_th == TH) { e_th = 0; ++e_img; } }
       const int oh = 2 * th + (lq >> 1), ow = 2 * tw + (lq & 1);
       const bool ok = (go < T) & (oh < a.Ho) & (ow < a.Wo);
       const int64_t obase = (((int64_t)img * a.Ho + oh) * a.Wo + ow) * a.Cout + ncol;

@@ -84,6 +84,34 @@ def gather_poses(poses: torch.Tensor, scores: Optional[torch.Tensor], start: int
     return res[:, :16].reshape(n_total, 4, 4), res[:, 16]
 
 
+def refine_sharded(model, images: torch.Tensor, K: torch.Tensor, labels, TCO: torch.Tensor, n_iterations: int,
+                   im_ids: Optional[torch.Tensor] = None, scores_fn=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """every rank holds the frame(s), meshes and weights; the hypotheses -- sorted by
+    (detection, hypothesis id) by the caller -- are split into contiguous shards, each rank runs the
+    refiner loop on its shard (no collective inside the loop) and ONE ``all_gather_into_tensor``
+    hands every rank all refined poses (``[N,4,4]`` in the caller's order) and scores.
+
+    ``model`` is a predictor (``PosePredictor`` / ``CosyPosePosePredictor``: anything whose
+    ``forward(images, K, labels, TCO, n_iterations=, im_ids=)`` returns the per-iteration outputs);
+    ``scores_fn(last_output) -> [n_local]`` optionally attaches a score to every hypothesis."""
+    n = len(labels)
+    assert TCO.shape == (n, 4, 4)
+    s, e = shard_range(n)
+    labels = list(labels)
+    ids = None if im_ids is None else im_ids[s:e]
+    if K.shape[0] == n and images.shape[0] == n:  # reference convention: gathered per hypothesis
+        images, K = images[s:e], K[s:e]
+    if e > s:
+        out = model.forward(images, K, labels[s:e], TCO[s:e], n_iterations=n_iterations, im_ids=ids)
+        last = out[f"iteration={n_iterations}"]
+        poses = last.TCO_output
+        scores = None if scores_fn is None else scores_fn(last)
+    else:  # more ranks than hypotheses
+        poses = TCO[:0].to(torch.float32)
+        scores = None
+    return gather_poses(poses, scores, s, n)
+
+
 def gather_collection(coll):
     """``PandasTensorCollection.gather_distributed`` without the filesystem: tensors go
     through ``all_gather`` (ragged lengths allowed), ``infos`` through ``all_gather_object``."""

@@ -43,6 +43,26 @@ WORKER = textwrap.dedent("""
     full = coll.gather_distributed()
     assert len(full) == n_total and full.infos.hypothesis_id.tolist() == list(range(n_total))
     assert torch.equal(full.poses, poses_all)
+    # sharded refinement (SURVEY.md 8e) with a stand-in predictor: the result must not depend on
+    # the number of ranks
+    from types import SimpleNamespace
+
+    class FakeModel:
+        def forward(self, images, K, labels, TCO, n_iterations=1, im_ids=None):
+            out = TCO.clone()
+            for _ in range(n_iterations):
+                out = out * 0.5 + images[im_ids.long()].mean(dim=(1, 2, 3))[:, None, None] + torch.as_tensor(
+                    [float(l[3:]) for l in labels])[:, None, None]
+            return {f"iteration={n_iterations}": SimpleNamespace(TCO_output=out)}
+
+    images = torch.as_tensor(rs.normal(size=(2, 3, 4, 5)).astype(np.float32))
+    Kc = torch.eye(3)[None].repeat(2, 1, 1)
+    labels = [f"obj{i % 5}" for i in range(n_total)]
+    im_ids = torch.as_tensor(np.arange(n_total) % 2, dtype=torch.int32)
+    ref = FakeModel().forward(images, Kc, labels, poses_all, n_iterations=3, im_ids=im_ids)["iteration=3"].TCO_output
+    got, sc = D.refine_sharded(FakeModel(), images, Kc, labels, poses_all, 3, im_ids=im_ids,
+                               scores_fn=lambda o: o.TCO_output[:, 0, 0])
+    assert torch.equal(got, ref) and torch.equal(sc, ref[:, 0, 0])
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
     print(f"rank {rank} ok")
