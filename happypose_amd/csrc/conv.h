@@ -76,8 +76,9 @@ int launch_head(const HeadArgs& a, int batch, hipStream_t stream);
 int launch_dwconv(const DwArgs& a, hipStream_t stream);
 // squeeze-excitation: pooled [n][C] = mean over HW of y; gate [n][C] = sigmoid(W2 swish(W1 pooled + b1) + b2)
 int se_partial_floats(int n, int C);  // workspace of launch_se
-int launch_se(const float* y, float* partial, float* pooled, float* gate, const float* w1, const float* b1, const float* w2,
-              const float* b2, int n, int HW, int C, int Cse, hipStream_t stream);
+int launch_se(const float* y, float* partial, float* pooled, float* sq, float* gate, const float* w1, const float* b1,
+              const float* w2t /* expand weights transposed to [Cse][C] */, const float* b2, int n, int HW, int C, int Cse,
+              hipStream_t stream);
 int launch_conv_f16(const ConvArgsH& a, hipStream_t stream);
 int launch_cast_pad_f16(const float* x, void* y, int64_t pixels, int c_in, int c_out, hipStream_t stream);
 int launch_maxpool_f16(const void* x, void* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);

@@ -76,33 +76,43 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const float* y, float* par
     partial[((int64_t)img * kSeStrips + strip) * C + c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
-// gate = sigmoid(W2 swish(W1 mean + b1) + b2): one block per image (Cse <= 128, C <= 4096)
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* partial, float* pooled, const float* w1, const float* b1,
-                                                      const float* w2, const float* b2, float* gate, int HW, int C, int Cse) {
-  __shared__ float sq[128];
-  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* pv = pooled + (int64_t)img * C;
-  for (int c = tid; c < C; c += 256) {
-    float s = 0.f;
-    for (int st = 0; st < kSeStrips; ++st) s += partial[((int64_t)img * kSeStrips + st) * C + c];
-    pv[c] = s / (float)HW;
-  }
-  __syncthreads();
-  for (int j = wave; j < Cse; j += 4) {
-    const float* w = w1 + (int64_t)j * C;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(w[c], pv[c], s);
+// squeeze-excitation vector in three small, wide launches (one block per image left most of the
+// chip idle and re-read both weight matrices per image: 2 ms of a forward):
+//   se_mean_kernel:   pooled[n][c]  = sum of the strip partials / HW            (fixed order)
+//   se_reduce_kernel: sq[n][j]      = swish(W1[j] . pooled[n] + b1[j])          one wave per (n, j)
+//   se_expand_kernel: gate[n][c]    = sigmoid(W2t[.][c] . sq[n] + b2[c])        W2 transposed: coalesced
+__global__ __launch_bounds__(256) void se_mean_kernel(const float* partial, float* pooled, int HW, int C, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int img = idx / C, c = idx - img * C;
+  float s = 0.f;
+  for (int st = 0; st < kSeStrips; ++st) s += partial[((int64_t)img * kSeStrips + st) * C + c];
+  pooled[idx] = s / (float)HW;
+}
+
+__global__ __launch_bounds__(256) void se_reduce_kernel(const float* pooled, const float* w1, const float* b1, float* sq, int C,
+                                                        int Cse) {
+  const int img = blockIdx.y, j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= Cse) return;
+  const float* pv = pooled + (int64_t)img * C;
+  const float* w = w1 + (int64_t)j * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s = fmaf(w[c], pv[c], s);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) { s += b1[j]; sq[j] = s / (1.f + __expf(-s)); }
-  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) { s += b1[j]; sq[(int64_t)img * Cse + j] = s / (1.f + __expf(-s)); }
+}
+
+__global__ __launch_bounds__(256) void se_expand_kernel(const float* sq, const float* w2t, const float* b2, float* gate, int C,
+                                                        int Cse) {
+  __shared__ float sv[128];
+  const int img = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < Cse) sv[threadIdx.x] = sq[(int64_t)img * Cse + threadIdx.x];
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const float* w = w2 + (int64_t)c * Cse;
-    float s = b2[c];
-    for (int j = 0; j < Cse; ++j) s = fmaf(w[j], sq[j], s);
-    gate[(int64_t)img * C + c] = 1.f / (1.f + __expf(-s));
-  }
+  if (c >= C) return;
+  float s = b2[c];
+  for (int j = 0; j < Cse; ++j) s = fmaf(w2t[(int64_t)j * C + c], sv[j], s);
+  gate[(int64_t)img * C + c] = 1.f / (1.f + __expf(-s));
 }
 
 }  // namespace
@@ -118,14 +128,19 @@ int launch_dwconv(const DwArgs& a, hipStream_t stream) {
 
 int se_partial_floats(int n, int C) { return n * kSeStrips * C; }
 
-int launch_se(const float* y, float* partial, float* pooled, float* gate, const float* w1, const float* b1, const float* w2,
-              const float* b2, int n, int HW, int C, int Cse, hipStream_t stream) {
-  if (Cse > 128) return fail(HP_ERR_ARG, "se_gate_kernel: more than 128 squeezed channels");
+// w2t = the expand weights transposed to [Cse][C]; sq = workspace [n][Cse]
+int launch_se(const float* y, float* partial, float* pooled, float* sq, float* gate, const float* w1, const float* b1,
+              const float* w2t, const float* b2, int n, int HW, int C, int Cse, hipStream_t stream) {
+  if (Cse > 128) return fail(HP_ERR_ARG, "squeeze-excitation: more than 128 squeezed channels");
   hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, n, kSeStrips), dim3(256), 0, stream, y, partial, HW, C);
   int rc = check_launch("se_pool_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(se_gate_kernel, dim3(n), dim3(256), 0, stream, partial, pooled, w1, b1, w2, b2, gate, HW, C, Cse);
-  return check_launch("se_gate_kernel");
+  hipLaunchKernelGGL(se_mean_kernel, dim3((n * C + 255) / 256), dim3(256), 0, stream, partial, pooled, HW, C, n * C);
+  if ((rc = check_launch("se_mean_kernel"))) return rc;
+  hipLaunchKernelGGL(se_reduce_kernel, dim3((Cse + 3) / 4, n), dim3(256), 0, stream, pooled, w1, b1, sq, C, Cse);
+  if ((rc = check_launch("se_reduce_kernel"))) return rc;
+  hipLaunchKernelGGL(se_expand_kernel, dim3((C + 255) / 256, n), dim3(256), 0, stream, sq, w2t, b2, gate, C, Cse);
+  return check_launch("se_expand_kernel");
 }
 
 }  // namespace hp

@@ -85,7 +85,7 @@ struct Net {
   std::vector<std::unique_ptr<ConvLayer>> convs;
   std::vector<std::unique_ptr<DwLayer>> dws;
   std::vector<std::unique_ptr<SeLayer>> ses;
-  DevBuf se_pooled, se_gate, se_partial;  // [max_batch][max expanded channels] (+ strip partial sums)
+  DevBuf se_pooled, se_gate, se_partial, se_sq;  // [max_batch][max expanded channels] (+ strip partial sums)
   int se_max_c = 0;
   float bn_eps = 1e-5f;       // nn.BatchNorm2d default (ResNets); 1e-3 for EfficientNet
   int n_features = 512;
@@ -382,7 +382,12 @@ int pack_se(Net& n, SeLayer& S) {
   if ((rc = need(n, S.prefix + "._se_reduce.bias", S.Cse, &v))) return rc;
   if ((rc = S.b1.upload(v->data(), v->size() * 4))) return rc;
   if ((rc = need(n, S.prefix + "._se_expand.weight", (size_t)S.C * S.Cse, &v))) return rc;
-  if ((rc = S.w2.upload(v->data(), v->size() * 4))) return rc;
+  {  // [C][Cse] -> [Cse][C]: lanes over c read it coalesced
+    std::vector<float> t((size_t)S.C * S.Cse);
+    for (int c = 0; c < S.C; ++c)
+      for (int j = 0; j < S.Cse; ++j) t[(size_t)j * S.C + c] = (*v)[(size_t)c * S.Cse + j];
+    if ((rc = S.w2.upload(t.data(), t.size() * 4))) return rc;
+  }
   if ((rc = need(n, S.prefix + "._se_expand.bias", S.C, &v))) return rc;
   return S.b2.upload(v->data(), v->size() * 4);
 }
@@ -488,6 +493,7 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   if (net->se_max_c > 0) {
     if ((rc = net->se_pooled.alloc((size_t)max_batch * net->se_max_c * 4))) return rc;
     if ((rc = net->se_gate.alloc((size_t)max_batch * net->se_max_c * 4))) return rc;
+    if ((rc = net->se_sq.alloc((size_t)max_batch * 128 * 4))) return rc;
     if ((rc = net->se_partial.alloc((size_t)se_partial_floats(max_batch, net->se_max_c) * 4))) return rc;
   }
   for (auto& L : net->convs)
@@ -627,7 +633,8 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
       if ((rc = launch_dwconv(d, stream))) return rc;
     } else if (op.kind == OP_SE) {
       const SeLayer& S = *net->ses[op.conv];
-      if ((rc = launch_se((const float*)net->bufs[S.in_buf].p, (float*)net->se_partial.p, (float*)net->se_pooled.p, (float*)net->se_gate.p,
+      if ((rc = launch_se((const float*)net->bufs[S.in_buf].p, (float*)net->se_partial.p, (float*)net->se_pooled.p, (float*)net->se_sq.p,
+                          (float*)net->se_gate.p,
                           (const float*)S.w1.p, (const float*)S.b1.p, (const float*)S.w2.p, (const float*)S.b2.p, batch, S.HW,
                           S.C, S.Cse, stream)))
         return rc;
