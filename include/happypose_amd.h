@@ -245,10 +245,16 @@ int hp_icp_refine(int n, int B, int H, int W, const float* d_depth_rendered, con
                   float depth_delta_thresh, float* d_TCO_out, int32_t* d_retval, float* d_residual,
                   void* stream);
 
-/* Single layer entry (used by the parity tests of the conv kernel itself):
- * y[n][ho][wo][cout] = act( conv(x_act, w) + bias + residual ),
- * x_act = pre_scale ? relu(x * pre_scale[c] + pre_shift[c]) : x   (zero padding AFTER it).
- * x NHWC [n][h][w][cin] (cin % 4 == 0), w packed [cout][kh][kw][cin], stride 1|2. */
+/* Single layer entry (used by the parity tests of the conv kernels themselves):
+ * y[n][ho][wo][cout] = act( conv(x_act, w) + bias + residual ),   act = relu: 0 none, 1 ReLU, 2 swish
+ * x_act = x                                              (pre_scale == NULL)
+ *       = relu(x * pre_scale[c] + pre_shift[c])           (both given: pre-activation BatchNorm, zero
+ *                                                          padding AFTER it)
+ *       = x * pre_scale[img][c]                           (pre_shift == NULL: squeeze-excitation gate
+ *                                                          [n][cin] of an MBConv projection)
+ * x NHWC [n][h][w][cin] (cin % 4 == 0), w packed [cout][kh][kw][cin] (cout % 4 == 0), stride 1|2,
+ * symmetric padding.  The kernel family follows hp_conv_select_algo (Winograd / patch-staged direct
+ * for 3x3 stride-1 layers with cin % 32 == 0 and cout % 64 == 0, the generic implicit GEMM else). */
 int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, const float* d_w, int cout,
                    int kh, int kw, int stride, int pad, const float* d_bias,
                    const float* d_residual, const float* d_pre_scale, const float* d_pre_shift,
