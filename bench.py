@@ -36,7 +36,7 @@ PEAK_F16_MFMA_TFLOPS = 2516.6  # dense fp16 MFMA: 16x the fp32 rate (same table)
 N_DET, N_HYP, N_ITERS = 8, 16, 5
 
 
-WORKLOADS = ("C2", "C3", "C5")
+WORKLOADS = ("C2", "C3", "C5", "E2E")
 
 
 def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32"):
@@ -76,6 +76,94 @@ def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32")
                    predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
         model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=576, precision=precision)
     return ds, renderer, scene, weights, model
+
+
+def bench_e2e(args, device, rank, world):
+    """End-to-end frames/s of SURVEY.md 8(d): the whole ``PoseEstimator.run_inference_pipeline`` of the
+    ``megapose-1.0-RGB-multi-hypothesis`` configuration (TB/utils/load_model.py:26-34) on one 640x480 frame
+    with 8 detections per GPU: coarse scoring of 8 x 576 SO(3)-grid poses, top-5 hypotheses per detection,
+    5 refiner iterations over the 40 hypotheses (4 views x RGB + normals, 27 channels), re-scoring, top-1 --
+    host orchestration (pandas bookkeeping, chunking) included."""
+    from happypose_amd.models import create_model_pose, pose_model_param_shapes
+    from happypose_amd.pose_estimator import ObservationTensor, PoseEstimator, make_detections_from_object_data
+    from happypose_amd.renderer import BatchRenderer
+    from happypose_amd.synthetic import make_object_dataset, make_scene, predictor_weights
+
+    coarse_precision = args.precision or "f32"
+    ds = make_object_dataset(8, seed=1, tex_size=1024)
+    renderer = BatchRenderer(ds, device=device)
+    store = renderer.store
+    scene = make_scene(n_detections=N_DET, n_hypotheses=1, n_objects=8, seed=2 + rank)
+    ccfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
+                predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
+    rcfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+                depth_augmentation=False)
+    wc = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 9, pose_dim=0, n_views_logits=1), seed=0)
+    wr = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 27), seed=1)
+    coarse = create_model_pose(ccfg, renderer, state_dict=wc, max_batch=576, precision=coarse_precision)
+    refiner = create_model_pose(rcfg, renderer, state_dict=wr, max_batch=64, precision="f32")
+    est = PoseEstimator(refiner_model=refiner, coarse_model=coarse, bsz_objects=8, bsz_images=576, SO3_grid_size=576)
+
+    # detections = bounding boxes of the projected objects (what a detector would hand over)
+    pts = store.mesh_db.points[scene["det_obj_ids"]].astype(np.float64)
+    T = scene["TCO_det"].astype(np.float64)
+    pc = np.einsum("nij,npj->npi", T[:, :3, :3], pts) + T[:, None, :3, 3]
+    uv = np.einsum("ij,npj->npi", scene["K"][0].astype(np.float64), pc)
+    uv = uv[..., :2] / uv[..., 2:]
+    boxes = np.concatenate([uv.min(1), uv.max(1)], -1).astype(np.float32)
+    det = make_detections_from_object_data([store.labels[i] for i in scene["det_obj_ids"]], boxes).to(device)
+    obs = ObservationTensor(torch.as_tensor(scene["images"][:, :3].copy(), device=device),
+                            torch.as_tensor(scene["K"], device=device))
+
+    def step():
+        final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=N_ITERS, n_pose_hypotheses=5)
+        return final, extra
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    for m in (coarse, refiner):
+        m.backbone.set_profiling(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        final, extra = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = [m.backbone.profile_collect() for m in (coarse, refiner)]
+    for m in (coarse, refiner):
+        m.backbone.set_profiling(False)
+    assert len(final) == N_DET and torch.isfinite(final.poses).all()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    conv_ms = sum(p[0] for p in prof)
+    conv_flops = sum(p[2] for p in prof)
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+    peak = PEAK_F32_MFMA_TFLOPS  # the refiner (fp32) dominates; an fp16 coarse net only raises `achieved`
+    line = {
+        "metric": "end-to-end frames/sec (640x480, 8 detections, 576-pose coarse grid, 5 hyp/det, 5 refiner iters)",
+        "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if coarse_precision == "f32" else "f32 refiner + f16 coarse net",
+        "data": "synthetic",
+        "config": {"workload": "E2E: PoseEstimator.run_inference_pipeline, megapose-1.0-RGB-multi-hypothesis shape: one 640x480 "
+                               "frame per GPU, 8 detections, coarse 8 x 576 views (vanilla_resnet34 on 9 ch), top-5 hypotheses, "
+                               "5 refiner iterations x 40 hypotheses x 4 views (vanilla_resnet34 on 27 ch), re-scoring, top-1",
+                   "detections_per_gpu": N_DET, "parallelism": f"frame-replica x{world}"},
+        "roofline": {"bound": "mfma", "kernel": "all conv launches of the coarse and refiner backbones",
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "launches": int(sum(p[1] for p in prof)), "conv_time_share": conv_ms * 1e-3 / elapsed},
+        "stage_seconds_last_frame": extra["timing_str"],
+    }
+    print(json.dumps(line), flush=True)
 
 
 def effective_cpu_count() -> int:
@@ -195,6 +283,12 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
+    if args.workload == "E2E":
+        bench_e2e(args, device, rank, world)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     precision = args.precision or ("f16" if args.workload == "C5" else "f32")
     peak = PEAK_F16_MFMA_TFLOPS if precision == "f16" else PEAK_F32_MFMA_TFLOPS
     ds, renderer, scene, weights, model = build_world(device, args.arch, seed=rank, workload=args.workload,

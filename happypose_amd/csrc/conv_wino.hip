@@ -58,7 +58,30 @@ constexpr int BN = 32;        // output channels per item
 constexpr int TPB = 64;       // tiles per item (16 per wave)
 constexpr int U_BUF = 16 * 4 * BN * 4;  // floats per weight buffer: [pos][kg][cout] float4
 
+// division by a launch-time constant as multiply-high + shift (an integer division costs ~35
+// instructions on the vector unit, and the tile / item decodes need a dozen per item):
+// n / d = (umulhi(n, m) + n) >> l for n < 2^31, m = floor(2^32 (2^l - d) / d) + 1, l = ceil(log2 d)
+struct FastDiv { unsigned m, l; };
+inline FastDiv make_fastdiv(unsigned d) {
+  if (d <= 1) return FastDiv{0u, 0u};
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  return FastDiv{(unsigned)((((1ull << l) - d) << 32) / d + 1), l};
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) { return (int)((__umulhi((unsigned)n, f.m) + (unsigned)n) >> f.l); }
+struct WinoDiv { FastDiv per, tw, tn; };  // by TH*TW, TW, tiles_n
+
 // pixel-linear range [lo, lo + P) that the tiles of item row bm touch (whole image rows)
+__device__ __forceinline__ void item_range_dev(int bm, int T, int TH, int TW, int H, int W, const WinoDiv& fd, int& lo, int& P) {
+  const int per = TH * TW;
+  const int t0 = bm * TPB, t1 = (t0 + TPB - 1 < T - 1) ? t0 + TPB - 1 : T - 1;
+  const int i0 = fdiv(t0, fd.per), th0 = fdiv(t0 - i0 * per, fd.tw);
+  const int i1 = fdiv(t1, fd.per), th1 = fdiv(t1 - i1 * per, fd.tw);
+  const int r0 = 2 * th0 - 1 > 0 ? 2 * th0 - 1 : 0;
+  const int r1 = 2 * th1 + 2 < H - 1 ? 2 * th1 + 2 : H - 1;
+  lo = (i0 * H + r0) * W;
+  P = (i1 * H + r1) * W + W - lo;
+}
 __host__ __device__ inline void item_range(int bm, int T, int TH, int TW, int H, int W, int& lo, int& P) {
   const int per = TH * TW;
   const int t0 = bm * TPB, t1 = (t0 + TPB - 1 < T - 1) ? t0 + TPB - 1 : T - 1;
@@ -86,9 +109,17 @@ __device__ __forceinline__ floatx4 sub4(floatx4 a, floatx4 b) {
   return floatx4{lo.x, lo.y, hi.x, hi.y};
 }
 
+#ifdef HP_WABL_TIMING  // per-block time stamps (diagnostic build only): [block][0 start, 1 first K loop, 2+i end of item i]
+constexpr int kStampSlots = 64;
+__device__ long long g_wino_stamps[512 * kStampSlots];
+#define HP_STAMP(slot) do { if (threadIdx.x == 0 && (slot) < kStampSlots) g_wino_stamps[blockIdx.x * kStampSlots + (slot)] = wall_clock64(); } while (0)
+#else
+#define HP_STAMP(slot) do { } while (0)
+#endif
+
 template <bool PRE, int NLD>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino_f32(
-    ConvArgs a, int TH, int TW, int T, int tiles_n, int n_items, int Pmax) {
+    ConvArgs a, int TH, int TW, int T, int tiles_n, int n_items, int Pmax, WinoDiv fd) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int Pp = plane_len(Pmax);
   float* const rawl = lds;               // [4 kg][Pp] float4; slot Pmax = zeros, slot Pmax+1 = dump
@@ -105,6 +136,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   const int kg = lane >> 4;
   const int H = a.H, W = a.W, Cin = a.Cin;
   const int nchunks = Cin / CK;
+  HP_STAMP(0);
+#ifdef HP_WABL_TIMING
+  int stamp_slot = 2;
+  if (threadIdx.x == 0) g_wino_stamps[blockIdx.x * kStampSlots + 62] = clock64();  // shader-clock counter at the start
+#endif
   const int c4 = tid & 3, srow = tid >> 2;  // channel quad / first pixel row this thread stages
   if (tid < 16) rawl[((tid >> 2) * Pp + Pmax) * 4 + (tid & 3)] = 0.f;
 
@@ -130,20 +166,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   //      pixel data comes from HBM / the far L2 and needs more than one chunk of MFMAs to arrive),
   //      the weight cursor two (L2 resident).  Past the last stage they keep re-reading it
   //      (harmless, keeps the loop branch free).
-  struct Cursor { int item, c, lo, P; };
-  auto advance = [&](Cursor& k) {
+  struct Cursor { int item, c, lo, P, nb; };  // nb = cout block of the item
+  auto locate = [&](Cursor& k, bool range) {
+    const int bm = fdiv(k.item, fd.tn);
+    k.nb = k.item - bm * tiles_n;
+    if (range) item_range_dev(bm, T, TH, TW, H, W, fd, k.lo, k.P);
+  };
+  auto advance = [&](Cursor& k, bool range) {
     const bool wrap = k.c + 1 == nchunks;
     const bool more = !wrap || k.item + nslot < item_end;
     if (more) {
       k.c = wrap ? 0 : k.c + 1;
       if (wrap) {
         k.item += nslot;
-        item_range(k.item / tiles_n, T, TH, TW, H, W, k.lo, k.P);
+        locate(k, range);
       }
     }
   };
-  Cursor rc{item, 0, 0, 0}, uc{item, 0, 0, 0};
-  item_range(item / tiles_n, T, TH, TW, H, W, rc.lo, rc.P);
+  Cursor rc{item, 0, 0, 0, 0}, uc{item, 0, 0, 0, 0};
+  locate(rc, true);
+  locate(uc, false);
   floatx4 rsA[NLD], rsB[NLD], us[8];
   floatx4 psA = {1.f, 1.f, 1.f, 1.f}, pbA = {0.f, 0.f, 0.f, 0.f}, psB = psA, pbB = pbA;  // prologue of the held chunks
   int heldA = 0, heldB = 0;  // P of the stage held in each set
@@ -162,15 +204,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       (decltype(set)::value ? pbB : pbA) = *reinterpret_cast<const floatx4*>(a.pre_shift + rc.c * CK + 4 * c4);
     }
     (decltype(set)::value ? heldB : heldA) = rc.P;
-    advance(rc);
+    advance(rc, true);
   };
   auto issue_u = [&](int part) {
-    const int s = (uc.item % tiles_n) * (4 * BN * 16) + uc.c * u_chunk_stride;
+    const int s = uc.nb * (4 * BN * 16) + uc.c * u_chunk_stride;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (part < 0 || i == part)
         us[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, u_voff, s + 2 * i * u_pos_stride, 0));
-    if (part < 0 || part == 7) advance(uc);
+    if (part < 0 || part == 7) advance(uc, false);
   };
   // held stage -> LDS (pixels: the single buffer; weights: buffer ubuf), in eight parts (or all: -1)
   auto store_held = [&](auto set, int ubuf, int part) {
@@ -205,64 +247,84 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   issue_raw(SET_A, -1);  // stage 2: stored during chunk 1
   issue_u(-1);           // stage 1
 
-  for (;;) {
-    const int bm = item / tiles_n, n0 = (item % tiles_n) * BN;
+  // ---- the lane's input tile: LDS offsets of its 4x4 pixels (padding -> the zero slot), in three
+  //      parts so that the set-up of the NEXT item can be dealt out under the last chunk's MFMAs
+  int doff[16];
+  int s_prow = 0, s_ih0 = 0, s_iw0 = 0;
+  bool s_in = false;
+  auto setup_tile = [&](int it) {
+    const int bm = fdiv(it, fd.tn);
     int lo, P;
-    item_range(bm, T, TH, TW, H, W, lo, P);
-
-    // ---- the lane's input tile: LDS offsets of its 4x4 pixels (padding -> the zero slot)
-    int doff[16];
-    {
-      const int g = bm * TPB + wave * 16 + (lane & 15);
-      const int gg = g < T ? g : 0;
-      const int img = gg / (TH * TW), r = gg - img * (TH * TW);
-      const int th = r / TW, tw = r - th * TW;
-      const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
-      const int prow = (img * H + ih0) * W + iw0 - lo;
+    item_range_dev(bm, T, TH, TW, H, W, fd, lo, P);
+    const int g = bm * TPB + wave * 16 + (lane & 15);
+    const int gg = g < T ? g : 0;
+    const int img = fdiv(gg, fd.per), r = gg - img * (TH * TW);
+    const int th = fdiv(r, fd.tw), tw = r - th * TW;
+    s_ih0 = 2 * th - 1;
+    s_iw0 = 2 * tw - 1;
+    s_prow = (img * H + s_ih0) * W + s_iw0 - lo;
+    s_in = g < T;
+  };
+  auto setup_doff = [&](int half) {
 #pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        const bool ok = (g < T) & ((unsigned)(ih0 + p / 4) < (unsigned)H) & ((unsigned)(iw0 + p % 4) < (unsigned)W);
-        doff[p] = (kg * Pp + (ok ? prow + (p / 4) * W + (p % 4) : Pmax)) * 4;
-      }
+    for (int p = 8 * half; p < 8 * half + 8; ++p) {
+      const bool ok = s_in & ((unsigned)(s_ih0 + p / 4) < (unsigned)H) & ((unsigned)(s_iw0 + p % 4) < (unsigned)W);
+      doff[p] = (kg * Pp + (ok ? s_prow + (p / 4) * W + (p % 4) : Pmax)) * 4;
     }
-    floatx4 d[16], V[16];
-    auto read_d_rows = [&](const float* rb, int r0, int r1) {  // pixel rows r0 and r1 of the 4x4 patch
+  };
+  floatx4 d[16], V[16];
+  auto read_d_rows = [&](const float* rb, int r0, int r1) {  // pixel rows r0 and r1 of the 4x4 patch
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        d[4 * r0 + j] = *reinterpret_cast<const floatx4*>(rb + doff[4 * r0 + j]);
-        if (r1 != r0) d[4 * r1 + j] = *reinterpret_cast<const floatx4*>(rb + doff[4 * r1 + j]);
-      }
-    };
-    // V row i = (B^T d) row i times B
-    auto xform_row = [&](int i) {
-      floatx4 t[4];
+    for (int j = 0; j < 4; ++j) {
+      d[4 * r0 + j] = *reinterpret_cast<const floatx4*>(rb + doff[4 * r0 + j]);
+      if (r1 != r0) d[4 * r1 + j] = *reinterpret_cast<const floatx4*>(rb + doff[4 * r1 + j]);
+    }
+  };
+  // V row i = (B^T d) row i times B
+  auto xform_row = [&](int i) {
+    floatx4 t[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        t[j] = i == 0 ? sub4(d[0 + j], d[8 + j]) : i == 1 ? d[4 + j] + d[8 + j] : i == 2 ? sub4(d[8 + j], d[4 + j]) : sub4(d[4 + j], d[12 + j]);
+    for (int j = 0; j < 4; ++j)
+      t[j] = i == 0 ? sub4(d[0 + j], d[8 + j]) : i == 1 ? d[4 + j] + d[8 + j] : i == 2 ? sub4(d[8 + j], d[4 + j]) : sub4(d[4 + j], d[12 + j]);
 #ifdef HP_WABL_NO_XFORM
-      V[4 * i + 0] = d[4 * i + 0]; V[4 * i + 1] = d[4 * i + 1]; V[4 * i + 2] = d[4 * i + 2]; V[4 * i + 3] = d[4 * i + 3];
+    V[4 * i + 0] = d[4 * i + 0]; V[4 * i + 1] = d[4 * i + 1]; V[4 * i + 2] = d[4 * i + 2]; V[4 * i + 3] = d[4 * i + 3];
 #else
-      V[4 * i + 0] = sub4(t[0], t[2]);
-      V[4 * i + 1] = t[1] + t[2];
-      V[4 * i + 2] = sub4(t[2], t[1]);
-      V[4 * i + 3] = sub4(t[1], t[3]);
+    V[4 * i + 0] = sub4(t[0], t[2]);
+    V[4 * i + 1] = t[1] + t[2];
+    V[4 * i + 2] = sub4(t[2], t[1]);
+    V[4 * i + 3] = sub4(t[1], t[3]);
 #endif
-    };
-    read_d_rows(rawl, 0, 2);
-    read_d_rows(rawl, 1, 3);
+  };
+  setup_tile(item);
+  setup_doff(0);
+  setup_doff(1);
+  read_d_rows(rawl, 0, 2);
+  read_d_rows(rawl, 1, 3);
+  __syncthreads();  // every wave holds its pixels of chunk 0: the pixel buffer may be refilled
+  HP_STAMP(1);
 
+  for (;;) {
+    const int bm = fdiv(item, fd.tn), n0 = (item - bm * tiles_n) * BN;
+    const bool has_next = item + nslot < item_end;
+#ifdef HP_WABL_TIMING
+    HP_STAMP(stamp_slot);  // K loop starts
+#endif
     floatx4 acc[16][2];
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[p][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();  // every wave holds its pixels of chunk 0: the pixel buffer may be refilled
 
     // one chunk; `odd` = parity of the chunk = register set of the stage two ahead (the set of
     // the next stage is the other one)
-    auto chunk = [&](int c, auto odd) {
+    // LAST (compile time: the steps must stay branch free, a branch inside a step splits the
+    // scheduling region): the chunk that ends the item; it sets up the tile of the NEXT item
+    auto chunk = [&](int c, auto odd, auto is_last) {
       constexpr std::integral_constant<int, 1 - decltype(odd)::value> nxt{};
-      const bool last = c + 1 == nchunks;
+      constexpr bool LAST = decltype(is_last)::value;
+#ifdef HP_WABL_TIMING
+      if (stamp_slot == 5) HP_STAMP(32 + c);  // chunk starts of the block's second item
+#endif
       // One chunk = 16 steps (one transform position each: 2 weight fragment reads for the next
       // step, 8 MFMAs), with the rest of the work dealt out between them so that the matrix pipe
       // never waits: input transform rows 1-3 under steps 0/4/8, the next stage's LDS stores under
@@ -293,6 +355,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
           issue_u(p - 8);
         }
 #endif
+        // the last chunk of an item sets up the tile of the NEXT item (its first stage is what the
+        // barrier below publishes), so an item boundary costs no pixel-read latency
+        // (after the block's last item: the same item again, read and never used)
+        if (LAST) {
+          if (p == 9) setup_tile(has_next ? item + nslot : item);
+          if (p == 10) setup_doff(0);
+          if (p == 11) setup_doff(1);
+        }
         if (p == 12) {
 #ifndef HP_WABL_NO_BARRIER
           __syncthreads();  // the next stage is in LDS
@@ -300,10 +370,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 
         }
 #ifndef HP_WABL_NO_READD
-        if (p == 12 && !last) read_d_rows(rawl, 0, 0);
-        if (p == 13 && !last) read_d_rows(rawl, 2, 2);
-        if (p == 14 && !last) read_d_rows(rawl, 1, 1);
-        if (p == 15 && !last) read_d_rows(rawl, 3, 3);
+        if (p == 12) read_d_rows(rawl, 0, 0);
+        if (p == 13) read_d_rows(rawl, 2, 2);
+        if (p == 14) read_d_rows(rawl, 1, 1);
+        if (p == 15) read_d_rows(rawl, 3, 3);
 #endif
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -319,14 +389,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
       // every wave holds its pixels of chunk c+1 and is done with this chunk's weights: both
       // buffers may be refilled (a third weight buffer + a second pixel buffer would save this
       // barrier, but the 60x80 layers have no LDS left for them)
-      if (!last) __syncthreads();
+      __syncthreads();
 #endif
     };
-    for (int c = 0; c < nchunks; c += 2) {
-      chunk(c, SET_A);
-      chunk(c + 1, SET_B);
+    for (int c = 0; c + 2 < nchunks; c += 2) {
+      chunk(c, SET_A, std::false_type{});
+      chunk(c + 1, SET_B, std::false_type{});
     }
-
+    chunk(nchunks - 2, SET_A, std::false_type{});
+    chunk(nchunks - 1, SET_B, std::true_type{});
+#ifdef HP_WABL_TIMING
+    HP_STAMP(stamp_slot + 1);  // K loop done
+#endif
     // ---- output transform Y = A^T M A per (tile row i of the lane, cout tile), epilogue.
     //      A lane holds the 2x2 pixels of ONE cout; a 4x4 transpose inside each lane quad (two
     //      DPP butterfly stages) turns that into 4 consecutive couts of ONE pixel, so bias,
@@ -338,9 +412,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     int e_img, e_th, e_tw;
     {
       const int gc = go0 < T ? go0 : 0;
-      e_img = gc / (TH * TW);
+      e_img = fdiv(gc, fd.per);
       const int r = gc - e_img * (TH * TW);
-      e_th = r / TW;
+      e_th = fdiv(r, fd.tw);
       e_tw = r - e_th * TW;
     }
 #pragma unroll
@@ -395,8 +469,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
           }
           *reinterpret_cast<floatx4*>(a.y + obase + nt * 16) = v;
         }
+        // one (row, cout tile) group at a time: the next item's pixels and the staged loads stay
+        // live across the epilogue, there are no registers for reading all accumulators up front
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+#ifdef HP_WABL_TIMING
+    HP_STAMP(stamp_slot + 2);  // epilogue done
+    if (stamp_slot == 2 && threadIdx.x == 0) g_wino_stamps[blockIdx.x * kStampSlots + 63] = clock64();  // ... and after item 0
+    stamp_slot += 3;
+#endif
     item += nslot;
     if (item >= item_end) break;
   }
@@ -471,7 +553,8 @@ int launch(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
   const int ipx = (n_items + 7) / 8;
   const int slots = std::max(1, std::min(ipx, cus / 8));
   hipLaunchKernelGGL((conv3x3_wino_f32<PRE, NLD>), dim3(8 * slots), dim3(kThreads), wino_lds_bytes(g.Pmax), stream, a,
-                     g.TH, g.TW, g.T, tiles_n, n_items, g.Pmax);
+                     g.TH, g.TW, g.T, tiles_n, n_items, g.Pmax,
+                     WinoDiv{make_fastdiv((unsigned)(g.TH * g.TW)), make_fastdiv((unsigned)g.TW), make_fastdiv((unsigned)tiles_n)});
   return check_launch("conv3x3_wino_f32");
 }
 
@@ -533,3 +616,9 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t stream) {
 }
 
 }  // namespace hp
+
+#ifdef HP_WABL_TIMING
+extern "C" int hp_debug_wino_stamps(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(hp::g_wino_stamps), sizeof(long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
