@@ -101,6 +101,13 @@ __host__ __device__ inline int plane_len(int Pmax) {
   return n;
 }
 
+// plane length of the two-waves-per-SIMD kernel: 128 NLD staged rows + the zero slot, = 3 (mod 8)
+__host__ __device__ constexpr int plane_len8(int nld) {
+  int n = 128 * nld + 1;
+  while (n % 8 != 3) ++n;
+  return n;
+}
+
 // a - b on the packed-f32 pipe (hipcc packs float adds but not subtractions)
 __device__ __forceinline__ floatx4 sub4(floatx4 a, floatx4 b) {
   floatx2 lo, hi;
@@ -115,6 +122,33 @@ __device__ long long g_wino_stamps[512 * kStampSlots];
 #define HP_STAMP(slot) do { if (threadIdx.x == 0 && (slot) < kStampSlots) g_wino_stamps[blockIdx.x * kStampSlots + (slot)] = wall_clock64(); } while (0)
 #else
 #define HP_STAMP(slot) do { } while (0)
+#endif
+
+// Single-instruction f32 arithmetic for the code that runs beside the MFMAs.  The f32 MFMA executes
+// on the f32 vector lanes, and a packed v_pk_*_f32 next to it costs ~13 cycles beyond its issue slot
+// (MI355X_MICROARCH.md, per-instruction constants) -- hipcc SLP-packs adjacent float adds on its
+// own, so the transform spells its adds out as opaque one-lane-op instructions.
+__device__ __forceinline__ float add1(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float sub1(float a, float b) {
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float fma1(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+#ifdef HP_W8_SCALAR
+__device__ __forceinline__ floatx4 add4s(floatx4 a, floatx4 b) { return floatx4{add1(a.x, b.x), add1(a.y, b.y), add1(a.z, b.z), add1(a.w, b.w)}; }
+__device__ __forceinline__ floatx4 sub4s(floatx4 a, floatx4 b) { return floatx4{sub1(a.x, b.x), sub1(a.y, b.y), sub1(a.z, b.z), sub1(a.w, b.w)}; }
+#else
+__device__ __forceinline__ floatx4 add4s(floatx4 a, floatx4 b) { return a + b; }
+__device__ __forceinline__ floatx4 sub4s(floatx4 a, floatx4 b) { return sub4(a, b); }
 #endif
 
 template <bool PRE, int NLD>
@@ -484,6 +518,421 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Two waves per SIMD.  With one wave per SIMD the matrix pipe idles whenever that wave waits (a
+// barrier, an LDS read that is not back yet): the wave cannot queue more than one MFMA ahead, so
+// every stall longer than 32 cycles is a bubble -- 27 % of a chunk in the kernel above.  Here the
+// block has 8 waves: wave w and wave w + 4 share the 16 tiles of tile group w & 3 and split the 16
+// transform positions BY ROWS of the 4x4 position grid (role 0: rows 0-1, role 1: rows 2-3), each
+// for all 32 couts: 64 accumulators per wave, <= 256 registers, and one wave's waits are covered
+// by the other wave's MFMAs.  Splitting by rows (not by couts) keeps the LDS traffic and the
+// transform work per SIMD the same as above: V rows i need only three pixel rows of the 4x4 patch
+//   role 0: t0 = d0 - d2, t1 = d1 + d2        role 1: t3 = d1 - d3, t2 = d2 - d1
+// With role 1 reading its pixel rows in reversed order (E0,E1,E2) = (d3,d2,d1) both roles compute
+//   first = E0 - E2  (= t0 | -t3),   second = E1 + s E2  (s = +1 | -1)  (= t1 | t2)
+// so the K loop is the same code for both; role 1's first row is -V row 3, which the output
+// transform absorbs.  The output transform Y = A^T M A is linear in the rows of M, so each wave
+// reduces its two rows to a 2x2 partial result per (tile, cout), the partners swap half of it
+// through LDS (role 0 finishes couts 0-15 of the item, role 1 couts 16-31) and each stores half.
+constexpr int kThreads8 = 512;
+constexpr int X_BUF = 8 * 4 * 64 * 4;  // floats of the exchange buffer: [wave][4][lane] float4
+
+template <bool PRE, int NLD, int SETS>
+__global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wino8_f32(
+    ConvArgs a, int TH, int TW, int T, int tiles_n, int n_items, int Pmax, WinoDiv fd) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // every staged row has its own LDS slot (128 NLD of them, the zero slot after them), so the
+  // stores need no clamping -- VALU work beside the f32 MFMAs is not free (see the chunk loop)
+  constexpr int ZS = 128 * NLD;          // index of the zero slot
+  constexpr int Pp = plane_len8(NLD);
+  float* const rawl = lds;               // [4 kg][Pp] float4
+  float* const ul = lds + 4 * Pp * 4;    // [2][16 pos][4 kg][BN] float4
+  float* const xl = ul + 2 * U_BUF;      // [8 waves][4][64 lanes] float4
+  float* const pl = xl + X_BUF;          // PRE: [Cin] scale, [Cin] shift of the prologue
+
+  const int nslot = gridDim.x / 8;
+  const int ipx = (n_items + 7) / 8;
+  const int item_begin = (blockIdx.x % 8) * ipx;
+  const int item_end = item_begin + ipx < n_items ? item_begin + ipx : n_items;
+  int item = item_begin + blockIdx.x / 8;
+  if (item >= item_end) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave & 3, role = wave >> 2;
+  const int kg = lane >> 4;
+  const int H = a.H, W = a.W, Cin = a.Cin;
+  const int nchunks = Cin / CK;
+  HP_STAMP(0);
+#ifdef HP_WABL_TIMING
+  int stamp_slot = 2;
+  if (threadIdx.x == 0) g_wino_stamps[blockIdx.x * kStampSlots + 62] = clock64();
+#endif
+  const int c4 = tid & 3, srow = tid >> 2;  // channel quad / first pixel row this thread stages
+  if (tid < 16) rawl[((tid >> 2) * Pp + ZS) * 4 + (tid & 3)] = 0.f;
+  if (PRE) {  // the prologue constants live in LDS: held in registers they would stay live across the epilogue
+    for (int i = tid; i < Cin; i += kThreads8) {
+      pl[i] = a.pre_scale[i];
+      pl[Cin + i] = a.pre_shift[i];
+    }
+  }
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((int64_t)a.M / ((int64_t)a.Ho * a.Wo) * H * W * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ursrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 16 * a.Cout * Cin * 4, 0x00020000);
+  const int x_voff = (srow * Cin + 4 * c4) * 4;
+  const int x_kstride = 128 * Cin * 4;  // bytes between the rows a thread stages
+  const int u_pos_stride = (a.Cout / BN) * (4 * BN * 16);  // bytes between positions
+  const int u_chunk_stride = 16 * u_pos_stride;
+  const int u_voff = (tid >> 7) * u_pos_stride + (tid & 127) * 16;  // + nb*2048 + 4 i pos
+  float* const udst = ul + ((tid >> 7) * 128 + (tid & 127)) * 4;    // + 2048 i floats
+  // weight fragments: local step q multiplies position q (role 0) | 12 + q for q < 4, 4 + q for q >= 4 (role 1)
+  const float* const ufr_lo = ul + (kg * BN + (lane & 15)) * 4 + role * 12 * 128 * 4;
+  const float* const ufr_hi = ul + (kg * BN + (lane & 15)) * 4 + role * 4 * 128 * 4;
+  float* const rdst = rawl + (c4 * Pp) * 4;
+  const float s_second = role ? -1.f : 1.f;
+
+  struct Cursor { int item, c, lo, P, nb; };
+  auto locate = [&](Cursor& k, bool range) {
+    const int bm = fdiv(k.item, fd.tn);
+    k.nb = k.item - bm * tiles_n;
+    if (range) item_range_dev(bm, T, TH, TW, H, W, fd, k.lo, k.P);
+  };
+  auto advance = [&](Cursor& k, bool range) {
+    const bool wrap = k.c + 1 == nchunks;
+    const bool more = !wrap || k.item + nslot < item_end;
+    if (more) {
+      k.c = wrap ? 0 : k.c + 1;
+      if (wrap) {
+        k.item += nslot;
+        locate(k, range);
+      }
+    }
+  };
+  Cursor rc{item, 0, 0, 0, 0}, uc{item, 0, 0, 0, 0};
+  locate(rc, true);
+  locate(uc, false);
+  floatx4 rsA[NLD], rsB[NLD], us[4];
+  floatx4 ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};  // prologue constants of the stage being stored
+  auto load_pre = [&](int c) {  // chunk c of the input channels
+    ps = *reinterpret_cast<const floatx4*>(pl + c * CK + 4 * c4);
+    pb = *reinterpret_cast<const floatx4*>(pl + Cin + c * CK + 4 * c4);
+  };
+  auto issue_raw = [&](auto set, int part) {  // part 0..3 (or -1: all)
+    floatx4(&rs)[NLD] = (SETS == 2 && decltype(set)::value) ? rsB : rsA;
+    const int xs = (rc.lo * Cin + rc.c * CK) * 4;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (part < 0 || k % 4 == part)
+        rs[k] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, x_voff, xs + k * x_kstride, 0));
+    if (part < 0 || part == 3) advance(rc, true);
+  };
+  auto issue_u = [&](int part) {
+    const int s = uc.nb * (4 * BN * 16) + uc.c * u_chunk_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (part < 0 || i == part)
+        us[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, u_voff, s + 4 * i * u_pos_stride, 0));
+    if (part < 0 || part == 3) advance(uc, false);
+  };
+  auto store_held = [&](auto set, int ubuf, int part) {
+    floatx4(&rs)[NLD] = (SETS == 2 && decltype(set)::value) ? rsB : rsA;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      if (part >= 0 && k % 4 != part) continue;
+      floatx4 v = rs[k];
+      if (PRE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], ps[q], pb[q]), 0.f);
+      }
+      *reinterpret_cast<floatx4*>(rdst + (srow + 128 * k) * 4) = v;  // rows past the item's range: never read
+    }
+    float* d = udst + ubuf * U_BUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (part < 0 || i == part) *reinterpret_cast<floatx4*>(d + 2048 * i) = us[i];
+  };
+  constexpr std::integral_constant<int, 0> SET_A{};
+  constexpr std::integral_constant<int, 1> SET_B{};
+
+  int ubuf = 0;
+  issue_raw(SET_A, -1);  // stage 0
+  issue_u(-1);
+  if (PRE) {
+    __syncthreads();
+    load_pre(0);
+  }
+  store_held(SET_A, ubuf, -1);
+  __syncthreads();
+  if (PRE) load_pre(1);  // chunk 0 stores stage 1
+  // pixel stages run two ahead of the one being stored in two alternating register sets, or
+  // (SETS == 1: the large staged ranges, where two sets would spill) one ahead in a single set
+  issue_raw(SET_B, -1);                 // stage 1: stored during chunk 0
+  if (SETS == 2) issue_raw(SET_A, -1);  // stage 2: stored during chunk 1
+  issue_u(-1);                          // stage 1
+
+  // ---- the lane's three pixel rows (E0,E1,E2) of its tile: LDS offsets (padding -> the zero slot)
+  int doff[12];
+  int s_prow = 0, s_ih0 = 0, s_iw0 = 0;
+  bool s_in = false;
+  auto setup_tile = [&](int it) {
+    const int bm = fdiv(it, fd.tn);
+    int lo, P;
+    item_range_dev(bm, T, TH, TW, H, W, fd, lo, P);
+    const int g = bm * TPB + tg * 16 + (lane & 15);
+    const int gg = g < T ? g : 0;
+    const int img = fdiv(gg, fd.per), r = gg - img * (TH * TW);
+    const int th = fdiv(r, fd.tw), tw = r - th * TW;
+    s_ih0 = 2 * th - 1;
+    s_iw0 = 2 * tw - 1;
+    s_prow = (img * H + s_ih0) * W + s_iw0 - lo;
+    s_in = g < T;
+  };
+  auto setup_doff = [&]() {
+#pragma unroll
+    for (int p = 0; p < 12; ++p) {
+      const int pr = role ? 3 - p / 4 : p / 4;  // pixel row of E_(p/4)
+      const bool ok = s_in & ((unsigned)(s_ih0 + pr) < (unsigned)H) & ((unsigned)(s_iw0 + p % 4) < (unsigned)W);
+      doff[p] = (kg * Pp + (ok ? s_prow + pr * W + (p % 4) : ZS)) * 4;
+    }
+  };
+  floatx4 d[12], V[8];
+  auto read_d = [&](int p0, int p1) {
+#pragma unroll
+    for (int p = p0; p < p1; ++p) d[p] = *reinterpret_cast<const floatx4*>(rawl + doff[p]);
+  };
+  auto col_xform = [&](const floatx4 (&t)[4], int row) {
+#ifdef HP_WABL_NO_XFORM
+    V[4 * row + 0] = t[0]; V[4 * row + 1] = t[1]; V[4 * row + 2] = t[2]; V[4 * row + 3] = t[3];
+    return;
+#endif
+    V[4 * row + 0] = sub4s(t[0], t[2]);
+    V[4 * row + 1] = add4s(t[1], t[2]);
+    V[4 * row + 2] = sub4s(t[2], t[1]);
+    V[4 * row + 3] = sub4s(t[1], t[3]);
+  };
+  // row part of both transforms as soon as the pixels are there (E0, E1, E2 die, the second row
+  // waits as 4 float4 for V[4..7] to be consumed); column parts: V[0..3] at once, V[4..7] in step 0
+  floatx4 tS[4];
+  auto xform_first = [&]() {  // needs E0, E2; E0 dies
+    floatx4 t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#ifdef HP_WABL_NO_XFORM
+      t[j] = d[0 + j];
+#else
+      t[j] = sub4s(d[0 + j], d[8 + j]);
+#endif
+    }
+    col_xform(t, 0);
+  };
+  auto xform_second_rows = [&]() {  // needs E1, E2; both die
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#ifdef HP_WABL_NO_XFORM
+      tS[j] = d[4 + j];
+#else
+      tS[j] = d[4 + j] + s_second * d[8 + j];
+#endif
+    }
+  };
+  auto xform_second = [&]() { col_xform(tS, 1); };
+  floatx4 bf[2][2];
+  setup_tile(item);
+  setup_doff();
+  read_d(0, 12);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) bf[0][nt] = *reinterpret_cast<const floatx4*>(ufr_lo + nt * 16 * 4);
+  xform_first();
+  xform_second_rows();
+  __syncthreads();  // every wave holds its pixels of chunk 0: the pixel buffer may be refilled
+  HP_STAMP(1);
+
+  for (;;) {
+    const int bm = fdiv(item, fd.tn), n0 = (item - bm * tiles_n) * BN;
+    const bool has_next = item + nslot < item_end;
+#ifdef HP_WABL_TIMING
+    HP_STAMP(stamp_slot);
+#endif
+    floatx4 acc[8][2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[q][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // one chunk = 8 steps (one position each: 2 weight-fragment reads for the next step, 8 MFMAs);
+    // the next stage's LDS stores go under steps 0-3, the loads of the stages after it under
+    // steps 4-7, the next chunk's pixel reads under steps 4-7 after the barrier that publishes them
+    auto chunk = [&](int c, auto odd, auto is_last) {
+      constexpr std::integral_constant<int, 1 - decltype(odd)::value> nxt{};
+      constexpr bool LAST = decltype(is_last)::value;
+#ifdef HP_WABL_TIMING
+      if (stamp_slot == 5) HP_STAMP(32 + c);
+#endif
+      const float* ub_lo = ufr_lo + ubuf * U_BUF;
+      const float* ub_hi = ufr_hi + ubuf * U_BUF;
+      // bf[0] and V[0..3] of this chunk were prepared under the last step of the previous one (the
+      // weights were published by its mid-chunk barrier), so the MFMAs of step 0 issue right away
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (q + 1 < 8) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            bf[(q + 1) & 1][nt] = *reinterpret_cast<const floatx4*>((q + 1 < 4 ? ub_lo : ub_hi) + ((q + 1) * 128 + nt * 16) * 4);
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            bf[0][nt] = *reinterpret_cast<const floatx4*>(ufr_lo + (ubuf ^ 1) * U_BUF + nt * 16 * 4);
+        }
+        if (q == 0) xform_second();
+#if !defined(HP_WABL_NO_STAGE) && !defined(HP_WABL_NO_LSTORE)
+        if (q < 4) store_held(nxt, ubuf ^ 1, q);
+#endif
+#if !defined(HP_WABL_NO_STAGE) && !defined(HP_WABL_NO_GLOAD)
+        if (q >= 4) {
+          issue_raw(nxt, q - 4);
+          issue_u(q - 4);
+        }
+#endif
+        if (LAST) {  // tile of the NEXT item (after the block's last item: the same again, never used)
+          if (q == 2) setup_tile(has_next ? item + nslot : item);
+          if (q == 3) setup_doff();
+        }
+#ifndef HP_WABL_NO_BARRIER
+        if (q == 4) __syncthreads();  // the next stage is in LDS
+#endif
+#ifndef HP_WABL_NO_READD
+        if (q == 4) read_d(0, 4);     // E0
+        if (q == 5) read_d(8, 12);    // E2
+        if (q == 6) read_d(4, 8);     // E1
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[q][j], bf[q & 1][nt][j], acc[q][nt], 0, 0, 0);
+        if (q == 6) xform_first();        // V[0..3] of the next chunk (this chunk's were consumed by steps 0-3)
+        if (q == 7) xform_second_rows();
+        if (PRE && q == 4) load_pre(c + 2 < nchunks ? c + 2 : c + 2 - nchunks);  // stage stored during the next chunk
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ubuf ^= 1;
+#ifndef HP_WABL_NO_BARRIER
+      __syncthreads();  // pixels of the next chunk held by every wave, this chunk's weights consumed
+#endif
+    };
+    for (int c = 0; c + 2 < nchunks; c += 2) {
+      chunk(c, SET_A, std::false_type{});
+      chunk(c + 1, SET_B, std::false_type{});
+    }
+    chunk(nchunks - 2, SET_A, std::false_type{});
+    chunk(nchunks - 1, SET_B, std::true_type{});
+#ifdef HP_WABL_TIMING
+    HP_STAMP(stamp_slot + 1);
+#endif
+
+    // ---- output transform.  Local rows L0 = acc[0..3], L1 = acc[4..7]:
+    //      role 0: L0 = M row 0, L1 = M row 1   ->  partial of Y row 0: L0 + L1,  of Y row 1: L1
+    //      role 1: L0 = -M row 3, L1 = M row 2  ->  partial of Y row 0: L1,       of Y row 1: L0 - L1
+    //      then the column transform; the partners swap the half they do not finish through LDS.
+    //      (two copies of the code behind a wave-uniform branch: with the role known at compile
+    //      time half of the row arithmetic and all keep/send selects disappear)
+    float yk[4][4];  // [i][pixel]: the cout half this wave finishes (nt == role)
+    auto partial = [&](auto role_c) {
+      constexpr int R = decltype(role_c)::value;
+      auto half = [&](auto nt_c, float(&y)[4][4]) {
+        constexpr int nt = decltype(nt_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float p0[4], p1[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            p0[j] = R == 0 ? acc[j][nt][i] + acc[4 + j][nt][i] : acc[4 + j][nt][i];
+            p1[j] = R == 0 ? acc[4 + j][nt][i] : acc[j][nt][i] - acc[4 + j][nt][i];
+          }
+          y[i][0] = p0[0] + p0[1] + p0[2];
+          y[i][1] = p0[1] - p0[2] - p0[3];
+          y[i][2] = p1[0] + p1[1] + p1[2];
+          y[i][3] = p1[1] - p1[2] - p1[3];
+        }
+      };
+      {  // the half the partner finishes goes out first, so its registers are free again
+        float ys[4][4];
+        half(std::integral_constant<int, 1 - R>{}, ys);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<floatx4*>(xl + ((wave * 4 + i) * 64 + lane) * 4) = floatx4{ys[i][0], ys[i][1], ys[i][2], ys[i][3]};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      half(std::integral_constant<int, R>{}, yk);
+    };
+    if (role == 0) partial(std::integral_constant<int, 0>{});
+    else partial(std::integral_constant<int, 1>{});
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const floatx4 o = *reinterpret_cast<const floatx4*>(xl + (((wave ^ 4) * 4 + i) * 64 + lane) * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) yk[i][q] += o[q];
+    }
+    // epilogue as in the kernel above, for the cout half nt = role
+    const int lq = lane & 3;
+    const int ncol = n0 + role * 16 + ((lane & 15) & ~3);
+    const int go0 = bm * TPB + tg * 16 + 4 * kg;
+    int e_img, e_th, e_tw;
+    {
+      const int gc = go0 < T ? go0 : 0;
+      e_img = fdiv(gc, fd.per);
+      const int r = gc - e_img * (TH * TW);
+      e_th = fdiv(r, fd.tw);
+      e_tw = r - e_th * TW;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int go = go0 + i;
+      const int img = e_img, th = e_th, tw = e_tw;
+      if (++e_tw == TW) { e_tw = 0; if (++e_th == TH) { e_th = 0; ++e_img; } }
+      const int oh = 2 * th + (lq >> 1), ow = 2 * tw + (lq & 1);
+      const bool ok = (go < T) & (oh < a.Ho) & (ow < a.Wo);
+      const int64_t obase = (((int64_t)img * a.Ho + oh) * a.Wo + ow) * a.Cout + ncol;
+      float y[4] = {yk[i][0], yk[i][1], yk[i][2], yk[i][3]};
+      {
+        const bool odd = lq & 1;
+        const float s0 = odd ? y[0] : y[1], s1 = odd ? y[2] : y[3];
+        const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+        const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+        if (odd) { y[0] = x0; y[2] = x1; } else { y[1] = x0; y[3] = x1; }
+      }
+      {
+        const bool hi = lq & 2;
+        const float s0 = hi ? y[0] : y[2], s1 = hi ? y[1] : y[3];
+        const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));
+        const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
+        if (hi) { y[0] = x0; y[1] = x1; } else { y[2] = x0; y[3] = x1; }
+      }
+      if (ok) {
+        floatx4 v = {y[0], y[1], y[2], y[3]};
+        if (a.bias) v += *reinterpret_cast<const floatx4*>(a.bias + ncol);
+        if (a.residual) v += *reinterpret_cast<const floatx4*>(a.residual + obase);
+        if (a.relu) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        *reinterpret_cast<floatx4*>(a.y + obase) = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef HP_WABL_TIMING
+    HP_STAMP(stamp_slot + 2);
+    if (stamp_slot == 2 && threadIdx.x == 0) g_wino_stamps[blockIdx.x * kStampSlots + 63] = clock64();
+    stamp_slot += 3;
+#endif
+    item += nslot;
+    if (item >= item_end) break;
+  }
+}
+
 // w [Cout][Kpad] with K ordered (kh, kw, c) (BN already folded)  ->
 // U [Cin/16][16 positions][Cout/32][4 kg][32 couts][4 channels],  U = G g G^T,
 // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -558,8 +1007,50 @@ int launch(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
   return check_launch("conv3x3_wino_f32");
 }
 
+int wino8_nld(int Pmax) { return std::max(2, (Pmax + 127) / 128); }
+size_t wino8_lds_bytes(int Pmax, int Cin = 512) {
+  return ((size_t)4 * plane_len8(wino8_nld(Pmax)) * 4 + 2 * (size_t)U_BUF + (size_t)X_BUF + 2 * (size_t)Cin) * sizeof(float);
+}
+
+template <bool PRE, int NLD>
+int launch8(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
+  constexpr int SETS = (PRE && NLD >= 5) || NLD >= 6 ? 1 : 2;
+  static bool opted = false;
+  static int cus = 0;
+  if (!opted) {
+    int dev = 0;
+    HP_CHECK_HIP(hipGetDevice(&dev));
+    HP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32<PRE, NLD, SETS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    opted = true;
+  }
+  const int tiles_m = (g.T + TPB - 1) / TPB, tiles_n = a.Cout / BN;
+  const int n_items = tiles_m * tiles_n;
+  const int ipx = (n_items + 7) / 8;
+  const int slots = std::max(1, std::min(ipx, cus / 8));
+  hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS>), dim3(8 * slots), dim3(kThreads8), wino8_lds_bytes(g.Pmax, a.Cin), stream, a,
+                     g.TH, g.TW, g.T, tiles_n, n_items, g.Pmax,
+                     WinoDiv{make_fastdiv((unsigned)(g.TH * g.TW)), make_fastdiv((unsigned)g.TW), make_fastdiv((unsigned)tiles_n)});
+  return check_launch("conv3x3_wino8_f32");
+}
+
+// 1: the one-wave-per-SIMD kernel (HP_WINO_V1 set), else the two-waves-per-SIMD kernel
+bool wino_use_v1() {
+  static const bool v1 = std::getenv("HP_WINO_V1") != nullptr;
+  return v1;
+}
+
 template <bool PRE>
 int launch_nld(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
+  if (!wino_use_v1() && wino8_nld(g.Pmax) <= 6 && wino8_lds_bytes(g.Pmax, a.Cin) <= 160 * 1024) {
+    const int nld8 = wino8_nld(g.Pmax);
+    if (nld8 <= 2) return launch8<PRE, 2>(a, g, stream);
+    if (nld8 <= 3) return launch8<PRE, 3>(a, g, stream);
+    if (nld8 <= 4) return launch8<PRE, 4>(a, g, stream);
+    if (nld8 <= 5) return launch8<PRE, 5>(a, g, stream);
+    return launch8<PRE, 6>(a, g, stream);
+  }
   const int nld = (g.Pmax * 4 + kThreads - 1) / kThreads;
   if (nld <= 4) return launch<PRE, 4>(a, g, stream);
   if (nld <= 6) return launch<PRE, 6>(a, g, stream);
