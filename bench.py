@@ -360,11 +360,13 @@ def main():
             # the 36 convs run as Winograd F(2x2,3x3) and execute 2.25x fewer MFMA FLOPs than that, so
             # the fraction of the pipe actually busy is reported separately (mfma_executed_*).
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv3x3_wino_f32 + conv_igemm_f32 (+ conv3x3_patch_f32 when Winograd does not apply): "
+                         "kernel": ("conv3x3_wino8_f32 + conv_igemm_f32 (+ conv3x3_patch_f32 when Winograd does not apply): "
                                     "fp32 MFMA conv kernels" if precision == "f32" else
                                     "conv_igemm_f16: fp16 MFMA implicit-GEMM conv (fp32 accumulate)") + ", all conv launches of a forward",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": measured_traffic(args.workload, precision),
+                         "mfma_executed_tflops": mfma_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+                         "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else 0.0,
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }

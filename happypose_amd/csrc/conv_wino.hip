@@ -812,8 +812,10 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
             acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[q][j], bf[q & 1][nt][j], acc[q][nt], 0, 0, 0);
-        if (q == 6) xform_first();        // V[0..3] of the next chunk (this chunk's were consumed by steps 0-3)
-        if (q == 7) xform_second_rows();
+        if (q == 7) {  // V[0..3] of the next chunk (this chunk's were consumed by steps 0-3) and the rows of V[4..7]
+          xform_first();
+          xform_second_rows();
+        }
         if (PRE && q == 4) load_pre(c + 2 < nchunks ? c + 2 : c + 2 - nchunks);  // stage stored during the next chunk
         __builtin_amdgcn_sched_barrier(0);
       }
