@@ -124,6 +124,14 @@ __device__ long long g_wino_stamps[512 * kStampSlots];
 #define HP_STAMP(slot) do { } while (0)
 #endif
 
+// a * s + c with a wave-uniform s (an SGPR pair): two v_pk_fma_f32 per float4
+__device__ __forceinline__ floatx4 pk_fma4(floatx4 a, floatx2 s, floatx4 c) {
+  floatx2 lo, hi;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(a.xy), "s"(s), "v"(c.xy));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(a.zw), "s"(s), "v"(c.zw));
+  return floatx4{lo.x, lo.y, hi.x, hi.y};
+}
+
 // Single-instruction f32 arithmetic for the code that runs beside the MFMAs.  The f32 MFMA executes
 // on the f32 vector lanes, and a packed v_pk_*_f32 next to it costs ~13 cycles beyond its issue slot
 // (MI355X_MICROARCH.md, per-instruction constants) -- hipcc SLP-packs adjacent float adds on its
@@ -592,6 +600,7 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
   const float* const ufr_hi = ul + (kg * BN + (lane & 15)) * 4 + role * 4 * 128 * 4;
   float* const rdst = rawl + (c4 * Pp) * 4;
   const float s_second = role ? -1.f : 1.f;
+  const floatx2 s_second2 = {s_second, s_second};
 
   struct Cursor { int item, c, lo, P, nb; };
   auto locate = [&](Cursor& k, bool range) {
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
 #ifdef HP_WABL_NO_XFORM
       tS[j] = d[4 + j];
 #else
-      tS[j] = d[4 + j] + s_second * d[8 + j];
+      tS[j] = pk_fma4(d[8 + j], s_second2, d[4 + j]);
 #endif
     }
   };
@@ -756,16 +765,15 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
     HP_STAMP(stamp_slot);
 #endif
     floatx4 acc[8][2];
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[q][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     // one chunk = 8 steps (one position each: 2 weight-fragment reads for the next step, 8 MFMAs);
     // the next stage's LDS stores go under steps 0-3, the loads of the stages after it under
     // steps 4-7, the next chunk's pixel reads under steps 4-7 after the barrier that publishes them
-    auto chunk = [&](int c, auto odd, auto is_last) {
+    // FIRST: the chunk that starts the item -- its first MFMA per accumulator takes C = 0 instead of
+    // 64 register clears per wave and item
+    auto chunk = [&](int c, auto odd, auto is_first, auto is_last) {
       constexpr std::integral_constant<int, 1 - decltype(odd)::value> nxt{};
+      constexpr bool FIRST = decltype(is_first)::value;
       constexpr bool LAST = decltype(is_last)::value;
 #ifdef HP_WABL_TIMING
       if (stamp_slot == 5) HP_STAMP(32 + c);
@@ -811,7 +819,8 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
-            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[q][j], bf[q & 1][nt][j], acc[q][nt], 0, 0, 0);
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[q][j], bf[q & 1][nt][j],
+                                                              FIRST && j == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[q][nt], 0, 0, 0);
         if (q == 7) {  // V[0..3] of the next chunk (this chunk's were consumed by steps 0-3) and the rows of V[4..7]
           xform_first();
           xform_second_rows();
@@ -824,12 +833,16 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
       __syncthreads();  // pixels of the next chunk held by every wave, this chunk's weights consumed
 #endif
     };
-    for (int c = 0; c + 2 < nchunks; c += 2) {
-      chunk(c, SET_A, std::false_type{});
-      chunk(c + 1, SET_B, std::false_type{});
+    constexpr std::false_type NO{};
+    constexpr std::true_type YES{};
+    chunk(0, SET_A, YES, NO);  // nchunks >= 4 (the launcher sends Cin = 32 to the other kernel)
+    chunk(1, SET_B, NO, NO);
+    for (int c = 2; c + 2 < nchunks; c += 2) {
+      chunk(c, SET_A, NO, NO);
+      chunk(c + 1, SET_B, NO, NO);
     }
-    chunk(nchunks - 2, SET_A, std::false_type{});
-    chunk(nchunks - 1, SET_B, std::true_type{});
+    chunk(nchunks - 2, SET_A, NO, NO);
+    chunk(nchunks - 1, SET_B, NO, YES);
 #ifdef HP_WABL_TIMING
     HP_STAMP(stamp_slot + 1);
 #endif
@@ -1016,7 +1029,7 @@ size_t wino8_lds_bytes(int Pmax, int Cin = 512) {
 
 template <bool PRE, int NLD>
 int launch8(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
-  constexpr int SETS = (PRE && NLD >= 5) || NLD >= 6 ? 1 : 2;
+  constexpr int SETS = NLD >= 6 ? 1 : 2;
   static bool opted = false;
   static int cus = 0;
   if (!opted) {
@@ -1045,7 +1058,7 @@ bool wino_use_v1() {
 
 template <bool PRE>
 int launch_nld(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
-  if (!wino_use_v1() && wino8_nld(g.Pmax) <= 6 && wino8_lds_bytes(g.Pmax, a.Cin) <= 160 * 1024) {
+  if (!wino_use_v1() && a.Cin >= 4 * CK && wino8_nld(g.Pmax) <= 6 && wino8_lds_bytes(g.Pmax, a.Cin) <= 160 * 1024) {
     const int nld8 = wino8_nld(g.Pmax);
     if (nld8 <= 2) return launch8<PRE, 2>(a, g, stream);
     if (nld8 <= 3) return launch8<PRE, 3>(a, g, stream);
