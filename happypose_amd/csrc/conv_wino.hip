@@ -124,6 +124,17 @@ __device__ long long g_wino_stamps[512 * kStampSlots];
 #define HP_STAMP(slot) do { } while (0)
 #endif
 
+__device__ __forceinline__ floatx2 add2(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ floatx2 sub2(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // a * s + c with a wave-uniform s (an SGPR pair): two v_pk_fma_f32 per float4
 __device__ __forceinline__ floatx4 pk_fma4(floatx4 a, floatx2 s, floatx4 c) {
   floatx2 lo, hi;
@@ -544,7 +555,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 // reduces its two rows to a 2x2 partial result per (tile, cout), the partners swap half of it
 // through LDS (role 0 finishes couts 0-15 of the item, role 1 couts 16-31) and each stores half.
 constexpr int kThreads8 = 512;
-constexpr int X_BUF = 8 * 4 * 64 * 4;  // floats of the exchange buffer: [wave][4][lane] float4
+constexpr int X_BUF = 8 * 8 * 64 * 2;  // floats of the exchange buffer: [wave][8][lane] float2
 
 template <bool PRE, int NLD, int SETS>
 __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wino8_f32(
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
   constexpr int Pp = plane_len8(NLD);
   float* const rawl = lds;               // [4 kg][Pp] float4
   float* const ul = lds + 4 * Pp * 4;    // [2][16 pos][4 kg][BN] float4
-  float* const xl = ul + 2 * U_BUF;      // [8 waves][4][64 lanes] float4
+  float* const xl = ul + 2 * U_BUF;      // [8 waves][8][64 lanes] float2
   float* const pl = xl + X_BUF;          // PRE: [Cin] scale, [Cin] shift of the prologue
 
   const int nslot = gridDim.x / 8;
@@ -853,31 +864,35 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
     //      then the column transform; the partners swap the half they do not finish through LDS.
     //      (two copies of the code behind a wave-uniform branch: with the role known at compile
     //      time half of the row arithmetic and all keep/send selects disappear)
-    float yk[4][4];  // [i][pixel]: the cout half this wave finishes (nt == role)
+    //      All of it on register PAIRS over the accumulator elements (i, i+1) -- the pairs the MFMA
+    //      results already sit in -- with explicit packed adds: left to itself hipcc SLP-packs these
+    //      adds across other dimensions and spends more v_mov on building the pairs than it saves.
+    floatx2 yk[2][4];  // [i pair][pixel]: the cout half this wave finishes (nt == role)
     auto partial = [&](auto role_c) {
       constexpr int R = decltype(role_c)::value;
-      auto half = [&](auto nt_c, float(&y)[4][4]) {
+      auto half = [&](auto nt_c, floatx2(&y)[2][4]) {
         constexpr int nt = decltype(nt_c)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float p0[4], p1[4];
+        for (int ip = 0; ip < 2; ++ip) {
+          floatx2 p0[4], p1[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            p0[j] = R == 0 ? acc[j][nt][i] + acc[4 + j][nt][i] : acc[4 + j][nt][i];
-            p1[j] = R == 0 ? acc[4 + j][nt][i] : acc[j][nt][i] - acc[4 + j][nt][i];
+            const floatx2 l0 = ip ? acc[j][nt].zw : acc[j][nt].xy, l1 = ip ? acc[4 + j][nt].zw : acc[4 + j][nt].xy;
+            p0[j] = R == 0 ? add2(l0, l1) : l1;
+            p1[j] = R == 0 ? l1 : sub2(l0, l1);
           }
-          y[i][0] = p0[0] + p0[1] + p0[2];
-          y[i][1] = p0[1] - p0[2] - p0[3];
-          y[i][2] = p1[0] + p1[1] + p1[2];
-          y[i][3] = p1[1] - p1[2] - p1[3];
+          y[ip][0] = add2(add2(p0[0], p0[1]), p0[2]);
+          y[ip][1] = sub2(sub2(p0[1], p0[2]), p0[3]);
+          y[ip][2] = add2(add2(p1[0], p1[1]), p1[2]);
+          y[ip][3] = sub2(sub2(p1[1], p1[2]), p1[3]);
         }
       };
       {  // the half the partner finishes goes out first, so its registers are free again
-        float ys[4][4];
+        floatx2 ys[2][4];
         half(std::integral_constant<int, 1 - R>{}, ys);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          *reinterpret_cast<floatx4*>(xl + ((wave * 4 + i) * 64 + lane) * 4) = floatx4{ys[i][0], ys[i][1], ys[i][2], ys[i][3]};
+        for (int k = 0; k < 8; ++k)
+          *reinterpret_cast<floatx2*>(xl + ((wave * 8 + k) * 64 + lane) * 2) = ys[k >> 2][k & 3];
       }
       __builtin_amdgcn_sched_barrier(0);
       half(std::integral_constant<int, R>{}, yk);
@@ -886,11 +901,8 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
     else partial(std::integral_constant<int, 1>{});
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const floatx4 o = *reinterpret_cast<const floatx4*>(xl + (((wave ^ 4) * 4 + i) * 64 + lane) * 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) yk[i][q] += o[q];
-    }
+    for (int k = 0; k < 8; ++k)
+      yk[k >> 2][k & 3] = add2(yk[k >> 2][k & 3], *reinterpret_cast<const floatx2*>(xl + (((wave ^ 4) * 8 + k) * 64 + lane) * 2));
     // epilogue as in the kernel above, for the cout half nt = role
     const int lq = lane & 3;
     const int ncol = n0 + role * 16 + ((lane & 15) & ~3);
@@ -911,7 +923,7 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
       const int oh = 2 * th + (lq >> 1), ow = 2 * tw + (lq & 1);
       const bool ok = (go < T) & (oh < a.Ho) & (ow < a.Wo);
       const int64_t obase = (((int64_t)img * a.Ho + oh) * a.Wo + ow) * a.Cout + ncol;
-      float y[4] = {yk[i][0], yk[i][1], yk[i][2], yk[i][3]};
+      float y[4] = {yk[i >> 1][0][i & 1], yk[i >> 1][1][i & 1], yk[i >> 1][2][i & 1], yk[i >> 1][3][i & 1]};
       {
         const bool odd = lq & 1;
         const float s0 = odd ? y[0] : y[1], s1 = odd ? y[2] : y[3];
