@@ -110,7 +110,7 @@ extern "C" void hp_mesh_store_destroy(hp_mesh_store* s) {
   if (!s) return;
   (void)hipFree(s->verts); (void)hipFree(s->normals); (void)hipFree(s->uvs); (void)hipFree(s->colors);
   (void)hipFree(s->faces); (void)hipFree(s->tex); (void)hipFree(s->obj); (void)hipFree(s->points);
-  (void)hipFree(s->bin_list); (void)hipFree(s->bin_count);
+  (void)hipFree(s->bin_list); (void)hipFree(s->bin_count); (void)hipFree(s->xverts);
   (void)hipFree(s->verts4); (void)hipFree(s->normals4);
   delete s;
 }

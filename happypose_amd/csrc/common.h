@@ -54,6 +54,8 @@ struct MeshStore {
   size_t bin_list_bytes = 0;
   int32_t* bin_count = nullptr;
   size_t bin_count_bytes = 0;
+  float4* xverts = nullptr;  // per-(view, vertex) screen-space vertices of the current chunk (2 float4 each)
+  size_t xverts_bytes = 0;
   int n_obj = 0;
   int n_pad = 0;
   int64_t max_verts = 0;  // max vertices of a single object

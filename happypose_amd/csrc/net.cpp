@@ -608,7 +608,8 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
       const int algo = conv_algo();
       // FLOPs the matrix cores actually execute (padded tiles / K included): 16 multiplies per
       // 2x2 output tile, cin and cout for the Winograd layers, M x Cout x Kpad otherwise
-      if (algo == HP_CONV_ALGO_AUTO && L.w_wino.p && conv_wino_launchable(a)) {
+      const bool wino_ok = algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINOGRAD_1WAVE;
+      if (wino_ok && L.w_wino.p && conv_wino_launchable(a)) {
         a.w = (const float*)L.w_wino.p;
         rc = launch_conv_wino(a, stream);
         ev.mfma_flops = 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout;
@@ -787,7 +788,7 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   a.M = (int64_t)n * a.Ho * a.Wo;
   const bool classic = !padded && relu != HP_ACT_SWISH && (d_pre_shift || !d_pre_scale);  // what the 3x3 kernels support
   const int algo = classic ? conv_algo() : HP_CONV_ALGO_IGEMM;
-  if (algo == HP_CONV_ALGO_AUTO && conv_wino_applicable(a, kh, kw) && conv_wino_launchable(a)) {
+  if ((algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINOGRAD_1WAVE) && conv_wino_applicable(a, kh, kw) && conv_wino_launchable(a)) {
     // test entry: the weights are transformed on every call into a per-process scratch buffer
     static float* d_U = nullptr;
     static size_t U_floats = 0;

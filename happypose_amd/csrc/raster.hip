@@ -24,6 +24,17 @@
 //     consecutive hypotheses share an object, hence the mesh stays in that XCD's L2.
 #include "common.h"
 
+// Band size: a band is one workgroup.  Only the bands the object covers carry work (5 of 8 bands of
+// 30 rows on the benchmark scenes), so the launch is as long as the busiest CU's sequence of busy
+// bands; 15-row bands with 512 threads (4 workgroups per CU, the same 8 waves per SIMD) halve that
+// granularity.
+#ifndef HP_RASTER_BAND_PIXELS
+#define HP_RASTER_BAND_PIXELS 4800
+#endif
+#ifndef HP_RASTER_THREADS
+#define HP_RASTER_THREADS 512
+#endif
+
 namespace hp {
 
 #pragma clang fp contract(off)
@@ -31,10 +42,10 @@ namespace hp {
 constexpr float kZNear = 0.1f;
 constexpr float kZFar = 10.0f;
 constexpr unsigned long long kKeyEmpty = 0xFFFFFFFFFFFFFFFFull;
-constexpr int kBandPixels = 9600;  // 76.8 KB of LDS z-buffer
-constexpr int kBigQueue = 1024;
+constexpr int kBandPixels = HP_RASTER_BAND_PIXELS;  // LDS z-buffer of a band, 8 B per pixel
+constexpr int kBigQueue = 512;
 constexpr int kBigArea = 128;  // bbox pixels above which a triangle is walked cooperatively
-constexpr int kThreads = 1024;    // band kernel: 16 waves per workgroup, 2 workgroups per CU = full occupancy
+constexpr int kThreads = HP_RASTER_THREADS;  // band kernel
 constexpr int kBinThreads = 1024;  // binning kernel
 constexpr int kMaxBands = 128;
 
@@ -64,7 +75,10 @@ struct RasterArgs {
   // per-(view, band) triangle lists built by raster_bin_kernel
   int32_t* bin_count;   // [chunk views][n_bands]
   int32_t* bin_list;    // [chunk views][n_bands][bin_cap]
-  int bin_cap, view0, max_faces;
+  int bin_cap, view0, max_faces, max_verts;
+  // screen-space vertices of the chunk's views, written by raster_xform_kernel:
+  // [view][vertex] {X, Y, Z, X/Z}, {Y/Z, -, -, -}
+  float4* xverts;
 };
 
 __device__ __forceinline__ void edge_fn(const float* P0, int i0, const float* P1, int i1, float* e) {
@@ -136,18 +150,18 @@ struct TriSetup {
 
 // Screen-space vertices + inclusive pixel bbox (clipped to the image).  Returns false when the
 // triangle is outside the clip range or the image.
-__device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const float* T, const float* Kv, const float4* vbase,
-                                         const int32_t* tri, float (&V0)[3], float (&V1)[3], float (&V2)[3],
-                                         int& x0, int& x1, int& y0, int& y1) {
-  xform_vertex(T, Kv, vbase[tri[0]], V0);
-  xform_vertex(T, Kv, vbase[tri[1]], V1);
-  xform_vertex(T, Kv, vbase[tri[2]], V2);
+__device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const float4* xv, const int32_t* tri, float (&V0)[3],
+                                         float (&V1)[3], float (&V2)[3], int& x0, int& x1, int& y0, int& y1) {
+  const float4 p0 = xv[2 * tri[0]], p1 = xv[2 * tri[1]], p2 = xv[2 * tri[2]];
+  V0[0] = p0.x; V0[1] = p0.y; V0[2] = p0.z;
+  V1[0] = p1.x; V1[1] = p1.y; V1[2] = p1.z;
+  V2[0] = p2.x; V2[1] = p2.y; V2[2] = p2.z;
   float zmin = fminf(V0[2], fminf(V1[2], V2[2])), zmax = fmaxf(V0[2], fmaxf(V1[2], V2[2]));
   if (!(zmax >= kZNear) || !(zmin <= kZFar)) return false;
   x0 = 0; x1 = a.w - 1; y0 = 0; y1 = a.h - 1;
   if (zmin > 1e-6f) {
-    float u0 = V0[0] / V0[2], u1 = V1[0] / V1[2], u2 = V2[0] / V2[2];
-    float v0 = V0[1] / V0[2], v1 = V1[1] / V1[2], v2 = V2[1] / V2[2];
+    const float u0 = p0.w, u1 = p1.w, u2 = p2.w;  // X / Z, Y / Z: divided once per vertex and view
+    const float v0 = xv[2 * tri[0] + 1].x, v1 = xv[2 * tri[1] + 1].x, v2 = xv[2 * tri[2] + 1].x;
     float umin = fminf(u0, fminf(u1, u2)), umax = fmaxf(u0, fmaxf(u1, u2));
     float vmin = fminf(v0, fminf(v1, v2)), vmax = fmaxf(v0, fmaxf(v1, v2));
     if (!(umax >= 0.0f) || !(umin <= (float)a.w) || !(vmax >= 0.0f) || !(vmin <= (float)a.h)) return false;
@@ -160,11 +174,10 @@ __device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const float* T, co
 }
 
 // Returns false when the triangle cannot touch rows [row0, row1] of this view.
-__device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const float* T, const float* Kv,
-                                               const float4* vbase, const int32_t* tri, int row0,
+__device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const float4* xv, const int32_t* tri, int row0,
                                                int row1, TriSetup& s) {
   float V0[3], V1[3], V2[3];
-  if (!tri_bbox(a, T, Kv, vbase, tri, V0, V1, V2, s.x0, s.x1, s.y0, s.y1)) return false;
+  if (!tri_bbox(a, xv, tri, V0, V1, V2, s.x0, s.x1, s.y0, s.y1)) return false;
   if (s.y0 < row0) s.y0 = row0;
   if (s.y1 > row1) s.y1 = row1;
   if (s.y0 > s.y1) return false;
@@ -211,6 +224,26 @@ __device__ __forceinline__ ViewXform load_view(const RasterArgs& a, int view) {
   return x;
 }
 
+// Pass 0: one lane per (view, vertex): camera + intrinsics transform and the perspective division,
+// once instead of once per (triangle corner, band, covered pixel).  Same operations in the same
+// order as xform_vertex / the divisions of the per-triangle code it replaces.
+__global__ __launch_bounds__(256) void raster_xform_kernel(RasterArgs a) {
+  const int lv = blockIdx.y, view = a.view0 + lv;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int item = view / a.views_per_item;
+  const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
+  if (v >= (int)ob[1]) return;
+  float T[12], Kv[9], o[3];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = a.TCO[16 * (int64_t)view + k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Kv[k] = a.K[9 * (int64_t)view + k];
+  xform_vertex(T, Kv, a.verts4[ob[0] + v], o);
+  float4* dst = a.xverts + 2 * ((int64_t)lv * a.max_verts + v);
+  dst[0] = make_float4(o[0], o[1], o[2], o[0] / o[2]);
+  dst[1] = make_float4(o[1] / o[2], 0.f, 0.f, 0.f);
+}
+
 // Pass 1: one lane per (view, triangle) -> append the triangle to the list of every band its
 // bounding box touches.  Appends are aggregated per wave (one atomic per band per wave).
 __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
@@ -227,7 +260,7 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
     int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
     float V0[3], V1[3], V2[3];
     int x0, x1, y0, y1;
-    if (tri_bbox(a, x.T, x.Kv, a.verts4 + ob[0], tri, V0, V1, V2, x0, x1, y0, y1)) {
+    if (tri_bbox(a, a.xverts + 2 * (int64_t)lv * a.max_verts, tri, V0, V1, V2, x0, x1, y0, y1)) {
       b0 = y0 / a.band_rows;
       b1 = y1 / a.band_rows;
     }
@@ -295,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   const int64_t voff = ob[0], foff = ob[2], toff = ob[4];
   const int nf = finite ? (int)ob[3] : 0;
   const int tw = (int)ob[5], th = (int)ob[6];
-  const float4* vbase = a.verts4 + voff;
+  const float4* xv = a.xverts + 2 * (int64_t)(lin / a.n_bands) * a.max_verts;
   const int32_t* fbase = a.faces + 3 * foff;
 
   for (int p = tid; p < npix; p += kThreads) zb[p] = kKeyEmpty;
@@ -313,7 +346,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
     const int f = list[k];
     int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
     TriSetup s;
-    if (!setup_triangle(a, T, Kv, vbase, tri, row0, row1, s)) continue;
+    if (!setup_triangle(a, xv, tri, row0, row1, s)) continue;
     const int area = (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
     if (area > kBigArea) {
       int q = atomicAdd(&big_n, 1);
@@ -328,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
     const int f = big_q[q];
     int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
     TriSetup s;
-    if (!setup_triangle(a, T, Kv, vbase, tri, row0, row1, s)) continue;
+    if (!setup_triangle(a, xv, tri, row0, row1, s)) continue;
     const int bw = s.x1 - s.x0 + 1;
     const int area = bw * (s.y1 - s.y0 + 1);
     for (int p = tid; p < area; p += kThreads)
@@ -355,10 +388,9 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
 #endif
       const int f = (int)(key & 0xFFFFFFFFull);
       int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
-      float V0[3], V1[3], V2[3], e0[3], e1[3], e2[3];
-      xform_vertex(T, Kv, vbase[tri[0]], V0);
-      xform_vertex(T, Kv, vbase[tri[1]], V1);
-      xform_vertex(T, Kv, vbase[tri[2]], V2);
+      float e0[3], e1[3], e2[3];
+      const float4 q0 = xv[2 * tri[0]], q1 = xv[2 * tri[1]], q2 = xv[2 * tri[2]];
+      const float V0[3] = {q0.x, q0.y, q0.z}, V1[3] = {q1.x, q1.y, q1.z}, V2[3] = {q2.x, q2.y, q2.z};
       edge_fn(V1, tri[1], V2, tri[2], e0);
       edge_fn(V2, tri[2], V0, tri[0], e1);
       edge_fn(V0, tri[0], V1, tri[1], e2);
@@ -509,14 +541,24 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
     HP_CHECK_HIP(hipMalloc((void**)&ms->bin_count, need_cnt));
     ms->bin_count_bytes = need_cnt;
   }
+  a.max_verts = (int)store->max_verts;
+  const size_t need_xv = (size_t)chunk * a.max_verts * 2 * sizeof(float4);
+  if (ms->xverts_bytes < need_xv) {
+    if (ms->xverts) (void)hipFree(ms->xverts);
+    ms->xverts = nullptr; ms->xverts_bytes = 0;
+    HP_CHECK_HIP(hipMalloc((void**)&ms->xverts, need_xv));
+    ms->xverts_bytes = need_xv;
+  }
   a.bin_list = ms->bin_list;
   a.bin_count = ms->bin_count;
+  a.xverts = ms->xverts;
   hipStream_t st = (hipStream_t)stream;
   for (int v0 = 0; v0 < n; v0 += chunk) {
     const int nv = n - v0 < chunk ? n - v0 : chunk;
     a.view0 = v0;
     a.n = nv;
     HP_CHECK_HIP(hipMemsetAsync(ms->bin_count, 0, (size_t)nv * a.n_bands * sizeof(int32_t), st));
+    hipLaunchKernelGGL(raster_xform_kernel, dim3((a.max_verts + 255) / 256, nv), dim3(256), 0, st, a);
     hipLaunchKernelGGL(raster_bin_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
     const int total = nv * a.n_bands;
     hipLaunchKernelGGL(raster_kernel, dim3(8 * ((total + 7) / 8)), dim3(kThreads), 0, st, a);

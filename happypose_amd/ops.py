@@ -318,12 +318,13 @@ class Net:
         return ms.value, n.value, fl.value, mfl.value
 
 
-CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2}
+CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2, "winograd-1wave": 3}
 
 
 def select_conv_algo(name: str = "auto") -> None:
     """Restrict the conv kernels the library may pick (process wide; parity tests / diagnostics):
-    ``auto`` = Winograd F(2x2,3x3) where it applies, ``direct`` = no Winograd, ``igemm`` = the
+    ``auto`` = Winograd F(2x2,3x3) where it applies (two waves per SIMD), ``winograd-1wave`` = the same
+    with the one-wave-per-SIMD schedule of that kernel, ``direct`` = no Winograd, ``igemm`` = the
     generic implicit-GEMM kernel only (``hp_conv_select_algo``)."""
     check(lib().hp_conv_select_algo(CONV_ALGOS[name]), "hp_conv_select_algo")
 

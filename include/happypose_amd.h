@@ -222,6 +222,7 @@ int hp_net_set_profiling(hp_net* net, int enabled);
 #define HP_CONV_ALGO_AUTO 0
 #define HP_CONV_ALGO_DIRECT 1
 #define HP_CONV_ALGO_IGEMM 2
+#define HP_CONV_ALGO_WINOGRAD_1WAVE 3 /* AUTO, but the one-wave-per-SIMD schedule of the Winograd kernel */
 int hp_conv_select_algo(int algo);
 /* diagnostics: workgroups per CU the runtime grants conv tile variant 0 (128x128) / 1 (128x64) */
 int hp_conv_occupancy(int variant);

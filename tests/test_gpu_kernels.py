@@ -328,8 +328,9 @@ def test_conv2d_vs_fp64(dev, case):
 
 
 # the three kernel families behind 3x3 / stride-1 layers must agree with fp64: Winograd F(2x2,3x3)
-# ("auto"), the patch-staged direct kernel ("direct") and the generic implicit GEMM ("igemm")
-@pytest.mark.parametrize("algo", ["auto", "direct", "igemm"])
+# ("auto" and its one-wave-per-SIMD schedule), the patch-staged direct kernel ("direct") and the generic
+# implicit GEMM ("igemm")
+@pytest.mark.parametrize("algo", ["auto", "winograd-1wave", "direct", "igemm"])
 @pytest.mark.parametrize("case", [
     dict(n=3, h=30, w=40, cin=128, cout=128, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=True),
     dict(n=7, h=15, w=20, cin=256, cout=256, k=3, s=1, p=1, bias=False, res=True, pre=True, relu=False),  # odd H
@@ -337,6 +338,8 @@ def test_conv2d_vs_fp64(dev, case):
     dict(n=5, h=9, w=7, cin=32, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=False),        # odd H and W, ragged
     dict(n=1, h=2, w=2, cin=32, cout=64, k=3, s=1, p=1, bias=False, res=False, pre=False, relu=False),     # a single tile
     dict(n=130, h=8, w=10, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=False, relu=True),     # > 1 item per block
+    dict(n=2, h=60, w=80, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=True),       # 640-pixel staged ranges
+    dict(n=3, h=20, w=96, cin=64, cout=32, k=3, s=1, p=1, bias=False, res=False, pre=True, relu=False),    # 768: single register set
 ])
 def test_conv3x3_kernel_families(dev, case, algo):
     from happypose_amd import ops
@@ -344,7 +347,7 @@ def test_conv3x3_kernel_families(dev, case, algo):
     ops.select_conv_algo(algo)
     try:
         # Winograd's transforms cost about one extra bit of round-off
-        _check_conv(dev, case, tol=4e-5 if algo == "auto" else 2e-5)
+        _check_conv(dev, case, tol=4e-5 if algo in ("auto", "winograd-1wave") else 2e-5)
     finally:
         ops.select_conv_algo("auto")
 
