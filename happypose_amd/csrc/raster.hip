@@ -338,13 +338,23 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   // ---- coverage + depth: only the triangles binned to this band ----
   const int cnt = nf > 0 ? min(a.bin_count[lin], a.bin_cap) : 0;
   const int32_t* list = a.bin_list + (int64_t)lin * a.bin_cap;
+  // the list entry and the corner indices of the NEXT triangle are fetched while this one is set up:
+  // the loop is a chain of dependent gathers (list -> faces -> vertices), not arithmetic
 #ifdef HP_RABL_NO_COVER
-  for (int k = tid; k < 0; k += kThreads) {
+  const int cnt_loop = 0;
 #else
-  for (int k = tid; k < cnt; k += kThreads) {
+  const int cnt_loop = cnt;
 #endif
-    const int f = list[k];
-    int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
+  // two-deep: list entry two triangles ahead, corner indices one ahead (each needs the previous load)
+  int f1 = tid < cnt_loop ? list[tid] : 0;
+  int f2 = tid + kThreads < cnt_loop ? list[tid + kThreads] : 0;
+  int32_t tri1[3] = {fbase[3 * f1], fbase[3 * f1 + 1], fbase[3 * f1 + 2]};
+  for (int k = tid; k < cnt_loop; k += kThreads) {
+    const int f = f1;
+    const int32_t tri[3] = {tri1[0], tri1[1], tri1[2]};
+    f1 = f2;
+    tri1[0] = fbase[3 * f1]; tri1[1] = fbase[3 * f1 + 1]; tri1[2] = fbase[3 * f1 + 2];  // f1 = 0 past the end: harmless
+    f2 = k + 2 * kThreads < cnt_loop ? list[k + 2 * kThreads] : 0;
     TriSetup s;
     if (!setup_triangle(a, xv, tri, row0, row1, s)) continue;
     const int area = (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
