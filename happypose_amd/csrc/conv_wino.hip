@@ -536,9 +536,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
 constexpr int kThreads8 = 512;
 constexpr int X_BUF = 8 * 8 * 64 * 2;  // floats of the exchange buffer: [wave][8][lane] float2
 
-template <bool PRE, int NLD, int SETS>
+// NT = cout tiles (of 16) per item: 2 = the whole 32-cout block; 1 = HALF items, used for the last,
+// partially filled round of a launch (see launch8): an item is then split into two 16-cout halves that
+// go to different blocks, and the partner waves split the finishing work by tile pairs instead.
+template <bool PRE, int NLD, int SETS, int NT>
 __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wino8_f32(
-    ConvArgs a, int TH, int TW, int T, int tiles_n, int n_items, int Pmax, WinoDiv fd) {
+    ConvArgs a, int TH, int TW, int T, int tiles_n, int n_items, int Pmax, WinoDiv fd, int range_off, int range_len) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // every staged row has its own LDS slot (128 NLD of them, the zero slot after them), so the
   // stores need no clamping -- VALU work beside the f32 MFMAs is not free (see the chunk loop)
@@ -549,12 +552,18 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
   float* const xl = ul + 2 * U_BUF;      // [8 waves][8][64 lanes] float2
   float* const pl = xl + X_BUF;          // PRE: [Cin] scale, [Cin] shift of the prologue
 
+  // items [rb, re) of this XCD's share; `item` counts VIRTUAL items from 0: whole items (NT = 2) or halves
   const int nslot = gridDim.x / 8;
   const int ipx = (n_items + 7) / 8;
-  const int item_begin = (blockIdx.x % 8) * ipx;
-  const int item_end = item_begin + ipx < n_items ? item_begin + ipx : n_items;
-  int item = item_begin + blockIdx.x / 8;
+  const int xb = (blockIdx.x % 8) * ipx;
+  const int xe = xb + ipx < n_items ? xb + ipx : n_items;
+  const int rb = xb + range_off < xe ? xb + range_off : xe;
+  const int re = rb + range_len < xe ? rb + range_len : xe;
+  const int item_end = (re - rb) * (3 - NT);
+  int item = blockIdx.x / 8;
   if (item >= item_end) return;
+  auto real_item = [&](int v) { return rb + (NT == 1 ? v >> 1 : v); };
+  auto half_off = [&](int v) { return NT == 1 ? (v & 1) * 16 * 4 : 0; };  // floats: second 16 couts of the block
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tg = wave & 3, role = wave >> 2;
@@ -594,8 +603,9 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
 
   struct Cursor { int item, c, lo, P, nb; };
   auto locate = [&](Cursor& k, bool range) {
-    const int bm = fdiv(k.item, fd.tn);
-    k.nb = k.item - bm * tiles_n;
+    const int it = real_item(k.item);
+    const int bm = fdiv(it, fd.tn);
+    k.nb = it - bm * tiles_n;
     if (range) item_range_dev(bm, T, TH, TW, H, W, fd, k.lo, k.P);
   };
   auto advance = [&](Cursor& k, bool range) {
@@ -675,8 +685,8 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
   int doff[12];
   int s_prow = 0, s_ih0 = 0, s_iw0 = 0;
   bool s_in = false;
-  auto setup_tile = [&](int it) {
-    const int bm = fdiv(it, fd.tn);
+  auto setup_tile = [&](int v) {
+    const int bm = fdiv(real_item(v), fd.tn);
     int lo, P;
     item_range_dev(bm, T, TH, TW, H, W, fd, lo, P);
     const int g = bm * TPB + tg * 16 + (lane & 15);
@@ -737,24 +747,25 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
   };
   auto xform_second = [&]() { col_xform(tS, 1); };
-  floatx4 bf[2][2];
+  floatx4 bf[2][NT];
   setup_tile(item);
   setup_doff();
   read_d(0, 12);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) bf[0][nt] = *reinterpret_cast<const floatx4*>(ufr_lo + nt * 16 * 4);
+  for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const floatx4*>(ufr_lo + half_off(item) + nt * 16 * 4);
   xform_first();
   xform_second_rows();
   __syncthreads();  // every wave holds its pixels of chunk 0: the pixel buffer may be refilled
   HP_STAMP(1);
 
   for (;;) {
-    const int bm = fdiv(item, fd.tn), n0 = (item - bm * tiles_n) * BN;
+    const int bm = fdiv(real_item(item), fd.tn), n0 = (real_item(item) - bm * tiles_n) * BN;
     const bool has_next = item + nslot < item_end;
+    const int hoff = half_off(item), hoff_next = half_off(has_next ? item + nslot : item);
 #ifdef HP_WABL_TIMING
     HP_STAMP(stamp_slot);
 #endif
-    floatx4 acc[8][2];
+    floatx4 acc[8][NT];
 
     // one chunk = 8 steps (one position each: 2 weight-fragment reads for the next step, 8 MFMAs);
     // the next stage's LDS stores go under steps 0-3, the loads of the stages after it under
@@ -768,20 +779,20 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
 #ifdef HP_WABL_TIMING
       if (stamp_slot == 5) HP_STAMP(32 + c);
 #endif
-      const float* ub_lo = ufr_lo + ubuf * U_BUF;
-      const float* ub_hi = ufr_hi + ubuf * U_BUF;
+      const float* ub_lo = ufr_lo + ubuf * U_BUF + hoff;
+      const float* ub_hi = ufr_hi + ubuf * U_BUF + hoff;
       // bf[0] and V[0..3] of this chunk were prepared under the last step of the previous one (the
       // weights were published by its mid-chunk barrier), so the MFMAs of step 0 issue right away
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         if (q + 1 < 8) {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < NT; ++nt)
             bf[(q + 1) & 1][nt] = *reinterpret_cast<const floatx4*>((q + 1 < 4 ? ub_lo : ub_hi) + ((q + 1) * 128 + nt * 16) * 4);
         } else {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            bf[0][nt] = *reinterpret_cast<const floatx4*>(ufr_lo + (ubuf ^ 1) * U_BUF + nt * 16 * 4);
+          for (int nt = 0; nt < NT; ++nt)
+            bf[0][nt] = *reinterpret_cast<const floatx4*>(ufr_lo + (ubuf ^ 1) * U_BUF + (LAST ? hoff_next : hoff) + nt * 16 * 4);
         }
         if (q == 0) xform_second();
 #if !defined(HP_WABL_NO_STAGE) && !defined(HP_WABL_NO_LSTORE)
@@ -808,7 +819,7 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < NT; ++nt)
             acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[q][j], bf[q & 1][nt][j],
                                                               FIRST && j == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[q][nt], 0, 0, 0);
         if (q == 7) {  // V[0..3] of the next chunk (this chunk's were consumed by steps 0-3) and the rows of V[4..7]
@@ -866,26 +877,37 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
           y[ip][3] = sub2(sub2(p1[1], p1[2]), p1[3]);
         }
       };
-      {  // the half the partner finishes goes out first, so its registers are free again
-        floatx2 ys[2][4];
-        half(std::integral_constant<int, 1 - R>{}, ys);
+      if constexpr (NT == 2) {
+        {  // the half the partner finishes goes out first, so its registers are free again
+          floatx2 ys[2][4];
+          half(std::integral_constant<int, 1 - R>{}, ys);
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          *reinterpret_cast<floatx2*>(xl + ((wave * 8 + k) * 64 + lane) * 2) = ys[k >> 2][k & 3];
+          for (int k = 0; k < 8; ++k)
+            *reinterpret_cast<floatx2*>(xl + ((wave * 8 + k) * 64 + lane) * 2) = ys[k >> 2][k & 3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        half(std::integral_constant<int, R>{}, yk);
+      } else {  // half item: one cout tile; role r finishes tile pair r and sends the other pair
+        floatx2 y[2][4];
+        half(std::integral_constant<int, 0>{}, y);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          *reinterpret_cast<floatx2*>(xl + ((wave * 8 + k) * 64 + lane) * 2) = y[1 - R][k];
+          yk[0][k] = y[R][k];
+        }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      half(std::integral_constant<int, R>{}, yk);
     };
     if (role == 0) partial(std::integral_constant<int, 0>{});
     else partial(std::integral_constant<int, 1>{});
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < 4 * NT; ++k)
       yk[k >> 2][k & 3] = add2(yk[k >> 2][k & 3], *reinterpret_cast<const floatx2*>(xl + (((wave ^ 4) * 8 + k) * 64 + lane) * 2));
-    // epilogue as in the kernel above, for the cout half nt = role
+    // epilogue as in the kernel above: whole items -- all four tiles of the lane group for the cout
+    // half nt = role; half items -- tiles 2 role, 2 role + 1 for the item's cout half
     const int lq = lane & 3;
-    const int ncol = n0 + role * 16 + ((lane & 15) & ~3);
-    const int go0 = bm * TPB + tg * 16 + 4 * kg;
+    const int ncol = n0 + (NT == 2 ? role * 16 : hoff / 4) + ((lane & 15) & ~3);
+    const int go0 = bm * TPB + tg * 16 + 4 * kg + (NT == 2 ? 0 : 2 * role);
     int e_img, e_th, e_tw;
     {
       const int gc = go0 < T ? go0 : 0;
@@ -895,7 +917,7 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
       e_tw = r - e_th * TW;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2 * NT; ++i) {
       const int go = go0 + i;
       const int img = e_img, th = e_th, tw = e_tw;
       if (++e_tw == TW) { e_tw = 0; if (++e_th == TH) { e_th = 0; ++e_img; } }
@@ -1027,17 +1049,34 @@ int launch8(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
     int dev = 0;
     HP_CHECK_HIP(hipGetDevice(&dev));
     HP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32<PRE, NLD, SETS>),
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32<PRE, NLD, SETS, 2>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32<PRE, NLD, SETS, 1>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     opted = true;
   }
   const int tiles_m = (g.T + TPB - 1) / TPB, tiles_n = a.Cout / BN;
   const int n_items = tiles_m * tiles_n;
-  const int ipx = (n_items + 7) / 8;
-  const int slots = std::max(1, std::min(ipx, cus / 8));
-  hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS>), dim3(8 * slots), dim3(kThreads8), wino8_lds_bytes(g.Pmax, a.Cin), stream, a,
-                     g.TH, g.TW, g.T, tiles_n, n_items, g.Pmax,
-                     WinoDiv{make_fastdiv((unsigned)(g.TH * g.TW)), make_fastdiv((unsigned)g.TW), make_fastdiv((unsigned)tiles_n)});
+  const int ipx = (n_items + 7) / 8;  // items per XCD
+  const int per_xcd = std::max(1, cus / 8);
+  const WinoDiv fd{make_fastdiv((unsigned)(g.TH * g.TW)), make_fastdiv((unsigned)g.TW), make_fastdiv((unsigned)tiles_n)};
+  const size_t lds = wino8_lds_bytes(g.Pmax, a.Cin);
+  // Rounds: every block of an XCD walks ipx / per_xcd items.  A last round that fills at most half of
+  // the blocks (8x10 maps at batch 128: 2.5 rounds) would cost a whole round; its items are split into
+  // two 16-cout halves instead and run as a second launch on twice as many blocks -- a half item costs
+  // ~0.6 of a whole one (half the MFMAs, the same staging).  HP_WINO_NO_TAIL_SPLIT disables it.
+  static const bool no_tail_split = std::getenv("HP_WINO_NO_TAIL_SPLIT") != nullptr;
+  const int full = (ipx / per_xcd) * per_xcd, tail = ipx - full;
+  if (!no_tail_split && full > 0 && tail > 0 && 2 * tail <= per_xcd) {
+    hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS, 2>), dim3(8 * per_xcd), dim3(kThreads8), lds, stream, a, g.TH, g.TW,
+                       g.T, tiles_n, n_items, g.Pmax, fd, 0, full);
+    hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS, 1>), dim3(8 * 2 * tail), dim3(kThreads8), lds, stream, a, g.TH, g.TW,
+                       g.T, tiles_n, n_items, g.Pmax, fd, full, tail);
+  } else {
+    const int slots = std::max(1, std::min(ipx, per_xcd));
+    hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS, 2>), dim3(8 * slots), dim3(kThreads8), lds, stream, a, g.TH, g.TW,
+                       g.T, tiles_n, n_items, g.Pmax, fd, 0, ipx);
+  }
   return check_launch("conv3x3_wino8_f32");
 }
 

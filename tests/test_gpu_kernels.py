@@ -340,6 +340,7 @@ def test_conv2d_vs_fp64(dev, case):
     dict(n=130, h=8, w=10, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=False, relu=True),     # > 1 item per block
     dict(n=2, h=60, w=80, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=True),       # 640-pixel staged ranges
     dict(n=3, h=20, w=96, cin=64, cout=32, k=3, s=1, p=1, bias=False, res=False, pre=True, relu=False),    # 768: single register set
+    dict(n=128, h=8, w=10, cin=64, cout=256, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=True),     # 1.25 rounds: half-item tail launch
 ])
 def test_conv3x3_kernel_families(dev, case, algo):
     from happypose_amd import ops
