@@ -56,7 +56,9 @@ struct ConvLayer {
   DevBuf w16, lut16, pre_scale16, pre_shift16;
 };
 
-struct EventPair { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0.0, mfma_flops = 0.0; int conv = -1; };
+// one timed stretch of conv launches: a single launch (per-layer table, HP_PROFILE_LAYERS) or a run of
+// consecutive conv launches (default: an event pair per launch costs 3 % of a refiner step)
+struct EventPair { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0.0, mfma_flops = 0.0; int conv = -1; int n = 0; };
 
 // MBConv pieces (EfficientNet): depthwise conv + BN + swish, squeeze-excitation
 struct DwLayer {
@@ -539,6 +541,27 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
                                        net->convs[0]->cin16, stream)))
     return rc;
   static const bool sync_ops = std::getenv("HP_NET_SYNC") != nullptr;  // diagnostics: fault isolation
+  static const bool per_launch = std::getenv("HP_PROFILE_LAYERS") != nullptr;
+  // profiling: events are recorded on the launch stream and only READ in hp_net_profile_collect
+  EventPair run{};
+  bool run_open = false;
+  auto prof_begin = [&](int conv) -> int {
+    if (!net->profiling || run_open) return HP_OK;
+    if (!net->ev_pool.empty()) { run = net->ev_pool.back(); net->ev_pool.pop_back(); }
+    else { run = EventPair{}; HP_CHECK_HIP(hipEventCreate(&run.e0)); HP_CHECK_HIP(hipEventCreate(&run.e1)); }
+    run.flops = run.mfma_flops = 0.0; run.n = 0; run.conv = per_launch ? conv : -1;
+    HP_CHECK_HIP(hipEventRecord(run.e0, stream));
+    run_open = true;
+    return HP_OK;
+  };
+  auto prof_add = [&](double flops, double mfma_flops) { if (run_open) { run.flops += flops; run.mfma_flops += mfma_flops; ++run.n; } };
+  auto prof_end = [&](bool force) -> int {
+    if (!run_open || !(force || per_launch)) return HP_OK;
+    HP_CHECK_HIP(hipEventRecord(run.e1, stream));
+    net->ev_pending.push_back(run);
+    run_open = false;
+    return HP_OK;
+  };
   int op_index = 0;
   for (const Op& op : net->ops) {
     if (sync_ops) {
@@ -563,20 +586,10 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
       a.kh = L.kh; a.kw = L.kw;
       a.x_bytes = (int64_t)batch * L.H * L.W * L.cin16 * 2;
       a.w_bytes = (int64_t)L.cout * L.Kpad16 * 2;
-      EventPair ev{};
-      if (net->profiling) {
-        if (!net->ev_pool.empty()) { ev = net->ev_pool.back(); net->ev_pool.pop_back(); }
-        else { HP_CHECK_HIP(hipEventCreate(&ev.e0)); HP_CHECK_HIP(hipEventCreate(&ev.e1)); }
-        ev.flops = 2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real;
-        ev.mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout * L.Kpad16;
-        ev.conv = op.conv;
-        HP_CHECK_HIP(hipEventRecord(ev.e0, stream));
-      }
+      if ((rc = prof_begin(op.conv))) return rc;
       if ((rc = launch_conv_f16(a, stream))) return rc;
-      if (net->profiling) {
-        HP_CHECK_HIP(hipEventRecord(ev.e1, stream));
-        net->ev_pending.push_back(ev);
-      }
+      prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout * L.Kpad16);
+      if ((rc = prof_end(false))) return rc;
     } else if (op.kind == OP_CONV) {
       ConvLayer& L = *net->convs[op.conv];
       ConvArgs a{};
@@ -597,14 +610,8 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
         std::fprintf(stderr, "[hp net]   conv %s M=%lld H=%d W=%d Cin=%d Ho=%d Wo=%d Cout=%d pad=%d Kpad=%d act=%d se=%d in=%d out=%d res=%d x=%p y=%p r=%p\n",
                      L.wname.c_str(), (long long)a.M, a.H, a.W, a.Cin, a.Ho, a.Wo, a.Cout, a.pad, a.Kpad, a.relu, L.se, L.in_buf,
                      L.out_buf, L.res_buf, (const void*)a.x, (void*)a.y, (const void*)a.residual);
-      EventPair ev{};
-      if (net->profiling) {  // events are only READ in hp_net_profile_collect: no sync here
-        if (!net->ev_pool.empty()) { ev = net->ev_pool.back(); net->ev_pool.pop_back(); }
-        else { HP_CHECK_HIP(hipEventCreate(&ev.e0)); HP_CHECK_HIP(hipEventCreate(&ev.e1)); }
-        ev.flops = 2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real;
-        ev.conv = op.conv;
-        HP_CHECK_HIP(hipEventRecord(ev.e0, stream));
-      }
+      if ((rc = prof_begin(op.conv))) return rc;
+      double mfma_flops = 0.0;
       const int algo = conv_algo();
       // FLOPs the matrix cores actually execute (padded tiles / K included): 16 multiplies per
       // 2x2 output tile, cin and cout for the Winograd layers, M x Cout x Kpad otherwise
@@ -612,19 +619,18 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
       if (wino_ok && L.w_wino.p && conv_wino_launchable(a)) {
         a.w = (const float*)L.w_wino.p;
         rc = launch_conv_wino(a, stream);
-        ev.mfma_flops = 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout;
+        mfma_flops = 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout;
       } else {
         if (algo != HP_CONV_ALGO_IGEMM && a.relu != HP_ACT_SWISH && !L.se && conv_patch_applicable(a, L.kh, L.kw))
           rc = launch_conv_patch(a, variant, stream);
         else rc = launch_conv(a, variant, stream);
-        ev.mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout_pad * L.Kpad;
+        mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout_pad * L.Kpad;
       }
       if (rc) return rc;
-      if (net->profiling) {
-        HP_CHECK_HIP(hipEventRecord(ev.e1, stream));
-        net->ev_pending.push_back(ev);
-      }
+      prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, mfma_flops);
+      if ((rc = prof_end(false))) return rc;
     } else if (op.kind == OP_DW) {
+      if ((rc = prof_end(true))) return rc;
       const DwLayer& D = *net->dws[op.conv];
       DwArgs d{};
       d.x = (const float*)net->bufs[D.in_buf].p; d.w = (const float*)D.w.p; d.bias = (const float*)D.bias.p;
@@ -633,6 +639,7 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
       d.pad_t = d.pad_l = D.pad;
       if ((rc = launch_dwconv(d, stream))) return rc;
     } else if (op.kind == OP_SE) {
+      if ((rc = prof_end(true))) return rc;
       const SeLayer& S = *net->ses[op.conv];
       if ((rc = launch_se((const float*)net->bufs[S.in_buf].p, (float*)net->se_partial.p, (float*)net->se_pooled.p, (float*)net->se_sq.p,
                           (float*)net->se_gate.p,
@@ -640,14 +647,17 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
                           S.C, S.Cse, stream)))
         return rc;
     } else if (op.kind == OP_MAXPOOL && f16) {
+      if ((rc = prof_end(true))) return rc;
       if ((rc = launch_maxpool_f16(net->bufs[op.in_buf].p, net->bufs[op.out_buf].p, batch, op.H, op.W, op.C, op.Ho,
                                    op.Wo, stream)))
         return rc;
     } else if (op.kind == OP_MAXPOOL) {
+      if ((rc = prof_end(true))) return rc;
       if ((rc = launch_maxpool((const float*)net->bufs[op.in_buf].p, (float*)net->bufs[op.out_buf].p, batch,
                                op.H, op.W, op.C, op.Ho, op.Wo, stream)))
         return rc;
     } else {
+      if ((rc = prof_end(true))) return rc;
       HeadArgs h{};
       h.x = net->bufs[op.in_buf].p; h.x_is_half = f16 ? 1 : 0; h.HW = op.H * op.W; h.C = op.C;
       h.fc_w = (const float*)net->fc_w.p; h.fc_b = (const float*)net->fc_b.p;
@@ -659,7 +669,7 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
       if ((rc = launch_head(h, batch, stream))) return rc;
     }
   }
-  return HP_OK;
+  return prof_end(true);
 }
 
 extern "C" int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d_pose, float* d_logits,
@@ -710,7 +720,9 @@ extern "C" int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_l
     }
   }
   if (conv_ms) *conv_ms = ms_total;
-  if (n_launches) *n_launches = (int64_t)net->ev_pending.size();
+  int64_t nl = 0;
+  for (auto& p : net->ev_pending) nl += p.n;
+  if (n_launches) *n_launches = nl;
   if (conv_flops) *conv_flops = fl;
   if (mfma_flops) *mfma_flops = mfl;
   net->ev_pending.clear();
