@@ -373,6 +373,8 @@ def main():
                          "mfma_executed_tflops": mfma_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else 0.0,
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
+                         "launch_note": "a launch = one conv layer of a forward; the Winograd kernel runs a partially filled last round "
+                                        "as a second kernel, so rocprofv3 lists 48 conv kernels per WideResNet-34 forward for these 36 launches",
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }
         if precision == "f32":

@@ -21,7 +21,7 @@ def per_kernel(d, counter):
     return df.groupby("Kernel_Name").Counter_Value.agg(["sum", "count"])
 
 
-def main(fetch_dir, write_dir, out):
+def main(fetch_dir, write_dir, out, layer_launches=None):
     f, w = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     launches = int(f["count"].sum())
     assert launches == int(w["count"].sum()), "the two passes must profile the same command"
@@ -31,10 +31,13 @@ def main(fetch_dir, write_dir, out):
     for k in f.index:
         rows[k] = {"launches": int(f.loc[k, "count"]), "fetch_bytes_per_launch": 2.0 * 1024.0 * f.loc[k, "sum"] / f.loc[k, "count"],
                    "write_bytes_per_launch": 1024.0 * w.loc[k, "sum"] / w.loc[k, "count"] if k in w.index else None}
-    res = {"conv_launches": launches, "fetch_bytes_per_launch": fetch / launches, "write_bytes_per_launch": write / launches,
-           "hbm_bytes_per_launch": (fetch + write) / launches,
+    # a conv LAYER may run as two kernels (the Winograd kernel launches the last, partially filled round
+    # separately): bench.py counts layer launches, so the per-launch figure is normalised by those
+    layer_launches = int(layer_launches) if layer_launches else launches
+    res = {"conv_kernel_launches": launches, "conv_launches": layer_launches, "fetch_bytes_per_launch": fetch / layer_launches,
+           "write_bytes_per_launch": write / layer_launches, "hbm_bytes_per_launch": (fetch + write) / layer_launches,
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over `bench.py --steps 4 --warmup 1`; "
-                     "FETCH_SIZE x 2 (gfx950 wide-read correction), units of 1024 B, averaged over all conv launches",
+                     "FETCH_SIZE x 2 (gfx950 wide-read correction), units of 1024 B, summed over all conv kernels and divided by the number of conv layer launches (25 forwards x 36 layers)",
            "per_kernel": rows}
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
@@ -42,4 +45,4 @@ def main(fetch_dir, write_dir, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
