@@ -848,6 +848,34 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
     HP_STAMP(stamp_slot + 1);
 #endif
 
+    // ---- where the lane's results go: whole items -- all four tiles of the lane group for the cout half
+    //      nt = role; half items -- tiles 2 role, 2 role + 1 for the item's cout half.  The residual is
+    //      requested NOW, so that its latency (HBM for the 60x80 layers) passes under the output
+    //      transform and the exchange instead of inside the store loop.
+    const int lq = lane & 3;
+    const int ncol = n0 + (NT == 2 ? role * 16 : hoff / 4) + ((lane & 15) & ~3);
+    int e_off[2 * NT];
+    bool e_ok[2 * NT];
+    floatx4 e_res[2 * NT];
+    {
+      const int go0 = bm * TPB + tg * 16 + 4 * kg + (NT == 2 ? 0 : 2 * role);
+      const int gc = go0 < T ? go0 : 0;
+      int e_img = fdiv(gc, fd.per);
+      const int r = gc - e_img * (TH * TW);
+      int e_th = fdiv(r, fd.tw);
+      int e_tw = r - e_th * TW;
+#pragma unroll
+      for (int i = 0; i < 2 * NT; ++i) {
+        const int oh = 2 * e_th + (lq >> 1), ow = 2 * e_tw + (lq & 1);
+        e_ok[i] = (go0 + i < T) & (oh < a.Ho) & (ow < a.Wo);
+        e_off[i] = ((e_img * a.Ho + oh) * a.Wo + ow) * a.Cout + ncol;  // < 2^31: conv_wino_launchable
+        if (++e_tw == TW) { e_tw = 0; if (++e_th == TH) { e_th = 0; ++e_img; } }
+        e_res[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // (not in the PRE instantiations: they are at the register limit, and the layers that take the
+        // BN+ReLU prologue -- the first conv of a residual block -- have no residual input)
+        if (!PRE && a.residual && e_ok[i]) e_res[i] = *reinterpret_cast<const floatx4*>(a.residual + e_off[i]);
+      }
+    }
     // ---- output transform.  Local rows L0 = acc[0..3], L1 = acc[4..7]:
     //      role 0: L0 = M row 0, L1 = M row 1   ->  partial of Y row 0: L0 + L1,  of Y row 1: L1
     //      role 1: L0 = -M row 3, L1 = M row 2  ->  partial of Y row 0: L1,       of Y row 1: L0 - L1
@@ -903,27 +931,11 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
     for (int k = 0; k < 4 * NT; ++k)
       yk[k >> 2][k & 3] = add2(yk[k >> 2][k & 3], *reinterpret_cast<const floatx2*>(xl + (((wave ^ 4) * 8 + k) * 64 + lane) * 2));
-    // epilogue as in the kernel above: whole items -- all four tiles of the lane group for the cout
-    // half nt = role; half items -- tiles 2 role, 2 role + 1 for the item's cout half
-    const int lq = lane & 3;
-    const int ncol = n0 + (NT == 2 ? role * 16 : hoff / 4) + ((lane & 15) & ~3);
-    const int go0 = bm * TPB + tg * 16 + 4 * kg + (NT == 2 ? 0 : 2 * role);
-    int e_img, e_th, e_tw;
-    {
-      const int gc = go0 < T ? go0 : 0;
-      e_img = fdiv(gc, fd.per);
-      const int r = gc - e_img * (TH * TW);
-      e_th = fdiv(r, fd.tw);
-      e_tw = r - e_th * TW;
-    }
+    // epilogue as in the kernel above, with the addresses and the residual fetched up front
 #pragma unroll
     for (int i = 0; i < 2 * NT; ++i) {
-      const int go = go0 + i;
-      const int img = e_img, th = e_th, tw = e_tw;
-      if (++e_tw == TW) { e_tw = 0; if (++e_th == TH) { e_th = 0; ++e_img; } }
-      const int oh = 2 * th + (lq >> 1), ow = 2 * tw + (lq & 1);
-      const bool ok = (go < T) & (oh < a.Ho) & (ow < a.Wo);
-      const int64_t obase = (((int64_t)img * a.Ho + oh) * a.Wo + ow) * a.Cout + ncol;
+      const bool ok = e_ok[i];
+      const int obase = e_off[i];
       float y[4] = {yk[i >> 1][0][i & 1], yk[i >> 1][1][i & 1], yk[i >> 1][2][i & 1], yk[i >> 1][3][i & 1]};
       {
         const bool odd = lq & 1;
@@ -942,7 +954,8 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
       if (ok) {
         floatx4 v = {y[0], y[1], y[2], y[3]};
         if (a.bias) v += *reinterpret_cast<const floatx4*>(a.bias + ncol);
-        if (a.residual) v += *reinterpret_cast<const floatx4*>(a.residual + obase);
+        if (PRE) { if (a.residual) v += *reinterpret_cast<const floatx4*>(a.residual + obase); }
+        else v += e_res[i];
         if (a.relu) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -1135,7 +1148,8 @@ const WinoGeom& cached_geom(int H, int W, int64_t n_img) {
 // batch-dependent part of the applicability test: 32-bit buffer offsets, staged range fits
 bool conv_wino_launchable(const ConvArgs& a) {
   const int64_t n_img = a.M / ((int64_t)a.Ho * a.Wo);
-  if (n_img * a.H * a.W * a.Cin * 4 >= (1ll << 31)) return false;
+  if (n_img * a.H * a.W * a.Cin * 4 >= (1ll << 31)) return false;  // 32-bit buffer offsets
+  if (a.M * a.Cout >= (1ll << 31)) return false;                  // 32-bit output element offsets
   const WinoGeom& g = cached_geom(a.H, a.W, n_img);
   return g.ok && g.Pmax <= kMaxNld * 64 && wino_lds_bytes(g.Pmax) <= 160 * 1024;
 }
