@@ -666,8 +666,13 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
   constexpr std::integral_constant<int, 1> SET_B{};
 
   int ubuf = 0;
-  issue_raw(SET_A, -1);  // stage 0
+  // pixel stages run two ahead of the one being stored in two alternating register sets, or
+  // (SETS == 1: the large staged ranges, where two sets would spill) one ahead in a single set.
+  // With two sets the loads of stage 1 leave together with those of stage 0: one memory latency
+  // at the head of the launch instead of two.
+  issue_raw(SET_A, -1);                 // stage 0
   issue_u(-1);
+  if (SETS == 2) issue_raw(SET_B, -1);  // stage 1: stored during chunk 0
   if (PRE) {
     __syncthreads();
     load_pre(0);
@@ -675,10 +680,8 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
   store_held(SET_A, ubuf, -1);
   __syncthreads();
   if (PRE) load_pre(1);  // chunk 0 stores stage 1
-  // pixel stages run two ahead of the one being stored in two alternating register sets, or
-  // (SETS == 1: the large staged ranges, where two sets would spill) one ahead in a single set
-  issue_raw(SET_B, -1);                 // stage 1: stored during chunk 0
   if (SETS == 2) issue_raw(SET_A, -1);  // stage 2: stored during chunk 1
+  else issue_raw(SET_B, -1);            // stage 1 (the single set is free again)
   issue_u(-1);                          // stage 1
 
   // ---- the lane's three pixel rows (E0,E1,E2) of its tile: LDS offsets (padding -> the zero slot)
