@@ -8,6 +8,21 @@ namespace hp {
 // activation applied by the conv epilogues (ConvArgs::relu)
 enum { HP_ACT_NONE = 0, HP_ACT_RELU = 1, HP_ACT_SWISH = 2 };
 
+// Division by a launch-time constant as multiply-high + shift: n / d = (umulhi(n, m) + n) >> l for
+// 0 <= n < 2^31, m = floor(2^32 (2^l - d) / d) + 1, l = ceil(log2 d).  A runtime integer division costs
+// ~40 vector instructions (a 64-bit one ~200), and the tile decodes at the head of every workgroup need
+// several per thread: a quarter of the 5x5 stem's time before they were replaced.
+struct FastDiv { unsigned m, l; };
+inline FastDiv make_fastdiv(unsigned d) {
+  if (d <= 1) return FastDiv{0u, 0u};
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  return FastDiv{(unsigned)((((1ull << l) - d) << 32) / d + 1), l};
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) { return (int)((__umulhi((unsigned)n, f.m) + (unsigned)n) >> f.l); }
+#endif
+
 struct ConvArgs {
   const float* x;          // NHWC [n][H][W][Cin]
   const float* w;          // packed [Cout][Kpad]
@@ -21,6 +36,7 @@ struct ConvArgs {
   int64_t M;               // n * Ho * Wo
   int H, W, Cin, Ho, Wo, Cout, stride, pad, Kpad, ktiles, relu;
   int tiles_m, tiles_n;    // filled by launch_conv
+  FastDiv fd_howo, fd_wo, fd_tn;  // by Ho*Wo, Wo, tiles_n (filled by the launchers; M < 2^31)
   // tail split-K of the patch kernel (filled by launch_conv_patch)
   int sk_regular, sk_S, sk_tail_items;
   float* sk_slabs;
@@ -41,6 +57,7 @@ struct ConvArgsH {
   int H, W, Cin, Ho, Wo, Cout, stride, pad, Kpad, ktiles, relu;
   int kh, kw;                 // filter size (selects the patch-staged 3x3 kernel)
   int tiles_m, tiles_n;       // filled by the launcher
+  FastDiv fd_howo, fd_wo, fd_tn;  // by Ho*Wo, Wo, tiles_n (filled by the launcher; M < 2^31)
 };
 
 // depthwise k x k conv + folded BN + swish (mbconv.hip)

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   int lin, slice;
   bool split;
   if (!splitk_decode(a, lin, slice, split)) return;
-  const int tile_m = lin / a.tiles_n, tile_n = lin % a.tiles_n;
+  const int tile_m = fdiv(lin, a.fd_tn), tile_n = lin - tile_m * a.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -216,9 +216,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   for (int i = 0; i < NA; ++i) {
     const int64_t m = m0 + r0 + 32 * i;
     if (m < a.M) {
-      const int img = (int)(m / HoWo);
-      const int rem = (int)(m - (int64_t)img * HoWo);
-      const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+      const int img = fdiv((int)m, a.fd_howo);
+      const int rem = (int)m - img * HoWo;
+      const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * a.Wo;
       ih0[i] = oh * a.stride - a.pad;
       iw0[i] = ow * a.stride - a.pad;
       rowoff[i] = (((int64_t)img * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
@@ -335,6 +335,10 @@ template <int BM, int BN, int PRE>
 static int launch_variant(ConvArgs args, hipStream_t stream) {
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = (args.Cout + BN - 1) / BN;  // weights / bias are padded to whole tiles; stores are not
+  if (args.M >= (1ll << 31)) return fail(HP_ERR_ARG, "conv: more than 2^31 output pixels");
+  args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
+  args.fd_wo = make_fastdiv((unsigned)args.Wo);
+  args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
   const int nblk = args.tiles_m * args.tiles_n;
   const size_t lds = Tile<BM, BN>::LDS_FLOATS * sizeof(float);
   int rc = conv_plan_split(args, nblk, lds, args.ktiles, 1, stream);

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int per_xcd = (nblk + 7) / 8;
   const int lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (lin >= nblk) return;
-  const int tile_m = lin / a.tiles_n, tile_n = lin % a.tiles_n;
+  const int tile_m = fdiv(lin, a.fd_tn), tile_n = lin - tile_m * a.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -90,9 +90,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   for (int i = 0; i < NA; ++i) {
     const int64_t m = m0 + r0 + 32 * i;
     if (m < a.M) {
-      const int img = (int)(m / HoWo);
-      const int rem = (int)(m - (int64_t)img * HoWo);
-      const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+      const int img = fdiv((int)m, a.fd_howo);
+      const int rem = (int)m - img * HoWo;
+      const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * a.Wo;
       ih0[i] = oh * a.stride - a.pad;
       iw0[i] = ow * a.stride - a.pad;
       rowoff[i] = (unsigned)(((((int64_t)img * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin) * 2);
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int per_xcd = (nblk + 7) / 8;
   const int lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (lin >= nblk) return;
-  const int tile_m = lin / a.tiles_n, tile_n = lin % a.tiles_n;
+  const int tile_m = fdiv(lin, a.fd_tn), tile_n = lin - tile_m * a.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int64_t g = m0 + wm + mt * 32 + frow;
     unsigned mk = 0;
     if (g < a.M) {
-      const int rem = (int)(g % ((int64_t)H * W));
-      const int oh = rem / W, ow = rem - oh * W;
+      const int rem = (int)g - fdiv((int)g, a.fd_howo) * (H * W);  // stride 1: Ho x Wo = H x W
+      const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * W;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
@@ -484,6 +484,10 @@ int launch_patch_variant(ConvArgsH args, hipStream_t stream) {
   if (lds < epi) lds = epi;
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = args.Cout / BN;
+  if (args.M >= (1ll << 31)) return fail(HP_ERR_ARG, "conv: more than 2^31 output pixels");
+  args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
+  args.fd_wo = make_fastdiv((unsigned)args.Wo);
+  args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
   const int nblk = args.tiles_m * args.tiles_n;
   hipLaunchKernelGGL((conv3x3_patch_f16<BN, PRE, NPC>), dim3(8 * ((nblk + 7) / 8)), dim3(kThreads), lds, stream, args, P);
   return check_launch("conv3x3_patch_f16");
@@ -518,6 +522,10 @@ int launch_variant(ConvArgsH args, hipStream_t stream) {
   }
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = args.Cout / BN;
+  if (args.M >= (1ll << 31)) return fail(HP_ERR_ARG, "conv: more than 2^31 output pixels");
+  args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
+  args.fd_wo = make_fastdiv((unsigned)args.Wo);
+  args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
   const int nblk = args.tiles_m * args.tiles_n;
   hipLaunchKernelGGL((conv_igemm_f16<BN, PRE>), dim3(8 * ((nblk + 7) / 8)), dim3(kThreads), lds_bytes_f16<BN>(), stream, args);
   return check_launch("conv_igemm_f16");

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   int tile, slice;
   bool split;
   if (!splitk_decode(a, tile, slice, split)) return;
-  const int tile_m = tile / a.tiles_n, tile_n = tile % a.tiles_n;
+  const int tile_m = fdiv(tile, a.fd_tn), tile_n = tile - tile_m * a.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int64_t g = m0 + wm + mt * 32 + frow;
     unsigned mk = 0;
     if (g < a.M) {
-      const int rem = (int)(g % ((int64_t)H * W));
-      const int oh = rem / W, ow = rem - oh * W;
+      const int rem = (int)g - fdiv((int)g, a.fd_howo) * (H * W);  // stride 1: Ho x Wo = H x W
+      const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * W;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
@@ -307,6 +307,10 @@ int launch(ConvArgs args, hipStream_t stream, bool* opted) {
   }
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = args.Cout / BN;
+  if (args.M >= (1ll << 31)) return fail(HP_ERR_ARG, "conv: more than 2^31 output pixels");
+  args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
+  args.fd_wo = make_fastdiv((unsigned)args.Wo);
+  args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
   const int T = args.tiles_m * args.tiles_n;
   int rc = conv_plan_split(args, T, lds, args.Cin / BK, 9, stream);
   if (rc) return rc;

@@ -58,17 +58,7 @@ constexpr int BN = 32;        // output channels per item
 constexpr int TPB = 64;       // tiles per item (16 per wave)
 constexpr int U_BUF = 16 * 4 * BN * 4;  // floats per weight buffer: [pos][kg][cout] float4
 
-// division by a launch-time constant as multiply-high + shift (an integer division costs ~35
-// instructions on the vector unit, and the tile / item decodes need a dozen per item):
-// n / d = (umulhi(n, m) + n) >> l for n < 2^31, m = floor(2^32 (2^l - d) / d) + 1, l = ceil(log2 d)
-struct FastDiv { unsigned m, l; };
-inline FastDiv make_fastdiv(unsigned d) {
-  if (d <= 1) return FastDiv{0u, 0u};
-  unsigned l = 0;
-  while ((1ull << l) < d) ++l;
-  return FastDiv{(unsigned)((((1ull << l) - d) << 32) / d + 1), l};
-}
-__device__ __forceinline__ int fdiv(int n, const FastDiv& f) { return (int)((__umulhi((unsigned)n, f.m) + (unsigned)n) >> f.l); }
+// (FastDiv / fdiv: conv.h)
 struct WinoDiv { FastDiv per, tw, tn; };  // by TH*TW, TW, tiles_n
 
 // pixel-linear range [lo, lo + P) that the tiles of item row bm touch (whole image rows)
