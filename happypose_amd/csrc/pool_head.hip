@@ -7,17 +7,17 @@
 namespace hp {
 
 // ---- 3x3 stride-2 pad-1 max pooling, NHWC, 4 channels per lane ------------------------
-__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* x, float* y, int n, int H, int W,
-                                                         int C, int Ho, int Wo) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// grid.y = output row (img * Ho + oh), threads over (ow, channel quad): the index decode is one
+// multiply-high per thread -- with a flat 64-bit index it was three 64-bit divisions (~600 instructions)
+// for nine loads, which made this bandwidth kernel instruction-bound.
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* x, float* y, int H, int W, int C, int Ho, int Wo,
+                                                         FastDiv fd_c4, FastDiv fd_ho) {
   const int C4 = C / 4;
-  const int64_t total = (int64_t)n * Ho * Wo * C4;
-  if (idx >= total) return;
-  const int c4 = (int)(idx % C4);
-  int64_t p = idx / C4;
-  const int ow = (int)(p % Wo); p /= Wo;
-  const int oh = (int)(p % Ho);
-  const int img = (int)(p / Ho);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Wo * C4) return;
+  const int ow = fdiv(t, fd_c4), c4 = t - ow * C4;
+  const int row = blockIdx.y, img = fdiv(row, fd_ho), oh = row - img * Ho;
+  const float* xin = x + (int64_t)img * H * W * C + 4 * c4;
   float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy) {
@@ -27,11 +27,11 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* x, float* 
     for (int dx = 0; dx < 3; ++dx) {
       const int iw = ow * 2 - 1 + dx;
       if ((unsigned)iw >= (unsigned)W) continue;
-      const float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)img * H + ih) * W + iw) * C + 4 * c4);
+      const float4 v = *reinterpret_cast<const float4*>(xin + (ih * W + iw) * C);
       m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
   }
-  *reinterpret_cast<float4*>(y + (((int64_t)img * Ho + oh) * Wo + ow) * C + 4 * c4) = m;
+  *reinterpret_cast<float4*>(y + ((int64_t)row * Wo + ow) * C + 4 * c4) = m;
 }
 
 // ---- head: spatial mean -> [fc 512x512 + bias] -> pose / logits linear heads -----------
@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
 }
 
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream) {
-  const int64_t total = (int64_t)n * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(maxpool3x3s2_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, n, H, W, C, Ho, Wo);
+  if ((int64_t)n * Ho >= 65536 || (int64_t)H * W * C >= (1ll << 31)) return fail(HP_ERR_ARG, "maxpool3x3s2_nhwc: tensor too large");
+  const int per_row = Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc, dim3((unsigned)((per_row + 255) / 256), (unsigned)(n * Ho)), dim3(256), 0, stream, x, y, H, W,
+                     C, Ho, Wo, make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)Ho));
   return check_launch("maxpool3x3s2_nhwc");
 }
 
