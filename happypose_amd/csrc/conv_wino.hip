@@ -813,7 +813,7 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[q][j], bf[q & 1][nt][j],
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[q & 1][nt][j], V[q][j],  // D[cout][tile]
                                                               FIRST && j == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[q][nt], 0, 0, 0);
         if (q == 7) {  // V[0..3] of the next chunk (this chunk's were consumed by steps 0-3) and the rows of V[4..7]
           xform_first();
@@ -841,28 +841,30 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
     HP_STAMP(stamp_slot + 1);
 #endif
 
-    // ---- where the lane's results go: whole items -- all four tiles of the lane group for the cout half
-    //      nt = role; half items -- tiles 2 role, 2 role + 1 for the item's cout half.  The residual is
-    //      requested NOW, so that its latency (HBM for the 60x80 layers) passes under the output
-    //      transform and the exchange instead of inside the store loop.
-    const int lq = lane & 3;
-    const int ncol = n0 + (NT == 2 ? role * 16 : hoff / 4) + ((lane & 15) & ~3);
-    int e_off[2 * NT];
-    bool e_ok[2 * NT];
-    floatx4 e_res[2 * NT];
+    // ---- where the lane's results go.  The weights are the A operand of the MFMAs, so a lane's four
+    //      accumulator elements are 4 CONSECUTIVE COUTS (4 kg .. 4 kg + 3 of the 16-cout tile) of ONE
+    //      tile (lane & 15): after the output transform it holds the 2x2 pixels of that tile for those
+    //      couts and stores them as 16-B accesses with no cross-lane transpose.  Whole items: all four
+    //      pixels for the cout half nt = role; half items: pixels 2 role, 2 role + 1 of the one cout
+    //      tile.  The residual is requested NOW, so that its latency (HBM for the 60x80 layers) passes
+    //      under the output transform and the exchange instead of inside the store loop.
+    constexpr int NPX = 2 * NT;  // pixels this wave finishes
+    const int ncol = n0 + (NT == 2 ? role * 16 : hoff / 4) + 4 * kg;
+    int e_off[NPX];
+    bool e_ok[NPX];
+    floatx4 e_res[NPX];
     {
-      const int go0 = bm * TPB + tg * 16 + 4 * kg + (NT == 2 ? 0 : 2 * role);
-      const int gc = go0 < T ? go0 : 0;
-      int e_img = fdiv(gc, fd.per);
+      const int g = bm * TPB + tg * 16 + (lane & 15);
+      const int gc = g < T ? g : 0;
+      const int e_img = fdiv(gc, fd.per);
       const int r = gc - e_img * (TH * TW);
-      int e_th = fdiv(r, fd.tw);
-      int e_tw = r - e_th * TW;
+      const int e_th = fdiv(r, fd.tw), e_tw = r - e_th * TW;
 #pragma unroll
-      for (int i = 0; i < 2 * NT; ++i) {
-        const int oh = 2 * e_th + (lq >> 1), ow = 2 * e_tw + (lq & 1);
-        e_ok[i] = (go0 + i < T) & (oh < a.Ho) & (ow < a.Wo);
+      for (int i = 0; i < NPX; ++i) {
+        const int px = NT == 2 ? i : 2 * role + i;
+        const int oh = 2 * e_th + (px >> 1), ow = 2 * e_tw + (px & 1);
+        e_ok[i] = (g < T) & (oh < a.Ho) & (ow < a.Wo);
         e_off[i] = ((e_img * a.Ho + oh) * a.Wo + ow) * a.Cout + ncol;  // < 2^31: conv_wino_launchable
-        if (++e_tw == TW) { e_tw = 0; if (++e_th == TH) { e_th = 0; ++e_img; } }
         e_res[i] = floatx4{0.f, 0.f, 0.f, 0.f};
         // (not in the PRE instantiations: they are at the register limit, and the layers that take the
         // BN+ReLU prologue -- the first conv of a residual block -- have no residual input)
@@ -872,13 +874,13 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
     // ---- output transform.  Local rows L0 = acc[0..3], L1 = acc[4..7]:
     //      role 0: L0 = M row 0, L1 = M row 1   ->  partial of Y row 0: L0 + L1,  of Y row 1: L1
     //      role 1: L0 = -M row 3, L1 = M row 2  ->  partial of Y row 0: L1,       of Y row 1: L0 - L1
-    //      then the column transform; the partners swap the half they do not finish through LDS.
+    //      then the column transform; the partners swap what they do not finish through LDS.
     //      (two copies of the code behind a wave-uniform branch: with the role known at compile
     //      time half of the row arithmetic and all keep/send selects disappear)
-    //      All of it on register PAIRS over the accumulator elements (i, i+1) -- the pairs the MFMA
-    //      results already sit in -- with explicit packed adds: left to itself hipcc SLP-packs these
-    //      adds across other dimensions and spends more v_mov on building the pairs than it saves.
-    floatx2 yk[2][4];  // [i pair][pixel]: the cout half this wave finishes (nt == role)
+    //      All of it on the register PAIRS (couts c, c+1) the MFMA results already sit in, with
+    //      explicit packed adds: left to itself hipcc SLP-packs these adds across other dimensions
+    //      and spends more v_mov on building the pairs than it saves.
+    floatx2 yk[2][NPX];  // [cout pair][pixel this wave finishes]
     auto partial = [&](auto role_c) {
       constexpr int R = decltype(role_c)::value;
       auto half = [&](auto nt_c, floatx2(&y)[2][4]) {
@@ -908,13 +910,13 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
         }
         __builtin_amdgcn_sched_barrier(0);
         half(std::integral_constant<int, R>{}, yk);
-      } else {  // half item: one cout tile; role r finishes tile pair r and sends the other pair
+      } else {  // half item: one cout tile; role r finishes pixels 2r, 2r + 1 and sends the other two
         floatx2 y[2][4];
         half(std::integral_constant<int, 0>{}, y);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          *reinterpret_cast<floatx2*>(xl + ((wave * 8 + k) * 64 + lane) * 2) = y[1 - R][k];
-          yk[0][k] = y[R][k];
+          *reinterpret_cast<floatx2*>(xl + ((wave * 8 + k) * 64 + lane) * 2) = y[k >> 1][2 * (1 - R) + (k & 1)];
+          yk[k >> 1][k & 1] = y[k >> 1][2 * R + (k & 1)];
         }
       }
     };
@@ -922,40 +924,21 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
     else partial(std::integral_constant<int, 1>{});
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4 * NT; ++k)
-      yk[k >> 2][k & 3] = add2(yk[k >> 2][k & 3], *reinterpret_cast<const floatx2*>(xl + (((wave ^ 4) * 8 + k) * 64 + lane) * 2));
-    // epilogue as in the kernel above, with the addresses and the residual fetched up front
+    for (int k = 0; k < 2 * NPX; ++k)  // slot k = [cout pair k / NPX][pixel k % NPX]: the layout both sides wrote
+      yk[k / NPX][k % NPX] = add2(yk[k / NPX][k % NPX], *reinterpret_cast<const floatx2*>(xl + (((wave ^ 4) * 8 + k) * 64 + lane) * 2));
 #pragma unroll
-    for (int i = 0; i < 2 * NT; ++i) {
-      const bool ok = e_ok[i];
-      const int obase = e_off[i];
-      float y[4] = {yk[i >> 1][0][i & 1], yk[i >> 1][1][i & 1], yk[i >> 1][2][i & 1], yk[i >> 1][3][i & 1]};
-      {
-        const bool odd = lq & 1;
-        const float s0 = odd ? y[0] : y[1], s1 = odd ? y[2] : y[3];
-        const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
-        const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
-        if (odd) { y[0] = x0; y[2] = x1; } else { y[1] = x0; y[3] = x1; }
-      }
-      {
-        const bool hi = lq & 2;
-        const float s0 = hi ? y[0] : y[2], s1 = hi ? y[1] : y[3];
-        const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));
-        const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
-        if (hi) { y[0] = x0; y[1] = x1; } else { y[2] = x0; y[3] = x1; }
-      }
-      if (ok) {
-        floatx4 v = {y[0], y[1], y[2], y[3]};
+    for (int i = 0; i < NPX; ++i) {
+      if (e_ok[i]) {
+        floatx4 v = {yk[0][i].x, yk[0][i].y, yk[1][i].x, yk[1][i].y};
         if (a.bias) v += *reinterpret_cast<const floatx4*>(a.bias + ncol);
-        if (PRE) { if (a.residual) v += *reinterpret_cast<const floatx4*>(a.residual + obase); }
+        if (PRE) { if (a.residual) v += *reinterpret_cast<const floatx4*>(a.residual + e_off[i]); }
         else v += e_res[i];
         if (a.relu) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
         }
-        *reinterpret_cast<floatx4*>(a.y + obase) = v;
+        *reinterpret_cast<floatx4*>(a.y + e_off[i]) = v;
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef HP_WABL_TIMING
     HP_STAMP(stamp_slot + 2);
