@@ -51,6 +51,9 @@ _PROTOS = {
     "hp_crop_roi_align": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, c_f32p, C.POINTER(Strides), c_f32p,
                                     C.c_int, C.c_void_p]),
+    "hp_crop_roi_align_f16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Strides), c_f32p,
+                                        C.c_int, C.c_void_p]),
     "hp_pose_update": (C.c_int, [C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "hp_tco_init_autodepth": (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p,
                                         c_f32p, c_i32p, c_i32p, C.c_int, c_f32p, C.c_void_p]),
@@ -62,6 +65,8 @@ _PROTOS = {
     "hp_net_precision": (C.c_int, [C.c_void_p]),
     "hp_net_finalize": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_net_forward": (C.c_int, [C.c_void_p, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "hp_net_forward_f16in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "hp_net_input_channels_f16": (C.c_int, [C.c_void_p]),
     "hp_net_flops_per_sample": (C.c_double, [C.c_void_p]),
     "hp_net_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_conv_occupancy": (C.c_int, [C.c_int]),

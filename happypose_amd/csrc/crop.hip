@@ -25,7 +25,7 @@ namespace hp {
 struct CropArgs {
   const float* images; int Bi, C, NC, H, W;
   const float* boxes; const int32_t* im_ids; int n, oh, ow, sr;
-  float* out; hp_strides os;
+  void* out; int out_half; hp_strides os;  // fp32, or fp16 when the crop feeds an fp16 network input directly
   const float* depth_norm_z; int depth_norm_mode;
 };
 
@@ -210,23 +210,27 @@ __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
   }
   // channel-interleaved destination (NHWC slice of the network input): one 12-B store per pixel
   typedef float float3v __attribute__((ext_vector_type(3)));
-  if (a.os.s_chan == 1 && a.NC == 3) {
-    *reinterpret_cast<float3v*>(a.out + obase) = float3v{outv[0], outv[1], outv[2]};
-  } else {
+  if (a.out_half) {  // strides count fp16 elements
+    _Float16* const o = reinterpret_cast<_Float16*>(a.out);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      if (c < a.NC) a.out[obase + (int64_t)c * a.os.s_chan] = outv[c];
+      if (c < a.NC) o[obase + (int64_t)c * a.os.s_chan] = (_Float16)outv[c];
+  } else if (a.os.s_chan == 1 && a.NC == 3) {
+    *reinterpret_cast<float3v*>(reinterpret_cast<float*>(a.out) + obase) = float3v{outv[0], outv[1], outv[2]};
+  } else {
+    float* const o = reinterpret_cast<float*>(a.out);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < a.NC) o[obase + (int64_t)c * a.os.s_chan] = outv[c];
   }
 }
 
 }  // namespace hp
 
-extern "C" int hp_crop_roi_align(const float* d_images, int Bi, int C, int n_channels, int H, int W,
-                                 const float* d_boxes, const int32_t* d_im_ids, int n, int out_h,
-                                 int out_w, int sampling_ratio, float* d_out,
-                                 const hp_strides* out_strides, const float* d_depth_norm_z,
-                                 int depth_norm_mode, void* stream) {
-  using namespace hp;
+namespace hp {
+static int crop_launch(const float* d_images, int Bi, int C, int n_channels, int H, int W, const float* d_boxes,
+                       const int32_t* d_im_ids, int n, int out_h, int out_w, int sampling_ratio, void* d_out, int out_half,
+                       const hp_strides* out_strides, const float* d_depth_norm_z, int depth_norm_mode, void* stream) {
   HP_REQUIRE(d_images && out_strides, "hp_crop_roi_align: null pointer");
   HP_REQUIRE(C == 3 || C == 4, "hp_crop_roi_align: images must have 3 (rgb) or 4 (rgbd) channels");
   HP_REQUIRE((n_channels == 3 || n_channels == 4) && n_channels <= C, "hp_crop_roi_align: n_channels must be 3 or 4 and <= C");
@@ -237,8 +241,27 @@ extern "C" int hp_crop_roi_align(const float* d_images, int Bi, int C, int n_cha
   if (n == 0) return HP_OK;
   HP_REQUIRE(d_boxes && d_im_ids && d_out, "hp_crop_roi_align: null pointer");
   CropArgs a{d_images, Bi, C, n_channels, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio,
-             d_out, *out_strides, d_depth_norm_z, depth_norm_mode};
+             d_out, out_half, *out_strides, d_depth_norm_z, depth_norm_mode};
   dim3 grid((out_w + 15) / 16, (out_h + 15) / 16, n);
   hipLaunchKernelGGL(crop_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("crop_kernel");
+}
+}  // namespace hp
+
+extern "C" int hp_crop_roi_align(const float* d_images, int Bi, int C, int n_channels, int H, int W,
+                                 const float* d_boxes, const int32_t* d_im_ids, int n, int out_h,
+                                 int out_w, int sampling_ratio, float* d_out,
+                                 const hp_strides* out_strides, const float* d_depth_norm_z,
+                                 int depth_norm_mode, void* stream) {
+  return hp::crop_launch(d_images, Bi, C, n_channels, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio, d_out, 0,
+                         out_strides, d_depth_norm_z, depth_norm_mode, stream);
+}
+
+extern "C" int hp_crop_roi_align_f16(const float* d_images, int Bi, int C, int n_channels, int H, int W,
+                                     const float* d_boxes, const int32_t* d_im_ids, int n, int out_h,
+                                     int out_w, int sampling_ratio, void* d_out_f16,
+                                     const hp_strides* out_strides, const float* d_depth_norm_z,
+                                     int depth_norm_mode, void* stream) {
+  return hp::crop_launch(d_images, Bi, C, n_channels, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio, d_out_f16, 1,
+                         out_strides, d_depth_norm_z, depth_norm_mode, stream);
 }

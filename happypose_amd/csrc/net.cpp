@@ -533,13 +533,16 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   return HP_OK;
 }
 
-static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose, float* d_logits,
+// d_x: fp32 input [batch][h][w][c_pad]; or (fp16 plan only) d_x16: fp16 input [batch][h][w][cin16 of the stem]
+static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int batch, float* d_pose, float* d_logits,
                          float* d_features, hipStream_t stream) {
   int rc;
   const bool f16 = net->precision == HP_PRECISION_F16;
-  if (f16 && (rc = launch_cast_pad_f16(d_x, net->x16.p, (int64_t)batch * net->h * net->w, net->c_pad,
-                                       net->convs[0]->cin16, stream)))
-    return rc;
+  if (f16 && !d_x16) {
+    if ((rc = launch_cast_pad_f16(d_x, net->x16.p, (int64_t)batch * net->h * net->w, net->c_pad, net->convs[0]->cin16, stream)))
+      return rc;
+    d_x16 = net->x16.p;
+  }
   static const bool sync_ops = std::getenv("HP_NET_SYNC") != nullptr;  // diagnostics: fault isolation
   static const bool per_launch = std::getenv("HP_PROFILE_LAYERS") != nullptr;
   // profiling: events are recorded on the launch stream and only READ in hp_net_profile_collect
@@ -572,7 +575,7 @@ static int forward_chunk(hp_net* net, const float* d_x, int batch, float* d_pose
     if (op.kind == OP_CONV && f16) {
       ConvLayer& L = *net->convs[op.conv];
       ConvArgsH a{};
-      a.x = (const _Float16*)(L.in_buf < 0 ? net->x16.p : net->bufs[L.in_buf].p);
+      a.x = (const _Float16*)(L.in_buf < 0 ? d_x16 : net->bufs[L.in_buf].p);
       a.w = (const _Float16*)L.w16.p;
       a.bias = (const float*)L.bias.p;
       a.residual = L.res_buf < 0 ? nullptr : (const _Float16*)net->bufs[L.res_buf].p;
@@ -684,7 +687,33 @@ extern "C" int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d
   const size_t in_stride = (size_t)net->h * net->w * net->c_pad;
   for (int b0 = 0; b0 < batch; b0 += net->max_batch) {
     const int nb = batch - b0 < net->max_batch ? batch - b0 : net->max_batch;
-    int rc = forward_chunk(net, d_x + (size_t)b0 * in_stride, nb,
+    int rc = forward_chunk(net, d_x + (size_t)b0 * in_stride, nullptr, nb,
+                           d_pose ? d_pose + (size_t)b0 * net->pose_dim : nullptr,
+                           d_logits ? d_logits + (size_t)b0 * net->n_logits : nullptr,
+                           d_features ? d_features + (size_t)b0 * net->n_features : nullptr, st);
+    if (rc) return rc;
+  }
+  return HP_OK;
+}
+
+extern "C" int hp_net_input_channels_f16(const hp_net* net) {
+  return net && net->finalized && net->precision == HP_PRECISION_F16 ? net->convs[0]->cin16 : HP_ERR_ARG;
+}
+
+extern "C" int hp_net_forward_f16in(hp_net* net, const void* d_x16, int batch, float* d_pose, float* d_logits,
+                                    float* d_features, void* stream) {
+  HP_REQUIRE(net && net->finalized, "hp_net_forward_f16in: network not finalized");
+  HP_REQUIRE(net->precision == HP_PRECISION_F16, "hp_net_forward_f16in: the network was not planned in fp16");
+  HP_REQUIRE(batch >= 0, "hp_net_forward_f16in: negative batch");
+  if (batch == 0) return HP_OK;
+  HP_REQUIRE(d_x16, "hp_net_forward_f16in: null input");
+  HP_REQUIRE(!d_pose || net->pose_dim > 0, "hp_net_forward_f16in: network has no pose head");
+  HP_REQUIRE(!d_logits || net->n_logits > 0, "hp_net_forward_f16in: network has no logits head");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t in_stride = (size_t)net->h * net->w * net->convs[0]->cin16 * sizeof(_Float16);
+  for (int b0 = 0; b0 < batch; b0 += net->max_batch) {
+    const int nb = batch - b0 < net->max_batch ? batch - b0 : net->max_batch;
+    int rc = forward_chunk(net, nullptr, (const char*)d_x16 + (size_t)b0 * in_stride, nb,
                            d_pose ? d_pose + (size_t)b0 * net->pose_dim : nullptr,
                            d_logits ? d_logits + (size_t)b0 * net->n_logits : nullptr,
                            d_features ? d_features + (size_t)b0 * net->n_features : nullptr, st);

@@ -465,15 +465,24 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
     // channel-interleaved destinations (NHWC slices of the network input): one 12-B store per pixel
     // instead of three 4-B ones (the slice is 4-B aligned only, so no wider)
     typedef float float3v __attribute__((ext_vector_type(3)));
+    const bool half_out = (a.flags & HP_RASTER_OUT_F16) != 0;  // fp16 network input written directly
     if (a.rgb) {
-      if (a.cs.s_chan == 1) *reinterpret_cast<float3v*>(a.rgb + co) = float3v{o_rgb[0], o_rgb[1], o_rgb[2]};
+      if (half_out) {
+        _Float16* const o = reinterpret_cast<_Float16*>(a.rgb);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[co + c * a.cs.s_chan] = (_Float16)o_rgb[c];
+      } else if (a.cs.s_chan == 1) *reinterpret_cast<float3v*>(a.rgb + co) = float3v{o_rgb[0], o_rgb[1], o_rgb[2]};
       else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) a.rgb[co + c * a.cs.s_chan] = o_rgb[c];
       }
     }
     if (a.nrm) {
-      if (a.cs.s_chan == 1) *reinterpret_cast<float3v*>(a.nrm + co) = float3v{o_n[0], o_n[1], o_n[2]};
+      if (half_out) {
+        _Float16* const o = reinterpret_cast<_Float16*>(a.nrm);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[co + c * a.cs.s_chan] = (_Float16)o_n[c];
+      } else if (a.cs.s_chan == 1) *reinterpret_cast<float3v*>(a.nrm + co) = float3v{o_n[0], o_n[1], o_n[2]};
       else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) a.nrm[co + c * a.cs.s_chan] = o_n[c];
@@ -485,7 +494,9 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
       if (a.depth_norm_mode == 1) d = d / zn;
       else if (a.depth_norm_mode == 2) d = fminf(fmaxf(d / zn, 0.0f), 2.0f) - 1.0f;
       else if (a.depth_norm_mode == 3) d = fminf(fmaxf(d - zn, -2.0f), 2.0f);
-      a.depth[dbase + (int64_t)i * a.ds.s_row + (int64_t)j * a.ds.s_col] = d;
+      const int64_t dof = dbase + (int64_t)i * a.ds.s_row + (int64_t)j * a.ds.s_col;
+      if (half_out) reinterpret_cast<_Float16*>(a.depth)[dof] = (_Float16)d;
+      else a.depth[dof] = d;
     }
   }
 }

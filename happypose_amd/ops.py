@@ -137,13 +137,16 @@ def rasterize_into(store: MeshStore, x: torch.Tensor, chan0: int, obj_ids: torch
     assert chan0 + V * c_r <= cp
     TCV_O, KV, obj_ids = _f32(TCV_O, dev), _f32(KV, dev), _i32(obj_ids, dev)
     cs = Strides(h * w * cp, c_r, 1, w * cp, cp)
-    base = x.data_ptr() + 4 * chan0
+    assert x.dtype in (torch.float32, torch.float16) and x.is_contiguous()
+    esz = x.element_size()  # fp16: the input of an fp16 network plan, written directly (HP_RASTER_OUT_F16)
+    base = x.data_ptr() + esz * chan0
     rgb_p = C.c_void_p(base)
-    nrm_p = C.c_void_p(base + 4 * 3) if render_normals else None
-    dep_p = C.c_void_p(base + 4 * (6 if render_normals else 3)) if render_depth else None
+    nrm_p = C.c_void_p(base + esz * 3) if render_normals else None
+    dep_p = C.c_void_p(base + esz * (6 if render_normals else 3)) if render_depth else None
+    flags = 8 | (16 if x.dtype == torch.float16 else 0)
     with torch.cuda.device(dev):
         check(lib().hp_rasterize(store.handle, b * V, V, ptr(obj_ids), ptr(TCV_O), ptr(KV), ptr(ambient), 0,
-                                 None, None, h, w, 8, rgb_p, nrm_p, C.byref(cs), dep_p, C.byref(cs), None,
+                                 None, None, h, w, flags, rgb_p, nrm_p, C.byref(cs), dep_p, C.byref(cs), None,
                                  ptr(depth_norm_z), depth_norm_mode if render_depth else 0, stream_ptr(dev)),
               "hp_rasterize")
 
@@ -197,12 +200,14 @@ def crop_roi_align(images: torch.Tensor, boxes: torch.Tensor, im_ids: torch.Tens
     else:
         res = out
         assert out.shape[:3] == (n, oh, ow) and out.shape[3] >= Cc and out.is_contiguous()
+        assert out.dtype in (torch.float32, torch.float16)
         cp = out.shape[3]
         st = Strides(oh * ow * cp, 0, 1, ow * cp, cp)
+    fn = lib().hp_crop_roi_align_f16 if res.dtype == torch.float16 else lib().hp_crop_roi_align
     with torch.cuda.device(dev):
-        check(lib().hp_crop_roi_align(ptr(images), Bi, Ct, Cc, H, W, ptr(boxes), ptr(im_ids), n, oh, ow,
-                                      sampling_ratio, ptr(res), C.byref(st), ptr(depth_norm_z),
-                                      depth_norm_mode if Cc == 4 else 0, stream_ptr(dev)),
+        check(fn(ptr(images), Bi, Ct, Cc, H, W, ptr(boxes), ptr(im_ids), n, oh, ow,
+                 sampling_ratio, ptr(res), C.byref(st),
+                 ptr(depth_norm_z), depth_norm_mode if Cc == 4 else 0, stream_ptr(dev)),
               "hp_crop_roi_align")
     return res
 
@@ -289,13 +294,29 @@ class Net:
         return C.c_void_p(self._h)
 
     def new_input(self, batch: int) -> torch.Tensor:
-        """Zeroed NHWC input buffer ``[batch,h,w,c_pad]`` (pad channels must stay 0)."""
+        """Zeroed NHWC input buffer (pad channels must stay 0): fp32 ``[batch,h,w,c_pad]``, or for an
+        fp16 plan fp16 ``[batch,h,w,c16]`` -- crop and rasteriser write it directly and ``forward``
+        skips the conversion pass (``hp_net_forward_f16in``)."""
+        if self.precision == "f16":
+            c16 = lib().hp_net_input_channels_f16(self.handle)
+            assert c16 > 0, lib().hp_last_error().decode()
+            return torch.zeros((batch, self.h, self.w, c16), dtype=torch.float16, device=self.device)
         return torch.zeros((batch, self.h, self.w, self.c_pad), dtype=torch.float32, device=self.device)
 
     def forward(self, x: torch.Tensor, want_pose=True, want_logits=False, want_features=False):
         b = x.shape[0]
-        assert x.shape == (b, self.h, self.w, self.c_pad) and x.is_contiguous() and x.dtype == torch.float32
         f = dict(dtype=torch.float32, device=self.device)
+        if x.dtype == torch.float16:
+            assert self.precision == "f16" and x.is_contiguous() and x.shape[:3] == (b, self.h, self.w)
+            assert x.shape[3] == lib().hp_net_input_channels_f16(self.handle)
+            pose = torch.empty((b, self.pose_dim), **f) if (want_pose and self.pose_dim) else None
+            logits = torch.empty((b, self.n_logits), **f) if (want_logits and self.n_logits) else None
+            feats = torch.empty((b, self.n_features), **f) if want_features else None
+            with torch.cuda.device(self.device):
+                check(lib().hp_net_forward_f16in(self.handle, C.c_void_p(x.data_ptr()), b, ptr(pose), ptr(logits), ptr(feats),
+                                                 stream_ptr(self.device)), "hp_net_forward_f16in")
+            return pose, logits, feats
+        assert x.shape == (b, self.h, self.w, self.c_pad) and x.is_contiguous() and x.dtype == torch.float32
         pose = torch.empty((b, self.pose_dim), **f) if (want_pose and self.pose_dim) else None
         logits = torch.empty((b, self.n_logits), **f) if (want_logits and self.n_logits) else None
         feats = torch.empty((b, self.n_features), **f) if want_features else None

@@ -147,7 +147,7 @@ class _RenderAndCompare:
     def _pixels(self, x, n_img_channels, n_render_channels):
         if not self.keep_pixels:
             return None, None
-        nchw = x.permute(0, 3, 1, 2)
+        nchw = x.permute(0, 3, 1, 2).float()  # fp16 when the backbone is planned in fp16
         return (nchw[:, :n_img_channels].contiguous(),
                 nchw[:, n_img_channels:n_img_channels + n_render_channels].contiguous())
 

@@ -87,6 +87,9 @@ const float* hp_mesh_store_points(const hp_mesh_store* store);
  * 3 tCR_center_clamp (clamp(d-z,-2,2)).
  * ---------------------------------------------------------------------------------- */
 #define HP_RASTER_QUANT8 8
+/* d_rgb / d_nrm / d_depth point at fp16 tensors (strides in fp16 elements): views rendered straight into
+ * the input of an fp16 network plan (hp_net_forward_f16in).  The mask stays uint8. */
+#define HP_RASTER_OUT_F16 16
 
 typedef struct {
   int64_t s_item, s_view, s_chan, s_row, s_col;
@@ -143,6 +146,12 @@ int hp_crop_roi_align(const float* d_images, int Bi, int C, int n_channels, int 
                       int n, int out_h, int out_w, int sampling_ratio, float* d_out,
                       const hp_strides* out_strides, const float* d_depth_norm_z,
                       int depth_norm_mode, void* stream);
+/* The same with an fp16 destination (strides in fp16 elements): the crop of an fp16 network plan
+ * (hp_net_set_precision) written straight into the tensor hp_net_forward_f16in reads. */
+int hp_crop_roi_align_f16(const float* d_images, int Bi, int C, int n_channels, int H, int W,
+                          const float* d_boxes, const int32_t* d_im_ids, int n, int out_h, int out_w,
+                          int sampling_ratio, void* d_out_f16, const hp_strides* out_strides,
+                          const float* d_depth_norm_z, int depth_norm_mode, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Pose update.  Replaces PosePredictor.update_pose (MP/models/pose_rigid.py:339-350 ->
@@ -206,6 +215,12 @@ int hp_net_precision(const hp_net* net);
 int hp_net_finalize(hp_net* net, int max_batch);
 int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d_pose, float* d_logits,
                    float* d_features, void* stream);
+/* fp16 plan only: the input already in fp16, NHWC [batch][h][w][hp_net_input_channels_f16()] with the
+ * channels past n_inputs zero (hp_crop_roi_align_f16 / hp_rasterize with HP_RASTER_OUT_F16 write it):
+ * saves the fp32 -> fp16 conversion pass of hp_net_forward (5 % of a coarse-scoring step). */
+int hp_net_input_channels_f16(const hp_net* net);
+int hp_net_forward_f16in(hp_net* net, const void* d_x16, int batch, float* d_pose, float* d_logits,
+                         float* d_features, void* stream);
 /* total multiply-accumulate FLOPs (2*MAC) of one sample through conv + linear layers */
 double hp_net_flops_per_sample(const hp_net* net);
 /* Profiling of the dominant kernel: with hp_net_set_profiling(net, 1) every conv launch is

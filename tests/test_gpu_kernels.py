@@ -177,6 +177,29 @@ def test_rasterizer_lights_and_nhwc(dev, scene_store):
             assert (np.abs(sl[..., 6][ok] - dn[ok]) > 1e-5).mean() < 1e-3
 
 
+def test_crop_and_raster_into_f16_input(dev, scene_store):
+    """fp16 destinations (the input tensor of an fp16 network plan): the same values as the fp32
+    destinations, rounded to fp16 once -- bit for bit."""
+    from happypose_amd import ops
+
+    rs = np.random.RandomState(3)
+    img = torch.as_tensor(rs.rand(2, 4, 480, 640).astype(np.float32), device=dev)
+    boxes = torch.as_tensor(np.array([[100.3, 80.2, 420.7, 320.1], [-50, -40, 300, 222.5], [0, 0, 640, 480]], np.float32))
+    ids = torch.as_tensor(np.array([0, 1, 1], np.int32))
+    z = torch.tensor([0.5, 0.7, 0.6], device=dev)
+    T = torch.as_tensor(_poses(6, 12)).view(3, 2, 4, 4)
+    K = torch.as_tensor(np.tile(np.array([[800.0, 0, 160], [0, 800.0, 120], [0, 0, 1]], np.float32), (3, 2, 1, 1)))
+    obj = torch.as_tensor(np.array([0, 2, 1], np.int32))
+    xs = {}
+    for dt in (torch.float32, torch.float16):
+        x = torch.zeros((3, 240, 320, 24), device=dev, dtype=dt)
+        ops.crop_roi_align(img, boxes, ids, out=x, depth_norm_z=z, depth_norm_mode=2, n_channels=4)
+        ops.rasterize_into(scene_store, x, 4, obj, T, K, True, True, z, 2)
+        xs[dt] = x
+    assert xs[torch.float32][..., 4:18].abs().sum() > 0
+    assert torch.equal(xs[torch.float32].half(), xs[torch.float16])
+
+
 # ------------------------------------------------------------------------------------ crop
 def test_crop_vs_oracle(dev):
     from happypose_amd import ops
@@ -458,6 +481,14 @@ def test_backbone_f16_vs_f32(dev, arch, cin):
         xin[..., :cin] = torch.as_tensor(x, device=dev)
         pose, logits, feats = net.forward(xin, want_pose=True, want_logits=True, want_features=True)
         outs[prec] = [t.cpu().numpy() for t in (pose, logits, feats)]
+        if prec == "f16":
+            # the fp16 plan fed with fp32 input (conversion pass inside hp_net_forward) gives the same
+            # bits as the fp16 input written directly (hp_net_forward_f16in)
+            assert xin.dtype == torch.float16
+            x32 = torch.zeros((3, 240, 320, net.c_pad), device=dev)
+            x32[..., :cin] = torch.as_tensor(x, device=dev)
+            for a, b_ in zip(net.forward(x32, want_pose=True, want_logits=True, want_features=True), (pose, logits, feats)):
+                assert torch.equal(a, b_)
     scale = np.abs(outs["f32"][2]).max()
     assert np.abs(outs["f16"][2] - outs["f32"][2]).max() <= 2e-2 * scale
     np.testing.assert_allclose(outs["f16"][0], outs["f32"][0], atol=2e-2 * max(1.0, np.abs(outs["f32"][0]).max()))
