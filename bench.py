@@ -365,22 +365,22 @@ def main():
             # the 36 convs run as Winograd F(2x2,3x3) and execute 2.25x fewer MFMA FLOPs than that, so
             # the fraction of the pipe actually busy is reported separately (mfma_executed_*).
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv3x3_wino8_f32 + conv_igemm_f32 (+ conv3x3_patch_f32 when Winograd does not apply): "
-                                    "fp32 MFMA conv kernels" if precision == "f32" else
+                         "kernel": ("conv3x3_split_f32 (3x3 stride-1 layers: fp32 operands as fp16 hi/lo halves, three fp16 MFMAs per "
+                                    "product, fp32 accumulate) + conv_igemm_f32 (stem, stride-2, 1x1: fp32 MFMA)" if precision == "f32" else
                                     "conv_igemm_f16: fp16 MFMA implicit-GEMM conv (fp32 accumulate)") + ", all conv launches of a forward",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": measured_traffic(args.workload, precision),
                          "mfma_executed_tflops": mfma_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else 0.0,
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
-                         "launch_note": "a launch = one conv layer of a forward; the Winograd kernel runs a partially filled last round "
-                                        "as a second kernel, so rocprofv3 lists 48 conv kernels per WideResNet-34 forward for these 36 launches",
+                         "launch_note": "a launch = one conv layer of a forward",
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }
         if precision == "f32":
-            line["roofline"]["frac_note"] = ("achieved counts the ALGORITHMIC FLOPs of the direct convolution (SURVEY.md 8d); the Winograd "
-                                             "F(2x2,3x3) layers execute 2.25x fewer, so frac can exceed 1 -- mfma_executed_frac is the busy "
-                                             "fraction of the matrix pipe")
+            line["roofline"]["frac_note"] = ("achieved counts the ALGORITHMIC fp32 FLOPs of the direct convolution (SURVEY.md 8d) against the "
+                                             "fp32 MFMA peak; the 3x3 stride-1 layers form each fp32 product from three fp16 MFMAs (16x the fp32 "
+                                             "rate), so frac can exceed 1 -- mfma_executed_* count executed MFMA work in fp32-rate equivalents "
+                                             "(an fp16 MFMA FLOP = 1/16): mfma_executed_frac is the busy fraction of the matrix pipe")
             if line["roofline"]["traffic"] is not None:
                 line["roofline"]["traffic_note"] = ("HBM bytes per conv launch (incl. Infinity-Cache hits), PMC passes of this command: "
                                                     "profiles/r01f_conv_hbm_traffic.json; the kernels are MFMA-bound")

@@ -392,6 +392,8 @@ int g_conv_algo = -1;  // -1: not initialised (environment), else HP_CONV_ALGO_*
 int conv_algo() {
   if (g_conv_algo < 0) {
     g_conv_algo = HP_CONV_ALGO_AUTO;
+    if (std::getenv("HP_CONV_NO_SPLIT")) g_conv_algo = HP_CONV_ALGO_WINOGRAD;
+    if (std::getenv("HP_CONV_SPLIT")) g_conv_algo = HP_CONV_ALGO_SPLIT;
     if (std::getenv("HP_WINO_V1")) g_conv_algo = HP_CONV_ALGO_WINOGRAD_1WAVE;
     if (std::getenv("HP_CONV_NO_WINOGRAD")) g_conv_algo = HP_CONV_ALGO_DIRECT;
     if (std::getenv("HP_CONV_NO_WINOGRAD") && std::getenv("HP_CONV_NO_PATCH")) g_conv_algo = HP_CONV_ALGO_IGEMM;
@@ -401,7 +403,7 @@ int conv_algo() {
 }  // namespace hp
 
 extern "C" int hp_conv_select_algo(int algo) {
-  HP_REQUIRE(algo >= HP_CONV_ALGO_AUTO && algo <= HP_CONV_ALGO_WINOGRAD_1WAVE, "hp_conv_select_algo: unknown algorithm");
+  HP_REQUIRE(algo >= HP_CONV_ALGO_AUTO && algo <= HP_CONV_ALGO_SPLIT, "hp_conv_select_algo: unknown algorithm");
   hp::g_conv_algo = algo;
   return HP_OK;
 }

@@ -1,0 +1,393 @@
+// fp32 convolution on the fp16 matrix path: every fp32 operand is split into two halves,
+//   x = x_hi + x_lo,  x_hi = fp16(x),  x_lo = fp16(x - x_hi)          (22 significant bits),
+// and a product is formed from three fp16 MFMAs accumulated in fp32,
+//   x * w ~= x_hi * w_hi + x_hi * w_lo + x_lo * w_hi                   (x_lo * w_lo ~ 2^-22 dropped).
+// v_mfma_f32_32x32x16_f16 does 16 K-steps in 32 cycles, v_mfma_f32_32x32x2_f32 two in 64: three of the
+// former replace eight of the latter, 5.3x less matrix-pipe time for the same contraction at fp32-level
+// accuracy (measured against fp64 in tests/test_gpu_kernels.py::test_conv3x3_kernel_families: the same
+// bound as the exact-fp32 direct kernels).  Replaces the same reference ops as conv.hip (ATen conv +
+// BatchNorm + ReLU [+ identity], MP/models/torchvision_resnet.py:110-126, MP/models/wide_resnet.py:59-65)
+// for the 3x3 / stride-1 / pad-1 layers; activations stay fp32 NHWC in HBM, so the rest of the network
+// plan (residuals, max-pool, heads, the other conv kernels) is unchanged.
+//
+// What makes the split exact enough:
+//   * gfx950's f16 MFMA honours fp16 subnormals (tools/probes/mfma_f16_denorm.hip), so the low half of a
+//     small activation is kept down to 2^-24: |x - x_hi - x_lo| <= max(2^-22 |x|, 2^-25);
+//   * weights are scaled per output channel by a power of two so that max |w| lands in [2^13, 2^14)
+//     (plan time, exact) and the accumulator is scaled back in the epilogue (exact): their low halves are
+//     normal numbers whatever the magnitude of the folded-BN weights;
+//   * activations must stay below the fp16 range (|x| < 65504): larger values become inf and poison the
+//     output visibly instead of silently losing accuracy (hp_conv_select_algo(HP_CONV_ALGO_DIRECT) or
+//     HP_CONV_NO_SPLIT=1 selects the exact-fp32 kernels).
+//
+// Kernel = the patch-staged direct 3x3 scheme of conv_patch.hip / conv_f16.hip: a block owns 128 output
+// pixels x BN output channels; per 32-channel chunk it stages the pixel range [m0 - W - 1, m0 + 127 + W + 1]
+// ONCE (fp32 buffer loads; pre-activation BN + ReLU in fp32; split; LDS rows [32 hi | 32 lo] halves = 128 B,
+// padded to 144 B) and forms the nine taps as row-shifted fragment reads with a per-lane border mask.
+// Weights are pre-split at plan time into the same [32 hi | 32 lo] rows, ordered (chunk, tap), double
+// buffered in LDS one tap ahead, their loads two taps ahead in alternating register sets.
+// Per tap and wave (64x64 wave tile): 16 ds_read_b128 feed 24 MFMAs.
+#include <cstdlib>
+#include <type_traits>
+
+#include "conv.h"
+#include "conv_epilogue.h"
+
+namespace hp {
+
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreads = 512;  // 8 waves: two per SIMD, ONE workgroup per CU
+constexpr int CK = 32;         // channels per chunk
+constexpr int LDH = 64 + 8;    // LDS row: 32 hi + 32 lo halves, padded to 36 dwords
+constexpr unsigned kOob = 0xFFFFFFF0u;
+
+__device__ __forceinline__ floatx4 loadf4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ halfx8 loadh8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(halfx8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+// ---- plan time: fp32 packed weights [Cout][9 * Cin] (K = (tap, c), BN folded) -> split rows
+// [Cout][Cin / 32 chunks][9 taps][32 hi | 32 lo] halves + per-cout scale-back factors [Cout] (fp32) behind them
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* w, _Float16* ws, float* unscale, int cin, int Kpad) {
+  const int o = blockIdx.x, K = 9 * cin;
+  const float* row = w + (size_t)o * Kpad;
+  __shared__ float red[256];
+  float mx = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(row[k]));
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  mx = red[0];
+  int e = 0;
+  if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);  // mx = m 2^e, m in [0.5, 1)
+  const int s = mx > 0.f ? 14 - e : 0;                  // mx 2^s in [2^13, 2^14)
+  if (threadIdx.x == 0) unscale[o] = ldexpf(1.f, -s);
+  _Float16* out = ws + (size_t)o * K * 2;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const int tap = k / cin, c = k - tap * cin, cc = c / CK, j = c - cc * CK;
+    const float v = ldexpf(row[k], s);
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    _Float16* d = out + ((size_t)(cc * 9 + tap)) * 64;
+    d[j] = hi;
+    d[32 + j] = lo;
+  }
+}
+
+// Block tile BM x BN = (64 WAVES_M) x (64 WAVES_N), WAVES_M * WAVES_N = 8, every wave a 64 x 64 tile:
+// 256 x 128 for the layers with >= 128 output channels, 512 x 64 for the 64-channel ones.
+// NPC: 128-row passes of the patch staging (8 channels = two 16-B loads per thread and pass).
+template <int WAVES_M, int WAVES_N>
+struct SplitTile {
+  static constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
+  static int P(int W) { return BM + 2 * W + 2; }
+  static int npc(int W) { return (P(W) + 127) / 128; }
+  static size_t lds_bytes(int W) {
+    const size_t loop = ((size_t)P(W) * LDH + 2 * (size_t)BN * LDH + LDH) * 2;  // patch, weights x 2, a zero row
+    const size_t epi = (size_t)BM * (BN + 4) * 4;
+    return loop < epi ? epi : loop;
+  }
+};
+
+template <int WAVES_M, int WAVES_N, bool PRE, int NPC>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_f32(ConvArgs a, int P) {
+  static_assert(WAVES_M * WAVES_N == 8, "8 waves");
+  constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N, MT = 2, NT = 2;
+  constexpr int NB = BN * 8 / kThreads;  // 16-B weight chunks per thread and tap (2 or 1)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  _Float16* const patch = reinterpret_cast<_Float16*>(lds_raw);  // [P][LDH]
+  _Float16* const Bs = patch + P * LDH;                            // [2][BN][LDH]
+  _Float16* const zrow = Bs + 2 * BN * LDH;                        // [LDH] zeros: what a masked tap reads
+
+  const int nblk = a.tiles_m * a.tiles_n;
+  const int per_xcd = (nblk + 7) / 8;
+  const int lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (lin >= nblk) return;
+  const int tile_m = fdiv(lin, a.fd_tn), tile_n = lin - tile_m * a.tiles_n;
+  const int64_t m0 = (int64_t)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = a.W, H = a.H, Cin = a.Cin;
+  const int ncc = Cin / CK, ntaps = ncc * 9;
+
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(a.M * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)((size_t)a.Cout * 9 * Cin * 4), 0x00020000);
+
+  // patch staging: row = pr0 + 128 j, channels 8 pk .. 8 pk + 7 of the chunk
+  const int pk = tid & 3, pr0 = tid >> 2;
+  const int64_t gp0 = m0 - (W + 1) + pr0;
+  auto patch_voff = [&](int j) -> unsigned {
+    const int64_t gp = gp0 + 128 * j;
+    return (pr0 + 128 * j < P && gp >= 0 && gp < a.M) ? (unsigned)((gp * Cin + 8 * pk) * 4) : kOob;
+  };
+  _Float16* const Pst = patch + pr0 * LDH + 8 * pk;
+  // weight staging: row = br0 + 64 i, 16-B chunk bk of the 128-B row
+  const int bk = tid & 7, br0 = tid >> 3;
+  unsigned wvoff[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) wvoff[i] = (unsigned)(((int64_t)(n0 + br0 + 64 * i) * (18 * Cin) + 8 * bk) * 2);
+  _Float16* const Bst = Bs + br0 * LDH + 8 * bk;
+  if (tid < LDH / 2) reinterpret_cast<unsigned*>(zrow)[tid] = 0u;
+
+  // fragment bases + validity of the 9 taps per fragment row
+  const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * 64;
+  const int frow = lane & 31, fk = 8 * (lane >> 5);
+  const _Float16* const Bfr = Bs + (wn + frow) * LDH + fk;
+  const _Float16* Afr[MT];
+  unsigned vmask[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    Afr[mt] = patch + (wm + mt * 32 + frow + W + 1) * LDH + fk;
+    const int64_t g = m0 + wm + mt * 32 + frow;
+    unsigned mk = 0;
+    if (g < a.M) {
+      const int rem = (int)g - fdiv((int)g, a.fd_howo) * (H * W);  // stride 1: Ho x Wo = H x W
+      const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+        mk |= ((((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W)) ? 1u : 0u) << t;
+      }
+    }
+    vmask[mt] = mk;
+  }
+  const _Float16* const Zfr = zrow + fk;
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  floatx4 pr[NPC][2];  // next channel chunk of the patch (fp32)
+  halfx8 rb[2][NB];    // weights of taps t+1 / t+2 (alternating sets)
+  auto load_patch = [&](int j, int cc) {
+    const unsigned vo = patch_voff(j);
+    pr[j][0] = loadf4(xrsrc, vo, (unsigned)(cc * CK * 4));
+    pr[j][1] = loadf4(xrsrc, vo, (unsigned)(cc * CK * 4 + 16));
+  };
+  auto store_patch = [&](int cc) {
+    floatx4 ps[2], pb[2];
+    if (PRE) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ps[h] = *reinterpret_cast<const floatx4*>(a.pre_scale + cc * CK + 8 * pk + 4 * h);
+        pb[h] = *reinterpret_cast<const floatx4*>(a.pre_shift + cc * CK + 8 * pk + 4 * h);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      if (pr0 + 128 * j < P) {
+        const bool real = patch_voff(j) != kOob;  // pixels outside the tensor stay zero
+        halfx4 hi[2], lo[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          floatx4 v = pr[j][h];
+          if (PRE) {
+            v = __builtin_elementwise_max(v * ps[h] + pb[h], floatx4{0.f, 0.f, 0.f, 0.f});
+            if (!real) v = floatx4{0.f, 0.f, 0.f, 0.f};
+          }
+          hi[h] = __builtin_convertvector(v, halfx4);
+          lo[h] = __builtin_convertvector(v - __builtin_convertvector(hi[h], floatx4), halfx4);
+        }
+        *reinterpret_cast<halfx8*>(Pst + 128 * j * LDH) = __builtin_shufflevector(hi[0], hi[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<halfx8*>(Pst + 128 * j * LDH + 32) = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+  };
+  auto load_b = [&](int set, int tt) {  // tt = cc * 9 + tap: the order of the split weight rows
+    const int t2 = tt < ntaps ? tt : ntaps - 1;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[set][i] = loadh8(wrsrc, wvoff[i], (unsigned)(t2 * 128));
+  };
+  auto store_b = [&](int set, int buf) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<halfx8*>(Bst + buf * BN * LDH + 64 * i * LDH) = rb[set][i];
+  };
+
+  // prologue: patch of chunk 0, weights of tap 0 (-> LDS), 1 and 2 (-> registers)
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) load_patch(j, 0);
+  load_b(0, 0);
+  load_b(1, 1);
+  store_patch(0);
+  store_b(0, 0);
+  load_b(0, 2);
+  __syncthreads();
+
+  auto tap_step = [&](int tt, int cc, int tap, auto par) {
+    constexpr int Pb = decltype(par)::value;  // tt & 1: LDS weight buffer of this tap
+    const int d = (tap / 3 - 1) * W + (tap % 3 - 1);
+    // rows whose shifted pixel lies across an image border read the zero row instead
+    const _Float16* Ab[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#ifndef HP_SABL_NOMASK
+      Ab[i] = ((vmask[i] >> tap) & 1u) ? Afr[i] + d * LDH : Zfr;
+#else
+      Ab[i] = Afr[i] + d * LDH;
+#endif
+    }
+    const _Float16* Bb = Bfr + Pb * BN * LDH;
+    const bool next_chunk = cc + 1 < ncc;
+    // fragment q of a row: 0 / 1 = hi halves of channels 0-15 / 16-31, 2 / 3 = their lo halves
+    auto read_a = [&](halfx8 (&f)[MT], int q) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) f[i] = *reinterpret_cast<const halfx8*>(Ab[i] + q * 16);
+    };
+    auto read_b = [&](halfx8 (&f)[NT], int q) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) f[i] = *reinterpret_cast<const halfx8*>(Bb + i * 32 * LDH + q * 16);
+    };
+    auto mm = [&](const halfx8 (&fa)[MT], const halfx8 (&fb)[NT]) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+    };
+    // six groups of MT x NT MFMAs; a fragment set is read one group before its first use and is dead after
+    // its second (hi) or only (lo) use: at most five sets are live
+    halfx8 ah[MT], al[MT], bh[NT], bl[NT], ah1[MT], bh1[NT];
+    // (the staging below is unconditional -- clamped addresses, a dead LDS buffer after the last tap -- so
+    // that the tap body is straight-line code: with branches the compiler waits for ALL outstanding loads)
+    read_a(ah, 0);
+    read_b(bh, 0);
+    read_b(bl, 2);
+#ifndef HP_SABL_NOBSTAGE
+#ifndef HP_SABL_NOBSTORE
+    store_b(1 - Pb, 1 - Pb);               // weights of tap tt+1 (register set (tt+1) & 1)
+#endif
+#ifndef HP_SABL_NOBLOAD
+    load_b(1 - Pb, tt + 3);                // ... and that set takes tap tt+3
+#endif
+#endif
+    mm(ah, bh);
+    read_a(al, 2);
+    mm(ah, bl);
+    read_a(ah1, 1);
+    read_b(bh1, 1);
+    mm(al, bh);
+    read_b(bl, 3);
+#ifndef HP_SABL_NOPATCH
+#pragma unroll
+    for (int j = 0; j < NPC; ++j)          // next chunk's patch: one pass per tap (taps 0 .. NPC-1)
+      if (j == tap) load_patch(j, cc + 1 < ncc ? cc + 1 : cc);
+#endif
+    mm(ah1, bh1);
+    read_a(al, 3);
+    mm(ah1, bl);
+    mm(al, bh1);
+#ifndef HP_SABL_NOBARRIER
+    __syncthreads();
+#endif
+#ifndef HP_SABL_NOPATCH
+    if (tap == 8 && next_chunk) {  // every wave is done with this chunk's patch: swap in the next one
+      store_patch(cc + 1);
+      __syncthreads();
+    }
+#endif
+  };
+  // tap (cc, t) uses weight buffer (cc + t) & 1: two chunks per loop iteration make that a compile-time value
+  auto chunk = [&](int cc, auto c0) {
+    constexpr int C0 = decltype(c0)::value;
+    using E = std::integral_constant<int, C0>;      // even taps
+    using O = std::integral_constant<int, 1 - C0>;  // odd taps
+    tap_step(cc * 9 + 0, cc, 0, E{}); tap_step(cc * 9 + 1, cc, 1, O{}); tap_step(cc * 9 + 2, cc, 2, E{});
+    tap_step(cc * 9 + 3, cc, 3, O{}); tap_step(cc * 9 + 4, cc, 4, E{}); tap_step(cc * 9 + 5, cc, 5, O{});
+    tap_step(cc * 9 + 6, cc, 6, E{}); tap_step(cc * 9 + 7, cc, 7, O{}); tap_step(cc * 9 + 8, cc, 8, E{});
+  };
+  int cc = 0;
+  for (; cc + 1 < ncc; cc += 2) {
+    chunk(cc, std::integral_constant<int, 0>{});
+    chunk(cc + 1, std::integral_constant<int, 1>{});
+  }
+  if (cc < ncc) chunk(cc, std::integral_constant<int, 0>{});
+
+  // ---- scale back (a lane holds one output channel per N tile), then the shared fp32 epilogue
+  const float* const unscale = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(a.w) + (size_t)a.Cout * 18 * Cin);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const float s = unscale[n0 + wn + nt * 32 + (lane & 31)];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= s;
+  }
+  conv_epilogue<BM, BN, MT, NT, kThreads>(a, reinterpret_cast<float*>(lds_raw), acc, m0, n0, wm, wn);
+}
+
+template <int WAVES_M, int WAVES_N, bool PRE, int NPC>
+int launch_split_variant(ConvArgs args, hipStream_t stream) {
+  using T = SplitTile<WAVES_M, WAVES_N>;
+  static bool opted = false;
+  if (!opted) {
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_f32<WAVES_M, WAVES_N, PRE, NPC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    opted = true;
+  }
+  args.tiles_m = (int)((args.M + T::BM - 1) / T::BM);
+  args.tiles_n = args.Cout / T::BN;
+  args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
+  args.fd_wo = make_fastdiv((unsigned)args.Wo);
+  args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
+  const int nblk = args.tiles_m * args.tiles_n;
+  hipLaunchKernelGGL((conv3x3_split_f32<WAVES_M, WAVES_N, PRE, NPC>), dim3(8 * ((nblk + 7) / 8)), dim3(kThreads),
+                     T::lds_bytes(args.W), stream, args, T::P(args.W));
+  return check_launch("conv3x3_split_f32");
+}
+
+template <int WAVES_M, int WAVES_N, bool PRE>
+int launch_split_npc(const ConvArgs& a, hipStream_t stream) {
+  const int npc = SplitTile<WAVES_M, WAVES_N>::npc(a.W);
+  if (npc <= 3) return launch_split_variant<WAVES_M, WAVES_N, PRE, 3>(a, stream);
+  if (npc == 4) return launch_split_variant<WAVES_M, WAVES_N, PRE, 4>(a, stream);
+  return launch_split_variant<WAVES_M, WAVES_N, PRE, 6>(a, stream);
+}
+
+}  // namespace
+
+bool conv_split_applicable(const ConvArgs& a, int kh, int kw) {
+  static const bool off = std::getenv("HP_CONV_NO_SPLIT") != nullptr;
+  if (off || kh != 3 || kw != 3 || a.stride != 1 || a.pad != 1 || a.Cin % CK != 0 || a.Cout % 64 != 0) return false;
+  if (a.Cout % 128 == 0) return SplitTile<4, 2>::npc(a.W) <= 6 && SplitTile<4, 2>::lds_bytes(a.W) <= 160 * 1024;
+  return SplitTile<8, 1>::npc(a.W) <= 6 && SplitTile<8, 1>::lds_bytes(a.W) <= 160 * 1024;
+}
+
+bool conv_split_launchable(const ConvArgs& a) {
+  // 32-bit buffer offsets; the activation may not be a pre-scale-only (squeeze-excitation) input
+  return a.M * a.Cin * 4 < (1ll << 31) && a.M < (1ll << 31) && (a.pre_shift || !a.pre_scale) && a.relu != HP_ACT_SWISH;
+}
+
+size_t conv_split_weight_bytes(int cout, int cin) { return (size_t)cout * 18 * cin * 2 + (size_t)cout * 4; }
+
+int conv_split_transform_weights(const float* d_w, void* d_ws, int cout, int cin, int Kpad, hipStream_t stream) {
+  _Float16* ws = reinterpret_cast<_Float16*>(d_ws);
+  float* unscale = reinterpret_cast<float*>(ws + (size_t)cout * 18 * cin);
+  hipLaunchKernelGGL(split_weights_kernel, dim3(cout), dim3(256), 0, stream, d_w, ws, unscale, cin, Kpad);
+  return check_launch("split_weights_kernel");
+}
+
+int launch_conv_split(const ConvArgs& a, hipStream_t stream) {
+  const bool pre = a.pre_scale != nullptr;
+  if (a.Cout % 128 == 0) return pre ? launch_split_npc<4, 2, true>(a, stream) : launch_split_npc<4, 2, false>(a, stream);
+  return pre ? launch_split_npc<8, 1, true>(a, stream) : launch_split_npc<8, 1, false>(a, stream);
+}
+
+}  // namespace hp

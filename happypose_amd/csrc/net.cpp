@@ -47,7 +47,8 @@ struct ConvLayer {
   int cin_real, cin, cout, kh, kw, stride, pad, relu;
   int H, W, Ho, Wo, Kpad;
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
-  DevBuf w, w_wino, bias, lut, pre_scale, pre_shift;  // w_wino: Winograd-transformed weights (3x3 s1 layers)
+  DevBuf w, w_wino, w_split, bias, lut, pre_scale, pre_shift;  // w_wino: Winograd-transformed weights (3x3 s1 layers)
+                                                               // w_split: fp16 hi/lo halves (conv_split.hip)
   int cout_pad = 0;        // weight rows / bias padded to whole 64-wide tiles
   int se = 0;              // the input is gated by the squeeze-excitation vector of this block (1x1 projections)
   int run_mode = 0;        // stem with K ordered (kh, [kw x cin run]) over an UNPADDED 6-channel input, see pack_conv
@@ -330,6 +331,11 @@ int pack_conv(Net& n, ConvLayer& L) {
     if (conv_wino_applicable(probe, L.kh, L.kw)) {
       if ((rc = L.w_wino.alloc(conv_wino_weight_floats(L.cout, L.cin) * 4))) return rc;
       if ((rc = conv_wino_transform_weights((const float*)L.w.p, (float*)L.w_wino.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
+      HP_CHECK_HIP(hipStreamSynchronize(nullptr));
+    }
+    if (conv_split_applicable(probe, L.kh, L.kw) && L.cout_pad == L.cout && L.relu != HP_ACT_SWISH && !L.se) {
+      if ((rc = L.w_split.alloc(conv_split_weight_bytes(L.cout, L.cin)))) return rc;
+      if ((rc = conv_split_transform_weights((const float*)L.w.p, L.w_split.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
     }
   }
@@ -618,8 +624,15 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       const int algo = conv_algo();
       // FLOPs the matrix cores actually execute (padded tiles / K included): 16 multiplies per
       // 2x2 output tile, cin and cout for the Winograd layers, M x Cout x Kpad otherwise
-      const bool wino_ok = algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINOGRAD_1WAVE;
-      if (wino_ok && L.w_wino.p && conv_wino_launchable(a)) {
+      const bool wino_ok = algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINOGRAD_1WAVE || algo == HP_CONV_ALGO_WINOGRAD;
+      if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_split.p && conv_split_launchable(a)) {
+        a.w = (const float*)L.w_split.p;
+        rc = launch_conv_split(a, stream);
+        // three fp16 MFMAs per product over whole 256- / 512-row tiles; an fp16 MFMA FLOP occupies the matrix pipe for
+        // 1/16 of an fp32 one, so it is counted as 1/16: mfma_flops / time / fp32 peak stays "how busy is the pipe"
+        const int64_t bm = L.cout % 128 == 0 ? 256 : 512;
+        mfma_flops = 3.0 * 2.0 * (double)((a.M + bm - 1) / bm * bm) * L.cout * L.Kpad / 16.0;
+      } else if (wino_ok && L.w_wino.p && conv_wino_launchable(a)) {
         a.w = (const float*)L.w_wino.p;
         rc = launch_conv_wino(a, stream);
         mfma_flops = 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout;
@@ -829,7 +842,22 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   a.M = (int64_t)n * a.Ho * a.Wo;
   const bool classic = !padded && relu != HP_ACT_SWISH && (d_pre_shift || !d_pre_scale);  // what the 3x3 kernels support
   const int algo = classic ? conv_algo() : HP_CONV_ALGO_IGEMM;
-  if ((algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINOGRAD_1WAVE) && conv_wino_applicable(a, kh, kw) && conv_wino_launchable(a)) {
+  if (conv_use_split(algo, h, w, cin, cout) && conv_split_applicable(a, kh, kw) && conv_split_launchable(a)) {
+    // test entry: the weights are split on every call into a per-process scratch buffer
+    static void* d_S = nullptr;
+    static size_t S_bytes = 0;
+    const size_t need_bytes = conv_split_weight_bytes(cout, cin);
+    if (S_bytes < need_bytes) {
+      if (d_S) (void)hipFree(d_S);
+      d_S = nullptr; S_bytes = 0;
+      HP_CHECK_HIP(hipMalloc(&d_S, need_bytes));
+      S_bytes = need_bytes;
+    }
+    if ((rc = conv_split_transform_weights(d_w, d_S, cout, cin, Kpad, (hipStream_t)stream))) return rc;
+    a.w = (const float*)d_S;
+    return launch_conv_split(a, (hipStream_t)stream);
+  }
+  if ((algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINOGRAD_1WAVE || algo == HP_CONV_ALGO_WINOGRAD) && conv_wino_applicable(a, kh, kw) && conv_wino_launchable(a)) {
     // test entry: the weights are transformed on every call into a per-process scratch buffer
     static float* d_U = nullptr;
     static size_t U_floats = 0;

@@ -339,7 +339,7 @@ class Net:
         return ms.value, n.value, fl.value, mfl.value
 
 
-CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2, "winograd-1wave": 3}
+CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2, "winograd-1wave": 3, "winograd": 4, "split": 5}
 
 
 def select_conv_algo(name: str = "auto") -> None:

@@ -228,16 +228,21 @@ double hp_net_flops_per_sample(const hp_net* net);
  * hp_net_profile_collect waits for the recorded pairs and returns the summed kernel time
  * (ms), the number of launches, their ALGORITHMIC FLOPs (2 x M x Cout x kh x kw x Cin of the
  * direct convolution) and the FLOPs the matrix cores actually executed (less for the Winograd
- * layers, more where tiles / K are padded) since the previous collect. */
+ * layers, more where tiles / K are padded; in fp32-MFMA equivalents: an fp16 MFMA FLOP of the
+ * split-fp16 layers counts 1/16, its share of matrix-pipe time) since the previous collect. */
 int hp_net_set_profiling(hp_net* net, int enabled);
 /* Diagnostics / parity tests: restrict the convolution kernels the dispatchers may pick
- * (process wide).  AUTO = Winograd F(2x2,3x3) for 3x3 stride-1 layers, else the patch-staged
- * direct kernel, else the generic implicit GEMM; DIRECT = no Winograd; IGEMM = generic kernel only.
- * Environment equivalents read at first use: HP_CONV_NO_WINOGRAD, HP_CONV_NO_PATCH. */
+ * (process wide).  AUTO = for 3x3 stride-1 layers the split-fp16 kernel (fp32 operands as two fp16 halves, three
+ * fp16 MFMAs per product, fp32 accumulation: fp32-level accuracy while |activations| < 65504), else Winograd
+ * F(2x2,3x3), else the patch-staged direct kernel, else the generic implicit GEMM; WINOGRAD = exact-fp32
+ * arithmetic only; DIRECT = no Winograd either; IGEMM = generic kernel only.
+ * Environment equivalents read at first use: HP_CONV_NO_SPLIT, HP_CONV_NO_WINOGRAD, HP_CONV_NO_PATCH. */
 #define HP_CONV_ALGO_AUTO 0
 #define HP_CONV_ALGO_DIRECT 1
 #define HP_CONV_ALGO_IGEMM 2
-#define HP_CONV_ALGO_WINOGRAD_1WAVE 3 /* AUTO, but the one-wave-per-SIMD schedule of the Winograd kernel */
+#define HP_CONV_ALGO_WINOGRAD_1WAVE 3 /* WINOGRAD, but the one-wave-per-SIMD schedule of the Winograd kernel */
+#define HP_CONV_ALGO_WINOGRAD 4 /* exact-fp32 kernels only: Winograd, else patch-staged, else generic */
+#define HP_CONV_ALGO_SPLIT 5 /* split-fp16 kernels (3 fp16 MFMAs per fp32 product) wherever they apply */
 int hp_conv_select_algo(int algo);
 /* diagnostics: workgroups per CU the runtime grants conv tile variant 0 (128x128) / 1 (128x64) */
 int hp_conv_occupancy(int variant);

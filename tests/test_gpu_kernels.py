@@ -350,10 +350,11 @@ def test_conv2d_vs_fp64(dev, case):
     _check_conv(dev, case)
 
 
-# the three kernel families behind 3x3 / stride-1 layers must agree with fp64: Winograd F(2x2,3x3)
-# ("auto" and its one-wave-per-SIMD schedule), the patch-staged direct kernel ("direct") and the generic
-# implicit GEMM ("igemm")
-@pytest.mark.parametrize("algo", ["auto", "winograd-1wave", "direct", "igemm"])
+# the kernel families behind 3x3 / stride-1 layers must agree with fp64: Winograd F(2x2,3x3)
+# ("winograd" and its one-wave-per-SIMD schedule), the split-fp16 kernel ("split": three fp16 MFMAs per fp32
+# product), the patch-staged direct kernel ("direct") and the generic implicit GEMM ("igemm"); "auto" is the
+# per-layer choice of the planner
+@pytest.mark.parametrize("algo", ["auto", "winograd", "winograd-1wave", "split", "direct", "igemm"])
 @pytest.mark.parametrize("case", [
     dict(n=3, h=30, w=40, cin=128, cout=128, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=True),
     dict(n=7, h=15, w=20, cin=256, cout=256, k=3, s=1, p=1, bias=False, res=True, pre=True, relu=False),  # odd H
@@ -371,7 +372,7 @@ def test_conv3x3_kernel_families(dev, case, algo):
     ops.select_conv_algo(algo)
     try:
         # Winograd's transforms cost about one extra bit of round-off
-        _check_conv(dev, case, tol=4e-5 if algo in ("auto", "winograd-1wave") else 2e-5)
+        _check_conv(dev, case, tol=4e-5 if algo in ("auto", "winograd", "winograd-1wave") else 2e-5)
     finally:
         ops.select_conv_algo("auto")
 
