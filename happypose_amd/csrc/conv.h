@@ -88,12 +88,12 @@ bool conv_wino_launchable(const ConvArgs& a);  // per launch: batch-dependent li
 size_t conv_wino_weight_floats(int cout, int cin);
 int conv_wino_transform_weights(const float* d_w, float* d_U, int cout, int cin, int Kpad, hipStream_t stream);
 int launch_conv_wino(const ConvArgs& a, hipStream_t stream);
-// 3x3 / stride 1 / pad 1 / Cin % 32 == 0 / Cout % 64 == 0: fp32 operands split into fp16 halves, three fp16
+// 3x3 / pad 1, stride 1 (Cin % 32 == 0, Cout % 64 == 0) or stride 2 (Cin % 64 == 0, Cout % 128 == 0): fp32 operands split into fp16 halves, three fp16
 // MFMAs per product (conv_split.hip); a.w must point at weights split by conv_split_transform_weights
 bool conv_split_applicable(const ConvArgs& a, int kh, int kw);
 bool conv_split_launchable(const ConvArgs& a);  // per launch: batch-dependent limits
 size_t conv_split_weight_bytes(int cout, int cin);
-int conv_split_transform_weights(const float* d_w, void* d_ws, int cout, int cin, int Kpad, hipStream_t stream);
+int conv_split_transform_weights(const float* d_w, void* d_ws, int cout, int cin, int Kpad, int stride, hipStream_t stream);
 int launch_conv_split(const ConvArgs& a, hipStream_t stream);
 // plan-time choice between the split-fp16 kernel and the exact-fp32 ones for a 3x3 stride-1 layer
 inline bool conv_use_split(int algo, int H, int W, int cin, int cout) {

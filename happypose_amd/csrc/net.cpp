@@ -335,7 +335,7 @@ int pack_conv(Net& n, ConvLayer& L) {
     }
     if (conv_split_applicable(probe, L.kh, L.kw) && L.cout_pad == L.cout && L.relu != HP_ACT_SWISH && !L.se) {
       if ((rc = L.w_split.alloc(conv_split_weight_bytes(L.cout, L.cin)))) return rc;
-      if ((rc = conv_split_transform_weights((const float*)L.w.p, L.w_split.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
+      if ((rc = conv_split_transform_weights((const float*)L.w.p, L.w_split.p, L.cout, L.cin, L.Kpad, L.stride, nullptr))) return rc;
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
     }
   }
@@ -853,7 +853,7 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
       HP_CHECK_HIP(hipMalloc(&d_S, need_bytes));
       S_bytes = need_bytes;
     }
-    if ((rc = conv_split_transform_weights(d_w, d_S, cout, cin, Kpad, (hipStream_t)stream))) return rc;
+    if ((rc = conv_split_transform_weights(d_w, d_S, cout, cin, Kpad, stride, (hipStream_t)stream))) return rc;
     a.w = (const float*)d_S;
     return launch_conv_split(a, (hipStream_t)stream);
   }

@@ -365,6 +365,10 @@ def test_conv2d_vs_fp64(dev, case):
     dict(n=2, h=60, w=80, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=True),       # 640-pixel staged ranges
     dict(n=3, h=20, w=96, cin=64, cout=32, k=3, s=1, p=1, bias=False, res=False, pre=True, relu=False),    # 768: single register set
     dict(n=128, h=8, w=10, cin=64, cout=256, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=True),     # 1.25 rounds: half-item tail launch
+    dict(n=40, h=15, w=20, cin=256, cout=256, k=3, s=1, p=1, bias=True, res=True, pre=True, relu=False),   # split kernel: K-sliced tail tiles
+    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),     # stride 2 (space-to-depth walk)
+    dict(n=5, h=15, w=20, cin=128, cout=256, k=3, s=2, p=1, bias=False, res=True, pre=True, relu=False),   # stride 2, odd H
+    dict(n=7, h=9, w=7, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=False, relu=True),      # stride 2, odd H and W, ragged
 ])
 def test_conv3x3_kernel_families(dev, case, algo):
     from happypose_amd import ops
