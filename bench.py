@@ -273,6 +273,7 @@ def main():
                     help="CosyPose backbone for C2: resnet34 = the WideResNet-34 BASELINE.json quotes; efficientnet-b3 = the released checkpoints' architecture")
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS),
                     help="BASELINE.json config (default C2 = the one the headline metric is quoted on)")
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the secondary run on the exact-fp32 kernels")
     ap.add_argument("--precision", default=None, choices=["f32", "f16"],
                     help="conv arithmetic (default: f32, the reference's; f16 for C5 as BASELINE.json names it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -336,10 +337,28 @@ def main():
     model.backbone.set_profiling(False)
     assert torch.isfinite(poses).all()
 
+    # the same job restricted to the exact-fp32 kernels (fp32 MFMA: Winograd / direct), a quarter of the steps, so the
+    # line also carries the number of the build whose every multiply is an fp32 FMA (reported beside `value`)
+    exact = None
+    if precision == "f32" and not args.no_exact_fp32:
+        from happypose_amd import ops
+        ops.select_conv_algo("winograd")
+        k_exact = max(2, args.steps // 4)
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(k_exact):
+            poses_exact = step()
+        fence()
+        exact = (time.perf_counter() - t1, k_exact, float((poses_exact - poses).abs().max()))
+        ops.select_conv_algo("auto")
+
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, exact[0] if exact else 0.0], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if exact:
+            exact = (float(t[1].item()),) + exact[1:]
 
     if rank == 0:
         total = world * B * args.steps
@@ -384,6 +403,16 @@ def main():
             if line["roofline"]["traffic"] is not None:
                 line["roofline"]["traffic_note"] = ("HBM bytes per conv launch (incl. Infinity-Cache hits), PMC passes of this command: "
                                                     "profiles/r01g_conv_hbm_traffic.json; the kernels are MFMA-bound")
+        if precision == "f32":
+            line["dtype_note"] = ("fp32 tensors and fp32 accumulation everywhere; the 3x3 convolutions multiply fp16 hi/lo halves of the fp32 "
+                                  "operands (three fp16 MFMAs per product, 22 significant bits), all other kernels are plain fp32")
+        if exact:
+            line["exact_fp32_kernels"] = {
+                "value": world * B * exact[1] / exact[0], "unit": line["unit"], "steps": exact[1], "ms_per_step": 1e3 * exact[0] / exact[1],
+                "max_abs_pose_diff_vs_default": exact[2],
+                "note": "same job with hp_conv_select_algo(WINOGRAD): fp32 MFMA only (Winograd F(2x2,3x3) / direct kernels); the default "
+                        "build forms the products of the 3x3 layers from three fp16 MFMAs on fp16 hi/lo halves of the fp32 operands with "
+                        "fp32 accumulation -- same stated tolerance vs fp64 (2e-5 of max|ref| per layer; DESIGN.md 4.1)"}
         if args.workload == "C2":
             line["stages"] = stage_rates(store, scene, images, K, TCO0, im_ids, device)
         if not args.no_cpu_baseline and args.workload == "C2":
