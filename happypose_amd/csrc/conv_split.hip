@@ -120,6 +120,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int tile_m = fdiv(lin, a.fd_tn), tile_n = lin - tile_m * a.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
+#ifdef HP_SPLIT_STAGGER
+  // first-round workgroups of every other CU start late, so that loop phases and (HBM-bound) epilogues of the
+  // two halves of the machine alternate instead of coinciding
+  if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < HP_SPLIT_STAGGER) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = a.W, H = a.H, Cin = a.Cin;
@@ -385,6 +393,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     tap_step(cc * 9 + 6, cc, 6, E{}); tap_step(cc * 9 + 7, cc, 7, O{}); tap_step(cc * 9 + 8, cc, 8, E{});
   };
   int cc = cc_begin;
+#ifdef HP_SABL_NOLOOP
+  cc = ncc;
+#endif
   for (; cc + 1 < ncc; cc += 2) {
     chunk(cc, std::integral_constant<int, 0>{});
     chunk(cc + 1, std::integral_constant<int, 1>{});
@@ -392,6 +403,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   if (cc < ncc) chunk(cc, std::integral_constant<int, 0>{});
 
   if (split && !splitk_reduce<BM, BN, MT, NT, kThreads>(a, acc, lin - a.sk_regular, slice)) return;
+#ifdef HP_SABL_NOEPI
+  if (acc[0][0][0] != 12345.f) return;
+#endif
 
   // ---- scale back (a lane holds one output channel per N tile), then the shared fp32 epilogue
   const float* const unscale = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(a.w) + (size_t)a.Cout * 18 * Cin);
