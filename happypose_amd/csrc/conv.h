@@ -1,6 +1,8 @@
 // Argument blocks and launchers of the conv-stack kernels (conv.hip), used by net.cpp.
 #pragma once
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hp {
@@ -95,10 +97,21 @@ bool conv_split_launchable(const ConvArgs& a);  // per launch: batch-dependent l
 size_t conv_split_weight_bytes(int cout, int cin);
 int conv_split_transform_weights(const float* d_w, void* d_ws, int cout, int cin, int Kpad, int stride, hipStream_t stream);
 int launch_conv_split(const ConvArgs& a, hipStream_t stream);
+// the same scheme for every other layer the generic kernel runs (stems, 1x1, odd 3x3): conv_igemm_split.hip
+size_t conv_igemm_split_weight_bytes(int rows_pad, int Kpad);
+int conv_igemm_split_transform_weights(const float* d_w, void* d_ws, int rows_pad, int Kpad, hipStream_t stream);
+bool conv_igemm_split_launchable(const ConvArgs& a);
+int launch_conv_igemm_split(const ConvArgs& a, int variant, hipStream_t stream);
 // plan-time choice between the split-fp16 kernel and the exact-fp32 ones for a 3x3 stride-1 layer
 inline bool conv_use_split(int algo, int H, int W, int cin, int cout) {
   (void)H; (void)W; (void)cin; (void)cout;  // measured faster than Winograd on every WideResNet / ResNet-34 layer shape
   return algo == HP_CONV_ALGO_SPLIT || algo == HP_CONV_ALGO_AUTO;
+}
+// which generic-kernel layers move to conv_igemm_split.hip (HP_ISPLIT_MIN_KH: smallest filter size, default 1)
+inline bool conv_use_igemm_split(int kh, int Kpad) {
+  static const int min_kh = std::getenv("HP_ISPLIT_MIN_KH") ? std::atoi(std::getenv("HP_ISPLIT_MIN_KH")) : 1;
+  (void)Kpad;
+  return kh >= min_kh;
 }
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream);

@@ -1,0 +1,265 @@
+// Generic implicit-GEMM convolution on the split-fp16 scheme of conv_split.hip (fp32 operands as fp16 hi / lo
+// halves, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation, per-cout power-of-two weight scaling):
+// the layers the patch-staged 3x3 kernels do not cover -- the 5x5 / 7x7 stride-2 stems (CP/models/wide_resnet.py
+// conv1, MP/models/torchvision_resnet.py conv1) and 1x1 / odd 3x3 layers.  Same GEMM view, K order, look-up table
+// and packed-weight geometry as conv.hip (K-tile = 32 floats = the 8 LUT chunks of 4 floats; the stem's "filter
+// row" packing included), so the planner reuses its LUT; only the staged tiles differ: LDS rows are
+// [32 hi | 32 lo] halves (144-B pitch), a K-tile is 2 k-steps x 3 MFMAs per 32x32 tile instead of 16 fp32 MFMAs.
+// These layers are short in K and long in M (the CosyPose stem: K = 160, 2.4 M output pixels, 629 MB written), so
+// the kernel is a plain double-buffered loop at 2-3 workgroups per CU and ends up bound by its output stream.
+#include <cstdlib>
+
+#include "conv.h"
+#include "conv_epilogue.h"
+#include "conv_splitk.h"
+
+namespace hp {
+
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int BM = 128;
+constexpr int LDH = 64 + 8;  // LDS row: 32 hi + 32 lo halves, padded to 36 dwords
+
+// NBUF = 2: double-buffered K loop, two workgroups per CU; NBUF = 1 (short K: the CosyPose stem has 5 K-tiles):
+// one LDS buffer and two barriers per K-tile, which lets FOUR workgroups share a CU -- these launches are gather /
+// store streams with a dozen MFMAs per K-tile, and occupancy is what hides their latency
+template <int BN, int NBUF>
+constexpr size_t igs_lds_bytes() {
+  const size_t loop = (size_t)NBUF * (BM + BN) * LDH * 2;
+  const size_t epi = (size_t)BM * (BN + 4) * 4;
+  return loop > epi ? loop : epi;
+}
+
+// fp32 packed weights [rows][Kpad] (BN folded, K padded to 32) -> [rows][Kpad / 32][32 hi | 32 lo] halves + per-row
+// scale-back factors [rows] (fp32) behind them
+__global__ __launch_bounds__(256) void split_weights_generic_kernel(const float* w, _Float16* ws, float* unscale, int Kpad) {
+  const int o = blockIdx.x;
+  const float* row = w + (size_t)o * Kpad;
+  __shared__ float red[256];
+  float mx = 0.f;
+  for (int k = threadIdx.x; k < Kpad; k += 256) mx = fmaxf(mx, fabsf(row[k]));
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  mx = red[0];
+  int e = 0;
+  if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);
+  const int s = mx > 0.f ? 14 - e : 0;  // max |w| 2^s in [2^13, 2^14)
+  if (threadIdx.x == 0) unscale[o] = ldexpf(1.f, -s);
+  _Float16* out = ws + (size_t)o * Kpad * 2;
+  for (int k = threadIdx.x; k < Kpad; k += 256) {
+    const float v = ldexpf(row[k], s);
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    out[(size_t)(k >> 5) * 64 + (k & 31)] = hi;
+    out[(size_t)(k >> 5) * 64 + 32 + (k & 31)] = lo;
+  }
+}
+
+template <int BN, bool PRE, int NBUF>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3 - NBUF), 2 * (3 - NBUF)))) void conv_igemm_split_f32(ConvArgs a) {
+  constexpr int MT = 2, NT = BN / 64;  // 4 waves 2 x 2, wave tile 64 x BN/2
+  constexpr int NA = 4, NB = BN / 32;  // staged 16-B pieces per thread and K-tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  _Float16* const As = reinterpret_cast<_Float16*>(lds_raw);  // [2][BM][LDH]
+  _Float16* const Bs = As + NBUF * BM * LDH;                    // [NBUF][BN][LDH]
+
+  int lin, slice;
+  bool split;
+  if (!splitk_decode(a, lin, slice, split)) return;
+  const int tile_m = fdiv(lin, a.fd_tn), tile_n = lin - tile_m * a.tiles_n;
+  const int64_t m0 = (int64_t)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kc = tid & 7, r0 = tid >> 3;
+
+  // per staged row (output pixel): input origin and offset
+  const float* xrow[NA];
+  int ih0[NA], iw0[NA];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int64_t m = m0 + r0 + 32 * i;
+    if (m < a.M) {
+      const int img = fdiv((int)m, a.fd_howo);
+      const int rem = (int)m - img * HoWo;
+      const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * a.Wo;
+      ih0[i] = oh * a.stride - a.pad;
+      iw0[i] = ow * a.stride - a.pad;
+      xrow[i] = a.x + (((int64_t)img * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
+    } else {
+      ih0[i] = -(1 << 28); iw0[i] = 0; xrow[i] = a.x;
+    }
+  }
+  const _Float16* const wsplit = reinterpret_cast<const _Float16*>(a.w);
+  const _Float16* wrow[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) wrow[i] = wsplit + (int64_t)(n0 + r0 + 32 * i) * a.Kpad * 2 + 8 * kc;
+
+  _Float16* const Ast = As + r0 * LDH + 4 * kc;
+  _Float16* const Bst = Bs + r0 * LDH + 8 * kc;
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
+  const int frow = lane & 31, fk = 8 * (lane >> 5);
+  const _Float16* const Afr = As + (wm + frow) * LDH + fk;
+  const _Float16* const Bfr = Bs + (wn + frow) * LDH + fk;
+
+  floatx4 ra[NA];
+  halfx8 rbw[NB];
+  floatx4 ps = {0.f, 0.f, 0.f, 0.f}, pb = ps;
+  unsigned ok = 0;
+  auto issue = [&](int t) {
+    const int4 e = a.lut[t * 8 + kc];  // {offset, kh, kw, channel}; kh < 0 marks K padding
+    ok = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int ih = ih0[i] + e.y, iw = iw0[i] + e.z;
+      const bool in = (e.y >= 0) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+      ra[i] = *reinterpret_cast<const floatx4*>(in ? xrow[i] + e.x : a.x);
+      ok |= (in ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rbw[i] = *reinterpret_cast<const halfx8*>(wrow[i] + (size_t)t * 64);
+    if (PRE) {
+      const int c = e.y >= 0 ? e.w : 0;
+      ps = *reinterpret_cast<const floatx4*>(a.pre_scale + c);
+      pb = *reinterpret_cast<const floatx4*>(a.pre_shift + c);
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      floatx4 v = ra[i];
+      if (PRE) v = __builtin_elementwise_max(v * ps + pb, floatx4{0.f, 0.f, 0.f, 0.f});
+      if (!((ok >> i) & 1u)) v = floatx4{0.f, 0.f, 0.f, 0.f};
+      const halfx4 hi = __builtin_convertvector(v, halfx4);
+      const halfx4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), halfx4);
+      *reinterpret_cast<halfx4*>(Ast + buf * BM * LDH + 32 * i * LDH) = hi;
+      *reinterpret_cast<halfx4*>(Ast + buf * BM * LDH + 32 * i * LDH + 32) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<halfx8*>(Bst + buf * BN * LDH + 32 * i * LDH) = rbw[i];
+  };
+
+  const int t_begin = split ? slice * a.ktiles / a.sk_S : 0;
+  const int t_end = split ? (slice + 1) * a.ktiles / a.sk_S : a.ktiles;
+  issue(t_begin);
+  store(0);
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = NBUF == 2 ? (t - t_begin) & 1 : 0;
+    const bool more = t + 1 < t_end;  // wave-uniform
+    if (more) issue(t + 1);
+    const _Float16* Ab = Afr + buf * BM * LDH;
+    const _Float16* Bb = Bfr + buf * BN * LDH;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      halfx8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        ah[i] = *reinterpret_cast<const halfx8*>(Ab + i * 32 * LDH + kk * 16);
+        al[i] = *reinterpret_cast<const halfx8*>(Ab + i * 32 * LDH + 32 + kk * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        bh[i] = *reinterpret_cast<const halfx8*>(Bb + i * 32 * LDH + kk * 16);
+        bl[i] = *reinterpret_cast<const halfx8*>(Bb + i * 32 * LDH + 32 + kk * 16);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    if (NBUF == 1) __syncthreads();  // every wave is done reading the only buffer
+    if (more) store(NBUF == 2 ? buf ^ 1 : 0);
+    __syncthreads();
+  }
+
+  if (split && !splitk_reduce<BM, BN, MT, NT, kThreads>(a, acc, lin - a.sk_regular, slice)) return;
+
+  // scale back (a lane holds one output channel per N tile), then the shared fp32 epilogue
+  const int rows_pad = a.tiles_n * BN;
+  const float* const unscale = reinterpret_cast<const float*>(wsplit + (size_t)rows_pad * a.Kpad * 2);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const float s = unscale[n0 + wn + nt * 32 + (lane & 31)];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= s;
+  }
+  conv_epilogue<BM, BN, MT, NT, kThreads>(a, reinterpret_cast<float*>(lds_raw), acc, m0, n0, wm, wn);
+}
+
+template <int BN, bool PRE, int NBUF>
+int launch_igs(ConvArgs args, hipStream_t stream) {
+  static bool opted = false;
+  if (!opted) {
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)igs_lds_bytes<BN, NBUF>()));
+    opted = true;
+  }
+  args.tiles_m = (int)((args.M + BM - 1) / BM);
+  args.tiles_n = (args.Cout + BN - 1) / BN;
+  if (args.M >= (1ll << 31)) return fail(HP_ERR_ARG, "conv: more than 2^31 output pixels");
+  args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
+  args.fd_wo = make_fastdiv((unsigned)args.Wo);
+  args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
+  const int nblk = args.tiles_m * args.tiles_n;
+  int rc = conv_plan_split(args, nblk, igs_lds_bytes<BN, NBUF>(), args.ktiles, 1, stream);
+  if (rc) return rc;
+  const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
+  const size_t lds = igs_lds_bytes<BN, NBUF>();
+  hipLaunchKernelGGL((conv_igemm_split_f32<BN, PRE, NBUF>), dim3(8 * per_xcd), dim3(kThreads), lds, stream, args);
+  return check_launch("conv_igemm_split_f32");
+}
+
+}  // namespace
+
+// rows = Cout padded to whole tiles (64, or 128 when a multiple of 128)
+size_t conv_igemm_split_weight_bytes(int rows_pad, int Kpad) { return (size_t)rows_pad * Kpad * 2 * 2 + (size_t)rows_pad * 4; }
+
+int conv_igemm_split_transform_weights(const float* d_w, void* d_ws, int rows_pad, int Kpad, hipStream_t stream) {
+  _Float16* ws = reinterpret_cast<_Float16*>(d_ws);
+  float* unscale = reinterpret_cast<float*>(ws + (size_t)rows_pad * Kpad * 2);
+  hipLaunchKernelGGL(split_weights_generic_kernel, dim3(rows_pad), dim3(256), 0, stream, d_w, ws, unscale, Kpad);
+  return check_launch("split_weights_generic_kernel");
+}
+
+// a.w = weights split by conv_igemm_split_transform_weights over cout_pad rows (variant 0: cout_pad % 128 == 0 -> 128-wide
+// tiles, variant 1: 64-wide); a.pre_scale needs a.pre_shift (no squeeze-excitation gate), no swish
+bool conv_igemm_split_launchable(const ConvArgs& a) {
+  static const bool off = std::getenv("HP_CONV_NO_SPLIT") != nullptr;
+  return !off && (a.pre_shift || !a.pre_scale) && a.relu != HP_ACT_SWISH && a.Kpad % 32 == 0;
+}
+
+int launch_conv_igemm_split(const ConvArgs& a, int variant, hipStream_t stream) {
+  const bool pre = a.pre_scale != nullptr;
+  if (variant == 0) return pre ? launch_igs<128, true, 2>(a, stream) : launch_igs<128, false, 2>(a, stream);
+  if (a.ktiles <= 8) return pre ? launch_igs<64, true, 1>(a, stream) : launch_igs<64, false, 1>(a, stream);
+  return pre ? launch_igs<64, true, 2>(a, stream) : launch_igs<64, false, 2>(a, stream);
+}
+
+}  // namespace hp

@@ -47,7 +47,7 @@ struct ConvLayer {
   int cin_real, cin, cout, kh, kw, stride, pad, relu;
   int H, W, Ho, Wo, Kpad;
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
-  DevBuf w, w_wino, w_split, bias, lut, pre_scale, pre_shift;  // w_wino: Winograd-transformed weights (3x3 s1 layers)
+  DevBuf w, w_wino, w_split, w_isplit, bias, lut, pre_scale, pre_shift;  // w_isplit: hi/lo halves for conv_igemm_split.hip  // w_wino: Winograd-transformed weights (3x3 s1 layers)
                                                                // w_split: fp16 hi/lo halves (conv_split.hip)
   int cout_pad = 0;        // weight rows / bias padded to whole 64-wide tiles
   int se = 0;              // the input is gated by the squeeze-excitation vector of this block (1x1 projections)
@@ -336,6 +336,10 @@ int pack_conv(Net& n, ConvLayer& L) {
     if (conv_split_applicable(probe, L.kh, L.kw) && L.cout_pad == L.cout && L.relu != HP_ACT_SWISH && !L.se) {
       if ((rc = L.w_split.alloc(conv_split_weight_bytes(L.cout, L.cin)))) return rc;
       if ((rc = conv_split_transform_weights((const float*)L.w.p, L.w_split.p, L.cout, L.cin, L.Kpad, L.stride, nullptr))) return rc;
+      HP_CHECK_HIP(hipStreamSynchronize(nullptr));
+    } else if (L.relu != HP_ACT_SWISH && !L.se && L.Kpad % 32 == 0) {
+      if ((rc = L.w_isplit.alloc(conv_igemm_split_weight_bytes(L.cout_pad, L.Kpad)))) return rc;
+      if ((rc = conv_igemm_split_transform_weights((const float*)L.w.p, L.w_isplit.p, L.cout_pad, L.Kpad, nullptr))) return rc;
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
     }
   }
@@ -637,10 +641,15 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         rc = launch_conv_wino(a, stream);
         mfma_flops = 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout;
       } else {
-        if (algo != HP_CONV_ALGO_IGEMM && a.relu != HP_ACT_SWISH && !L.se && conv_patch_applicable(a, L.kh, L.kw))
+        mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout_pad * L.Kpad;
+        if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_isplit.p && conv_igemm_split_launchable(a) &&
+            conv_use_igemm_split(L.kh, L.Kpad)) {
+          a.w = (const float*)L.w_isplit.p;
+          rc = launch_conv_igemm_split(a, variant, stream);
+          mfma_flops *= 3.0 / 16.0;  // three fp16 MFMAs per product, 1/16 of the pipe time each
+        } else if (algo != HP_CONV_ALGO_IGEMM && a.relu != HP_ACT_SWISH && !L.se && conv_patch_applicable(a, L.kh, L.kw))
           rc = launch_conv_patch(a, variant, stream);
         else rc = launch_conv(a, variant, stream);
-        mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout_pad * L.Kpad;
       }
       if (rc) return rc;
       prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, mfma_flops);
@@ -871,6 +880,21 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
     if ((rc = conv_wino_transform_weights(d_w, d_U, cout, cin, Kpad, (hipStream_t)stream))) return rc;
     a.w = d_U;
     return launch_conv_wino(a, (hipStream_t)stream);
+  }
+  if (conv_use_split(conv_algo(), h, w, cin, cout) && conv_igemm_split_launchable(a) && conv_use_igemm_split(kh, Kpad)) {
+    // test entry: the weights are split on every call into a per-process scratch buffer
+    static void* d_G = nullptr;
+    static size_t G_bytes = 0;
+    const size_t need_bytes = conv_igemm_split_weight_bytes(cout_pad, Kpad);
+    if (G_bytes < need_bytes) {
+      if (d_G) (void)hipFree(d_G);
+      d_G = nullptr; G_bytes = 0;
+      HP_CHECK_HIP(hipMalloc(&d_G, need_bytes));
+      G_bytes = need_bytes;
+    }
+    if ((rc = conv_igemm_split_transform_weights(d_w, d_G, cout_pad, Kpad, (hipStream_t)stream))) return rc;
+    a.w = (const float*)d_G;
+    return launch_conv_igemm_split(a, cout_pad % 128 == 0 ? 0 : 1, (hipStream_t)stream);
   }
   if (algo != HP_CONV_ALGO_IGEMM && conv_patch_applicable(a, kh, kw))
     return launch_conv_patch(a, cout % 128 == 0 ? 0 : 1, (hipStream_t)stream);
