@@ -257,7 +257,7 @@ def stage_rates(store, scene, images, K, TCO0, im_ids, device, reps=20):
 def measured_traffic(workload, precision):
     """HBM bytes per conv launch from the committed PMC summary (rocprofv3 FETCH_SIZE / WRITE_SIZE
     passes of this bench command, tools/pmc_traffic.py); None when no summary matches the run."""
-    path = os.path.join(ROOT, "profiles", "r01g_conv_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01h_conv_hbm_traffic.json")
     if workload != "C2" or precision != "f32" or not os.path.exists(path):
         return None
     with open(path) as fh:
@@ -402,7 +402,7 @@ def main():
                                              "(an fp16 MFMA FLOP = 1/16): mfma_executed_frac is the busy fraction of the matrix pipe")
             if line["roofline"]["traffic"] is not None:
                 line["roofline"]["traffic_note"] = ("HBM bytes per conv launch (incl. Infinity-Cache hits), PMC passes of this command: "
-                                                    "profiles/r01g_conv_hbm_traffic.json; the kernels are MFMA-bound")
+                                                    "profiles/r01h_conv_hbm_traffic.json; the kernels are MFMA-bound")
         if precision == "f32":
             line["dtype_note"] = ("fp32 tensors and fp32 accumulation everywhere; the 3x3 convolutions multiply fp16 hi/lo halves of the fp32 "
                                   "operands (three fp16 MFMAs per product, 22 significant bits), all other kernels are plain fp32")
