@@ -41,6 +41,7 @@ struct ConvArgs {
   FastDiv fd_howo, fd_wo, fd_tn;  // by Ho*Wo, Wo, tiles_n (filled by the launchers; M < 2^31)
   // tail split-K of the patch kernel (filled by launch_conv_patch)
   int sk_regular, sk_S, sk_tail_items;
+  int sk_S2, sk_S3;        // pooled-stem launch (conv_igemm_split.hip): tiles per image / per tile row
   float* sk_slabs;
   int* sk_counters;
 };
@@ -102,6 +103,8 @@ size_t conv_igemm_split_weight_bytes(int rows_pad, int Kpad);
 int conv_igemm_split_transform_weights(const float* d_w, void* d_ws, int rows_pad, int Kpad, hipStream_t stream);
 bool conv_igemm_split_launchable(const ConvArgs& a);
 int launch_conv_igemm_split(const ConvArgs& a, int variant, hipStream_t stream);
+bool conv_igemm_split_pool_launchable(const ConvArgs& a, int cout_pad);
+int launch_conv_igemm_split_pool(const ConvArgs& a, hipStream_t stream);
 // plan-time choice between the split-fp16 kernel and the exact-fp32 ones for a 3x3 stride-1 layer
 inline bool conv_use_split(int algo, int H, int W, int cin, int cout) {
   (void)H; (void)W; (void)cin; (void)cout;  // measured faster than Winograd on every WideResNet / ResNet-34 layer shape

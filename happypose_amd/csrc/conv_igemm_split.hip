@@ -65,7 +65,14 @@ __global__ __launch_bounds__(256) void split_weights_generic_kernel(const float*
   }
 }
 
-template <int BN, bool PRE, int NBUF>
+// POOL: the conv is followed by ReLU and a 3x3 / stride-2 / pad-1 max-pool (the stems: CP/models/wide_resnet.py:104-107,
+// MP/models/torchvision_resnet.py:216-219) and the kernel writes the POOLED map.  A workgroup owns 3 x 8 pooled pixels
+// of one image and computes the 7 x 17 conv pixels under them (119 of its 128 GEMM rows; 24 % of the conv pixels are
+// computed twice, which costs little: the launch is a store stream) -- the 629 MB conv map of a CosyPose stem is never
+// written or re-read.  Conv pixels outside the map do not take part in the max (PyTorch pads with -inf).
+constexpr int kPoolRows = 3, kPoolCols = 8, kPoolCW = 2 * kPoolCols + 1, kPoolCH = 2 * kPoolRows + 1;
+
+template <int BN, bool PRE, int NBUF, bool POOL>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3 - NBUF), 2 * (3 - NBUF)))) void conv_igemm_split_f32(ConvArgs a) {
   constexpr int MT = 2, NT = BN / 64;  // 4 waves 2 x 2, wave tile 64 x BN/2
   constexpr int NA = 4, NB = BN / 32;  // staged 16-B pieces per thread and K-tile
@@ -79,6 +86,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
   const int tile_m = fdiv(lin, a.fd_tn), tile_n = lin - tile_m * a.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
+  // POOL: tile_m -> (image, pooled tile row, pooled tile column); fd_howo / fd_wo divide by tiles per image / per row
+  int p_img = 0, p_oh0 = 0, p_ow0 = 0;
+  if (POOL) {
+    if (lin >= a.tiles_m * a.tiles_n) return;  // grid rounded up to the 8 XCDs
+    p_img = fdiv(tile_m, a.fd_howo);
+    const int rem = tile_m - p_img * (int)a.sk_S2;
+    const int ty = fdiv(rem, a.fd_wo), tx = rem - ty * (int)a.sk_S3;
+    p_oh0 = 2 * kPoolRows * ty - 1;
+    p_ow0 = 2 * kPoolCols * tx - 1;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kc = tid & 7, r0 = tid >> 3;
@@ -90,10 +107,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int64_t m = m0 + r0 + 32 * i;
-    if (m < a.M) {
-      const int img = fdiv((int)m, a.fd_howo);
+    bool live = m < a.M;
+    int img = 0, oh = 0, ow = 0;
+    if (POOL) {
+      const int r = r0 + 32 * i, dr = r / kPoolCW;
+      img = p_img; oh = p_oh0 + dr; ow = p_ow0 + (r - dr * kPoolCW);
+      live = r < kPoolCH * kPoolCW && (unsigned)oh < (unsigned)a.Ho && (unsigned)ow < (unsigned)a.Wo;
+    } else if (live) {
+      img = fdiv((int)m, a.fd_howo);
       const int rem = (int)m - img * HoWo;
-      const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * a.Wo;
+      oh = fdiv(rem, a.fd_wo); ow = rem - oh * a.Wo;
+    }
+    if (live) {
       ih0[i] = oh * a.stride - a.pad;
       iw0[i] = ow * a.stride - a.pad;
       xrow[i] = a.x + (((int64_t)img * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
@@ -122,52 +147,42 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
   const _Float16* const Afr = As + (wm + frow) * LDH + fk;
   const _Float16* const Bfr = Bs + (wn + frow) * LDH + fk;
 
-  floatx4 ra[NA];
-  halfx8 rbw[NB];
-  floatx4 ps = {0.f, 0.f, 0.f, 0.f}, pb = ps;
-  unsigned ok = 0;
-  auto issue = [&](int t) {
+  // staged K-tile in registers; two sets, so that the loads of K-tile t+2 are in flight while t is multiplied and
+  // t+1 is written to LDS (these launches are latency-bound: a dozen MFMAs per K-tile and wave)
+  struct Stage { floatx4 ra[NA]; halfx8 rbw[NB]; floatx4 ps, pb; unsigned ok; };
+  auto issue = [&](int t, Stage& st) {
     const int4 e = a.lut[t * 8 + kc];  // {offset, kh, kw, channel}; kh < 0 marks K padding
-    ok = 0;
+    st.ok = 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int ih = ih0[i] + e.y, iw = iw0[i] + e.z;
       const bool in = (e.y >= 0) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-      ra[i] = *reinterpret_cast<const floatx4*>(in ? xrow[i] + e.x : a.x);
-      ok |= (in ? 1u : 0u) << i;
+      st.ra[i] = *reinterpret_cast<const floatx4*>(in ? xrow[i] + e.x : a.x);
+      st.ok |= (in ? 1u : 0u) << i;
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rbw[i] = *reinterpret_cast<const halfx8*>(wrow[i] + (size_t)t * 64);
+    for (int i = 0; i < NB; ++i) st.rbw[i] = *reinterpret_cast<const halfx8*>(wrow[i] + (size_t)t * 64);
     if (PRE) {
       const int c = e.y >= 0 ? e.w : 0;
-      ps = *reinterpret_cast<const floatx4*>(a.pre_scale + c);
-      pb = *reinterpret_cast<const floatx4*>(a.pre_shift + c);
+      st.ps = *reinterpret_cast<const floatx4*>(a.pre_scale + c);
+      st.pb = *reinterpret_cast<const floatx4*>(a.pre_shift + c);
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, const Stage& st) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      floatx4 v = ra[i];
-      if (PRE) v = __builtin_elementwise_max(v * ps + pb, floatx4{0.f, 0.f, 0.f, 0.f});
-      if (!((ok >> i) & 1u)) v = floatx4{0.f, 0.f, 0.f, 0.f};
+      floatx4 v = st.ra[i];
+      if (PRE) v = __builtin_elementwise_max(v * st.ps + st.pb, floatx4{0.f, 0.f, 0.f, 0.f});
+      if (!((st.ok >> i) & 1u)) v = floatx4{0.f, 0.f, 0.f, 0.f};
       const halfx4 hi = __builtin_convertvector(v, halfx4);
       const halfx4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), halfx4);
       *reinterpret_cast<halfx4*>(Ast + buf * BM * LDH + 32 * i * LDH) = hi;
       *reinterpret_cast<halfx4*>(Ast + buf * BM * LDH + 32 * i * LDH + 32) = lo;
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<halfx8*>(Bst + buf * BN * LDH + 32 * i * LDH) = rbw[i];
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<halfx8*>(Bst + buf * BN * LDH + 32 * i * LDH) = st.rbw[i];
   };
-
-  const int t_begin = split ? slice * a.ktiles / a.sk_S : 0;
-  const int t_end = split ? (slice + 1) * a.ktiles / a.sk_S : a.ktiles;
-  issue(t_begin);
-  store(0);
-  __syncthreads();
-  for (int t = t_begin; t < t_end; ++t) {
-    const int buf = NBUF == 2 ? (t - t_begin) & 1 : 0;
-    const bool more = t + 1 < t_end;  // wave-uniform
-    if (more) issue(t + 1);
+  auto compute = [&](int buf) {
     const _Float16* Ab = Afr + buf * BM * LDH;
     const _Float16* Bb = Bfr + buf * BN * LDH;
 #pragma unroll
@@ -192,9 +207,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
         }
     }
+  };
+
+  const int t_begin = split ? slice * a.ktiles / a.sk_S : 0;
+  const int t_end = split ? (slice + 1) * a.ktiles / a.sk_S : a.ktiles;
+  Stage s0, s1;
+  issue(t_begin, s0);
+  if (t_begin + 1 < t_end) issue(t_begin + 1, s1);
+  store(0, s0);
+  __syncthreads();
+  // one K-tile: `cur` was written to LDS buffer `buf` (from the OTHER set), `nxt` holds t + 1 and takes t + 2 after it is stored
+  auto ktile = [&](int t, int buf, Stage& stored, Stage& nxt) {
+    if (t + 2 < t_end) issue(t + 2, stored);  // its registers are free: tile t went to LDS before the last barrier
+    compute(buf);
     if (NBUF == 1) __syncthreads();  // every wave is done reading the only buffer
-    if (more) store(NBUF == 2 ? buf ^ 1 : 0);
+    if (t + 1 < t_end) store(NBUF == 2 ? buf ^ 1 : 0, nxt);
     __syncthreads();
+  };
+  for (int t = t_begin; t < t_end; t += 2) {
+    ktile(t, 0, s0, s1);
+    if (t + 1 < t_end) ktile(t + 1, NBUF == 2 ? 1 : 0, s1, s0);
   }
 
   if (split && !splitk_reduce<BM, BN, MT, NT, kThreads>(a, acc, lin - a.sk_regular, slice)) return;
@@ -210,14 +242,77 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= s;
   }
-  conv_epilogue<BM, BN, MT, NT, kThreads>(a, reinterpret_cast<float*>(lds_raw), acc, m0, n0, wm, wn);
+  if (!POOL) {
+    conv_epilogue<BM, BN, MT, NT, kThreads>(a, reinterpret_cast<float*>(lds_raw), acc, m0, n0, wm, wn);
+    return;
+  }
+  // ---- pooled epilogue: conv tile -> LDS [row][BN + 4], then max over the 3 x 3 windows (bias and ReLU commute with max)
+  float* const cl = reinterpret_cast<float*>(lds_raw);
+  constexpr int LDC = BN + 4;
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        cl[row * LDC + wn + nt * 32 + (lane & 31)] = acc[mt][nt][r];
+      }
+  __syncthreads();
+  constexpr int C4 = BN / 4;
+  const int Hp = (a.Ho - 1) / 2 + 1, Wp = (a.Wo - 1) / 2 + 1;
+  for (int it = tid; it < kPoolRows * kPoolCols * C4; it += kThreads) {
+    const int c4 = it % C4, pp = it / C4, py = pp / kPoolCols, px = pp - py * kPoolCols;
+    const int ph = (p_oh0 + 1) / 2 + py, pw = (p_ow0 + 1) / 2 + px;
+    const int n = n0 + 4 * c4;
+    if (ph >= Hp || pw >= Wp || n >= a.Cout) continue;
+    floatx4 best = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int dr = 2 * py + dy, dc = 2 * px + dx;
+        if ((unsigned)(p_oh0 + dr) < (unsigned)a.Ho && (unsigned)(p_ow0 + dc) < (unsigned)a.Wo)
+          best = __builtin_elementwise_max(best, *reinterpret_cast<const floatx4*>(cl + (dr * kPoolCW + dc) * LDC + 4 * c4));
+      }
+    if (a.bias) best += *reinterpret_cast<const floatx4*>(a.bias + n);
+    best = __builtin_elementwise_max(best, floatx4{0.f, 0.f, 0.f, 0.f});
+    *reinterpret_cast<floatx4*>(a.y + (((int64_t)p_img * Hp + ph) * Wp + pw) * a.Cout + n) = best;
+  }
+}
+
+template <int BN, bool PRE, int NBUF>
+int launch_igs_pool(ConvArgs args, hipStream_t stream) {
+  static bool opted = false;
+  if (!opted) {
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)igs_lds_bytes<BN, NBUF>()));
+    opted = true;
+  }
+  const int Hp = (args.Ho - 1) / 2 + 1, Wp = (args.Wo - 1) / 2 + 1;
+  const int tiles_y = (Hp + kPoolRows - 1) / kPoolRows, tiles_x = (Wp + kPoolCols - 1) / kPoolCols;
+  const int n_img = (int)(args.M / ((int64_t)args.Ho * args.Wo));
+  args.tiles_m = n_img * tiles_y * tiles_x;
+  args.tiles_n = (args.Cout + BN - 1) / BN;
+  args.fd_howo = make_fastdiv((unsigned)(tiles_y * tiles_x));  // tiles per image
+  args.fd_wo = make_fastdiv((unsigned)tiles_x);
+  args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
+  args.sk_S2 = tiles_y * tiles_x;
+  args.sk_S3 = tiles_x;
+  const int nblk = args.tiles_m * args.tiles_n;
+  args.sk_regular = (nblk + 7) / 8 * 8; args.sk_S = 1; args.sk_tail_items = 0; args.sk_slabs = nullptr; args.sk_counters = nullptr;
+  args.M = (int64_t)args.tiles_m * BM;  // every GEMM row of a tile is addressed through the tile, not through M
+  const size_t lds = igs_lds_bytes<BN, NBUF>();
+  hipLaunchKernelGGL((conv_igemm_split_f32<BN, PRE, NBUF, true>), dim3(args.sk_regular), dim3(kThreads), lds, stream, args);
+  return check_launch("conv_igemm_split_f32<pool>");
 }
 
 template <int BN, bool PRE, int NBUF>
 int launch_igs(ConvArgs args, hipStream_t stream) {
   static bool opted = false;
   if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF>),
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)igs_lds_bytes<BN, NBUF>()));
     opted = true;
   }
@@ -232,7 +327,7 @@ int launch_igs(ConvArgs args, hipStream_t stream) {
   if (rc) return rc;
   const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
   const size_t lds = igs_lds_bytes<BN, NBUF>();
-  hipLaunchKernelGGL((conv_igemm_split_f32<BN, PRE, NBUF>), dim3(8 * per_xcd), dim3(kThreads), lds, stream, args);
+  hipLaunchKernelGGL((conv_igemm_split_f32<BN, PRE, NBUF, false>), dim3(8 * per_xcd), dim3(kThreads), lds, stream, args);
   return check_launch("conv_igemm_split_f32");
 }
 
@@ -261,5 +356,15 @@ int launch_conv_igemm_split(const ConvArgs& a, int variant, hipStream_t stream) 
   if (a.ktiles <= 8) return pre ? launch_igs<64, true, 1>(a, stream) : launch_igs<64, false, 1>(a, stream);
   return pre ? launch_igs<64, true, 2>(a, stream) : launch_igs<64, false, 2>(a, stream);
 }
+
+// conv + ReLU + 3x3 / stride-2 / pad-1 max-pool in one launch (a.y = the pooled map [n][Hp][Wp][Cout]); 64-wide tiles only
+// Only for short K (the 6-channel CosyPose stem, 5 K-tiles: stem + pool 481 -> 353 us): the 24 % of recomputed conv
+// pixels cost more than the saved traffic on the 7x7 / 32-channel MegaPose stem (49 K-tiles; C3 2440 -> 2312 poses/s).
+bool conv_igemm_split_pool_launchable(const ConvArgs& a, int cout_pad) {
+  return conv_igemm_split_launchable(a) && cout_pad % 128 != 0 && a.relu == HP_ACT_RELU && !a.residual && !a.pre_scale &&
+         a.ktiles <= 8;
+}
+
+int launch_conv_igemm_split_pool(const ConvArgs& a, hipStream_t stream) { return launch_igs_pool<64, false, 1>(a, stream); }
 
 }  // namespace hp

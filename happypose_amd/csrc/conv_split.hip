@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   };
 #else
-  constexpr int LDB = LDH;
+  [[maybe_unused]] constexpr int LDB = LDH;
   // weight staging: row = br0 + 64 i, 16-B chunk bk of the 128-B row
   const int bk = tid & 7, br0 = tid >> 3;
   unsigned wvoff[NB];

@@ -576,6 +576,8 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
     return HP_OK;
   };
   int op_index = 0;
+  bool pool_fused = false;  // the stem wrote the pooled map itself: skip the max-pool op that follows it
+  static const bool no_fuse = std::getenv("HP_NO_POOL_FUSION") != nullptr;
   for (const Op& op : net->ops) {
     if (sync_ops) {
       HP_CHECK_HIP(hipDeviceSynchronize());
@@ -642,10 +644,20 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         mfma_flops = 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout;
       } else {
         mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout_pad * L.Kpad;
+        const Op* next = op_index < (int)net->ops.size() ? &net->ops[op_index] : nullptr;  // op_index already points past this op
         if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_isplit.p && conv_igemm_split_launchable(a) &&
             conv_use_igemm_split(L.kh, L.Kpad)) {
           a.w = (const float*)L.w_isplit.p;
-          rc = launch_conv_igemm_split(a, variant, stream);
+          if (!no_fuse && next && next->kind == OP_MAXPOOL && next->in_buf == L.out_buf && next->H == L.Ho && next->W == L.Wo &&
+              conv_igemm_split_pool_launchable(a, L.cout_pad)) {
+            // stem + ReLU + 3x3/s2 max-pool in one launch: the conv map is never written
+            a.y = (float*)net->bufs[next->out_buf].p;
+            rc = launch_conv_igemm_split_pool(a, stream);
+            pool_fused = true;
+            mfma_flops *= 1.24;  // conv pixels under the tile borders are computed twice (7 x 17 per 6 x 16)
+          } else {
+            rc = launch_conv_igemm_split(a, variant, stream);
+          }
           mfma_flops *= 3.0 / 16.0;  // three fp16 MFMAs per product, 1/16 of the pipe time each
         } else if (algo != HP_CONV_ALGO_IGEMM && a.relu != HP_ACT_SWISH && !L.se && conv_patch_applicable(a, L.kh, L.kw))
           rc = launch_conv_patch(a, variant, stream);
@@ -676,6 +688,9 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       if ((rc = launch_maxpool_f16(net->bufs[op.in_buf].p, net->bufs[op.out_buf].p, batch, op.H, op.W, op.C, op.Ho,
                                    op.Wo, stream)))
         return rc;
+    } else if (op.kind == OP_MAXPOOL && pool_fused) {
+      pool_fused = false;
+      if ((rc = prof_end(true))) return rc;
     } else if (op.kind == OP_MAXPOOL) {
       if ((rc = prof_end(true))) return rc;
       if ((rc = launch_maxpool((const float*)net->bufs[op.in_buf].p, (float*)net->bufs[op.out_buf].p, batch,
