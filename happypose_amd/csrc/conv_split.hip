@@ -311,11 +311,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     // fragment q of a row: 0 / 1 = hi halves of channels 0-15 / 16-31, 2 / 3 = their lo halves
     auto read_a = [&](halfx8 (&f)[MT], int q) {
 #pragma unroll
+#ifdef HP_SABL_NOREAD
+      for (int i = 0; i < MT; ++i) f[i] = __builtin_bit_cast(halfx8, floatx4{(float)tt, (float)q, 1.f, 2.f});
+#else
       for (int i = 0; i < MT; ++i) f[i] = *reinterpret_cast<const halfx8*>(Ab[i] + q * 16);
+#endif
     };
     auto read_b = [&](halfx8 (&f)[NT], int q) {
 #pragma unroll
-#ifdef HP_SPLIT_GLDS
+#ifdef HP_SABL_NOREAD
+      for (int i = 0; i < NT; ++i) f[i] = __builtin_bit_cast(halfx8, floatx4{(float)tt, (float)q, 3.f, 4.f});
+#elif defined(HP_SPLIT_GLDS)
       for (int i = 0; i < NT; ++i) f[i] = *reinterpret_cast<const halfx8*>(Bfq[q] + Pb * BN * LDB + i * 32 * LDB);
 #else
       for (int i = 0; i < NT; ++i) f[i] = *reinterpret_cast<const halfx8*>(Bb + i * 32 * LDH + q * 16);
@@ -402,7 +408,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
   if (cc < ncc) chunk(cc, std::integral_constant<int, 0>{});
 
+#ifdef HP_SPLIT_FENCED_SLABS
   if (split && !splitk_reduce<BM, BN, MT, NT, kThreads>(a, acc, lin - a.sk_regular, slice)) return;
+#else
+  if (split && !splitk_reduce_sc1<BM, BN, MT, NT, kThreads>(a, acc, lin - a.sk_regular, slice)) return;
+#endif
 #ifdef HP_SABL_NOEPI
   if (acc[0][0][0] != 12345.f) return;
 #endif

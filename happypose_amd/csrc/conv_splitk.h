@@ -66,6 +66,56 @@ __device__ __forceinline__ bool splitk_reduce(const ConvArgs& a, sk_floatx16 (&a
   return true;
 }
 
+// The same hand-off with write-through (sc1) slab stores and sc1 slab loads instead of plain accesses bracketed by
+// agent-scope release / acquire fences (cdna_hip_programming.md, split-K recipe): the release fence writes back every
+// dirty line of the XCD's L2 -- mostly other workgroups' output -- once per slice, which cost more than the slices saved
+// on the 8x10 layers.  Slab offsets are 32-bit (the planner keeps the slab area below 2 GB).
+template <int BM, int BN, int MT, int NT, int THREADS>
+__device__ __forceinline__ bool splitk_reduce_sc1(const ConvArgs& a, sk_floatx16 (&acc)[MT][NT], int tail_tile, int slice) {
+  typedef unsigned int sk_uintx4 __attribute__((ext_vector_type(4)));
+  __shared__ int ticket_s1;
+  const int tid = threadIdx.x;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.sk_slabs, 0, 0x7FFFFFFF, 0x00020000);
+  const unsigned slab = (unsigned)(((size_t)tail_tile * a.sk_S + slice) * (BM * BN) * 4);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const sk_floatx4 v = {acc[mt][nt][4 * r4], acc[mt][nt][4 * r4 + 1], acc[mt][nt][4 * r4 + 2], acc[mt][nt][4 * r4 + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sk_uintx4, v), rsrc,
+                                               (int)(slab + ((((mt * NT + nt) * 4 + r4) * THREADS) + tid) * 16), 0, 16 /* sc1 */);
+      }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) ticket_s1 = __hip_atomic_fetch_add(a.sk_counters + tail_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket_s1 != a.sk_S - 1) return false;  // not the last slice of this tile
+  if (tid == 0) a.sk_counters[tail_tile] = 0;  // every slice has taken its ticket: re-arm for the next launch
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int s2 = 0; s2 < a.sk_S; ++s2) {
+    const unsigned other = (unsigned)(((size_t)tail_tile * a.sk_S + s2) * (BM * BN) * 4);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const sk_floatx4 v = __builtin_bit_cast(sk_floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+              rsrc, (int)(other + ((((mt * NT + nt) * 4 + r4) * THREADS) + tid) * 16), 0, 16 /* sc1 */));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[mt][nt][4 * r4 + q] += v[q];
+        }
+  }
+  return true;
+}
+
 // block index -> work item: per XCD (dispatch puts block b on XCD b % 8) first its share of the
 // regular tiles (whole K), then its share of the tail items (tile, slice).  Returns false for
 // the padding blocks of the grid.
