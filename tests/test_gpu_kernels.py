@@ -433,6 +433,34 @@ def _check_conv(dev, case, tol=2e-5):
     assert err <= tol * max(1.0, np.abs(ref).max()), err
 
 
+# The split-fp16 kernels keep their bound over the dynamic range a network sees: activations spread over five
+# decades (low halves down in the fp16 subnormals -- the f16 MFMA must not flush them) and folded-BN weights whose
+# magnitude differs by 1e6 between output channels (per-channel power-of-two scaling).
+@pytest.mark.parametrize("case", [
+    dict(n=4, h=30, w=40, cin=128, cout=128, k=3, s=1),
+    dict(n=4, h=30, w=40, cin=64, cout=128, k=3, s=2),
+    dict(n=2, h=64, w=64, cin=8, cout=64, k=5, s=2),   # generic split kernel (stem-like)
+])
+def test_split_conv_dynamic_range(dev, case):
+    from happypose_amd import ops
+
+    rs = np.random.RandomState(5)
+    c = case
+    x = (rs.normal(size=(c["n"], c["h"], c["w"], c["cin"])) * 10.0 ** rs.uniform(-5, 0, size=(c["n"], c["h"], c["w"], 1))).astype(np.float32)
+    w = (rs.normal(size=(c["cout"], c["cin"], c["k"], c["k"])) * 10.0 ** rs.uniform(-6, 0, size=(c["cout"], 1, 1, 1))).astype(np.float32)
+    ref = _conv_ref(x, w, c["s"], c["k"] // 2, None, None, None, False)
+    ops.select_conv_algo("split")
+    try:
+        y = ops.conv2d_nhwc(torch.as_tensor(x, device=dev), torch.as_tensor(np.ascontiguousarray(w.transpose(0, 2, 3, 1)), device=dev),
+                            c["s"], c["k"] // 2).cpu().numpy()
+    finally:
+        ops.select_conv_algo("auto")
+    # per output channel: 2e-5 of that channel's largest output (a global bound would hide the small-weight channels)
+    err = np.abs(y - ref).reshape(-1, c["cout"]).max(0)
+    scale = np.abs(ref).reshape(-1, c["cout"]).max(0)
+    assert (err <= 2e-5 * scale).all(), (err / scale).max()
+
+
 # fp16 kernel (configuration C5): operands rounded to fp16, fp32 accumulation, one rounding of the
 # result -> compare with fp64 on the SAME fp16-rounded operands; the only error left is the
 # accumulation order and the final rounding to fp16 (2^-11 relative)
