@@ -354,6 +354,25 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     load_b(1 - Pb, tt + 3);                // ... and that set takes tap tt+3
 #endif
 #endif
+#ifdef HP_SPLIT_2BATCH
+    halfx8 al1[MT], bl1[NT];
+    read_a(al, 2);
+    mm(ah, bh);
+    read_a(ah1, 1);
+    read_b(bh1, 1);
+    read_b(bl1, 3);
+    read_a(al1, 3);
+    mm(ah, bl);
+    mm(al, bh);
+#ifndef HP_SABL_NOPATCH
+#pragma unroll
+    for (int j = 0; j < NPC; ++j)          // next chunk's patch: one pass per tap (taps 0 .. NPC-1)
+      if (j == tap) load_patch(j, cc + 1 < ncc ? cc + 1 : cc);
+#endif
+    mm(ah1, bh1);
+    mm(ah1, bl1);
+    mm(al1, bh1);
+#else
     mm(ah, bh);
     read_a(al, 2);
     mm(ah, bl);
@@ -370,6 +389,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     read_a(al, 3);
     mm(ah1, bl);
     mm(al, bh1);
+#endif
 #ifdef HP_SPLIT_GLDS
     // the DMA of this tap must have landed; the (younger) patch loads of taps 0 .. NPC-1 stay in flight.  A raw
     // barrier: __syncthreads() would drain every outstanding load
