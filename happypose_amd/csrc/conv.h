@@ -103,6 +103,9 @@ size_t conv_igemm_split_weight_bytes(int rows_pad, int Kpad);
 int conv_igemm_split_transform_weights(const float* d_w, void* d_ws, int rows_pad, int Kpad, hipStream_t stream);
 bool conv_igemm_split_launchable(const ConvArgs& a);
 int launch_conv_igemm_split(const ConvArgs& a, int variant, hipStream_t stream);
+// the CosyPose stem (5x5 s2 on 6 channels + ReLU + max-pool) with the input region of a tile staged once (conv_stem_split.hip)
+bool conv_stem_split_applicable(const ConvArgs& a, int kh, int kw, int run_mode);
+int launch_conv_stem_split_pool(ConvArgs args, hipStream_t stream);
 bool conv_igemm_split_pool_launchable(const ConvArgs& a, int cout_pad);
 int launch_conv_igemm_split_pool(const ConvArgs& a, hipStream_t stream);
 // plan-time choice between the split-fp16 kernel and the exact-fp32 ones for a 3x3 stride-1 layer

@@ -652,9 +652,15 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
               conv_igemm_split_pool_launchable(a, L.cout_pad)) {
             // stem + ReLU + 3x3/s2 max-pool in one launch: the conv map is never written
             a.y = (float*)net->bufs[next->out_buf].p;
-            rc = launch_conv_igemm_split_pool(a, stream);
+            static const bool no_stem = std::getenv("HP_NO_STEM_KERNEL") != nullptr;
+            if (!no_stem && conv_stem_split_applicable(a, L.kh, L.kw, L.run_mode)) {
+              rc = launch_conv_stem_split_pool(a, stream);
+              mfma_flops *= 256.0 / 192.0;  // 256 GEMM rows per 6 x 32 conv pixels (7 x 33 computed, the rest padding)
+            } else {
+              rc = launch_conv_igemm_split_pool(a, stream);
+              mfma_flops *= 1.24;  // conv pixels under the tile borders are computed twice (7 x 17 per 6 x 16)
+            }
             pool_fused = true;
-            mfma_flops *= 1.24;  // conv pixels under the tile borders are computed twice (7 x 17 per 6 x 16)
           } else {
             rc = launch_conv_igemm_split(a, variant, stream);
           }
