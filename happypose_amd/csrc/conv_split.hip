@@ -93,7 +93,8 @@ template <int WAVES_M, int WAVES_N>
 struct SplitTile {
   static constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
   static int P(int W) { return BM + 2 * W + 2; }
-  static int npc(int W) { return (P(W) + 127) / 128; }
+  static constexpr int NTHR = 64 * WAVES_M * WAVES_N;  // 8 waves: one workgroup per CU; 4 waves: two
+  static int npc(int W) { return (P(W) + NTHR / 4 - 1) / (NTHR / 4); }
   static size_t lds_bytes(int W) {
     const size_t loop = ((size_t)P(W) * LDH + 2 * (size_t)BN * LDH + LDH) * 2;  // patch, weights x 2, a zero row
     const size_t epi = (size_t)BM * (BN + 4) * 4;
@@ -102,8 +103,10 @@ struct SplitTile {
 };
 
 template <int WAVES_M, int WAVES_N, bool PRE, int NPC>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_f32(ConvArgs a, int P) {
-  static_assert(WAVES_M * WAVES_N == 8, "8 waves");
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_f32(ConvArgs a, int P) {
+  static_assert(WAVES_M * WAVES_N == 8 || WAVES_M * WAVES_N == 4, "8 waves (one workgroup per CU) or 4 (two)");
+  constexpr int kThreads = 64 * WAVES_M * WAVES_N;  // shadows the file-level constant
+  constexpr int PROWS = kThreads / 4, BROWS = kThreads / 8;  // rows per staging pass: patch / weights
   constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N, MT = 2, NT = 2;
   constexpr int NB = BN * 8 / kThreads;  // 16-B weight chunks per thread and tap (2 or 1)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -144,8 +147,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int pk = tid & 3, pr0 = tid >> 2;
   const int64_t gp0 = m0 - (W + 1) + pr0;
   auto patch_voff = [&](int j) -> unsigned {
-    const int64_t gp = gp0 + 128 * j;
-    return (pr0 + 128 * j < P && gp >= 0 && gp < a.M) ? (unsigned)((gp * Cin + 8 * pk) * 4) : kOob;
+    const int64_t gp = gp0 + PROWS * j;
+    return (pr0 + PROWS * j < P && gp >= 0 && gp < a.M) ? (unsigned)((gp * Cin + 8 * pk) * 4) : kOob;
   };
   _Float16* const Pst = patch + pr0 * LDH + 8 * pk;
 #ifdef HP_SPLIT_GLDS
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int bk = tid & 7, br0 = tid >> 3;
   unsigned wvoff[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) wvoff[i] = (unsigned)(((int64_t)(n0 + br0 + 64 * i) * (18 * Cin) + 8 * bk) * 2);
+  for (int i = 0; i < NB; ++i) wvoff[i] = (unsigned)(((int64_t)(n0 + br0 + BROWS * i) * (18 * Cin) + 8 * bk) * 2);
   _Float16* const Bst = Bs + br0 * LDH + 8 * bk;
 #endif
   if (tid < LDH / 2) reinterpret_cast<unsigned*>(zrow)[tid] = 0u;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
-      if (pr0 + 128 * j < P) {
+      if (pr0 + PROWS * j < P) {
         const bool real = patch_voff(j) != kOob;  // pixels outside the tensor stay zero
         halfx4 hi[2], lo[2];
 #pragma unroll
@@ -257,8 +260,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
           hi[h] = __builtin_convertvector(v, halfx4);
           lo[h] = __builtin_convertvector(v - __builtin_convertvector(hi[h], floatx4), halfx4);
         }
-        *reinterpret_cast<halfx8*>(Pst + 128 * j * LDH) = __builtin_shufflevector(hi[0], hi[1], 0, 1, 2, 3, 4, 5, 6, 7);
-        *reinterpret_cast<halfx8*>(Pst + 128 * j * LDH + 32) = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<halfx8*>(Pst + PROWS * j * LDH) = __builtin_shufflevector(hi[0], hi[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<halfx8*>(Pst + PROWS * j * LDH + 32) = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
       }
     }
   };
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   };
   auto store_b = [&](int set, int buf) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<halfx8*>(Bst + buf * BN * LDH + 64 * i * LDH) = rb[set][i];
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<halfx8*>(Bst + buf * BN * LDH + BROWS * i * LDH) = rb[set][i];
   };
 #endif
 
@@ -755,7 +758,7 @@ int launch_split_s2_variant(ConvArgs args, hipStream_t stream) {
 // tail split: T tiles on `slots` CUs (one workgroup each); the tiles of the last partial round are cut into S slices
 struct SplitWs { float* slabs = nullptr; size_t slab_bytes = 0; int* counters = nullptr; size_t counter_bytes = 0; int slots = 0; };
 
-int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, hipStream_t stream) {
+int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_cu, hipStream_t stream) {
   static SplitWs ws;
   if (ws.slots == 0) {
     int dev = 0, cus = 256;
@@ -765,7 +768,7 @@ int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, hipStream_t
   }
   static const bool no_split = std::getenv("HP_CONV_NO_SPLITK") != nullptr;
   static const int force_s = std::getenv("HP_SPLIT_S") ? std::atoi(std::getenv("HP_SPLIT_S")) : 0;
-  const int slots = ws.slots;
+  const int slots = ws.slots * wg_per_cu;
   int regular = (T / slots) * slots, S = 1;
   int tail = T - regular;
   if (tail > 0 && ncc > 1 && !no_split) {
@@ -818,10 +821,10 @@ int launch_split_variant(ConvArgs args, hipStream_t stream) {
   args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
   args.fd_wo = make_fastdiv((unsigned)args.Wo);
   args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
-  const int rc = plan_tail_split(args, args.tiles_m * args.tiles_n, args.Cin / CK, (size_t)T::BM * T::BN, stream);
+  const int rc = plan_tail_split(args, args.tiles_m * args.tiles_n, args.Cin / CK, (size_t)T::BM * T::BN, 512 / T::NTHR, stream);
   if (rc) return rc;
   const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
-  hipLaunchKernelGGL((conv3x3_split_f32<WAVES_M, WAVES_N, PRE, NPC>), dim3(8 * per_xcd), dim3(kThreads),
+  hipLaunchKernelGGL((conv3x3_split_f32<WAVES_M, WAVES_N, PRE, NPC>), dim3(8 * per_xcd), dim3(T::NTHR),
                      T::lds_bytes(args.W), stream, args, T::P(args.W));
   return check_launch("conv3x3_split_f32");
 }
@@ -831,7 +834,8 @@ int launch_split_npc(const ConvArgs& a, hipStream_t stream) {
   const int npc = SplitTile<WAVES_M, WAVES_N>::npc(a.W);
   if (npc <= 3) return launch_split_variant<WAVES_M, WAVES_N, PRE, 3>(a, stream);
   if (npc == 4) return launch_split_variant<WAVES_M, WAVES_N, PRE, 4>(a, stream);
-  return launch_split_variant<WAVES_M, WAVES_N, PRE, 6>(a, stream);
+  if (npc <= 6) return launch_split_variant<WAVES_M, WAVES_N, PRE, 6>(a, stream);
+  return launch_split_variant<WAVES_M, WAVES_N, PRE, 7>(a, stream);
 }
 
 }  // namespace
@@ -866,7 +870,13 @@ int launch_conv_split(const ConvArgs& a, hipStream_t stream) {
   const bool pre = a.pre_scale != nullptr;
   if (a.stride == 2)
     return pre ? launch_split_s2_variant<4, 2, true, 3>(a, stream) : launch_split_s2_variant<4, 2, false, 3>(a, stream);
+  // (128 x 128 tiles in 4-wave workgroups, two per CU, measured 3-10 % slower than 256 x 128 on the >= 128-channel layers)
   if (a.Cout % 128 == 0) return pre ? launch_split_npc<4, 2, true>(a, stream) : launch_split_npc<4, 2, false>(a, stream);
+  // 64-channel layers (60x80 maps, K = 18 taps): 256 x 64 tiles in 4-wave workgroups, TWO per CU -- with one 512 x 64
+  // workgroup per CU nothing runs under its prologue, patch restaging and epilogue, a third of such a short tile
+  static const bool wide = std::getenv("HP_SPLIT_WIDE64") != nullptr;
+  if (!wide && SplitTile<4, 1>::npc(a.W) <= 7 && 2 * SplitTile<4, 1>::lds_bytes(a.W) + 1024 <= 160 * 1024)
+    return pre ? launch_split_npc<4, 1, true>(a, stream) : launch_split_npc<4, 1, false>(a, stream);
   return pre ? launch_split_npc<8, 1, true>(a, stream) : launch_split_npc<8, 1, false>(a, stream);
 }
 
