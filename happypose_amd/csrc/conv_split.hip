@@ -123,14 +123,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
   const int tile_m = fdiv(lin, a.fd_tn), tile_n = lin - tile_m * a.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
-#ifdef HP_SPLIT_STAGGER
-  // first-round workgroups of every other CU start late, so that loop phases and (HBM-bound) epilogues of the
-  // two halves of the machine alternate instead of coinciding
-  if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < HP_SPLIT_STAGGER) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = a.W, H = a.H, Cin = a.Cin;
@@ -151,54 +143,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
     return (pr0 + PROWS * j < P && gp >= 0 && gp < a.M) ? (unsigned)((gp * Cin + 8 * pk) * 4) : kOob;
   };
   _Float16* const Pst = patch + pr0 * LDH + 8 * pk;
-#ifdef HP_SPLIT_GLDS
-  // weights by LDS-DMA: wave w copies rows [w BN/8, (w+1) BN/8) of the tap's [BN][128 B] tile, 8 rows (1 KiB) per
-  // instruction, lane -> (row = lane >> 3, 16-B slot = lane & 7).  The LDS image is lane-linear (unpadded 128-B
-  // rows), so the bank spread comes from an XOR swizzle applied to the SOURCE chunk here and to the reads below:
-  // slot s of row r holds chunk s ^ ((r >> 1) & 7).
-  constexpr int GI = BN / 64;  // DMA instructions per wave and tap
-  constexpr int LDB = 64;      // halves per weight row in LDS
-  const char* gsrc[GI];
-  unsigned gdst[GI];
-#pragma unroll
-  for (int i = 0; i < GI; ++i) {
-    const int r = wave * (BN / 8) + 8 * i + (lane >> 3);
-    gsrc[i] = reinterpret_cast<const char*>(a.w) + ((int64_t)(n0 + r) * (18 * Cin)) * 2 + (((lane & 7) ^ ((r >> 1) & 7)) * 16);
-    gdst[i] = (unsigned)reinterpret_cast<size_t>(Bs + (wave * (BN / 8) + 8 * i) * LDB);
-  }
-  auto glds_b = [&](int tt, int buf) {  // tap tt's weights -> LDS buffer buf
-    const int t2 = tt < ntaps ? tt : ntaps - 1;
-#pragma unroll
-    for (int i = 0; i < GI; ++i) {
-      unsigned keep;
-      const char* src = gsrc[i] + (size_t)t2 * 128;
-      const unsigned dst = __builtin_amdgcn_readfirstlane(gdst[i]) + (unsigned)(buf * BN * LDB * 2);  // wave-uniform
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    }
-  };
-#else
-  [[maybe_unused]] constexpr int LDB = LDH;
   // weight staging: row = br0 + 64 i, 16-B chunk bk of the 128-B row
   const int bk = tid & 7, br0 = tid >> 3;
   unsigned wvoff[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) wvoff[i] = (unsigned)(((int64_t)(n0 + br0 + BROWS * i) * (18 * Cin) + 8 * bk) * 2);
   _Float16* const Bst = Bs + br0 * LDH + 8 * bk;
-#endif
   if (tid < LDH / 2) reinterpret_cast<unsigned*>(zrow)[tid] = 0u;
 
   // fragment bases + validity of the 9 taps per fragment row
   const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * 64;
   const int frow = lane & 31, fk = 8 * (lane >> 5);
-#ifdef HP_SPLIT_GLDS
-  // fragment q (32 B = chunks 2 q, 2 q + 1; this lane reads chunk 2 q + (lane >> 5)) of row wn + nt 32 + frow
-  const _Float16* Bfq[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) Bfq[q] = Bs + (wn + frow) * LDB + (((2 * q + (lane >> 5)) ^ ((frow >> 1) & 7)) * 8);
-#else
   const _Float16* const Bfr = Bs + (wn + frow) * LDH + fk;
-#endif
   const _Float16* Afr[MT];
   unsigned vmask[MT];
 #pragma unroll
@@ -228,9 +184,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   floatx4 pr[NPC][2];  // next channel chunk of the patch (fp32)
-#ifndef HP_SPLIT_GLDS
   halfx8 rb[2][NB];    // weights of taps t+1 / t+2 (alternating sets)
-#endif
   auto load_patch = [&](int j, int cc) {
     const unsigned vo = patch_voff(j);
     pr[j][0] = loadf4(xrsrc, vo, (unsigned)(cc * CK * 4));
@@ -265,7 +219,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
       }
     }
   };
-#ifndef HP_SPLIT_GLDS
   auto load_b = [&](int set, int tt) {  // tt = cc * 9 + tap: the order of the split weight rows
     const int t2 = tt < ntaps ? tt : ntaps - 1;
 #pragma unroll
@@ -275,24 +228,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
 #pragma unroll
     for (int i = 0; i < NB; ++i) *reinterpret_cast<halfx8*>(Bst + buf * BN * LDH + BROWS * i * LDH) = rb[set][i];
   };
-#endif
 
   // prologue: patch of chunk 0, weights of tap 0 (-> LDS), 1 and 2 (-> registers)
 #pragma unroll
   for (int j = 0; j < NPC; ++j) load_patch(j, cc_begin);
-#ifdef HP_SPLIT_GLDS
-  glds_b(cc_begin * 9, 0);
-  store_patch(cc_begin);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-#else
   load_b(0, cc_begin * 9);
   load_b(1, cc_begin * 9 + 1);
   store_patch(cc_begin);
   store_b(0, 0);
   load_b(0, cc_begin * 9 + 2);
   __syncthreads();
-#endif
 
   auto tap_step = [&](int tt, int cc, int tap, auto par) {
     constexpr int Pb = decltype(par)::value;  // tt & 1: LDS weight buffer of this tap
@@ -307,9 +252,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
       Ab[i] = Afr[i] + d * LDH;
 #endif
     }
-#ifndef HP_SPLIT_GLDS
     const _Float16* Bb = Bfr + Pb * BN * LDH;
-#endif
     const bool next_chunk = cc + 1 < ncc;
     // fragment q of a row: 0 / 1 = hi halves of channels 0-15 / 16-31, 2 / 3 = their lo halves
     auto read_a = [&](halfx8 (&f)[MT], int q) {
@@ -324,8 +267,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
 #pragma unroll
 #ifdef HP_SABL_NOREAD
       for (int i = 0; i < NT; ++i) f[i] = __builtin_bit_cast(halfx8, floatx4{(float)tt, (float)q, 3.f, 4.f});
-#elif defined(HP_SPLIT_GLDS)
-      for (int i = 0; i < NT; ++i) f[i] = *reinterpret_cast<const halfx8*>(Bfq[q] + Pb * BN * LDB + i * 32 * LDB);
 #else
       for (int i = 0; i < NT; ++i) f[i] = *reinterpret_cast<const halfx8*>(Bb + i * 32 * LDH + q * 16);
 #endif
@@ -342,10 +283,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
     halfx8 ah[MT], al[MT], bh[NT], bl[NT], ah1[MT], bh1[NT];
     // (the staging below is unconditional -- clamped addresses, a dead LDS buffer after the last tap -- so
     // that the tap body is straight-line code: with branches the compiler waits for ALL outstanding loads)
-#ifdef HP_SPLIT_GLDS
-    glds_b(tt + 1, 1 - Pb);                // weights of tap tt+1: the buffer every wave left at the last barrier
-#define HP_SABL_NOBSTAGE
-#endif
     read_a(ah, 0);
     read_b(bh, 0);
     read_b(bl, 2);
@@ -393,16 +330,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
     mm(ah1, bl);
     mm(al, bh1);
 #endif
-#ifdef HP_SPLIT_GLDS
-    // the DMA of this tap must have landed; the (younger) patch loads of taps 0 .. NPC-1 stay in flight.  A raw
-    // barrier: __syncthreads() would drain every outstanding load
-    if (tap < NPC) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
 #ifndef HP_SABL_NOBARRIER
     __syncthreads();
-#endif
 #endif
 #ifndef HP_SABL_NOPATCH
     if (tap == 8 && next_chunk) {  // every wave is done with this chunk's patch: swap in the next one
