@@ -39,7 +39,7 @@ N_DET, N_HYP, N_ITERS = 8, 16, 5
 WORKLOADS = ("C2", "C3", "C5", "E2E")
 
 
-def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32"):
+def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32", n_lanes=1):
     """Synthetic world of SURVEY.md 8(d) for a BASELINE.json config:
     C2 CosyPose refiner (8 det x 16 hyp, WideResNet-34 on 6 channels, 1 RGB view);
     C3 MegaPose RGB-D refiner (64 hypotheses, 4 views x (RGB + normals + depth), ResNet-34 on 32 ch);
@@ -54,14 +54,14 @@ def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32")
         scene = make_scene(n_detections=N_DET, n_hypotheses=N_HYP, n_objects=8, seed=2 + seed)
         weights = predictor_weights(pose_model_param_shapes(arch, 6), seed=0)
         model = create_pose_model_cosypose(dict(backbone_str=arch), renderer, state_dict=weights,
-                                           max_batch=N_DET * N_HYP, precision=precision)
+                                           max_batch=N_DET * N_HYP, precision=precision, n_lanes=n_lanes)
     elif workload == "C3":
         scene = make_scene(n_detections=8, n_hypotheses=8, n_objects=8, seed=2 + seed, with_depth=True)
         weights = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 32), seed=0)
         cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views",
                    render_normals=True, render_depth=True, input_depth=True, predict_pose_update=True,
                    depth_augmentation=False, depth_normalization_type="tCR_scale_clamp_center")
-        model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=64, precision=precision)
+        model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=64, precision=precision, n_lanes=n_lanes)
     else:
         from happypose_amd.pose_estimator import load_SO3_grid
 
@@ -274,6 +274,8 @@ def main():
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS),
                     help="BASELINE.json config (default C2 = the one the headline metric is quoted on)")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the secondary run on the exact-fp32 kernels")
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
+                    help="refiner workloads (C2, C3): 2 = two half-batch chains on two streams (TwoLanePredictor)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16"],
                     help="conv arithmetic (default: f32, the reference's; f16 for C5 as BASELINE.json names it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -297,8 +299,9 @@ def main():
         return
     precision = args.precision or ("f16" if args.workload == "C5" else "f32")
     peak = PEAK_F16_MFMA_TFLOPS if precision == "f16" else PEAK_F32_MFMA_TFLOPS
+    n_lanes = args.lanes if args.workload in ("C2", "C3") else 1
     ds, renderer, scene, weights, model = build_world(device, args.arch, seed=rank, workload=args.workload,
-                                                      precision=precision)
+                                                      precision=precision, n_lanes=n_lanes)
     store = renderer.store
     B = len(scene["TCO_hyp"])
     images = torch.as_tensor(scene["images"], device=device)  # inputs resident in HBM
@@ -328,12 +331,23 @@ def main():
         step()
     model.backbone.set_profiling(True)
     fence()
+    from happypose_amd import ops as _ops
+    _ops.profile_mark_reference(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         poses = step()
     fence()
     elapsed = time.perf_counter() - t0
-    conv_ms, n_launch, conv_flops, mfma_flops = model.backbone.profile_collect()
+    # time during which ANY conv kernel was running: the union of the timed stretches of all lanes (with two lanes
+    # the summed kernel time exceeds the wall time; with one lane the union is the sum)
+    ivs = sorted(model.backbone.profile_intervals())
+    conv_union_ms, end = 0.0, -1.0
+    for a0, a1 in ivs:
+        if a1 > end:
+            conv_union_ms += a1 - max(a0, end)
+            end = a1
+    conv_sum_ms, n_launch, conv_flops, mfma_flops = model.backbone.profile_collect()
+    conv_ms = conv_union_ms
     model.backbone.set_profiling(False)
     assert torch.isfinite(poses).all()
 
@@ -378,7 +392,8 @@ def main():
             "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
-            "config": {"workload": desc, "hypotheses_per_gpu": B, "iterations": N_ITERS if args.workload != "C5" else 1,
+            "config": {"workload": desc + (", two half-batch lanes on two streams" if n_lanes == 2 else ""),
+                       "hypotheses_per_gpu": B, "iterations": N_ITERS if args.workload != "C5" else 1,
                        "parallelism": f"hypothesis-shard x{world}"},
             # achieved = ALGORITHMIC FLOPs (direct-convolution 2*MAC) / kernel time.  30 of
             # the 36 convs run as Winograd F(2x2,3x3) and execute 2.25x fewer MFMA FLOPs than that, so
@@ -391,8 +406,13 @@ def main():
                          "frac": achieved / peak, "traffic": measured_traffic(args.workload, precision),
                          "mfma_executed_tflops": mfma_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else 0.0,
-                         "launches": n_launch, "avg_launch_us": 1e3 * conv_ms / max(n_launch, 1),
-                         "launch_note": "a launch = one conv layer of a forward",
+                         "launches": n_launch, "avg_launch_us": 1e3 * conv_sum_ms / max(n_launch, 1),
+                         "lanes": n_lanes, "conv_busy_ms_per_step": conv_ms / args.steps,
+                         "launch_note": ("a launch = one conv layer of a forward; achieved = FLOPs / conv_busy time = the union over "
+                                         "both lanes of the timed conv stretches (two lanes run concurrently: a kernel shares the "
+                                         "machine with the other lane's, so avg_launch_us is longer than its solo duration and the "
+                                         "summed kernel time exceeds the wall time)") if n_lanes == 2 else
+                                        "a launch = one conv layer of a forward",
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }
         if precision == "f32":

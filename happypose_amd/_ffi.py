@@ -70,6 +70,9 @@ _PROTOS = {
     "hp_net_flops_per_sample": (C.c_double, [C.c_void_p]),
     "hp_net_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_conv_occupancy": (C.c_int, [C.c_int]),
+    "hp_conv_set_tail_split": (C.c_int, [C.c_int]),
+    "hp_profile_mark_reference": (C.c_int, [C.c_void_p]),
+    "hp_net_profile_intervals": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "hp_conv_select_algo": (C.c_int, [C.c_int]),
     "hp_net_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -131,6 +131,8 @@ int launch_conv_f16(const ConvArgsH& a, hipStream_t stream);
 int launch_cast_pad_f16(const float* x, void* y, int64_t pixels, int c_in, int c_out, hipStream_t stream);
 int launch_maxpool_f16(const void* x, void* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
 int conv_setup_once();
+// K-slicing of the tiles of a partially filled last round (hp_conv_set_tail_split; off while two lanes share the GPU)
+bool conv_tail_split_enabled();
 // HP_CONV_ALGO_* currently selected (hp_conv_select_algo / HP_CONV_NO_WINOGRAD, HP_CONV_NO_PATCH)
 int conv_algo();
 

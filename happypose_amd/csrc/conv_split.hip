@@ -28,6 +28,7 @@
 // buffered in LDS one tap ahead, their loads two taps ahead in alternating register sets.
 // Per tap and wave (64x64 wave tile): 16 ds_read_b128 feed 24 MFMAs.
 #include <cstdlib>
+#include <map>
 #include <type_traits>
 
 #include "conv.h"
@@ -688,7 +689,9 @@ int launch_split_s2_variant(ConvArgs args, hipStream_t stream) {
 struct SplitWs { float* slabs = nullptr; size_t slab_bytes = 0; int* counters = nullptr; size_t counter_bytes = 0; int slots = 0; };
 
 int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_cu, hipStream_t stream) {
-  static SplitWs ws;
+  // one workspace per stream: launches on different streams (the lanes of a two-lane predictor) run concurrently
+  static std::map<hipStream_t, SplitWs> wss;
+  SplitWs& ws = wss[stream];
   if (ws.slots == 0) {
     int dev = 0, cus = 256;
     HP_CHECK_HIP(hipGetDevice(&dev));
@@ -700,7 +703,7 @@ int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_
   const int slots = ws.slots * wg_per_cu;
   int regular = (T / slots) * slots, S = 1;
   int tail = T - regular;
-  if (tail > 0 && ncc > 1 && !no_split) {
+  if (tail > 0 && ncc > 1 && !no_split && conv_tail_split_enabled()) {
     // cost in units of a whole tile: rounds x longest slice + parking / re-reading the slabs (~1.3 us per 128 KB
     // against ~1 us per tap of the K loop)
     double best = 1.0;

@@ -803,6 +803,33 @@ extern "C" int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_l
 
 extern "C" double hp_net_flops_per_sample(const hp_net* net) { return net ? net->flops_per_sample : 0.0; }
 
+// ---- profiling across several networks / streams: absolute positions of the timed stretches -------------
+namespace { hipEvent_t g_prof_ref = nullptr; }
+
+extern "C" int hp_profile_mark_reference(void* stream) {
+  if (!g_prof_ref) HP_CHECK_HIP(hipEventCreate(&g_prof_ref));
+  HP_CHECK_HIP(hipEventRecord(g_prof_ref, (hipStream_t)stream));
+  return HP_OK;
+}
+
+extern "C" int hp_net_profile_intervals(hp_net* net, double* t0_ms, double* t1_ms, int cap) {
+  HP_REQUIRE(net, "hp_net_profile_intervals: null net");
+  HP_REQUIRE(g_prof_ref, "hp_net_profile_intervals: hp_profile_mark_reference has not been called");
+  HP_REQUIRE(cap >= 0 && (cap == 0 || (t0_ms && t1_ms)), "hp_net_profile_intervals: bad buffers");
+  int n = 0;
+  for (auto& p : net->ev_pending) {
+    if (n < cap) {
+      HP_CHECK_HIP(hipEventSynchronize(p.e1));
+      float a = 0.f, b = 0.f;
+      HP_CHECK_HIP(hipEventElapsedTime(&a, g_prof_ref, p.e0));
+      HP_CHECK_HIP(hipEventElapsedTime(&b, g_prof_ref, p.e1));
+      t0_ms[n] = a; t1_ms[n] = b;
+    }
+    ++n;
+  }
+  return n;
+}
+
 extern "C" int hp_net_set_profiling(hp_net* net, int enabled) {
   HP_REQUIRE(net, "hp_net_set_profiling: null net");
   net->profiling = enabled != 0;

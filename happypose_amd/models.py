@@ -201,10 +201,23 @@ def _efficientnet_b3_param_shapes(n_inputs: int, pose_dim: int, n_views_logits: 
     return s
 
 
+def _two_lanes(make, renderer: BatchRenderer, max_batch: int):
+    """Two predictors for :class:`TwoLanePredictor`: lane 1 gets its own mesh store (rasteriser scratch)."""
+    from .pose_predictor import TwoLanePredictor
+
+    half = (max_batch + 1) // 2
+    r1 = BatchRenderer(renderer._object_dataset, device=renderer.device)
+    return TwoLanePredictor([make(renderer, half), make(r1, half)])
+
+
 def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Optional[Dict] = None,
-                      max_batch: int = 128, precision: str = "f32") -> PosePredictor:
+                      max_batch: int = 128, precision: str = "f32", n_lanes: int = 1) -> PosePredictor:
     """MegaPose predictor (``MP/training/pose_models_cfg.py:89-142``).  ``state_dict`` holds the
-    reference's keys (``backbone.*``, ``pose_fc.*``, ``views_logits_head.*``)."""
+    reference's keys (``backbone.*``, ``pose_fc.*``, ``views_logits_head.*``).  ``n_lanes=2``: the refiner's
+    ``forward`` runs two half-batch chains on two streams (:class:`TwoLanePredictor`)."""
+    if n_lanes == 2:
+        return _two_lanes(lambda r, mb: create_model_pose(cfg, r, mesh_db, state_dict, mb, precision), renderer, max_batch)
+    assert n_lanes == 1
     cfg = check_update_config(cfg)
     assert state_dict is not None, "weights are required (no training path here)"
     sd = change_keys_of_older_models(state_dict)
@@ -224,8 +237,13 @@ def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Op
 
 
 def create_pose_model_cosypose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Optional[Dict] = None,
-                               max_batch: int = 128, precision: str = "f32") -> CosyPosePosePredictor:
-    """``CP/training/pose_models_cfg.py:30-53`` (6 input channels; ``n_pose_dims`` = 9)."""
+                               max_batch: int = 128, precision: str = "f32", n_lanes: int = 1) -> CosyPosePosePredictor:
+    """``CP/training/pose_models_cfg.py:30-53`` (6 input channels; ``n_pose_dims`` = 9).  ``n_lanes`` as in
+    :func:`create_model_pose`."""
+    if n_lanes == 2:
+        return _two_lanes(lambda r, mb: create_pose_model_cosypose(cfg, r, mesh_db, state_dict, mb, precision), renderer,
+                          max_batch)
+    assert n_lanes == 1
     d = dict(cfg) if isinstance(cfg, dict) else dict(vars(cfg))
     d.setdefault("init_method", "v0")  # check_update_config, :24-27
     d.setdefault("n_pose_dims", 9)

@@ -338,6 +338,29 @@ class Net:
               "hp_net_profile_collect")
         return ms.value, n.value, fl.value, mfl.value
 
+    def profile_intervals(self):
+        """``[(t0_ms, t1_ms), ...]`` of the timed conv stretches pending for this network, relative to
+        :func:`profile_mark_reference` (call before :meth:`profile_collect`)."""
+        n = lib().hp_net_profile_intervals(self.handle, None, None, 0)
+        if n < 0:
+            check(n, "hp_net_profile_intervals")
+        a, b = (C.c_double * n)(), (C.c_double * n)()
+        got = lib().hp_net_profile_intervals(self.handle, a, b, n)
+        if got < 0:
+            check(got, "hp_net_profile_intervals")
+        return list(zip(list(a), list(b)))
+
+
+def set_conv_tail_split(on: bool) -> None:
+    """K-slicing of tail tiles in the conv kernels (``hp_conv_set_tail_split``)."""
+    check(lib().hp_conv_set_tail_split(int(on)), "hp_conv_set_tail_split")
+
+
+def profile_mark_reference(device) -> None:
+    """Record the process-wide reference event of :meth:`Net.profile_intervals` on the current stream."""
+    with torch.cuda.device(device):
+        check(lib().hp_profile_mark_reference(stream_ptr(device)), "hp_profile_mark_reference")
+
 
 CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2, "winograd-1wave": 3, "winograd": 4, "split": 5}
 

@@ -303,3 +303,131 @@ class CosyPosePosePredictor(_RenderAndCompare):
         return outputs
 
     __call__ = forward
+
+
+# ---------------------------------------------------------------------------------------------
+# Two half-batch lanes
+# ---------------------------------------------------------------------------------------------
+class _LaneBackbones:
+    """What ``bench.py`` needs from ``model.backbone`` when the model has two lanes: profiling of both networks."""
+
+    def __init__(self, nets):
+        self.nets = list(nets)
+
+    def __getattr__(self, name):
+        return getattr(self.nets[0], name)
+
+    def set_profiling(self, on: bool):
+        for n in self.nets:
+            n.set_profiling(on)
+
+    def profile_intervals(self):
+        return [iv for n in self.nets for iv in n.profile_intervals()]
+
+    def profile_collect(self):
+        tot = [0.0, 0, 0.0, 0.0]
+        for n in self.nets:
+            for i, v in enumerate(n.profile_collect()):
+                tot[i] += v
+        return tuple(tot)
+
+
+class _LaneOutputs:
+    """The ``PosePredictorOutput`` of one iteration over both lanes: a field is concatenated when it is first read
+    (a caller wants one or two of the dozen fields of one or two iterations; concatenating all of them for every
+    iteration cost 2.5 % of a step in small launches)."""
+
+    def __init__(self, parts: List[PosePredictorOutput]):
+        object.__setattr__(self, "_parts", list(parts))
+        object.__setattr__(self, "_cache", {})
+
+    def __getattr__(self, name):
+        cache = object.__getattribute__(self, "_cache")
+        if name in cache:
+            return cache[name]
+        parts = object.__getattribute__(self, "_parts")
+        if name not in PosePredictorOutput.__dataclass_fields__:
+            raise AttributeError(name)
+        vals = [getattr(p, name) for p in parts]
+        v0 = vals[0]
+        if isinstance(v0, torch.Tensor):
+            out = torch.cat(vals, 0)
+        elif isinstance(v0, list):
+            out = [x for v in vals for x in v]
+        elif name == "network_outputs":
+            out = {k: torch.cat([v[k] for v in vals], 0) for k in v0}
+        elif name == "timing_dict":
+            out = {k: max(v.get(k, 0.0) for v in vals) for k in v0}
+        else:
+            out = v0  # None (pixels not kept)
+        cache[name] = out
+        return out
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+def _cat_outputs(parts: List[PosePredictorOutput]) -> "_LaneOutputs":
+    return _LaneOutputs(parts)
+
+
+class TwoLanePredictor:
+    """A refiner whose ``forward`` runs the two halves of the hypothesis batch as two independent chains
+    (prep -> crop -> rasterise -> network -> update, all iterations) on two HIP streams.
+
+    Hypotheses are independent given (frame, meshes, weights), and a conv launch leaves CUs idle in its last,
+    partially filled round of tiles (8x10 layers: 160 tiles on 256 CUs); a second, independent chain fills them
+    (C2: 26.0 -> 23.1 ms per step).  Each lane owns everything that is written: its network (activation arena,
+    K-slice workspaces are per stream), its input buffer and its mesh store (rasteriser scratch).  Results are the
+    per-lane results concatenated -- identical to the single-lane ones up to the summation order inside K-sliced
+    tiles.  Everything but ``forward`` (coarse scoring, attributes) is lane 0's."""
+
+    MIN_BATCH = 32
+
+    def __init__(self, lanes):
+        assert len(lanes) == 2
+        self.lanes = list(lanes)
+        self.device = lanes[0].device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in lanes]
+        self.backbone = _LaneBackbones([l.backbone for l in lanes])
+
+    def __getattr__(self, name):
+        if name in ("lanes", "streams", "backbone", "device"):  # not set yet: no recursion through lanes[0]
+            raise AttributeError(name)
+        return getattr(self.lanes[0], name)
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        self.lanes[0].to(device)
+        return self
+
+    @torch.no_grad()
+    def forward(self, images, K, labels, TCO, n_iterations: int = 1, *, im_ids=None, **kw):
+        """``kw``: what the lanes' ``forward`` takes beyond this (MegaPose: ``random_ambient_light``)."""
+        bsz = len(labels)
+        if bsz < self.MIN_BATCH:
+            return self.lanes[0].forward(images, K, labels, TCO, n_iterations=n_iterations, im_ids=im_ids, **kw)
+        labels = list(labels)
+        h = bsz // 2
+        cur = torch.cuda.current_stream(self.device)
+        parts = []
+        # the other lane fills the CUs a partially filled round of tiles leaves idle: K-slicing those tiles would only
+        # add its reduction (C2: 24.5 ms with, 22.5 ms without)
+        ops.set_conv_tail_split(False)
+        try:
+            for lane, stream, sl in zip(self.lanes, self.streams, (slice(0, h), slice(h, bsz))):
+                per_hyp = im_ids is None  # the reference's calling convention: images / K already gathered per hypothesis
+                stream.wait_stream(cur)
+                with torch.cuda.stream(stream):
+                    parts.append(lane.forward(images[sl] if per_hyp else images, K[sl] if per_hyp else K, labels[sl], TCO[sl],
+                                              n_iterations=n_iterations,
+                                              im_ids=None if per_hyp else torch.as_tensor(im_ids)[sl], **kw))
+        finally:
+            ops.set_conv_tail_split(True)
+        for stream in self.streams:
+            cur.wait_stream(stream)
+        return {k: _cat_outputs([p[k] for p in parts]) for k in parts[0]}
+
+    __call__ = forward

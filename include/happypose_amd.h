@@ -244,10 +244,21 @@ int hp_net_set_profiling(hp_net* net, int enabled);
 #define HP_CONV_ALGO_WINOGRAD 4 /* exact-fp32 kernels only: Winograd, else patch-staged, else generic */
 #define HP_CONV_ALGO_SPLIT 5 /* split-fp16 kernels (3 fp16 MFMAs per fp32 product) wherever they apply */
 int hp_conv_select_algo(int algo);
+/* The conv kernels cut the tiles of a partially filled last round along K so that one launch fills the GPU.  When
+ * independent launches share the GPU (the two half-batch lanes of a predictor on two streams) the other stream fills
+ * those CUs and the slicing only costs its reduction: 0 switches it off (process wide), 1 back on (the default). */
+int hp_conv_set_tail_split(int enabled);
 /* diagnostics: workgroups per CU the runtime grants conv tile variant 0 (128x128) / 1 (128x64) */
 int hp_conv_occupancy(int variant);
 int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, double* conv_flops,
                            double* mfma_flops);
+/* Several networks on several streams (the two half-batch lanes of a predictor run concurrently, so their summed
+ * kernel time exceeds the wall time): hp_profile_mark_reference records a process-wide reference event on `stream`;
+ * hp_net_profile_intervals returns the number of timed stretches pending for `net` and writes the start / end of the
+ * first `cap` of them in ms after the reference (call it BEFORE hp_net_profile_collect, which releases them).  The
+ * caller takes the union over the networks: the time during which any conv kernel was running. */
+int hp_profile_mark_reference(void* stream);
+int hp_net_profile_intervals(hp_net* net, double* t0_ms, double* t1_ms, int cap);
 
 /* ------------------------------------------------------------------------------------
  * Depth refinement (run_depth_refiner=True): point-to-plane ICP between the depth rendered at

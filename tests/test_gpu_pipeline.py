@@ -347,3 +347,30 @@ def test_pipeline_with_depth_refiner(dev, world):
     with pytest.raises(AssertionError):
         PoseEstimator(refiner_model=refiner, coarse_model=coarse).run_inference_pipeline(
             obs, detections=det.to(dev), n_refiner_iterations=1, run_depth_refiner=True)
+
+
+def test_two_lane_refiner_matches_single_lane(dev, world):
+    """TwoLanePredictor: the halves of the hypothesis batch as two chains on two streams give the single-lane poses
+    (same kernels on the same data; only the summation order inside K-sliced tiles can differ)."""
+    from happypose_amd.models import create_pose_model_cosypose
+    from happypose_amd.synthetic import make_scene
+
+    renderer = world["renderer"]
+    sc = make_scene(n_detections=6, n_hypotheses=8, n_objects=len(renderer.store.labels), seed=9)
+    w = _weights("resnet18", 6, seed=3)
+    labels = [renderer.store.labels[i] for i in sc["hyp_obj_ids"]]
+    args = (torch.as_tensor(sc["images"], device=dev), torch.as_tensor(sc["K"], device=dev), labels, torch.as_tensor(sc["TCO_hyp"], device=dev))
+    im_ids = torch.zeros(len(labels), dtype=torch.int32)
+    outs = []
+    for lanes in (1, 2):
+        m = create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=w, max_batch=48, n_lanes=lanes)
+        o = m.forward(*args, n_iterations=3, im_ids=im_ids)
+        outs.append(o)
+    for k in outs[0]:
+        a, b = outs[0][k], outs[1][k]
+        assert a.labels == b.labels
+        for f in ("TCO_output", "TCO_input", "K_crop", "boxes_crop", "boxes_rend", "tCR"):
+            assert getattr(a, f).shape == getattr(b, f).shape
+        dT = (a.TCO_output - b.TCO_output).abs().max().item()
+        assert dT < 1e-4, (k, dT)
+        assert torch.allclose(a.network_outputs["pose"], b.network_outputs["pose"], atol=1e-3)
