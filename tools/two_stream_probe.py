@@ -15,9 +15,11 @@ images = torch.as_tensor(scene["images"], device=dev); K = torch.as_tensor(scene
 TCO0 = torch.as_tensor(scene["TCO_hyp"], device=dev)
 labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
 im_ids = torch.zeros(B, dtype=torch.int32, device=dev)
-halves = [create_pose_model_cosypose(dict(backbone_str="resnet34"), renderer, state_dict=weights, max_batch=B // 2, precision="f32")
-          for _ in range(2)]
-streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+NL = int(os.environ.get("LANES", 2))
+from happypose_amd.renderer import BatchRenderer
+halves = [create_pose_model_cosypose(dict(backbone_str="resnet34"), BatchRenderer(ds, device=dev), state_dict=weights,
+                                     max_batch=(B + NL - 1) // NL, precision="f32") for _ in range(NL)]
+streams = [torch.cuda.Stream(device=dev) for _ in range(NL)]
 
 
 def full():
@@ -27,8 +29,8 @@ def full():
 def split():
     outs = []
     cur = torch.cuda.current_stream(dev)
-    for h in range(2):
-        sl = slice(h * B // 2, (h + 1) * B // 2)
+    for h in range(NL):
+        sl = slice(h * B // NL, (h + 1) * B // NL)
         streams[h].wait_stream(cur)
         with torch.cuda.stream(streams[h]):
             outs.append(halves[h].forward(images, K, labels[sl], TCO0[sl], n_iterations=5, im_ids=im_ids[sl])["iteration=5"].TCO_output)
