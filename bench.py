@@ -74,7 +74,7 @@ def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32",
         weights = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 9, pose_dim=0, n_views_logits=1), seed=0)
         cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
                    predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
-        model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=576, precision=precision)
+        model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=576 * n_lanes, precision=precision, n_lanes=n_lanes)
     return ds, renderer, scene, weights, model
 
 
@@ -299,7 +299,7 @@ def main():
         return
     precision = args.precision or ("f16" if args.workload == "C5" else "f32")
     peak = PEAK_F16_MFMA_TFLOPS if precision == "f16" else PEAK_F32_MFMA_TFLOPS
-    n_lanes = args.lanes if args.workload in ("C2", "C3") else 1
+    n_lanes = args.lanes
     ds, renderer, scene, weights, model = build_world(device, args.arch, seed=rank, workload=args.workload,
                                                       precision=precision, n_lanes=n_lanes)
     store = renderer.store
@@ -311,9 +311,10 @@ def main():
     im_ids = torch.zeros(B, dtype=torch.int32, device=device)
 
     def step():
-        if args.workload == "C5":  # coarse scoring, one object (576 grid poses) per chunk as in 8(e)
-            scores = [model.forward_coarse(images, K, labels[i:i + 576], TCO0[i:i + 576], im_ids=im_ids[i:i + 576])["logits"]
-                      for i in range(0, B, 576)]
+        if args.workload == "C5":  # coarse scoring, one object (576 grid poses) per chunk and lane as in 8(e)
+            ck = 576 * n_lanes
+            scores = [model.forward_coarse(images, K, labels[i:i + ck], TCO0[i:i + ck], im_ids=im_ids[i:i + ck])["logits"]
+                      for i in range(0, B, ck)]
             poses, logits = TCO0, torch.cat(scores).reshape(-1)
         else:
             out = model.forward(images, K, labels, TCO0, n_iterations=N_ITERS, im_ids=im_ids)

@@ -431,3 +431,31 @@ class TwoLanePredictor:
         return {k: _cat_outputs([p[k] for p in parts]) for k in parts[0]}
 
     __call__ = forward
+
+    @torch.no_grad()
+    def forward_coarse(self, images, K, labels, TCO_input, cuda_timer: bool = False, return_debug_data: bool = False,
+                       im_ids=None):
+        """Coarse scoring with the two halves of the views on the two lanes (``MP/models/pose_rigid.py:708-788``)."""
+        bsz = len(labels)
+        if bsz < 2 * self.MIN_BATCH or cuda_timer or return_debug_data:
+            return self.lanes[0].forward_coarse(images, K, labels, TCO_input, cuda_timer, return_debug_data, im_ids)
+        labels = list(labels)
+        h = bsz // 2
+        cur = torch.cuda.current_stream(self.device)
+        parts = []
+        ops.set_conv_tail_split(False)
+        try:
+            for lane, stream, sl in zip(self.lanes, self.streams, (slice(0, h), slice(h, bsz))):
+                per_hyp = im_ids is None
+                stream.wait_stream(cur)
+                with torch.cuda.stream(stream):
+                    parts.append(lane.forward_coarse(images[sl] if per_hyp else images, K[sl] if per_hyp else K, labels[sl],
+                                                     TCO_input[sl], im_ids=None if per_hyp else torch.as_tensor(im_ids)[sl]))
+        finally:
+            ops.set_conv_tail_split(True)
+        for stream in self.streams:
+            cur.wait_stream(stream)
+        out = {k: torch.cat([p[k] for p in parts], 0) for k in ("logits", "scores")}
+        for k in ("time", "render_time", "model_time"):
+            out[k] = max(p[k] for p in parts)
+        return out
