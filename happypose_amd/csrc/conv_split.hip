@@ -703,12 +703,17 @@ int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_
   const int slots = ws.slots * wg_per_cu;
   int regular = (T / slots) * slots, S = 1;
   int tail = T - regular;
-  if (tail > 0 && ncc > 1 && !no_split && conv_tail_split_enabled()) {
+  // while two lanes share the GPU (tail split off) a launch is still sliced when it and its twin on the other lane
+  // together cannot fill the GPU: it then plans against half of the CUs (HP_LANE_SLICES=0 disables this)
+  static const bool lane_slices = !(std::getenv("HP_LANE_SLICES") && std::atoi(std::getenv("HP_LANE_SLICES")) == 0);
+  const bool shared = !conv_tail_split_enabled();
+  const int fill = shared ? slots / 2 : slots;
+  if (tail > 0 && ncc > 1 && !no_split && (!shared || (lane_slices && regular == 0 && tail <= fill))) {
     // cost in units of a whole tile: rounds x longest slice + parking / re-reading the slabs (~1.3 us per 128 KB
     // against ~1 us per tap of the K loop)
     double best = 1.0;
     for (int s = 2; s <= ncc && s <= 4; ++s) {
-      const double c = (double)((tail * s + slots - 1) / slots) * ((ncc + s - 1) / s) / ncc + 1.3 * (1 + s) / (9.0 * ncc);
+      const double c = (double)((tail * s + fill - 1) / fill) * ((ncc + s - 1) / s) / ncc + 1.3 * (1 + s) / (9.0 * ncc);
       if (c < 0.92 * best) { best = c; S = s; }
     }
     if (force_s > 0 && force_s <= ncc) S = force_s;
