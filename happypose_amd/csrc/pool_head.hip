@@ -50,11 +50,16 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   __syncthreads();
   const float* f = feat;
   if (a.fc_w) {  // torchvision ResNet: avgpool -> fc (MP/models/torchvision_resnet.py:337-341)
-    for (int o = tid; o < a.C; o += 256) {
+    // one wave per output row, lanes stride the features: the weight row is read as coalesced 256-B pieces (a thread
+    // per output row read 512 rows 2 KB apart: 90 us per launch, 3 % of a MegaPose refiner step)
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int o = wave; o < a.C; o += 4) {
       const float* w = a.fc_w + (int64_t)o * a.C;
       float s = 0.f;
-      for (int c = 0; c < a.C; ++c) s = fmaf(w[c], feat[c], s);
-      feat2[o] = s + a.fc_b[o];
+      for (int c = lane; c < a.C; c += 64) s = fmaf(w[c], feat[c], s);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0) feat2[o] = s + a.fc_b[o];
     }
     __syncthreads();
     f = feat2;
