@@ -44,7 +44,7 @@ _PROTOS = {
                                c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
                                C.POINTER(Strides), c_f32p, C.POINTER(Strides), c_u8p, c_f32p, C.c_int,
                                C.c_void_p]),
-    "hp_pose_prep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_i32p,
+    "hp_pose_prep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_i32p,
                                c_i32p, c_i32p, C.c_int, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                C.c_void_p]),
@@ -55,8 +55,8 @@ _PROTOS = {
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Strides), c_f32p,
                                         C.c_int, C.c_void_p]),
     "hp_pose_update": (C.c_int, [C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
-    "hp_tco_init_autodepth": (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p,
-                                        c_f32p, c_i32p, c_i32p, C.c_int, c_f32p, C.c_void_p]),
+    "hp_tco_init_autodepth": (C.c_int, [C.c_void_p, C.c_int, c_f32p, C.c_int, c_i32p, c_f32p, C.c_int, c_i32p, c_i32p,
+                                        c_f32p, C.c_int, c_i32p, c_i32p, C.c_int, c_f32p, C.c_void_p]),
     "hp_net_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "hp_net_destroy": (None, [C.c_void_p]),
     "hp_net_input_channels_padded": (C.c_int, [C.c_void_p]),
@@ -70,7 +70,9 @@ _PROTOS = {
     "hp_net_flops_per_sample": (C.c_double, [C.c_void_p]),
     "hp_net_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_conv_occupancy": (C.c_int, [C.c_int]),
-    "hp_conv_set_tail_split": (C.c_int, [C.c_int]),
+    "hp_net_set_tail_split": (C.c_int, [C.c_void_p, C.c_int]),
+    "hp_net_set_conv_algo": (C.c_int, [C.c_void_p, C.c_int]),
+    "hp_net_status": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "hp_profile_mark_reference": (C.c_int, [C.c_void_p]),
     "hp_net_profile_intervals": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "hp_conv_select_algo": (C.c_int, [C.c_int]),

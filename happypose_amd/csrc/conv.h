@@ -44,6 +44,12 @@ struct ConvArgs {
   int sk_S2, sk_S3;        // pooled-stem launch (conv_igemm_split.hip): tiles per image / per tile row
   float* sk_slabs;
   int* sk_counters;
+  // per-launch switches (zero-initialised = defaults), carried here instead of process-wide state so that
+  // networks on different host threads / streams cannot race:
+  int algo;                // HP_CONV_ALGO_* of the launching network (only the Winograd schedule reads it here)
+  int no_tail_split;       // 1: leave the tiles of a partially filled last round whole (a second lane fills the CUs)
+  unsigned* status;        // host-visible word or null: the epilogue stores 1 when it produced a non-finite value
+                           // (split-fp16 launches: an activation beyond the fp16 range turned into inf / NaN)
 };
 
 // fp16 path (conv_f16.hip): activations / weights / prologue vectors are halves, bias is fp32
@@ -131,9 +137,8 @@ int launch_conv_f16(const ConvArgsH& a, hipStream_t stream);
 int launch_cast_pad_f16(const float* x, void* y, int64_t pixels, int c_in, int c_out, hipStream_t stream);
 int launch_maxpool_f16(const void* x, void* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
 int conv_setup_once();
-// K-slicing of the tiles of a partially filled last round (hp_conv_set_tail_split; off while two lanes share the GPU)
-bool conv_tail_split_enabled();
-// HP_CONV_ALGO_* currently selected (hp_conv_select_algo / HP_CONV_NO_WINOGRAD, HP_CONV_NO_PATCH)
+// process-wide DEFAULT of the kernel-family choice (hp_conv_select_algo / HP_CONV_NO_WINOGRAD, HP_CONV_NO_PATCH); a
+// network overrides it with hp_net_set_conv_algo and hands its choice to the launchers in ConvArgs::algo
 int conv_algo();
 
 }  // namespace hp

@@ -402,16 +402,6 @@ int conv_algo() {
 }
 }  // namespace hp
 
-namespace hp {
-namespace { int g_tail_split = 1; }
-bool conv_tail_split_enabled() { return g_tail_split != 0; }
-}  // namespace hp
-
-extern "C" int hp_conv_set_tail_split(int enabled) {
-  hp::g_tail_split = enabled ? 1 : 0;
-  return HP_OK;
-}
-
 extern "C" int hp_conv_select_algo(int algo) {
   HP_REQUIRE(algo >= HP_CONV_ALGO_AUTO && algo <= HP_CONV_ALGO_SPLIT, "hp_conv_select_algo: unknown algorithm");
   hp::g_conv_algo = algo;

@@ -16,6 +16,13 @@ namespace hp {
 typedef float epi_floatx16 __attribute__((ext_vector_type(16)));
 typedef float epi_floatx4 __attribute__((ext_vector_type(4)));
 
+// Non-finite guard of the split-fp16 kernels (ConvArgs::status): an activation beyond the fp16 range becomes inf when
+// it is split and inf / NaN in the accumulators; ReLU would hide a NaN (fmaxf(NaN, 0) = 0), so the epilogues sum what
+// they are about to store BEFORE the activation and report a non-finite sum.  The store only happens in the failure case.
+__device__ __forceinline__ void conv_report_nonfinite(const ConvArgs& a, float chk) {
+  if (a.status && !(fabsf(chk) <= 3.0e38f)) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int BM, int BN>
 constexpr int epilogue_lds_floats() { return BM * (BN + 4); }
 
@@ -54,6 +61,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* lds, epi
   __syncthreads();
   epi_floatx4 bias = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) bias = *reinterpret_cast<const epi_floatx4*>(a.bias + n);  // padded to whole tiles by the planner
+  float chk = 0.f;  // running sum of everything this thread stores, before the activation: inf / NaN are sticky in it
 #pragma unroll
   for (int k = 0; k < ITERS; ++k) {
     const int row = tid / C4 + k * (THREADS / C4);
@@ -62,6 +70,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* lds, epi
       epi_floatx4 v = *reinterpret_cast<const epi_floatx4*>(lds + row * LDC + 4 * c4);
       v += bias;
       if (a.residual) v += res[k];
+      chk += (v[0] + v[1]) + (v[2] + v[3]);
       if (a.relu == HP_ACT_RELU) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -72,6 +81,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* lds, epi
       *reinterpret_cast<epi_floatx4*>(a.y + m * a.Cout + n) = v;
     }
   }
+  conv_report_nonfinite(a, chk);
 }
 
 }  // namespace hp

@@ -262,24 +262,32 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
   __syncthreads();
   constexpr int C4 = BN / 4;
   const int Hp = (a.Ho - 1) / 2 + 1, Wp = (a.Wo - 1) / 2 + 1;
+  float pool_chk = 0.f;
   for (int it = tid; it < kPoolRows * kPoolCols * C4; it += kThreads) {
     const int c4 = it % C4, pp = it / C4, py = pp / kPoolCols, px = pp - py * kPoolCols;
     const int ph = (p_oh0 + 1) / 2 + py, pw = (p_ow0 + 1) / 2 + px;
     const int n = n0 + 4 * c4;
     if (ph >= Hp || pw >= Wp || n >= a.Cout) continue;
     floatx4 best = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    floatx4 seen = {0.f, 0.f, 0.f, 0.f};  // v_max drops a NaN operand: the non-finite guard sums what the window reads
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int dr = 2 * py + dy, dc = 2 * px + dx;
         if ((unsigned)(p_oh0 + dr) < (unsigned)a.Ho && (unsigned)(p_ow0 + dc) < (unsigned)a.Wo)
-          best = __builtin_elementwise_max(best, *reinterpret_cast<const floatx4*>(cl + (dr * kPoolCW + dc) * LDC + 4 * c4));
+        {
+          const floatx4 cv = *reinterpret_cast<const floatx4*>(cl + (dr * kPoolCW + dc) * LDC + 4 * c4);
+          best = __builtin_elementwise_max(best, cv);
+          seen += cv;
+        }
       }
     if (a.bias) best += *reinterpret_cast<const floatx4*>(a.bias + n);
     best = __builtin_elementwise_max(best, floatx4{0.f, 0.f, 0.f, 0.f});
     *reinterpret_cast<floatx4*>(a.y + (((int64_t)p_img * Hp + ph) * Wp + pw) * a.Cout + n) = best;
+    pool_chk += (seen[0] + seen[1]) + (seen[2] + seen[3]);
   }
+  conv_report_nonfinite(a, pool_chk);
 }
 
 template <int BN, bool PRE, int NBUF>

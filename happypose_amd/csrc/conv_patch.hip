@@ -21,6 +21,8 @@
 #include <cstdlib>
 
 #include <map>
+#include <mutex>
+#include <utility>
 
 #include "conv.h"
 #include "conv_epilogue.h"
@@ -245,12 +247,15 @@ double rounds_cost(double r) {  // time of r rounds' worth of equal items; a par
 }  // namespace
 
 int conv_plan_split(ConvArgs& a, int T, size_t lds_bytes, int k_units, int ktiles_per_unit, hipStream_t stream) {
-  // one workspace per stream: launches on different streams (the lanes of a two-lane predictor) run concurrently
-  static std::map<hipStream_t, SplitWorkspace> wss;
-  SplitWorkspace& ws = wss[stream];
+  // one workspace per (device, stream), guarded: see plan_tail_split in conv_split.hip
+  static std::map<std::pair<int, hipStream_t>, SplitWorkspace> wss;
+  static std::mutex wss_mutex;
+  std::lock_guard<std::mutex> lock(wss_mutex);
+  int dev = 0;
+  HP_CHECK_HIP(hipGetDevice(&dev));
+  SplitWorkspace& ws = wss[std::make_pair(dev, stream)];
   if (ws.slots == 0) {
-    int dev = 0, cus = 256;
-    HP_CHECK_HIP(hipGetDevice(&dev));
+    int cus = 256;
     HP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     ws.slots = 2 * cus;  // two workgroups per CU
   }
@@ -260,7 +265,7 @@ int conv_plan_split(ConvArgs& a, int T, size_t lds_bytes, int k_units, int ktile
   int regular = (T / slots) * slots, tail = T - regular, S = 1;
   regular -= regular % 8;  // the kernel deals regular tiles to the 8 XCDs evenly
   tail = T - regular;
-  if (tail > 0 && ncc > 1 && !no_split && conv_tail_split_enabled()) {
+  if (tail > 0 && ncc > 1 && !no_split && !a.no_tail_split) {
     double best = rounds_cost((double)tail / slots);
     // a slice must stay long (>= 12 K-tiles of 32): parking and re-reading a 64-KB slab costs about
     // as much as 2-3 K-tiles, so splitting short tiles loses (measured on the 64->128 stride-2 layer)

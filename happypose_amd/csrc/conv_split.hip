@@ -29,7 +29,9 @@
 // Per tap and wave (64x64 wave tile): 16 ds_read_b128 feed 24 MFMAs.
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "conv.h"
 #include "conv_epilogue.h"
@@ -689,12 +691,17 @@ int launch_split_s2_variant(ConvArgs args, hipStream_t stream) {
 struct SplitWs { float* slabs = nullptr; size_t slab_bytes = 0; int* counters = nullptr; size_t counter_bytes = 0; int slots = 0; };
 
 int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_cu, hipStream_t stream) {
-  // one workspace per stream: launches on different streams (the lanes of a two-lane predictor) run concurrently
-  static std::map<hipStream_t, SplitWs> wss;
-  SplitWs& ws = wss[stream];
+  // one workspace per (device, stream): launches on different streams (the lanes of a two-lane predictor) run
+  // concurrently, and the default stream of two devices must not share slabs; the map is guarded because callers on
+  // several host threads plan concurrently (ctypes releases the GIL)
+  static std::map<std::pair<int, hipStream_t>, SplitWs> wss;
+  static std::mutex wss_mutex;
+  std::lock_guard<std::mutex> lock(wss_mutex);
+  int dev = 0;
+  HP_CHECK_HIP(hipGetDevice(&dev));
+  SplitWs& ws = wss[std::make_pair(dev, stream)];
   if (ws.slots == 0) {
-    int dev = 0, cus = 256;
-    HP_CHECK_HIP(hipGetDevice(&dev));
+    int cus = 256;
     HP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     ws.slots = cus - cus % 8;
   }
@@ -706,7 +713,7 @@ int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_
   // while two lanes share the GPU (tail split off) a launch is still sliced when it and its twin on the other lane
   // together cannot fill the GPU: it then plans against half of the CUs (HP_LANE_SLICES=0 disables this)
   static const bool lane_slices = !(std::getenv("HP_LANE_SLICES") && std::atoi(std::getenv("HP_LANE_SLICES")) == 0);
-  const bool shared = !conv_tail_split_enabled();
+  const bool shared = a.no_tail_split != 0;
   const int fill = shared ? slots / 2 : slots;
   if (tail > 0 && ncc > 1 && !no_split && (!shared || (lane_slices && regular == 0 && tail <= fill))) {
     // cost in units of a whole tile: rounds x longest slice + parking / re-reading the slabs (~1.3 us per 128 KB

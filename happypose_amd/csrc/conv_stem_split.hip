@@ -17,6 +17,7 @@
 // Epilogue: scale back, conv tile -> LDS [row][68], max over the 3 x 3 windows (conv pixels outside the map do not
 // take part, as with PyTorch's -inf padding), bias, ReLU, 16-B stores of the pooled map.
 #include "conv.h"
+#include "conv_epilogue.h"
 
 namespace hp {
 
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   __syncthreads();
   constexpr int C4 = BN / 4;
   const int Hp = (a.Ho - 1) / 2 + 1, Wp = (a.Wo - 1) / 2 + 1;
+  float pool_chk = 0.f;
 #pragma unroll
   for (int it0 = 0; it0 < PR * PC * C4; it0 += kThreads) {
     const int it = it0 + tid;
@@ -176,18 +178,25 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int ph = PR * ty + py, pw = PC * tx + px;
     if (ph >= Hp || pw >= Wp) continue;
     floatx4 best = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    floatx4 seen = {0.f, 0.f, 0.f, 0.f};  // v_max drops a NaN operand: the non-finite guard sums what the window reads
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int dr = 2 * py + dy, dc = 2 * px + dx;
         if ((unsigned)(oh0 + dr) < (unsigned)a.Ho && (unsigned)(ow0 + dc) < (unsigned)a.Wo)
-          best = __builtin_elementwise_max(best, *reinterpret_cast<const floatx4*>(cl + (dr * CW + dc) * LDC + 4 * c4));
+        {
+          const floatx4 cv = *reinterpret_cast<const floatx4*>(cl + (dr * CW + dc) * LDC + 4 * c4);
+          best = __builtin_elementwise_max(best, cv);
+          seen += cv;
+        }
       }
     if (a.bias) best += *reinterpret_cast<const floatx4*>(a.bias + 4 * c4);
     best = __builtin_elementwise_max(best, floatx4{0.f, 0.f, 0.f, 0.f});
     *reinterpret_cast<floatx4*>(a.y + (((int64_t)img * Hp + ph) * Wp + pw) * BN + 4 * c4) = best;
+    pool_chk += (seen[0] + seen[1]) + (seen[2] + seen[3]);
   }
+  conv_report_nonfinite(a, pool_chk);
 }
 
 }  // namespace

@@ -1070,11 +1070,11 @@ int launch8(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
 }
 
 // the one-wave-per-SIMD schedule on request (hp_conv_select_algo / HP_WINO_V1), else two waves per SIMD
-bool wino_use_v1() { return conv_algo() == HP_CONV_ALGO_WINOGRAD_1WAVE; }
+bool wino_use_v1(const ConvArgs& a) { return a.algo == HP_CONV_ALGO_WINOGRAD_1WAVE; }
 
 template <bool PRE>
 int launch_nld(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
-  if (!wino_use_v1() && a.Cin >= 4 * CK && wino8_nld(g.Pmax) <= 6 && wino8_lds_bytes(g.Pmax, a.Cin) <= 160 * 1024) {
+  if (!wino_use_v1(a) && a.Cin >= 4 * CK && wino8_nld(g.Pmax) <= 6 && wino8_lds_bytes(g.Pmax, a.Cin) <= 160 * 1024) {
     const int nld8 = wino8_nld(g.Pmax);
     if (nld8 <= 2) return launch8<PRE, 2>(a, g, stream);
     if (nld8 <= 3) return launch8<PRE, 3>(a, g, stream);

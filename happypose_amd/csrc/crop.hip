@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
   const float (&wx)[kSpan] = fx.w;
   const bool separable = nr <= kSpan && nc <= kSpan;
 
-  const float* img = a.images + (int64_t)a.im_ids[r] * a.C * H * W;
+  // an image id outside the batch reads frame 0 and writes zeros (the reference's indexing would raise)
+  const int im_id = a.im_ids[r];
+  const bool bad_id = (unsigned)im_id >= (unsigned)a.Bi;
+  const float* img = a.images + (int64_t)(bad_id ? 0 : im_id) * a.C * H * W;
   const int64_t obase = (int64_t)r * a.os.s_item + (int64_t)ph * a.os.s_row + (int64_t)pw * a.os.s_col;
   const int HW = H * W;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
         else val = fminf(fmaxf(val - zn, -2.0f), 2.0f);
       }
     }
-    outv[c] = val;
+    outv[c] = bad_id ? 0.0f : val;
   }
   // channel-interleaved destination (NHWC slice of the network input): one 12-B store per pixel
   typedef float float3v __attribute__((ext_vector_type(3)));

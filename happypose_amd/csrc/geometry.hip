@@ -106,6 +106,7 @@ struct PrepArgs {
   const float* TCO_in; const float* K; const int32_t* im_ids; const int32_t* obj_ids;
   const int32_t* ids_main; int n_main; const int32_t* ids_extra; int n_extra;
   int b, n_views, normalize, im_h, im_w, crop_h, crop_w; float lamb;
+  int n_images, n_obj;  // rows of K / objects of the store: an id outside them poisons the hypothesis (NaN outputs)
   float* TCO_out; float* tCR; float* TCV_O; float* boxes_rend; float* boxes_crop; float* K_crop;
 };
 
@@ -122,7 +123,11 @@ __global__ __launch_bounds__(kT) void pose_prep_kernel(PrepArgs a) {
     for (int k = 0; k < 16; ++k) T[k] = Tin[k];
   }
   view_pose(T, v, TV);
-  const float* Kp = a.K + 9 * (int64_t)a.im_ids[i];
+  // an image / object id outside the tables never leaves them: the hypothesis reads row 0 and its outputs are NaN
+  // (the reference's indexing would raise; a device-side check cannot, and NaN poses render as zero images)
+  const int im_id = a.im_ids[i], ob_id = a.obj_ids[i];
+  const bool bad_id = (unsigned)im_id >= (unsigned)a.n_images || (unsigned)ob_id >= (unsigned)a.n_obj;
+  const float* Kp = a.K + 9 * (int64_t)(bad_id ? 0 : im_id);
   float K[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) K[k] = Kp[k];
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(kT) void pose_prep_kernel(PrepArgs a) {
 
   const int32_t* ids = v == 0 ? a.ids_main : a.ids_extra;
   const int npts = v == 0 ? a.n_main : a.n_extra;
-  const float* pts = a.points + (int64_t)a.obj_ids[i] * a.n_pad * 3;
+  const float* pts = a.points + (int64_t)(bad_id ? 0 : ob_id) * a.n_pad * 3;
   float x1 = INFINITY, y1 = INFINITY, x2 = -INFINITY, y2 = -INFINITY;
   for (int j = tid; j < npts; j += kT) {
     const float* p = pts + 3 * (int64_t)ids[j];
@@ -183,6 +188,14 @@ __global__ __launch_bounds__(kT) void pose_prep_kernel(PrepArgs a) {
   Ko[4] = sy * K[4];
   Ko[2] = (fw - 1.0f) / 2.0f + sx * ocx;
   Ko[5] = (fh - 1.0f) / 2.0f + sy * ocy;
+  if (bad_id) {
+    const float nan = __builtin_nanf("");
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ko[k] = nan;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { T[k] = nan; TV[k] = nan; }
+    x1 = y1 = x2 = y2 = bx1 = by1 = bx2 = by2 = nan;
+  }
   if (a.TCV_O) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) a.TCV_O[16 * ((int64_t)i * a.n_views + v) + k] = TV[k];
@@ -241,16 +254,20 @@ struct InitArgs {
   const float* boxes; const int32_t* box_ids; const float* K; const int32_t* im_ids;
   const int32_t* obj_ids; const float* R; const int32_t* rot_ids; float* out;
   const int32_t* point_ids; int n_points;  // optional deterministic sub-sample (null = all n_pad)
+  int n_boxes, n_images, n_rots, n_obj;    // table sizes: an id outside its table gives a NaN pose
 };
 
 __global__ __launch_bounds__(kT) void tco_init_kernel(InitArgs a) {
   __shared__ float red[4][4];
   const int i = blockIdx.x, tid = threadIdx.x;
-  const float* box = a.boxes + 4 * (int64_t)(a.box_ids ? a.box_ids[i] : i);
-  const float* K = a.K + 9 * (int64_t)a.im_ids[i];
+  const int box_id = a.box_ids ? a.box_ids[i] : i, im_id = a.im_ids[i], rot_id = a.rot_ids ? a.rot_ids[i] : i, ob_id = a.obj_ids[i];
+  const bool bad_id = (unsigned)box_id >= (unsigned)a.n_boxes || (unsigned)im_id >= (unsigned)a.n_images ||
+                      (a.R && (unsigned)rot_id >= (unsigned)a.n_rots) || (unsigned)ob_id >= (unsigned)a.n_obj;
+  const float* box = a.boxes + 4 * (int64_t)(bad_id ? 0 : box_id);
+  const float* K = a.K + 9 * (int64_t)(bad_id ? 0 : im_id);
   float R[9] = {0, 1, 0, 0, 0, -1, -1, 0, 0};  // z-up canonical orientation (:196-201)
   if (a.R) {
-    const float* Rp = a.R + 9 * (int64_t)(a.rot_ids ? a.rot_ids[i] : i);
+    const float* Rp = a.R + 9 * (int64_t)(bad_id ? 0 : rot_id);
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = Rp[k];
   }
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(kT) void tco_init_kernel(InitArgs a) {
   const float bcx = (box[0] + box[2]) / 2.0f, bcy = (box[1] + box[3]) / 2.0f;
   const float z_guess = 1.0f;
   float tx = ((bcx - cx) * z_guess) / fx, ty = ((bcy - cy) * z_guess) / fy;
-  const float* pts = a.points + (int64_t)a.obj_ids[i] * a.n_pad * 3;
+  const float* pts = a.points + (int64_t)(bad_id ? 0 : ob_id) * a.n_pad * 3;
   float x1 = INFINITY, y1 = INFINITY, x2 = -INFINITY, y2 = -INFINITY;
   const int npts = a.point_ids ? a.n_points : a.n_pad;
   for (int j = tid; j < npts; j += kT) {
@@ -284,12 +301,16 @@ __global__ __launch_bounds__(kT) void tco_init_kernel(InitArgs a) {
   O[4] = R[3]; O[5] = R[4]; O[6] = R[5]; O[7] = ((bcy - cy) * z) / fy;
   O[8] = R[6]; O[9] = R[7]; O[10] = R[8]; O[11] = z;
   O[12] = 0.f; O[13] = 0.f; O[14] = 0.f; O[15] = 1.f;
+  if (bad_id) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) O[k] = __builtin_nanf("");
+  }
 }
 
 }  // namespace hp
 
 extern "C" int hp_pose_prep(const hp_mesh_store* store, int b, int n_views, int multiview_type,
-                            int normalize, const float* d_TCO_in, const float* d_K,
+                            int normalize, const float* d_TCO_in, const float* d_K, int n_images,
                             const int32_t* d_im_ids, const int32_t* d_obj_ids,
                             const int32_t* d_point_ids_main, int n_points_main,
                             const int32_t* d_point_ids_extra, int n_points_extra, int im_h,
@@ -298,7 +319,7 @@ extern "C" int hp_pose_prep(const hp_mesh_store* store, int b, int n_views, int 
                             float* d_boxes_crop, float* d_K_crop, void* stream) {
   using namespace hp;
   HP_REQUIRE(store && store->points, "hp_pose_prep: mesh store has no point table");
-  HP_REQUIRE(b >= 0, "hp_pose_prep: negative batch");
+  HP_REQUIRE(b >= 0 && n_images >= 1, "hp_pose_prep: negative batch / no intrinsics");
   HP_REQUIRE((multiview_type == 0 && n_views == 1) || (multiview_type == 1 && n_views == 2) ||
                  (multiview_type == 3 && n_views == 4) || (multiview_type == 5 && n_views == 6),
              "hp_pose_prep: n_views does not match multiview_type");
@@ -311,7 +332,7 @@ extern "C" int hp_pose_prep(const hp_mesh_store* store, int b, int n_views, int 
   if (b == 0) return HP_OK;
   PrepArgs a{store->points, store->n_pad, d_TCO_in, d_K, d_im_ids, d_obj_ids,
              d_point_ids_main, n_points_main, d_point_ids_extra, n_points_extra,
-             b, n_views, normalize, im_h, im_w, crop_h, crop_w, lamb,
+             b, n_views, normalize, im_h, im_w, crop_h, crop_w, lamb, n_images, store->n_obj,
              d_TCO_out, d_tCR, d_TCV_O, d_boxes_rend, d_boxes_crop, d_K_crop};
   hipLaunchKernelGGL(pose_prep_kernel, dim3(b * n_views), dim3(kT), 0, (hipStream_t)stream, a);
   return check_launch("pose_prep_kernel");
@@ -330,21 +351,22 @@ extern "C" int hp_pose_update(int b, const float* d_TCO, const float* d_K_crop, 
   return check_launch("pose_update_kernel");
 }
 
-extern "C" int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxes,
-                                     const int32_t* d_box_ids, const float* d_K,
+extern "C" int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxes, int n_boxes,
+                                     const int32_t* d_box_ids, const float* d_K, int n_images,
                                      const int32_t* d_im_ids, const int32_t* d_obj_ids,
-                                     const float* d_R, const int32_t* d_rot_ids,
+                                     const float* d_R, int n_rots, const int32_t* d_rot_ids,
                                      const int32_t* d_point_ids, int n_points, float* d_TCO_out,
                                      void* stream) {
   using namespace hp;
   HP_REQUIRE(store && store->points, "hp_tco_init_autodepth: mesh store has no point table");
   HP_REQUIRE(n >= 0, "hp_tco_init_autodepth: negative count");
+  HP_REQUIRE(n_boxes >= 1 && n_images >= 1 && (!d_R || n_rots >= 1), "hp_tco_init_autodepth: empty box / intrinsics / rotation table");
   if (n == 0) return HP_OK;
   HP_REQUIRE(d_boxes && d_K && d_im_ids && d_obj_ids && d_TCO_out, "hp_tco_init_autodepth: null input");
   HP_REQUIRE(!d_point_ids || (n_points > 0 && n_points <= store->n_pad),
              "hp_tco_init_autodepth: n_points must be in (0, n_pad]");
   InitArgs a{store->points, store->n_pad, n, d_boxes, d_box_ids, d_K, d_im_ids, d_obj_ids,
-             d_R, d_rot_ids, d_TCO_out, d_point_ids, n_points};
+             d_R, d_rot_ids, d_TCO_out, d_point_ids, n_points, n_boxes, n_images, n_rots, store->n_obj};
   hipLaunchKernelGGL(tco_init_kernel, dim3(n), dim3(kT), 0, (hipStream_t)stream, a);
   return check_launch("tco_init_kernel");
 }

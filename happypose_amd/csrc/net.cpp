@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -101,6 +102,14 @@ struct Net {
   double flops_per_sample = 0.0;
   bool profiling = false;
   std::vector<EventPair> ev_pending, ev_pool;  // conv-launch event pairs (profiling only)
+  // per-network switches (no process-wide state on the launch path)
+  int algo = -1;               // HP_CONV_ALGO_*; -1 = follow the process-wide default (hp_conv_select_algo / environment)
+  bool tail_split = true;      // K-slicing of tail tiles (off while a second lane shares the GPU)
+  // non-finite guard of the split-fp16 kernels: a host-visible word the epilogues set (hipHostMalloc, coherent)
+  unsigned* h_status = nullptr;  // host address
+  unsigned* d_status = nullptr;  // the same word as the device sees it
+  bool exact_only = false;       // sticky after the guard fired: exact-fp32 kernels only
+  ~Net() { if (h_status) (void)hipHostFree(h_status); }
 };
 
 namespace {
@@ -537,6 +546,11 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   for (size_t s = 0; s < net->bufs.size(); ++s)
     if ((rc = net->bufs[s].alloc(net->buf_floats_per_sample[s] * (size_t)max_batch * (f16 ? 2 : 4)))) return rc;
   if (f16 && (rc = net->x16.alloc((size_t)max_batch * net->h * net->w * net->convs[0]->cin16 * 2))) return rc;
+  if (!net->h_status) {
+    HP_CHECK_HIP(hipHostMalloc((void**)&net->h_status, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *net->h_status = 0u;
+    HP_CHECK_HIP(hipHostGetDevicePointer((void**)&net->d_status, net->h_status, 0));
+  }
   net->max_batch = max_batch;
   net->params.clear();  // host copies are no longer needed
   net->finalized = true;
@@ -575,6 +589,9 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
     run_open = false;
     return HP_OK;
   };
+  // the guard of an EARLIER forward fired (read without synchronising): from now on exact-fp32 kernels only
+  if (net->h_status && *(volatile unsigned*)net->h_status) net->exact_only = true;
+  const int net_algo = net->exact_only ? HP_CONV_ALGO_WINOGRAD : (net->algo >= 0 ? net->algo : conv_algo());
   int op_index = 0;
   bool pool_fused = false;  // the stem wrote the pooled map itself: skip the max-pool op that follows it
   static const bool no_fuse = std::getenv("HP_NO_POOL_FUSION") != nullptr;
@@ -619,6 +636,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       a.M = (int64_t)batch * L.Ho * L.Wo;
       a.H = L.H; a.W = L.W; a.Cin = L.cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.cout;
       a.stride = L.stride; a.pad = L.pad; a.Kpad = L.Kpad; a.ktiles = L.Kpad / 32; a.relu = L.relu;
+      a.algo = net_algo; a.no_tail_split = net->tail_split ? 0 : 1;
       if (L.se) { a.pre_scale = (const float*)net->se_gate.p; a.pre_shift = nullptr; }  // gate [batch][Cin]
       const int variant = L.cout_pad % 128 == 0 ? 0 : 1;  // 128x128 tiles, or 128x64
       if (sync_ops)
@@ -627,12 +645,13 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
                      L.out_buf, L.res_buf, (const void*)a.x, (void*)a.y, (const void*)a.residual);
       if ((rc = prof_begin(op.conv))) return rc;
       double mfma_flops = 0.0;
-      const int algo = conv_algo();
+      const int algo = net_algo;
       // FLOPs the matrix cores actually execute (padded tiles / K included): 16 multiplies per
       // 2x2 output tile, cin and cout for the Winograd layers, M x Cout x Kpad otherwise
       const bool wino_ok = algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINOGRAD_1WAVE || algo == HP_CONV_ALGO_WINOGRAD;
       if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_split.p && conv_split_launchable(a)) {
         a.w = (const float*)L.w_split.p;
+        a.status = net->d_status;
         rc = launch_conv_split(a, stream);
         // three fp16 MFMAs per product over whole 256- / 512-row tiles; an fp16 MFMA FLOP occupies the matrix pipe for
         // 1/16 of an fp32 one, so it is counted as 1/16: mfma_flops / time / fp32 peak stays "how busy is the pipe"
@@ -648,6 +667,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_isplit.p && conv_igemm_split_launchable(a) &&
             conv_use_igemm_split(L.kh, L.Kpad)) {
           a.w = (const float*)L.w_isplit.p;
+          a.status = net->d_status;
           if (!no_fuse && next && next->kind == OP_MAXPOOL && next->in_buf == L.out_buf && next->H == L.Ho && next->W == L.Wo &&
               conv_igemm_split_pool_launchable(a, L.cout_pad)) {
             // stem + ReLU + 3x3/s2 max-pool in one launch: the conv map is never written
@@ -830,6 +850,33 @@ extern "C" int hp_net_profile_intervals(hp_net* net, double* t0_ms, double* t1_m
   return n;
 }
 
+extern "C" int hp_net_set_conv_algo(hp_net* net, int algo) {
+  HP_REQUIRE(net, "hp_net_set_conv_algo: null net");
+  HP_REQUIRE(algo >= -1 && algo <= HP_CONV_ALGO_SPLIT, "hp_net_set_conv_algo: unknown algorithm");
+  net->algo = algo;
+  return HP_OK;
+}
+
+extern "C" int hp_net_set_tail_split(hp_net* net, int enabled) {
+  HP_REQUIRE(net, "hp_net_set_tail_split: null net");
+  net->tail_split = enabled != 0;
+  return HP_OK;
+}
+
+extern "C" int hp_net_status(hp_net* net, void* stream, int* flags) {
+  HP_REQUIRE(net && flags, "hp_net_status: null argument");
+  *flags = 0;
+  if (!net->finalized) return HP_OK;
+  HP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (*(volatile unsigned*)net->h_status) {
+    *flags |= HP_STATUS_NONFINITE;
+    net->exact_only = true;  // a re-run of the same inputs takes the exact-fp32 kernels
+    *(volatile unsigned*)net->h_status = 0u;
+  }
+  if (net->exact_only) *flags |= HP_STATUS_EXACT_ONLY;
+  return HP_OK;
+}
+
 extern "C" int hp_net_set_profiling(hp_net* net, int enabled) {
   HP_REQUIRE(net, "hp_net_set_profiling: null net");
   net->profiling = enabled != 0;
@@ -881,7 +928,11 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   // the LUT lives until the stream has consumed it: allocate, async copy, free after sync is
   // avoided by keeping a small per-process cache keyed on the geometry.
   static std::map<std::string, int4*> cache;
-  const std::string key = std::to_string(w) + "_" + std::to_string(cin) + "_" + std::to_string(kh);
+  static std::mutex cache_mutex;
+  std::lock_guard<std::mutex> cache_lock(cache_mutex);
+  int cur_dev = 0;
+  HP_CHECK_HIP(hipGetDevice(&cur_dev));
+  const std::string key = std::to_string(cur_dev) + "_" + std::to_string(w) + "_" + std::to_string(cin) + "_" + std::to_string(kh);
   int4* d_lut = nullptr;
   auto it = cache.find(key);
   if (it == cache.end()) {
@@ -897,6 +948,7 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   a.H = h; a.W = w; a.Cin = cin; a.Ho = (h + 2 * pad - kh) / stride + 1; a.Wo = (w + 2 * pad - kw) / stride + 1;
   a.Cout = cout; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.ktiles = Kpad / 32; a.relu = relu;
   a.M = (int64_t)n * a.Ho * a.Wo;
+  a.algo = conv_algo();
   const bool classic = !padded && relu != HP_ACT_SWISH && (d_pre_shift || !d_pre_scale);  // what the 3x3 kernels support
   const int algo = classic ? conv_algo() : HP_CONV_ALGO_IGEMM;
   if (conv_use_split(algo, h, w, cin, cout) && conv_split_applicable(a, kh, kw) && conv_split_launchable(a)) {
@@ -967,7 +1019,11 @@ extern "C" int hp_conv2d_nhwc_f16(const void* d_x, int n, int h, int w, int cin,
     lut[q] = make_int4((y * w + x) * cin + ch, y, x, ch);
   }
   static std::map<std::string, int4*> cache;
-  const std::string key = std::to_string(w) + "_" + std::to_string(cin) + "_" + std::to_string(kh);
+  static std::mutex cache_mutex;
+  std::lock_guard<std::mutex> cache_lock(cache_mutex);
+  int cur_dev = 0;
+  HP_CHECK_HIP(hipGetDevice(&cur_dev));
+  const std::string key = std::to_string(cur_dev) + "_" + std::to_string(w) + "_" + std::to_string(cin) + "_" + std::to_string(kh);
   int4* d_lut = nullptr;
   auto it = cache.find(key);
   if (it == cache.end()) {

@@ -99,8 +99,10 @@ def refine_sharded(model, images: torch.Tensor, K: torch.Tensor, labels, TCO: to
     s, e = shard_range(n)
     labels = list(labels)
     ids = None if im_ids is None else im_ids[s:e]
-    if K.shape[0] == n and images.shape[0] == n:  # reference convention: gathered per hypothesis
+    if im_ids is None:  # reference convention: images / K already gathered per hypothesis -> shard them too
+        assert K.shape[0] == n and images.shape[0] == n, "without im_ids, images and K must hold one row per hypothesis"
         images, K = images[s:e], K[s:e]
+    # with im_ids the frames stay whole on every rank: im_ids[s:e] keeps indexing the global frame list
     if e > s:
         out = model.forward(images, K, labels[s:e], TCO[s:e], n_iterations=n_iterations, im_ids=ids)
         last = out[f"iteration={n_iterations}"]

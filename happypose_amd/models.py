@@ -256,7 +256,10 @@ def create_pose_model_cosypose(cfg, renderer: BatchRenderer, mesh_db=None, state
     return model
 
 
-def load_checkpoint(run_dir) -> Dict[str, np.ndarray]:
-    """``<run_dir>/checkpoint.pth.tar`` -> ``{"state_dict": ...}`` (``TB/inference/utils.py:146-152``)."""
-    ckpt = torch.load(Path(run_dir) / "checkpoint.pth.tar", map_location="cpu", weights_only=False)
-    return {k: v for k, v in ckpt["state_dict"].items()}
+def load_checkpoint(run_dir) -> Dict[str, torch.Tensor]:
+    """``<run_dir>/checkpoint.pth.tar`` -> state dict (``TB/inference/utils.py:146-152``): tensors only
+    (``weights_only=True``: a downloaded checkpoint is never unpickled as code) with the legacy key renames
+    applied -- the same path ``load_model.load_pose_models`` takes."""
+    from .load_model import load_state_dict
+
+    return load_state_dict(run_dir)

@@ -36,6 +36,20 @@ def _i32(t, device) -> torch.Tensor:
     return torch.as_tensor(t).to(device=device, dtype=torch.int32).contiguous()
 
 
+def _check_ids(ids, n: int, what: str) -> None:
+    """Index tensors against the table they index.  Ids that still live on the host (numpy arrays, CPU tensors:
+    what the estimators build from ``infos``) are checked here for free and raise like the reference's indexing;
+    ids already on the device cannot be read without a synchronisation -- the kernels receive the table sizes and
+    answer an out-of-range id with NaN poses / zero crops instead of touching memory outside the table."""
+    if ids is None:
+        return
+    t = torch.as_tensor(ids)
+    if t.device.type == "cpu" and t.numel():
+        lo, hi = int(t.min()), int(t.max())
+        if lo < 0 or hi >= n:
+            raise IndexError(f"{what}: ids in [{lo}, {hi}] index a table of {n} rows")
+
+
 class MeshStore:
     """Device-resident object set: geometry/textures for the rasteriser and the padded
     mesh-point table for the projection kernels (``hp_mesh_store``)."""
@@ -161,6 +175,8 @@ def pose_prep(store: MeshStore, TCO: torch.Tensor, K: torch.Tensor, im_ids: torc
     assert TCO.shape == (b, 4, 4) and K.dim() == 3 and K.shape[1:] == (3, 3)
     mv, V = MULTIVIEW[multiview_type]
     TCO, K = _f32(TCO, dev), _f32(K, dev)
+    _check_ids(im_ids, K.shape[0], "pose_prep: im_ids -> K")
+    _check_ids(obj_ids, len(store.labels), "pose_prep: obj_ids -> objects")
     im_ids, obj_ids = _i32(im_ids, dev), _i32(obj_ids, dev)
     assert im_ids.shape == (b,) and obj_ids.shape == (b,)
     f = dict(dtype=torch.float32, device=dev)
@@ -170,7 +186,7 @@ def pose_prep(store: MeshStore, TCO: torch.Tensor, K: torch.Tensor, im_ids: torc
     ids_main = store.point_ids(n_points)
     ids_extra = store.point_ids(n_points_extra) if V > 1 else None
     with torch.cuda.device(dev):
-        check(lib().hp_pose_prep(store.handle, b, V, mv, int(normalize), ptr(TCO), ptr(K), ptr(im_ids),
+        check(lib().hp_pose_prep(store.handle, b, V, mv, int(normalize), ptr(TCO), ptr(K), K.shape[0], ptr(im_ids),
                                  ptr(obj_ids), ptr(ids_main), n_points, ptr(ids_extra),
                                  n_points_extra if V > 1 else 0, im_size[0], im_size[1], crop_size[0],
                                  crop_size[1], C.c_float(lamb), ptr(out["TCO"]), ptr(out["tCR"]),
@@ -192,6 +208,7 @@ def crop_roi_align(images: torch.Tensor, boxes: torch.Tensor, im_ids: torch.Tens
     n = boxes.shape[0]
     oh, ow = output_size
     assert images.dtype == torch.float32 and images.is_contiguous()
+    _check_ids(im_ids, Bi, "crop_roi_align: im_ids -> images")
     boxes, im_ids = _f32(boxes, dev), _i32(im_ids, dev)
     assert boxes.shape == (n, 4) and im_ids.shape == (n,)
     if out is None:
@@ -236,16 +253,26 @@ def tco_init_autodepth(store: MeshStore, boxes: torch.Tensor, K: torch.Tensor, i
     dev = store.device
     n = len(obj_ids)
     boxes, K = _f32(boxes, dev), _f32(K, dev)
+    if R is not None:
+        R = _f32(R, dev)
+    assert boxes.dim() == 2 and boxes.shape[1] == 4 and K.dim() == 3 and K.shape[1:] == (3, 3)
+    assert R is None or (R.dim() == 3 and R.shape[1:] == (3, 3))
+    assert box_ids is not None or boxes.shape[0] == n, "one box per hypothesis unless box_ids is given"
+    assert R is None or rot_ids is not None or R.shape[0] == n, "one rotation per hypothesis unless rot_ids is given"
+    _check_ids(im_ids, K.shape[0], "tco_init_autodepth: im_ids -> K")
+    _check_ids(obj_ids, len(store.labels), "tco_init_autodepth: obj_ids -> objects")
+    _check_ids(box_ids, boxes.shape[0], "tco_init_autodepth: box_ids -> boxes")
+    if R is not None:
+        _check_ids(rot_ids, R.shape[0], "tco_init_autodepth: rot_ids -> R")
     im_ids, obj_ids = _i32(im_ids, dev), _i32(obj_ids, dev)
     box_ids = None if box_ids is None else _i32(box_ids, dev)
     rot_ids = None if rot_ids is None else _i32(rot_ids, dev)
-    if R is not None:
-        R = _f32(R, dev)
     out = torch.empty((n, 4, 4), dtype=torch.float32, device=dev)
     pids = None if n_points is None else store.point_ids(n_points)
     with torch.cuda.device(dev):
-        check(lib().hp_tco_init_autodepth(store.handle, n, ptr(boxes), ptr(box_ids), ptr(K), ptr(im_ids),
-                                          ptr(obj_ids), ptr(R), ptr(rot_ids), ptr(pids), n_points or 0,
+        check(lib().hp_tco_init_autodepth(store.handle, n, ptr(boxes), boxes.shape[0], ptr(box_ids), ptr(K), K.shape[0],
+                                          ptr(im_ids), ptr(obj_ids), ptr(R), 0 if R is None else R.shape[0],
+                                          ptr(rot_ids), ptr(pids), n_points or 0,
                                           ptr(out), stream_ptr(dev)),
               "hp_tco_init_autodepth")
     return out
@@ -328,6 +355,27 @@ class Net:
     def set_profiling(self, on: bool):
         check(lib().hp_net_set_profiling(self.handle, int(on)), "hp_net_set_profiling")
 
+    def set_conv_algo(self, name: Optional[str] = None):
+        """Kernel families THIS network may use (``hp_net_set_conv_algo``; names of :data:`CONV_ALGOS`);
+        ``None`` returns it to the process-wide default."""
+        check(lib().hp_net_set_conv_algo(self.handle, -1 if name is None else CONV_ALGOS[name]), "hp_net_set_conv_algo")
+
+    def set_tail_split(self, on: bool):
+        """K-slicing of the tail tiles of this network's conv launches (``hp_net_set_tail_split``): off while a
+        second lane shares the GPU."""
+        check(lib().hp_net_set_tail_split(self.handle, int(on)), "hp_net_set_tail_split")
+
+    def status(self, stream=None) -> int:
+        """``hp_net_status``: waits for ``stream`` (default: the current one) and returns the guard flags --
+        bit 0 (:data:`STATUS_NONFINITE`): a forward since the last call produced inf / NaN in a split-fp16
+        layer (an activation beyond the fp16 range), its outputs are invalid; bit 1 (:data:`STATUS_EXACT_ONLY`):
+        the network now runs the exact-fp32 kernels only, so re-running the same inputs is valid."""
+        flags = C.c_int(0)
+        sp = stream_ptr(self.device) if stream is None else C.c_void_p(stream.cuda_stream)
+        with torch.cuda.device(self.device):
+            check(lib().hp_net_status(self.handle, sp, C.byref(flags)), "hp_net_status")
+        return flags.value
+
     def profile_collect(self):
         """``(conv_ms, n_launches, conv_flops, mfma_flops)`` of the conv launches recorded since
         the last call (HIP events on the launch stream; waits for them): algorithmic FLOPs of the
@@ -351,9 +399,7 @@ class Net:
         return list(zip(list(a), list(b)))
 
 
-def set_conv_tail_split(on: bool) -> None:
-    """K-slicing of tail tiles in the conv kernels (``hp_conv_set_tail_split``)."""
-    check(lib().hp_conv_set_tail_split(int(on)), "hp_conv_set_tail_split")
+STATUS_NONFINITE, STATUS_EXACT_ONLY = 1, 2
 
 
 def profile_mark_reference(device) -> None:
@@ -366,7 +412,8 @@ CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2, "winograd-1wave": 3, "winograd
 
 
 def select_conv_algo(name: str = "auto") -> None:
-    """Restrict the conv kernels the library may pick (process wide; parity tests / diagnostics):
+    """The process-wide DEFAULT of the conv kernel choice -- what ``conv2d_nhwc`` uses and what networks without a
+    choice of their own (:meth:`Net.set_conv_algo`) follow; parity tests / diagnostics:
     ``auto`` = Winograd F(2x2,3x3) where it applies (two waves per SIMD), ``winograd-1wave`` = the same
     with the one-wave-per-SIMD schedule of that kernel, ``direct`` = no Winograd, ``igemm`` = the
     generic implicit-GEMM kernel only (``hp_conv_select_algo``)."""

@@ -197,8 +197,25 @@ class _EstimatorBase:
     def eval(self):
         return self
 
+    @staticmethod
+    def _guarded(model, stage):
+        """Run ``stage()`` and ask the model's backbone for its numerical guard at the stage's end (one stream
+        synchronisation, where the pipeline synchronises anyway to read scores).  If an activation left the fp16 range
+        of the default split-fp16 conv kernels (``HP_STATUS_NONFINITE``) the results are invalid; the backbone has
+        switched to its exact-fp32 kernels, so the stage is simply run again -- the reference's fp32 arithmetic."""
+        out = stage()
+        status = getattr(model, "numerics_status", None)
+        if status is not None and status() & ops.STATUS_NONFINITE:
+            out = stage()
+        return out
+
     def _run_model_chunks(self, model, observation, data_TCO_input, n_iterations, bsz, tag,
                           keep_all_outputs=False, **kw) -> Tuple[dict, dict]:
+        return self._guarded(model, lambda: self._run_model_chunks_once(
+            model, observation, data_TCO_input, n_iterations, bsz, tag, keep_all_outputs, **kw))
+
+    def _run_model_chunks_once(self, model, observation, data_TCO_input, n_iterations, bsz, tag,
+                               keep_all_outputs=False, **kw) -> Tuple[dict, dict]:
         """Shared body of forward_refiner / CosyPose forward_coarse_model."""
         t_start = time.time()
         B = len(data_TCO_input)
@@ -258,6 +275,10 @@ class PoseEstimator(_EstimatorBase):
                               ) -> Tuple[PoseEstimatesType, dict]:
         """Adds ``pose_logit`` / ``pose_score`` (coarse net on the refined poses), in place
         (``:222-325``)."""
+        return self._guarded(self.coarse_model, lambda: self._forward_scoring_model_once(
+            observation, data_TCO, cuda_timer, return_debug_data))
+
+    def _forward_scoring_model_once(self, observation, data_TCO, cuda_timer, return_debug_data):
         t_start = time.time()
         assert self.coarse_model is not None
         df = data_TCO.infos
@@ -297,6 +318,10 @@ class PoseEstimator(_EstimatorBase):
                              ) -> Tuple[PoseEstimatesType, dict]:
         """Every detection x every grid rotation -> ``TCO_init_from_boxes_autodepth_with_R``
         -> coarse logits (``:327-485``)."""
+        return self._guarded(self.coarse_model, lambda: self._forward_coarse_model_once(
+            observation, detections, cuda_timer, return_debug_data))
+
+    def _forward_coarse_model_once(self, observation, detections, cuda_timer, return_debug_data):
         t_start = time.time()
         assert_detections_valid(detections)
         coarse_model = self.coarse_model

@@ -118,14 +118,28 @@ class _RenderAndCompare:
         return self._x[:b]
 
     def _ids(self, images, K, labels, im_ids):
+        """The ONE index convention of the path: ``images [Bi,C,H,W]`` and ``K [Bi,3,3]`` are per-FRAME tables and
+        hypothesis ``i`` uses row ``im_ids[i]`` of both.  ``im_ids=None`` is the reference's calling convention
+        (images / K already gathered per hypothesis): ``Bi == bsz`` and ``im_ids = arange(bsz)``.  Ids handed over
+        on the host are range-checked here (``IndexError``, like the reference's indexing); ids already on the
+        device are guarded inside the kernels (``ops._check_ids``)."""
         bsz = len(labels)
-        if im_ids is None:  # the reference passes images/K already gathered per hypothesis
-            assert images.shape[0] == bsz and K.shape[0] == bsz
+        assert K.shape[0] == images.shape[0], "K must hold one intrinsics matrix per frame of `images`"
+        if im_ids is None:
+            assert images.shape[0] == bsz, "without im_ids, images and K must hold one row per hypothesis"
             im_ids = torch.arange(bsz, dtype=torch.int32, device=self.device)
         else:
+            ops._check_ids(im_ids, images.shape[0], "im_ids -> images / K")
             im_ids = torch.as_tensor(im_ids).to(device=self.device, dtype=torch.int32)
             assert im_ids.shape == (bsz,)
         return im_ids, self.store.ids_of(labels)
+
+    def numerics_status(self) -> int:
+        """Guard flags of the backbone (``ops.Net.status``; synchronises the current stream): non-zero bit 0 means
+        the outputs of a forward since the last call are invalid (an activation left the fp16 range of the default
+        split-fp16 conv kernels); the backbone has then switched to the exact-fp32 kernels and the call can simply
+        be repeated.  The estimators do that at their existing synchronisation points."""
+        return self.backbone.status()
 
     def _one_pass(self, images, K, im_ids, obj_ids, TCO_in, *, n_img_channels, multiview_type, normalize,
                   render_normals, render_depth, depth_mode, want_pose, want_logits):
@@ -202,6 +216,7 @@ class PosePredictor(_RenderAndCompare):
         assert TCO.shape == (bsz, 4, 4)
         assert K.dim() == 3 and K.shape[1:] == (3, 3)
         assert images.dim() == 4 and images.shape[1] >= self._n_img, "images must be [B,C,H,W] with C>=3 (4 if input_depth)"
+        per_hyp = im_ids is None
         im_ids, obj_ids = self._ids(images, K, labels, im_ids)
         labels = list(labels)
         outputs: Dict[str, PosePredictorOutput] = {}
@@ -223,7 +238,7 @@ class PosePredictor(_RenderAndCompare):
             if logits is not None:
                 net_out["renderings_logits"] = logits
             images_crop, renders = self._pixels(x, self._n_img, self._n_single_render_channels * self.n_rendered_views)
-            Kb = K[im_ids.long()] if K.shape[0] != bsz else K
+            Kb = K if per_hyp else K[im_ids.long()]
             outputs[f"iteration={n + 1}"] = PosePredictorOutput(
                 renders=renders, images_crop=images_crop, TCO_input=TCO_norm, TCO_output=TCO_output,
                 TCV_O_input=prep["TCV_O"], tCR=prep["tCR"], labels=labels, K=Kb, K_crop=prep["K_crop"][:, 0],
@@ -283,6 +298,7 @@ class CosyPosePosePredictor(_RenderAndCompare):
         assert images.dim() == 4 and images.shape[1] >= 3
         assert K.dim() == 3 and K.shape[1:] == (3, 3)
         assert TCO.shape == (bsz, 4, 4)
+        per_hyp = im_ids is None
         im_ids, obj_ids = self._ids(images, K, labels, im_ids)
         labels = list(labels)
         outputs: Dict[str, PosePredictorOutput] = {}
@@ -293,7 +309,7 @@ class CosyPosePosePredictor(_RenderAndCompare):
                 render_normals=False, render_depth=False, depth_mode=0, want_pose=True, want_logits=False)
             TCO_output = ops.pose_update(TCO_input, prep["K_crop"], pose, None)
             images_crop, renders = self._pixels(x, 3, 3)
-            Kb = K[im_ids.long()] if K.shape[0] != bsz else K
+            Kb = K if per_hyp else K[im_ids.long()]
             outputs[f"iteration={n + 1}"] = PosePredictorOutput(
                 renders=renders, images_crop=images_crop, TCO_input=TCO_input, TCO_output=TCO_output,
                 TCV_O_input=prep["TCV_O"], tCR=prep["tCR"], labels=labels, K=Kb, K_crop=prep["K_crop"][:, 0],
@@ -320,6 +336,20 @@ class _LaneBackbones:
     def set_profiling(self, on: bool):
         for n in self.nets:
             n.set_profiling(on)
+
+    def set_conv_algo(self, name=None):
+        for n in self.nets:
+            n.set_conv_algo(name)
+
+    def set_tail_split(self, on: bool):
+        for n in self.nets:
+            n.set_tail_split(on)
+
+    def status(self, streams=None) -> int:
+        flags = 0
+        for i, n in enumerate(self.nets):
+            flags |= n.status(None if streams is None else streams[i])
+        return flags
 
     def profile_intervals(self):
         return [iv for n in self.nets for iv in n.profile_intervals()]
@@ -403,6 +433,11 @@ class TwoLanePredictor:
         self.lanes[0].to(device)
         return self
 
+    def numerics_status(self) -> int:
+        """Guard flags over both lanes' backbones (see ``_RenderAndCompare.numerics_status``)."""
+        torch.cuda.current_stream(self.device).synchronize()  # forward() already joined the lane streams into it
+        return self.backbone.status()
+
     @torch.no_grad()
     def forward(self, images, K, labels, TCO, n_iterations: int = 1, *, im_ids=None, **kw):
         """``kw``: what the lanes' ``forward`` takes beyond this (MegaPose: ``random_ambient_light``)."""
@@ -415,7 +450,7 @@ class TwoLanePredictor:
         parts = []
         # the other lane fills the CUs a partially filled round of tiles leaves idle: K-slicing those tiles would only
         # add its reduction (C2: 24.5 ms with, 22.5 ms without)
-        ops.set_conv_tail_split(False)
+        self.backbone.set_tail_split(False)  # per network: other predictors are not affected
         try:
             for lane, stream, sl in zip(self.lanes, self.streams, (slice(0, h), slice(h, bsz))):
                 per_hyp = im_ids is None  # the reference's calling convention: images / K already gathered per hypothesis
@@ -425,7 +460,7 @@ class TwoLanePredictor:
                                               n_iterations=n_iterations,
                                               im_ids=None if per_hyp else torch.as_tensor(im_ids)[sl], **kw))
         finally:
-            ops.set_conv_tail_split(True)
+            self.backbone.set_tail_split(True)
         for stream in self.streams:
             cur.wait_stream(stream)
         return {k: _cat_outputs([p[k] for p in parts]) for k in parts[0]}
@@ -443,7 +478,7 @@ class TwoLanePredictor:
         h = bsz // 2
         cur = torch.cuda.current_stream(self.device)
         parts = []
-        ops.set_conv_tail_split(False)
+        self.backbone.set_tail_split(False)
         try:
             for lane, stream, sl in zip(self.lanes, self.streams, (slice(0, h), slice(h, bsz))):
                 per_hyp = im_ids is None
@@ -452,7 +487,7 @@ class TwoLanePredictor:
                     parts.append(lane.forward_coarse(images[sl] if per_hyp else images, K[sl] if per_hyp else K, labels[sl],
                                                      TCO_input[sl], im_ids=None if per_hyp else torch.as_tensor(im_ids)[sl]))
         finally:
-            ops.set_conv_tail_split(True)
+            self.backbone.set_tail_split(True)
         for stream in self.streams:
             cur.wait_stream(stream)
         out = {k: torch.cat([p[k] for p in parts], 0) for k in ("logits", "scores")}

@@ -121,10 +121,14 @@ int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
  * 3 = "TCO+front_3views", 5 = "TCO+front_5views"; n_views must be 1 / 2 / 4 / 6.
  * Outputs: d_TCO_out [b][16] (normalised input pose), d_tCR [b][3], d_TCV_O [b][V][16],
  * d_boxes_rend [b][4], d_boxes_crop [b][4], d_K_crop [b][V][9] (view 0 = K_crop).
+ * Index convention of the whole library: intrinsics and frames are tables [n_images] indexed by d_im_ids, never
+ * per-hypothesis copies.  Ids live on the device, so they cannot be asserted here the way the reference's indexing
+ * raises; a hypothesis whose image or object id lies outside its table reads row 0 and gets NaN outputs (NaN poses
+ * render as zero images, an out-of-range image id crops to zeros) -- out-of-bounds memory is never touched.
  * ---------------------------------------------------------------------------------- */
 int hp_pose_prep(const hp_mesh_store* store, int b, int n_views, int multiview_type,
-                 int normalize, const float* d_TCO_in, const float* d_K /* [Bi][9] */,
-                 const int32_t* d_im_ids /* [b] */, const int32_t* d_obj_ids /* [b] */,
+                 int normalize, const float* d_TCO_in, const float* d_K /* [n_images][9] */, int n_images,
+                 const int32_t* d_im_ids /* [b], values in [0, n_images) */, const int32_t* d_obj_ids /* [b] */,
                  const int32_t* d_point_ids_main, int n_points_main,
                  const int32_t* d_point_ids_extra, int n_points_extra, int im_h, int im_w,
                  int crop_h, int crop_w, float lamb, float* d_TCO_out, float* d_tCR,
@@ -169,10 +173,12 @@ int hp_pose_update(int b, const float* d_TCO, const float* d_K_crop, int k_strid
  * (MegaPose, MP/inference/pose_estimator.py:393-410) or, when d_point_ids is given, over
  * that deterministic sub-sample (CosyPose, CP/integrated/pose_estimator.py:128-130).
  * Hypothesis i uses box d_boxes[d_box_ids ? d_box_ids[i] : i], intrinsics
- * d_K[d_im_ids[i]], object d_obj_ids[i], rotation d_R[d_rot_ids ? d_rot_ids[i] : i]. */
-int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxes,
-                          const int32_t* d_box_ids, const float* d_K, const int32_t* d_im_ids,
-                          const int32_t* d_obj_ids, const float* d_R, const int32_t* d_rot_ids,
+ * d_K[d_im_ids[i]], object d_obj_ids[i], rotation d_R[d_rot_ids ? d_rot_ids[i] : i]; an id outside its table
+ * (sizes n_boxes / n_images / n_rots / objects of the store) gives a NaN pose, see hp_pose_prep. */
+int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxes /* [n_boxes][4] */, int n_boxes,
+                          const int32_t* d_box_ids, const float* d_K /* [n_images][9] */, int n_images,
+                          const int32_t* d_im_ids, const int32_t* d_obj_ids,
+                          const float* d_R /* [n_rots][9] */, int n_rots, const int32_t* d_rot_ids,
                           const int32_t* d_point_ids, int n_points, float* d_TCO_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
@@ -232,7 +238,7 @@ double hp_net_flops_per_sample(const hp_net* net);
  * split-fp16 layers counts 1/16, its share of matrix-pipe time) since the previous collect. */
 int hp_net_set_profiling(hp_net* net, int enabled);
 /* Diagnostics / parity tests: restrict the convolution kernels the dispatchers may pick
- * (process wide).  AUTO = for 3x3 stride-1 layers the split-fp16 kernel (fp32 operands as two fp16 halves, three
+ * (the process-wide DEFAULT of networks that have no choice of their own, and the choice of hp_conv2d_nhwc).  AUTO = for 3x3 stride-1 layers the split-fp16 kernel (fp32 operands as two fp16 halves, three
  * fp16 MFMAs per product, fp32 accumulation: fp32-level accuracy while |activations| < 65504), else Winograd
  * F(2x2,3x3), else the patch-staged direct kernel, else the generic implicit GEMM; WINOGRAD = exact-fp32
  * arithmetic only; DIRECT = no Winograd either; IGEMM = generic kernel only.
@@ -244,10 +250,25 @@ int hp_net_set_profiling(hp_net* net, int enabled);
 #define HP_CONV_ALGO_WINOGRAD 4 /* exact-fp32 kernels only: Winograd, else patch-staged, else generic */
 #define HP_CONV_ALGO_SPLIT 5 /* split-fp16 kernels (3 fp16 MFMAs per fp32 product) wherever they apply */
 int hp_conv_select_algo(int algo);
+/* The same choice for ONE network (what the predictors use: no process-wide state on the launch path, networks on
+ * different host threads / streams do not interfere); algo = -1 returns the network to the process-wide default. */
+int hp_net_set_conv_algo(hp_net* net, int algo);
 /* The conv kernels cut the tiles of a partially filled last round along K so that one launch fills the GPU.  When
  * independent launches share the GPU (the two half-batch lanes of a predictor on two streams) the other stream fills
- * those CUs and the slicing only costs its reduction: 0 switches it off (process wide), 1 back on (the default). */
-int hp_conv_set_tail_split(int enabled);
+ * those CUs and the slicing only costs its reduction: 0 switches it off for this network, 1 back on (the default). */
+int hp_net_set_tail_split(hp_net* net, int enabled);
+/* Numerical guard of the default (split-fp16) kernels.  They carry fp32 activations through the fp16 matrix path as
+ * hi/lo halves, which needs |activation| < 65504; beyond that a half becomes inf and the layer's output inf / NaN where
+ * the reference's fp32 arithmetic stays finite.  Every split-fp16 launch reports a non-finite output to a host-visible
+ * word of its network.  hp_net_status synchronises `stream`, returns the flags and clears HP_STATUS_NONFINITE:
+ *   HP_STATUS_NONFINITE  a forward since the last call produced a non-finite value: ITS OUTPUTS ARE INVALID;
+ *   HP_STATUS_EXACT_ONLY the network has switched to the exact-fp32 kernels (Winograd / direct; sticky): re-running
+ *                        the same inputs now gives the reference's arithmetic.
+ * hp_net_forward also reads the word (without synchronising) on entry, so once a completed forward has tripped the
+ * guard every later forward runs on the exact kernels by itself. */
+#define HP_STATUS_NONFINITE 1
+#define HP_STATUS_EXACT_ONLY 2
+int hp_net_status(hp_net* net, void* stream, int* flags);
 /* diagnostics: workgroups per CU the runtime grants conv tile variant 0 (128x128) / 1 (128x64) */
 int hp_conv_occupancy(int variant);
 int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, double* conv_flops,

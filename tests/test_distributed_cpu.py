@@ -51,7 +51,8 @@ WORKER = textwrap.dedent("""
         def forward(self, images, K, labels, TCO, n_iterations=1, im_ids=None):
             out = TCO.clone()
             for _ in range(n_iterations):
-                out = out * 0.5 + images[im_ids.long()].mean(dim=(1, 2, 3))[:, None, None] + torch.as_tensor(
+                fr = images if im_ids is None else images[im_ids.long()]
+                out = out * 0.5 + fr.mean(dim=(1, 2, 3))[:, None, None] + torch.as_tensor(
                     [float(l[3:]) for l in labels])[:, None, None]
             return {f"iteration={n_iterations}": SimpleNamespace(TCO_output=out)}
 
@@ -63,6 +64,9 @@ WORKER = textwrap.dedent("""
     got, sc = D.refine_sharded(FakeModel(), images, Kc, labels, poses_all, 3, im_ids=im_ids,
                                scores_fn=lambda o: o.TCO_output[:, 0, 0])
     assert torch.equal(got, ref) and torch.equal(sc, ref[:, 0, 0])
+    # the reference's calling convention (im_ids=None: images / K gathered per hypothesis) shards the frames too
+    got2, _ = D.refine_sharded(FakeModel(), images[im_ids.long()], Kc[im_ids.long()], labels, poses_all, 3)
+    assert torch.equal(got2, ref)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
     print(f"rank {rank} ok")
@@ -75,7 +79,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n_total", [(2, 256), (3, 37), (2, 1)])
+@pytest.mark.parametrize("world,n_total", [(2, 256), (3, 37), (2, 1), (2, 2)])
 def test_shard_and_all_gather_gloo(tmp_path, world, n_total):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)

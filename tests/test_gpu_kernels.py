@@ -530,7 +530,9 @@ def test_backbone_f16_vs_f32(dev, arch, cin):
 
 @pytest.mark.parametrize("arch,cin,tag", [("vanilla_resnet34", 27, "vanilla_resnet34_27"),
                                           ("vanilla_resnet34", 9, "vanilla_resnet34_9"),
-                                          ("resnet34", 6, "resnet34_6"), ("resnet18", 6, "resnet18_6")])
+                                          ("vanilla_resnet34", 32, "vanilla_resnet34_32"),  # the C3 (RGB-D) stem
+                                          ("resnet34", 6, "resnet34_6"), ("resnet18", 6, "resnet18_6"),
+                                          ("resnet34", 6, "resnet34cp_6")])  # CosyPose's copy of the module
 def test_backbone_golden_g6(dev, golden_dir, arch, cin, tag):
     """Whole backbone (BN folded, NHWC, MFMA) against the reference modules' outputs."""
     from happypose_amd import ops
@@ -551,6 +553,7 @@ def test_backbone_golden_g6(dev, golden_dir, arch, cin, tag):
     err = np.abs(feats.cpu().numpy() - ref).max()
     assert err <= 2e-4 * np.abs(ref).max(), (err, np.abs(ref).max())
     assert abs(net.flops_per_sample / 1e9 - {("vanilla_resnet34", 27): 14.236, ("vanilla_resnet34", 9): 12.068,
+                                              ("vanilla_resnet34", 32): 14.838,
                                               ("resnet34", 6): 11.352, ("resnet18", 6): 5.64}[(arch, cin)]) < 0.02
 
 

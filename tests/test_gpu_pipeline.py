@@ -374,3 +374,332 @@ def test_two_lane_refiner_matches_single_lane(dev, world):
         dT = (a.TCO_output - b.TCO_output).abs().max().item()
         assert dT < 1e-4, (k, dT)
         assert torch.allclose(a.network_outputs["pose"], b.network_outputs["pose"], atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Parity at the BENCHMARKED sizes (BASELINE.json configs C2 / C3 / C5): the worlds are the ones bench.py times.
+# ---------------------------------------------------------------------------------------------------------------
+def _bench():
+    import importlib
+    import sys
+    from pathlib import Path
+
+    root = str(Path(__file__).resolve().parent.parent)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    return importlib.import_module("bench")
+
+
+def test_c2_full_size_two_lanes_vs_oracle(dev):
+    """C2 exactly as benchmarked: WideResNet-34, 8 detections x 16 hypotheses = 128, 5 iterations, two half-batch lanes
+    (64-sample launches: the planner's tail K-slicing / half-CU slicing paths) against the CPU oracle run in the
+    reference's chunks of bsz_objects = 8; T_TOL / R_TOL must hold at EVERY iteration."""
+    from oracle.pipeline import OraclePredictor
+
+    bench = _bench()
+    ds, renderer, scene, weights, model = bench.build_world(dev, "resnet34", seed=0, workload="C2", n_lanes=2)
+    store = renderer.store
+    B = len(scene["TCO_hyp"])
+    assert B == 128
+    images, K = torch.as_tensor(scene["images"], device=dev), torch.as_tensor(scene["K"], device=dev)
+    labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
+    im_ids = torch.zeros(B, dtype=torch.int32, device=dev)
+    out = model.forward(images, K, labels, torch.as_tensor(scene["TCO_hyp"], device=dev), n_iterations=5, im_ids=im_ids)
+    assert model.numerics_status() == 0
+    torch.set_num_threads(bench.effective_cpu_count())
+    ora = OraclePredictor(weights, store.packed, store.mesh_db.points, arch="resnet34", cosypose=True)
+    ref = ora.forward(scene["images"][:, :3], scene["K"], np.zeros(B, np.int32), scene["hyp_obj_ids"], scene["TCO_hyp"], 5,
+                      bsz_objects=8)
+    errs = []
+    for n in range(5):
+        dt, dr = _pose_err(out[f"iteration={n + 1}"].TCO_output.cpu().numpy(), ref[n]["TCO_output"])
+        errs.append((dt, dr))
+        assert dt <= T_TOL and dr <= R_TOL, (n, errs)
+    # the refinement moved the poses by far more than the tolerance
+    assert _pose_err(out["iteration=5"].TCO_output.cpu().numpy(), scene["TCO_hyp"])[1] > 10 * R_TOL
+
+
+def test_c3_full_size_vs_oracle(dev):
+    """C3 as benchmarked: MegaPose RGB-D refiner, 64 hypotheses x 4 views x (rgb + normals + depth), ResNet-34 on 32
+    channels, two lanes; 2 iterations against the oracle (the 7x7 / 32-channel stem, 256 renders per iteration)."""
+    from oracle.pipeline import OraclePredictor
+
+    bench = _bench()
+    ds, renderer, scene, weights, model = bench.build_world(dev, "resnet34", seed=0, workload="C3", n_lanes=2)
+    store = renderer.store
+    B = len(scene["TCO_hyp"])
+    assert B == 64
+    images, K = torch.as_tensor(scene["images"], device=dev), torch.as_tensor(scene["K"], device=dev)
+    labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
+    out = model.forward(images, K, labels, torch.as_tensor(scene["TCO_hyp"], device=dev), n_iterations=2,
+                        im_ids=torch.zeros(B, dtype=torch.int32, device=dev))
+    assert model.numerics_status() == 0
+    torch.set_num_threads(bench.effective_cpu_count())
+    ora = OraclePredictor(weights, store.packed, store.mesh_db.points, arch="vanilla_resnet34", n_views=4,
+                          multiview_type="TCO+front_3views", render_normals=True, render_depth=True, input_depth=True,
+                          depth_normalization_type="tCR_scale_clamp_center")
+    ref = ora.forward(scene["images"], scene["K"], np.zeros(B, np.int32), scene["hyp_obj_ids"], scene["TCO_hyp"], 2, bsz_objects=8)
+    for n in range(2):
+        dt, dr = _pose_err(out[f"iteration={n + 1}"].TCO_output.cpu().numpy(), ref[n]["TCO_output"])
+        assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
+
+
+C5_LOGIT_TOL = 2e-2  # fp16 weights / activations (fp32 accumulation) vs the fp32 oracle, on logits of O(1..5)
+
+
+def test_c5_fp16_coarse_scoring_vs_oracle(dev):
+    """C5 as benchmarked: coarse scoring in fp16 of one object x the 576 SO(3)-grid poses (one chunk of the bench) --
+    crop and rasteriser writing the fp16 network input directly, the fp16 conv stack -- against the fp32 CPU oracle:
+    logits within C5_LOGIT_TOL and the same top-5 hypotheses."""
+    from oracle.pipeline import OraclePredictor
+
+    bench = _bench()
+    ds, renderer, scene, weights, model = bench.build_world(dev, "resnet34", seed=0, workload="C5", precision="f16", n_lanes=1)
+    store = renderer.store
+    # spread the logits like a trained head would: the synthetic head has update-scale weights
+    sl = slice(0, 576)
+    images, K = torch.as_tensor(scene["images"], device=dev), torch.as_tensor(scene["K"], device=dev)
+    labels = [store.labels[i] for i in scene["hyp_obj_ids"][sl]]
+    T = torch.as_tensor(scene["TCO_hyp"][sl], device=dev)
+    got = model.forward_coarse(images, K, labels, T, im_ids=torch.zeros(576, dtype=torch.int32, device=dev))["logits"].cpu().numpy().reshape(-1)
+    torch.set_num_threads(bench.effective_cpu_count())
+    ora = OraclePredictor(weights, store.packed, store.mesh_db.points, arch="vanilla_resnet34", render_normals=True)
+    ref = np.concatenate([ora.forward_coarse(scene["images"][:, :3], scene["K"], np.zeros(64, np.int32), scene["hyp_obj_ids"][s:s + 64],
+                                             scene["TCO_hyp"][s:s + 64])["logits"].reshape(-1) for s in range(0, 576, 64)])
+    scale = max(1.0, np.abs(ref).max())
+    err = np.abs(got - ref).max()
+    assert err <= C5_LOGIT_TOL * scale, (err, scale)
+    # ranking: identical top-5 set wherever the oracle separates rank 5 from rank 6 by more than the stated tolerance
+    order = np.argsort(-ref)
+    margin = ref[order[4]] - ref[order[5]]
+    top_got, top_ref = set(np.argsort(-got)[:5].tolist()), set(order[:5].tolist())
+    if margin > 2 * err:
+        assert top_got == top_ref, (sorted(top_got), sorted(top_ref), margin, err)
+    else:  # an fp32-level tie at the cut: every selected hypothesis must be within the error of the oracle's cut
+        assert all(ref[i] >= ref[order[4]] - 2 * err for i in top_got), (sorted(top_got), sorted(top_ref), margin, err)
+    assert len(top_got & top_ref) >= 4
+
+
+def test_run_inference_pipeline_vs_oracle_estimator(dev, world):
+    """a-1: the whole MegaPose pipeline (coarse grid -> top-K -> refine -> score -> top-1) against an independent CPU
+    run of the same pipeline (oracle/estimator.py, itself pinned by golden G10 to the reference's own orchestrator):
+    coarse logits, the top-K ids and ORDER, refined poses, final ids / labels / row order / poses."""
+    from happypose_amd.models import create_model_pose
+    from happypose_amd.pose_estimator import ObservationTensor, PoseEstimator, make_detections_from_object_data
+    from oracle import geometry as G
+    from oracle.estimator import OracleEstimator
+    from oracle.pipeline import OraclePredictor
+
+    sc, store = world["scene"], world["store"]
+    ccfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
+                predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
+    rcfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+                depth_augmentation=False)
+    # head weights at He scale spread the logits; seed 5 separates ranks 1 / 2 / 3 of every detection by > 2 LOGIT_TOL
+    wc = _weights("vanilla_resnet34", 9, pose=False, logits=1, seed=5, scale=1.0)
+    wr = _weights("vanilla_resnet34", 27, seed=2)
+    coarse = create_model_pose(ccfg, world["renderer"], state_dict=wc, max_batch=72)
+    refiner = create_model_pose(rcfg, world["renderer"], state_dict=wr, max_batch=8)
+    obs = ObservationTensor(torch.as_tensor(sc["images"][:, :3].copy(), device=dev), torch.as_tensor(sc["K"], device=dev))
+    pts = store.mesh_db.points[sc["det_obj_ids"]]
+    boxes = G.boxes_from_uv(G.project_points(pts, np.repeat(sc["K"], 3, 0), sc["TCO_det"]))
+    labels = _labels(world, sc["det_obj_ids"])
+    det = make_detections_from_object_data(labels, boxes)
+    est = PoseEstimator(refiner_model=refiner, coarse_model=coarse, bsz_objects=8, bsz_images=72, SO3_grid_size=72)
+    final, extra = est.run_inference_pipeline(obs, detections=det.to(dev), n_refiner_iterations=2, n_pose_hypotheses=2)
+
+    oc = OraclePredictor(wc, store.packed, store.mesh_db.points, arch="vanilla_resnet34", render_normals=True)
+    orf = OraclePredictor(wr, store.packed, store.mesh_db.points, arch="vanilla_resnet34", n_views=4,
+                          multiview_type="TCO+front_3views", render_normals=True)
+    ref = OracleEstimator(orf, oc, store.labels, SO3_grid_size=72, bsz_objects=8, bsz_images=72).run_inference_pipeline(
+        sc["images"][:, :3], sc["K"], labels, boxes, n_refiner_iterations=2, n_pose_hypotheses=2, instance_id=np.arange(3))
+    LOGIT_TOL = 5e-3
+    cl = extra["coarse"]["preds"].infos.coarse_logit.values
+    np.testing.assert_allclose(cl, ref["coarse_df"]["coarse_logit"].values, rtol=0, atol=LOGIT_TOL)
+    np.testing.assert_allclose(extra["coarse"]["preds"].poses.cpu().numpy(), ref["coarse_TCO"], rtol=1e-5, atol=1e-6)
+    # top-K: same ids in the same order unless the oracle's own margin at a rank boundary is inside the logit tolerance
+    rl = ref["coarse_df"]["coarse_logit"].values.reshape(3, 72)
+    srt = -np.sort(-rl, axis=1)
+    decisive = bool((srt[:, 0] - srt[:, 1] > 2 * LOGIT_TOL).all() and (srt[:, 1] - srt[:, 2] > 2 * LOGIT_TOL).all())
+    f = extra["coarse_filter"]["preds"]
+    if decisive:
+        assert f.infos.hypothesis_id.tolist() == ref["filtered_df"]["hypothesis_id"].tolist()
+        assert f.infos.label.tolist() == ref["filtered_df"]["label"].tolist()
+        for n in (1, 2):
+            dt, dr = _pose_err(extra["refiner_all_hypotheses"]["preds"][f"iteration={n}"].poses.cpu().numpy(),
+                               ref["refiner_iterations"][n - 1]["TCO_output"])
+            assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
+        pl = extra["scoring"]["preds"].infos.pose_logit.values
+        np.testing.assert_allclose(pl, ref["scored_df"]["pose_logit"].values, rtol=0, atol=LOGIT_TOL)
+        sd = ref["scored_df"]
+        gaps = sd.groupby(["batch_im_id", "label", "instance_id"])["pose_logit"].apply(lambda v: np.abs(np.diff(np.sort(v.values))).min())
+        if (gaps > 2 * LOGIT_TOL).all():
+            assert final.infos.hypothesis_id.tolist() == ref["final_df"]["hypothesis_id"].tolist()
+            assert final.infos.label.tolist() == ref["final_df"]["label"].tolist()
+            assert final.infos.instance_id.tolist() == ref["final_df"]["instance_id"].tolist()
+            dt, dr = _pose_err(final.poses.cpu().numpy(), ref["final_TCO"])
+            assert dt <= T_TOL and dr <= R_TOL, (dt, dr)
+    assert decisive, "choose weights whose coarse logits separate the top ranks (test world)"
+
+
+def test_run_inference_pipeline_vs_reference_golden_g10(dev, golden_dir):
+    """The product's run_inference_pipeline against outputs of the REFERENCE's own PoseEstimator.run_inference_pipeline
+    (golden G10, tools/gen_golden_loop.py: the reference's orchestrator, loop and backbones executing, with roi_align /
+    render / lookAt supplied by the oracle): coarse logits, top-K ids and order, refined poses, final ids and poses."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import gen_golden_loop as ggl
+
+    from happypose_amd.models import create_model_pose
+    from happypose_amd.pose_estimator import ObservationTensor, PoseEstimator
+    from happypose_amd.renderer import BatchRenderer
+    from happypose_amd.tensor_collection import PandasTensorCollection
+    import pandas as pd
+
+    g = np.load(golden_dir / "g10_loop.npz")
+    ds, packed, mesh_db, sc = ggl.world()
+    renderer = BatchRenderer(ds, device=dev)
+    labels_all = list(renderer.store.labels)
+    ccfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
+                predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
+    rcfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+                depth_augmentation=False)
+    coarse = create_model_pose(ccfg, renderer, state_dict=ggl.case_weights("coarse"), max_batch=64)
+    refiner = create_model_pose(rcfg, renderer, state_dict=ggl.case_weights("mp_rgb4"), max_batch=8)
+    det_ids = g["e2e/det_ids"]
+    infos = pd.DataFrame({"label": [labels_all[i] for i in sc["det_obj_ids"][det_ids]], "batch_im_id": 0, "instance_id": np.arange(2)})
+    det = PandasTensorCollection(infos=infos, bboxes=torch.as_tensor(g["e2e/boxes"]).float()).to(dev)
+    obs = ObservationTensor(torch.as_tensor(sc["images"][:, :3].copy(), device=dev), torch.as_tensor(sc["K"], device=dev))
+    est = PoseEstimator(refiner_model=refiner, coarse_model=coarse, bsz_objects=8, bsz_images=64, SO3_grid_size=72)
+    final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=2, n_pose_hypotheses=2)
+    assert sorted(extra.keys()) == [str(k) for k in g["e2e/extra_keys"]]
+    assert sorted(final.tensors.keys()) == [str(k) for k in g["e2e/final_tensors"]]
+    assert set(str(c) for c in g["e2e/final_columns"]) <= set(final.infos.columns)
+    np.testing.assert_allclose(extra["coarse"]["preds"].poses.cpu().numpy(), g["e2e/coarse_TCO"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(extra["coarse"]["data"]["logits"].cpu().numpy(), g["e2e/coarse_logits"], rtol=0, atol=5e-3)
+    f = extra["coarse_filter"]["preds"]
+    assert f.infos.hypothesis_id.tolist() == g["e2e/filtered_hyp"].tolist()
+    assert f.infos.label.tolist() == [str(l) for l in g["e2e/filtered_label"]]
+    for n in (1, 2):
+        dt, dr = _pose_err(extra["refiner_all_hypotheses"]["preds"][f"iteration={n}"].poses.cpu().numpy(), g[f"e2e/refined_it{n}"])
+        assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
+    np.testing.assert_allclose(extra["scoring"]["preds"].infos.pose_logit.values, g["e2e/pose_logit"], rtol=0, atol=5e-3)
+    assert final.infos.hypothesis_id.tolist() == g["e2e/final_hyp"].tolist()
+    assert final.infos.label.tolist() == [str(l) for l in g["e2e/final_label"]]
+    assert final.infos.instance_id.tolist() == g["e2e/final_instance"].tolist()
+    dt, dr = _pose_err(final.poses.cpu().numpy(), g["e2e/final_TCO"])
+    assert dt <= T_TOL and dr <= R_TOL, (dt, dr)
+
+
+def test_refiners_vs_reference_golden_g10(dev, golden_dir):
+    """The predictors against outputs of the REFERENCE's own PosePredictor.forward (MegaPose 1 view, MegaPose RGB-D
+    4 views, CosyPose; golden G10) at every recorded iteration."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import gen_golden_loop as ggl
+
+    from happypose_amd.models import create_model_pose, create_pose_model_cosypose
+    from happypose_amd.renderer import BatchRenderer
+
+    g = np.load(golden_dir / "g10_loop.npz")
+    ds, packed, mesh_db, sc = ggl.world()
+    renderer = BatchRenderer(ds, device=dev)
+    labels_all = list(renderer.store.labels)
+    images, K = torch.as_tensor(sc["images"], device=dev), torch.as_tensor(sc["K"], device=dev)
+
+    def check(tag, out, n_it):
+        for n in range(1, n_it + 1):
+            o = out[f"iteration={n}"]
+            dt, dr = _pose_err(o.TCO_output.cpu().numpy(), g[f"{tag}/it{n}/TCO_output"])
+            assert dt <= T_TOL and dr <= R_TOL, (tag, n, dt, dr)
+            np.testing.assert_allclose(o.boxes_crop.cpu().numpy(), g[f"{tag}/it{n}/boxes_crop"], rtol=1e-4, atol=5e-2)
+            np.testing.assert_allclose(o.K_crop.cpu().numpy(), g[f"{tag}/it{n}/K_crop"], rtol=1e-4, atol=5e-2)
+            np.testing.assert_allclose(o.boxes_rend.cpu().numpy(), g[f"{tag}/it{n}/boxes_rend"], rtol=1e-4, atol=5e-2)
+
+    sel = g["cosy/sel"]
+    lab = [labels_all[i] for i in sc["hyp_obj_ids"][sel]]
+    ids = torch.zeros(len(sel), dtype=torch.int32)
+    cosy = create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=ggl.case_weights("cosy"), max_batch=8)
+    check("cosy", cosy.forward(images[:, :3].contiguous(), K, lab, torch.as_tensor(sc["TCO_hyp"][sel]), n_iterations=2, im_ids=ids), 2)
+    m1 = create_model_pose(dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
+                                depth_augmentation=False), renderer, state_dict=ggl.case_weights("mp_rgb1"), max_batch=8)
+    check("mp_rgb1", m1.forward(images, K, lab, torch.as_tensor(sc["TCO_hyp"][sel]), n_iterations=2, im_ids=ids), 2)
+    sel4 = g["mp_rgbd4/sel"]
+    lab4 = [labels_all[i] for i in sc["hyp_obj_ids"][sel4]]
+    m4 = create_model_pose(dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+                                render_depth=True, input_depth=True, depth_augmentation=False,
+                                depth_normalization_type="tCR_scale_clamp_center"), renderer, state_dict=ggl.case_weights("mp_rgbd4"),
+                           max_batch=4)
+    out4 = m4.forward(images, K, lab4, torch.as_tensor(sc["TCO_hyp"][sel4]), n_iterations=2, im_ids=torch.zeros(3, dtype=torch.int32))
+    check("mp_rgbd4", out4, 2)
+    np.testing.assert_allclose(out4["iteration=1"].KV_crop.cpu().numpy(), g["mp_rgbd4/it1/KV_crop"], rtol=1e-4, atol=5e-2)
+    np.testing.assert_allclose(out4["iteration=1"].TCV_O_input.cpu().numpy(), g["mp_rgbd4/it1/TCV_O_input"], rtol=0, atol=2e-5)
+
+
+def test_split_fp16_overflow_guard(dev):
+    """An activation beyond the fp16 range (7e4) turns into inf inside the default split-fp16 conv kernels.  The guard
+    must (1) flag it (HP_STATUS_NONFINITE), (2) switch the network to the exact-fp32 kernels, so that (3) the SAME
+    call repeated gives the finite fp32 result of the reference's arithmetic."""
+    from happypose_amd import ops
+    from oracle import backbones as ob
+
+    w = _weights("resnet18", 6, seed=3, scale=0.05)
+    net = ops.Net("resnet18", 6, w, max_batch=2, device=dev)
+    x = np.random.RandomState(1).uniform(0, 1, size=(2, 6, 240, 320)).astype(np.float32)
+    xin = net.new_input(2)
+    xin[..., :6] = torch.as_tensor(x, device=dev).permute(0, 2, 3, 1)
+    pose0, _, _ = net.forward(xin)
+    assert net.status() == 0 and torch.isfinite(pose0).all()
+    x[1, 2, 100:140, 100:160] = 7.0e4  # raw depth in a wrong unit, a saturated sensor ...
+    xin[..., :6] = torch.as_tensor(x, device=dev).permute(0, 2, 3, 1)
+    net.forward(xin)
+    flags = net.status()
+    assert flags & ops.STATUS_NONFINITE and flags & ops.STATUS_EXACT_ONLY, flags
+    pose, _, _ = net.forward(xin)  # repeated: exact-fp32 kernels now
+    assert net.status() == ops.STATUS_EXACT_ONLY  # nothing flagged any more, the switch is sticky
+    with torch.no_grad():
+        ref = ob.net_forward(torch.as_tensor(x), w, "resnet18", heads=("pose",))["pose"].numpy()
+    assert np.isfinite(ref).all()
+    np.testing.assert_allclose(pose.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    # the un-poisoned sample is the same as before the switch, to the kernels' tolerance
+    np.testing.assert_allclose(pose[0].cpu().numpy(), pose0[0].cpu().numpy(), rtol=1e-3, atol=1e-3)
+    # a per-network choice of kernels does not leak into other networks
+    net2 = ops.Net("resnet18", 6, w, max_batch=2, device=dev)
+    net2.set_conv_algo("winograd")
+    net3 = ops.Net("resnet18", 6, w, max_batch=2, device=dev)
+    xin[..., :6] = torch.as_tensor(np.random.RandomState(1).uniform(0, 1, size=(2, 6, 240, 320)).astype(np.float32), device=dev).permute(0, 2, 3, 1)
+    p2, p3 = net2.forward(xin)[0], net3.forward(xin)[0]
+    assert net2.status() == 0 and net3.status() == 0
+    np.testing.assert_allclose(p2.cpu().numpy(), p3.cpu().numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_index_guards(dev, world):
+    """Ids that index frames / intrinsics / objects: host-resident ids raise like the reference's indexing, device-resident
+    ids are guarded by the kernels (NaN poses, zero crops) -- never an out-of-bounds read."""
+    from happypose_amd import ops
+
+    sc, store = world["scene"], world["store"]
+    K = torch.as_tensor(sc["K"], device=dev)
+    T = torch.as_tensor(sc["TCO_hyp"][:4], device=dev)
+    obj = torch.as_tensor(sc["hyp_obj_ids"][:4])
+    with pytest.raises(IndexError):
+        ops.pose_prep(store, T, K, torch.tensor([0, 0, 1, 0], dtype=torch.int32), obj, (480, 640))
+    with pytest.raises(IndexError):
+        ops.pose_prep(store, T, K, torch.zeros(4, dtype=torch.int32), torch.tensor([0, 1, 99, 0]), (480, 640))
+    out = ops.pose_prep(store, T, K, torch.tensor([0, 0, 5, 0], dtype=torch.int32, device=dev), obj.to(dev), (480, 640))
+    bc = out["boxes_crop"].cpu().numpy()
+    assert np.isfinite(bc[[0, 1, 3]]).all() and np.isnan(bc[2]).all() and np.isnan(out["TCO"][2].cpu().numpy()).all()
+    images = torch.as_tensor(sc["images"][:, :3].copy(), device=dev)
+    boxes = torch.tensor([[100.0, 100, 300, 250]] * 2, device=dev)
+    with pytest.raises(IndexError):
+        ops.crop_roi_align(images, boxes, torch.tensor([0, 3], dtype=torch.int32))
+    crops = ops.crop_roi_align(images, boxes, torch.tensor([0, 3], dtype=torch.int32, device=dev)).cpu().numpy()
+    assert np.abs(crops[0]).sum() > 0 and np.abs(crops[1]).sum() == 0
+    bx = torch.as_tensor(np.array([[100.0, 100, 300, 250]], np.float32), device=dev)
+    init = ops.tco_init_autodepth(store, bx, K, torch.zeros(2, dtype=torch.int32, device=dev), obj[:2].to(dev),
+                                  box_ids=torch.tensor([0, 4], dtype=torch.int32, device=dev)).cpu().numpy()
+    assert np.isfinite(init[0]).all() and np.isnan(init[1]).all()

@@ -235,3 +235,27 @@ def test_load_cfg_restricted_yaml_and_named_models(tmp_path):
     assert m["megapose-1.0-RGB-multi-hypothesis-icp"]["inference_parameters"] == {
         "n_refiner_iterations": 5, "n_pose_hypotheses": 5, "run_depth_refiner": True}
     assert m["megapose-1.0-RGB"]["inference_parameters"] == {"n_refiner_iterations": 5, "n_pose_hypotheses": 1}
+
+
+def test_legacy_keys_and_config_defaults_golden(golden_dir):
+    """``change_keys_of_older_models`` (TB/utils/models_compat.py:17-27) and ``check_update_config``
+    (MP/training/pose_models_cfg.py:36-86) against what the reference's own functions returned
+    (tools/gen_golden_loop.py, G10): SURVEY.md 8f-2."""
+    import json
+
+    from happypose_amd.models import change_keys_of_older_models, check_update_config
+
+    g = np.load(golden_dir / "g10_loop.npz")
+    keys = [str(k) for k in g["compat/keys_in"]]
+    new = change_keys_of_older_models({k: i for i, k in enumerate(keys)})
+    assert list(new.keys()) == [str(k) for k in g["compat/keys_out"]]
+    assert list(new.values()) == g["compat/vals_out"].tolist()
+    cfgs, outs = json.loads(str(g["cfg/in"])), json.loads(str(g["cfg/out"]))
+    assert len(cfgs) == len(outs) == 5
+    for c, want in zip(cfgs, outs):
+        got = vars(check_update_config(dict(c)))
+        for k, v in want.items():  # every field the reference sets / keeps has the reference's value
+            assert k in got and got[k] == v, (c, k, got.get(k), v)
+        # fields only this implementation adds are defaults the reference reads from TrainingConfig
+        assert set(got) - set(want) <= {"views_inplane_rotations", "depth_normalization_type", "backbone_str", "renderer",
+                                        "render_normals", "render_depth", "input_depth"}

@@ -99,8 +99,11 @@ def test_g6_backbones(golden_dir):
 
     g = load(golden_dir, "g6_backbones.npz")
     torch.set_num_threads(8)
-    for arch, cin, tag in [("vanilla_resnet34", 27, "vanilla_resnet34_27"),
-                           ("resnet34", 6, "resnet34_6"), ("resnet18", 6, "resnet18_6")]:
+    # every case tools/gen_golden.py records: the three MegaPose stems (9 coarse / 27 RGB refiner / 32 RGB-D refiner),
+    # the WideResNets of MP/models/wide_resnet.py and CosyPose's own copy of WideResNet-34 (CP/models/wide_resnet.py)
+    for arch, cin, tag in [("vanilla_resnet34", 27, "vanilla_resnet34_27"), ("vanilla_resnet34", 9, "vanilla_resnet34_9"),
+                           ("vanilla_resnet34", 32, "vanilla_resnet34_32"), ("resnet34", 6, "resnet34_6"),
+                           ("resnet18", 6, "resnet18_6"), ("resnet34", 6, "resnet34cp_6")]:
         shapes = ob.param_shapes(arch, cin)
         assert list(shapes.keys()) == list(g[tag + "/keys"])
         assert [str(s) for s in shapes.values()] == list(g[tag + "/shapes"])
@@ -167,3 +170,140 @@ def test_g9_efficientnet_b3_restatement(golden_dir):
     assert tuple(y.shape) == tuple(g["out_shape"]) == (2, 1536, 7, 10)
     np.testing.assert_allclose(y.mean(dim=(2, 3)).numpy(), g["out_mean"], atol=1e-6)
     np.testing.assert_allclose(y.flatten()[::211].numpy(), g["out_sample"], atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G10: the LOOP and the ORCHESTRATOR.  tools/gen_golden_loop.py ran the reference's own PosePredictor.forward /
+# forward_coarse (MegaPose and CosyPose) and PoseEstimator.run_inference_pipeline in the build container, with only
+# torchvision's roi_align, Panda3D's render and Panda3D's lookAt supplied by the oracle's restatement.  The oracle's
+# loop (oracle/pipeline.py) and orchestrator (oracle/estimator.py) must reproduce what the reference's code produced.
+# ---------------------------------------------------------------------------------------------------------------
+LOOP_T_ATOL = 2e-5  # metres / matrix entries: identical formulas; oneDNN picks other conv kernels per thread count and CPU (the golden ran on 1 thread)
+
+
+@pytest.fixture(scope="module")
+def loop_world():
+    import sys
+
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tools"))
+    import gen_golden_loop as ggl
+    import torch
+
+    torch.set_num_threads(8)
+    ds, packed, mesh_db, scene = ggl.world()
+    return dict(packed=packed, points=np.asarray(mesh_db.points, np.float32), scene=scene, labels=list(packed.labels),
+                weights=ggl.case_weights)
+
+
+def _check_iters(g, tag, ref, n_it, extra=()):
+    for n in range(1, n_it + 1):
+        for f in ("TCO_output", "TCO_input", "K_crop", "boxes_rend", "boxes_crop") + tuple(extra):
+            want = g[f"{tag}/it{n}/{f}"]
+            atol = LOOP_T_ATOL if f.startswith("TCO") else 2e-3  # boxes / intrinsics are in pixels (values ~1e2..1e3)
+            np.testing.assert_allclose(ref[n - 1][f], want, rtol=2e-6, atol=atol, err_msg=f"{tag} it{n} {f}")
+
+
+def test_g10_cosypose_loop(golden_dir, loop_world):
+    """CP/models/pose.py:116-199 run by the reference vs OraclePredictor(cosypose=True)."""
+    from oracle.pipeline import OraclePredictor
+
+    g, w = load(golden_dir, "g10_loop.npz"), loop_world
+    sc, sel = w["scene"], load(golden_dir, "g10_loop.npz")["cosy/sel"]
+    ora = OraclePredictor(w["weights"]("cosy"), w["packed"], w["points"], arch="resnet18", cosypose=True)
+    ref = ora.forward(sc["images"][:, :3], sc["K"], np.zeros(len(sel), np.int32), sc["hyp_obj_ids"][sel], sc["TCO_hyp"][sel], 2)
+    _check_iters(g, "cosy", ref, 2)
+    np.testing.assert_allclose(ref[1]["pose"], g["cosy/it2/pose"], rtol=0, atol=2e-5)
+
+
+def test_g10_megapose_loops(golden_dir, loop_world):
+    """MP/models/pose_rigid.py:546-674 run by the reference (1 view RGB; 4 views RGB-D with depth normalisation) vs
+    OraclePredictor, including the assembled 32-channel network input (normalize_images + cat, :455-544,629)."""
+    from oracle.pipeline import OraclePredictor
+
+    g, w = load(golden_dir, "g10_loop.npz"), loop_world
+    sc = w["scene"]
+    sel = g["cosy/sel"]
+    ora = OraclePredictor(w["weights"]("mp_rgb1"), w["packed"], w["points"], arch="vanilla_resnet34", n_views=1,
+                          multiview_type="TCO", render_normals=True)
+    ref = ora.forward(sc["images"], sc["K"], np.zeros(len(sel), np.int32), sc["hyp_obj_ids"][sel], sc["TCO_hyp"][sel], 2)
+    _check_iters(g, "mp_rgb1", ref, 2)
+    sel4 = g["mp_rgbd4/sel"]
+    ora4 = OraclePredictor(w["weights"]("mp_rgbd4"), w["packed"], w["points"], arch="vanilla_resnet34", n_views=4,
+                           multiview_type="TCO+front_3views", render_normals=True, render_depth=True, input_depth=True,
+                           depth_normalization_type="tCR_scale_clamp_center")
+    ref4 = ora4.forward(sc["images"], sc["K"], np.zeros(3, np.int32), sc["hyp_obj_ids"][sel4], sc["TCO_hyp"][sel4], 2)
+    _check_iters(g, "mp_rgbd4", ref4, 2)
+    it = ora4._iteration(sc["images"], np.repeat(sc["K"], 3, 0), np.zeros(3, np.int32), sc["hyp_obj_ids"][sel4],
+                         sc["TCO_hyp"][sel4], heads=("pose",))
+    np.testing.assert_allclose(it["KV_crop"], g["mp_rgbd4/it1/KV_crop"], rtol=2e-6, atol=2e-3)
+    np.testing.assert_allclose(it["TCV_O"], g["mp_rgbd4/it1/TCV_O_input"], rtol=0, atol=LOOP_T_ATOL)
+    x = it["x"]
+    assert tuple(x.shape) == tuple(g["mp_rgbd4/it1/x_shape"]) == (3, 32, 240, 320)
+    # camera matrices agree to fp32 rounding, so a handful of silhouette pixels of the renders may flip coverage:
+    # channel statistics to 5e-5, the sampled pixels identical except <= 0.1 % of them
+    np.testing.assert_allclose(x.astype(np.float64).mean(axis=(0, 2, 3)), g["mp_rgbd4/it1/x_chan_mean"], atol=5e-5)
+    np.testing.assert_allclose(np.abs(x.astype(np.float64)).mean(axis=(0, 2, 3)), g["mp_rgbd4/it1/x_chan_absmean"], atol=5e-5)
+    dx = np.abs(x[:, :, ::7, ::11] - g["mp_rgbd4/it1/x_sample"])
+    depth_ch = [10, 17, 24, 31]
+    color_ch = [c for c in range(4, 32) if c not in depth_ch]
+    assert dx[:, :4].max() < 3e-4  # crop of a white-noise frame: boxes agree to ~1e-4 px
+    assert (dx[:, color_ch] > 1e-5).mean() < 1e-2 and np.median(dx[:, color_ch]) == 0  # silhouette / 8-bit step flips only
+    # rendered depth: Z = det / s of the homogeneous rasteriser cancels to ~5e-4 relative in fp32 on pixel-sized
+    # triangles, so a 1e-3 px change of the camera moves it by ~1e-4 (DESIGN.md, rasteriser)
+    assert (dx[:, depth_ch] > 2e-3).mean() < 1e-2
+
+
+def test_g10_coarse_logits(golden_dir, loop_world):
+    """forward_coarse (MP/models/pose_rigid.py:708-788) run by the reference vs OraclePredictor.forward_coarse."""
+    from oracle.pipeline import OraclePredictor
+
+    g, w = load(golden_dir, "g10_loop.npz"), loop_world
+    sc, sel = w["scene"], g["coarse/sel"]
+    ora = OraclePredictor(w["weights"]("coarse"), w["packed"], w["points"], arch="vanilla_resnet34", render_normals=True)
+    rc = ora.forward_coarse(sc["images"][:, :3], sc["K"], np.zeros(len(sel), np.int32), sc["hyp_obj_ids"][sel], sc["TCO_hyp"][sel])
+    # crop boxes agree to ~1e-3 px (fp32 association in numpy vs torch), which flips a few 8-bit steps / silhouette
+    # pixels of the render: 5e-4 relative on logits whose head has He-scaled weights
+    np.testing.assert_allclose(rc["logits"], g["coarse/logits"], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(rc["scores"], g["coarse/scores"], rtol=0, atol=1e-4)
+
+
+def test_g10_run_inference_pipeline(golden_dir, loop_world):
+    """PoseEstimator.run_inference_pipeline (MP/inference/pose_estimator.py:515-668) run by the reference vs
+    oracle/estimator.py: coarse logits of every (detection, grid pose), the top-K set and ORDER, refined poses per
+    iteration, re-scoring logits, final ids / labels / poses."""
+    from oracle.estimator import OracleEstimator
+    from oracle.pipeline import OraclePredictor
+
+    g, w = load(golden_dir, "g10_loop.npz"), loop_world
+    sc = w["scene"]
+    coarse = OraclePredictor(w["weights"]("coarse"), w["packed"], w["points"], arch="vanilla_resnet34", render_normals=True)
+    refiner = OraclePredictor(w["weights"]("mp_rgb4"), w["packed"], w["points"], arch="vanilla_resnet34", n_views=4,
+                              multiview_type="TCO+front_3views", render_normals=True)
+    est = OracleEstimator(refiner, coarse, w["labels"], SO3_grid_size=72, bsz_objects=8, bsz_images=64)
+    det = g["e2e/det_ids"]
+    out = est.run_inference_pipeline(sc["images"][:, :3], sc["K"], [w["labels"][i] for i in sc["det_obj_ids"][det]],
+                                     g["e2e/boxes"], n_refiner_iterations=2, n_pose_hypotheses=2, instance_id=np.arange(2))
+    np.testing.assert_allclose(out["coarse_TCO"], g["e2e/coarse_TCO"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["coarse_df"]["coarse_logit"].values.reshape(2, 72), g["e2e/coarse_logits"], rtol=0, atol=5e-3)
+    np.testing.assert_array_equal(out["filtered_df"]["hypothesis_id"].values, g["e2e/filtered_hyp"])
+    assert list(out["filtered_df"]["label"].values) == list(g["e2e/filtered_label"])
+    np.testing.assert_allclose(out["filtered_TCO"], g["e2e/filtered_TCO"], rtol=1e-5, atol=1e-6)
+    for n in (1, 2):
+        np.testing.assert_allclose(out["refiner_iterations"][n - 1]["TCO_output"], g[f"e2e/refined_it{n}"], rtol=0, atol=LOOP_T_ATOL)
+    np.testing.assert_allclose(out["scored_df"]["pose_logit"].values, g["e2e/pose_logit"], rtol=0, atol=5e-3)
+    np.testing.assert_array_equal(out["final_df"]["hypothesis_id"].values, g["e2e/final_hyp"])
+    assert list(out["final_df"]["label"].values) == list(g["e2e/final_label"])
+    np.testing.assert_array_equal(out["final_df"]["instance_id"].values, g["e2e/final_instance"])
+    np.testing.assert_allclose(out["final_TCO"], g["e2e/final_TCO"], rtol=0, atol=LOOP_T_ATOL)
+
+
+def test_g10_normalize_depth(golden_dir):
+    """normalize_depth (MP/models/pose_rigid.py:512-544), every mode, vs the oracle's restatement."""
+    from oracle.pipeline import _depth_norm
+
+    g = load(golden_dir, "g10_loop.npz")
+    d, z = g["depthnorm/d"], g["depthnorm/tCR"]
+    for mode in ("tCR_scale", "tCR_scale_clamp_center", "tCR_center_clamp", "none"):
+        np.testing.assert_allclose(_depth_norm(d.copy(), z[:, 2], mode), g[f"depthnorm/{mode}"], rtol=1e-6, atol=1e-7, err_msg=mode)
+    with pytest.raises(ValueError):
+        _depth_norm(d, z[:, 2], "bogus")

@@ -47,22 +47,84 @@ def _shim():
     os.environ.setdefault("HAPPYPOSE_DATA_DIR", tempfile.mkdtemp(prefix="hp_data_"))
     m = types.ModuleType("happypose")
     m.__path__ = [str(REF / "happypose")]
+    m.__file__ = str(REF / "happypose" / "__init__.py")  # MP/config.py:28 derives PROJECT_ROOT from it
     sys.modules["happypose"] = m
 
-    class _Any:
+    class _AnyMeta(type):
+        """Attributes of a stub CLASS are stub classes again (``p3d.core.NodePath``, ``pin.SE3`` ...): usable in
+        ``isinstance`` (never true for real data), annotations and as constructors of inert objects."""
+
+        def __getattr__(cls, k):
+            if k.startswith("__") and k.endswith("__"):
+                raise AttributeError(k)
+            return _AnyMeta(k, (_Any,), {})
+
+        def __getitem__(cls, k):
+            return cls
+
+        def __iter__(cls):
+            return iter(())
+
+        def __or__(cls, other):
+            return cls
+
+        def __ror__(cls, other):
+            return cls
+
+    class _Any(metaclass=_AnyMeta):
+        """An inert object (callable, subscriptable, usable as a decorator).  No arithmetic lives here: everything
+        recorded in the golden files is computed by the reference's own source."""
+
+        def __init__(self, *a, **k):
+            pass
+
         def __getattr__(self, k):
+            if k.startswith("__") and k.endswith("__"):
+                raise AttributeError(k)
             return _Any()
 
         def __call__(self, *a, **k):
+            if len(a) == 1 and callable(a[0]) and not k:  # used as a decorator
+                return a[0]
             return _Any()
 
-    for name in ["transforms3d", "transforms3d.euler", "torchvision", "trimesh", "pinocchio",
-                 "panda3d", "panda3d.core", "roma", "pybullet", "direct", "direct.showbase",
-                 "direct.showbase.ShowBase", "simplejson", "omegaconf", "bokeh"]:
-        mod = types.ModuleType(name)
-        mod.__getattr__ = lambda k, _n=name: _Any()  # type: ignore[attr-defined]
-        sys.modules[name] = mod
-    sys.modules["transforms3d"].euler = sys.modules["transforms3d.euler"]
+        def __getitem__(self, k):
+            return _Any()
+
+        def __iter__(self):
+            return iter(())
+
+    # third-party packages of the reference that are not installed here: every (sub)module of them resolves to an
+    # EMPTY stub module through a meta-path finder
+    STUB_TOPS = {"transforms3d", "torchvision", "trimesh", "pinocchio", "panda3d", "roma", "pybullet", "direct",
+                 "simplejson", "omegaconf", "bokeh", "cv2", "open3d", "joblib_missing", "seaborn", "imageio", "pypng", "png",
+                 "webdataset", "bop_toolkit_lib", "colorama", "ipdb", "meshcat", "plyfile", "pyarrow_missing", "xarray"}
+
+    import importlib.abc
+    import importlib.machinery
+
+    class _StubLoader(importlib.abc.Loader):
+        def create_module(self, spec):
+            mod = types.ModuleType(spec.name)
+            mod.__path__ = []  # a package: submodules resolve through the finder as well
+            def _attr(k, _n=spec.name):
+                if k.startswith("__") and k.endswith("__"):
+                    raise AttributeError(k)
+                return _AnyMeta(k, (_Any,), {})
+
+            mod.__getattr__ = _attr
+            return mod
+
+        def exec_module(self, module):
+            pass
+
+    class _StubFinder(importlib.abc.MetaPathFinder):
+        def find_spec(self, fullname, path, target=None):
+            if fullname.split(".")[0] in STUB_TOPS:
+                return importlib.machinery.ModuleSpec(fullname, _StubLoader(), is_package=True)
+            return None
+
+    sys.meta_path.insert(0, _StubFinder())
     if not hasattr(np, "float_"):  # alias removed in NumPy 2 (reference pins numpy 1.x)
         np.float_ = np.float64
 
