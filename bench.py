@@ -144,15 +144,16 @@ def bench_e2e(args, device, rank, world):
         elapsed = float(t.item())
     if rank != 0:
         return
-    # dominant backbone = the one with more conv time (the coarse net unless it runs in fp16)
+    # dominant backbone = the one with more conv time (the coarse net unless it runs in fp16); roofline of the issued
+    # instruction, v_mfma_f32_32x32x16_f16: executed fp16-MFMA FLOPs (fp32-MFMA-time equivalents x 16) / conv time
     names = ("coarse", "refiner")
-    peaks = (PEAK_F16_MFMA_TFLOPS if coarse_precision == "f16" else PEAK_F32_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS)
     dom = 0 if prof[0][0] >= prof[1][0] else 1
     conv_ms = sum(p[0] for p in prof)
-    per_net = {names[i]: {"achieved": prof[i][2] / (prof[i][0] * 1e-3) / 1e12, "peak": peaks[i],
-                          "frac": prof[i][2] / (prof[i][0] * 1e-3) / 1e12 / peaks[i], "conv_ms_per_frame": prof[i][0] / args.steps}
+    per_net = {names[i]: {"achieved": 16.0 * prof[i][3] / (prof[i][0] * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
+                          "frac": 16.0 * prof[i][3] / (prof[i][0] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                          "algorithmic_tflops": prof[i][2] / (prof[i][0] * 1e-3) / 1e12, "conv_ms_per_frame": prof[i][0] / args.steps}
                for i in range(2)}
-    achieved, peak = per_net[names[dom]]["achieved"], peaks[dom]
+    achieved, peak = per_net[names[dom]]["achieved"], PEAK_F16_MFMA_TFLOPS
     line = {
         "metric": "end-to-end frames/sec (640x480, 8 detections, 576-pose coarse grid, 5 hyp/det, 5 refiner iters)",
         "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -198,10 +199,13 @@ def cpu_baseline(ds_store, scene, weights, arch, budget_s=15.0, cores=None):
     torch.set_num_threads(cores)
     ora = OraclePredictor(weights, ds_store.packed, ds_store.mesh_db.points, arch=arch, cosypose=True)
 
+    last = {}
+
     def run(n):
         t0 = time.time()
-        ora.forward(scene["images"][:, :3], scene["K"], np.zeros(n, np.int32), scene["hyp_obj_ids"][:n],
-                    scene["TCO_hyp"][:n], N_ITERS, bsz_objects=8)
+        its = ora.forward(scene["images"][:, :3], scene["K"], np.zeros(n, np.int32), scene["hyp_obj_ids"][:n],
+                          scene["TCO_hyp"][:n], N_ITERS, bsz_objects=8)
+        last["poses"] = its[-1]["TCO_output"]
         return time.time() - t0
 
     run(8)  # warm-up (thread pools, oneDNN primitive cache)
@@ -210,7 +214,23 @@ def cpu_baseline(ds_store, scene, weights, arch, budget_s=15.0, cores=None):
     t = run(n) if n != 8 else t8
     return {"value": n / t, "unit": "refined poses/s", "cores": cores, "kind": "port",
             "sample": f"{n} of {N_DET * N_HYP} hypotheses x {N_ITERS} iterations in chunks of 8 "
-                      f"(oracle/pipeline.py: torch-CPU unfused conv stack + C rasteriser/roi_align), {t:.1f} s"}
+                      f"(oracle/pipeline.py: torch-CPU unfused conv stack + C rasteriser/roi_align), {t:.1f} s"}, last["poses"]
+
+
+T_TOL, R_TOL = 1e-4, 1e-3  # the stated tolerance of the fp32 path (tests/test_gpu_pipeline.py)
+
+
+def pose_parity(gpu_poses: np.ndarray, cpu_poses: np.ndarray) -> dict:
+    """Same-run CPU <-> GPU check (last row): the CPU baseline's final poses of its sample against the
+    poses the timed HIP path produced for the same hypotheses."""
+    n = len(cpu_poses)
+    A, B = np.asarray(gpu_poses[:n], np.float64), np.asarray(cpu_poses, np.float64)
+    dt = np.linalg.norm(A[:, :3, 3] - B[:, :3, 3], axis=1)
+    R = A[:, :3, :3] @ np.swapaxes(B[:, :3, :3], 1, 2)
+    ang = np.arccos(np.clip((np.trace(R, axis1=1, axis2=2) - 1) / 2, -1, 1))
+    ok = bool(np.isfinite(A).all() and dt.max() <= T_TOL and ang.max() <= R_TOL)
+    return {"hypotheses_compared": n, "iterations": N_ITERS, "max_dt_m": float(dt.max()), "max_dR_rad": float(ang.max()),
+            "tol": {"dt_m": T_TOL, "dR_rad": R_TOL}, "ok": ok}
 
 
 def stage_rates(store, scene, images, K, TCO0, im_ids, device, reps=20):
@@ -254,14 +274,25 @@ def stage_rates(store, scene, images, K, TCO0, im_ids, device, reps=20):
     }
 
 
-def measured_traffic(workload, precision):
-    """HBM bytes per conv launch from the committed PMC summary (rocprofv3 FETCH_SIZE / WRITE_SIZE
-    passes of this bench command, tools/pmc_traffic.py); None when no summary matches the run."""
-    path = os.path.join(ROOT, "profiles", "r01h_conv_hbm_traffic.json")
-    if workload != "C2" or precision != "f32" or not os.path.exists(path):
-        return None
-    with open(path) as fh:
-        return float(json.load(fh)["hbm_bytes_per_launch"])
+def spawn_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N ranks (one per GPU) as child processes BEFORE this
+    process touches the GPU, wire them up like ``torch.distributed.run`` does (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*), pass their output through (rank 0 prints the JSON line) and return the worst exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
@@ -283,10 +314,14 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: this process only spawns the ranks
+        assert torch.cuda.device_count() >= args.gpus, f"--gpus {args.gpus} but {torch.cuda.device_count()} visible"
+        sys.exit(spawn_ranks(args.gpus))
+
     from happypose_amd import distributed as D
 
     rank, local_rank, world = D.init_distributed("nccl" if args.gpus > 1 else None)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required (no CPU fallback)"
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
@@ -339,34 +374,54 @@ def main():
         poses = step()
     fence()
     elapsed = time.perf_counter() - t0
-    # time during which ANY conv kernel was running: the union of the timed stretches of all lanes (with two lanes
-    # the summed kernel time exceeds the wall time; with one lane the union is the sum)
-    ivs = sorted(model.backbone.profile_intervals())
-    conv_union_ms, end = 0.0, -1.0
-    for a0, a1 in ivs:
-        if a1 > end:
-            conv_union_ms += a1 - max(a0, end)
-            end = a1
-    conv_sum_ms, n_launch, conv_flops, mfma_flops = model.backbone.profile_collect()
-    conv_ms = conv_union_ms
+    def conv_profile():
+        """(union ms, sum ms, launches, algorithmic FLOPs, matrix-pipe FLOPs in fp32-MFMA-time equivalents) of the conv
+        launches timed since profiling was switched on.  Union = the time during which ANY conv kernel was running: with
+        two lanes the timed stretches of the two networks overlap (the summed kernel time exceeds the wall time)."""
+        ivs = sorted(model.backbone.profile_intervals())
+        union, end = 0.0, -1.0
+        for a0, a1 in ivs:
+            if a1 > end:
+                union += a1 - max(a0, end)
+                end = a1
+        return (union,) + tuple(model.backbone.profile_collect())
+
+    conv_ms, conv_sum_ms, n_launch, conv_flops, mfma_flops = conv_profile()
     model.backbone.set_profiling(False)
     assert torch.isfinite(poses).all()
+    if hasattr(model, "numerics_status"):
+        assert model.numerics_status() == 0, "the split-fp16 guard fired inside the timed region"
+
+    # all-gather of the refined poses alone (N > 1): [N_local, 18] fp32 rows over RCCL
+    all_gather_us = None
+    if world > 1:
+        g_poses = poses[rank * B:(rank + 1) * B].contiguous() if poses.shape[0] == world * B else poses
+        for _ in range(3):
+            D.gather_poses(g_poses, None, rank * B, world * B)
+        fence()
+        t_ag = time.perf_counter()
+        for _ in range(20):
+            D.gather_poses(g_poses, None, rank * B, world * B)
+        fence()
+        all_gather_us = (time.perf_counter() - t_ag) / 20 * 1e6
 
     # the same job restricted to the exact-fp32 kernels (fp32 MFMA: Winograd / direct), a quarter of the steps, so the
     # line also carries the number of the build whose every multiply is an fp32 FMA (reported beside `value`)
     exact = None
     if precision == "f32" and not args.no_exact_fp32:
-        from happypose_amd import ops
-        ops.select_conv_algo("winograd")
+        model.backbone.set_conv_algo("winograd")  # this network only
         k_exact = max(2, args.steps // 4)
         step()
+        model.backbone.set_profiling(True)
         fence()
+        _ops.profile_mark_reference(device)
         t1 = time.perf_counter()
         for _ in range(k_exact):
             poses_exact = step()
         fence()
-        exact = (time.perf_counter() - t1, k_exact, float((poses_exact - poses).abs().max()))
-        ops.select_conv_algo("auto")
+        exact = (time.perf_counter() - t1, k_exact, float((poses_exact - poses).abs().max())) + conv_profile()
+        model.backbone.set_profiling(False)
+        model.backbone.set_conv_algo(None)
 
     if world > 1:
         t = torch.tensor([elapsed, exact[0] if exact else 0.0], device=device, dtype=torch.float64)
@@ -375,9 +430,15 @@ def main():
         if exact:
             exact = (float(t[1].item()),) + exact[1:]
 
+    parity_failed = False
     if rank == 0:
         total = world * B * args.steps
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        sec = conv_ms * 1e-3
+        algorithmic = conv_flops / sec / 1e12 if sec > 0 else 0.0
+        # matrix-pipe work in units of the instruction that dominates it.  net.cpp counts executed MFMA FLOPs (padded
+        # tiles and the 3 MFMAs per product of the split scheme included) in fp32-MFMA-time equivalents: an fp16 MFMA
+        # FLOP occupies the pipe 1/16 as long as an fp32 one.  fp16-rate units = x16.
+        executed_f16 = 16.0 * mfma_flops / sec / 1e12 if sec > 0 else 0.0
         desc = {
             "C2": f"C2: CosyPose refiner, one 640x480 frame per GPU, {N_DET} detections x {N_HYP} hypotheses = {B} "
                   f"hypotheses/GPU, {N_ITERS} iterations, {args.arch}{' (WideResNet)' if 'resnet' in args.arch else ''} on 6x240x320",
@@ -396,56 +457,64 @@ def main():
             "config": {"workload": desc + (", two half-batch lanes on two streams" if n_lanes == 2 else ""),
                        "hypotheses_per_gpu": B, "iterations": N_ITERS if args.workload != "C5" else 1,
                        "parallelism": f"hypothesis-shard x{world}"},
-            # achieved = ALGORITHMIC FLOPs (direct-convolution 2*MAC) / kernel time.  30 of
-            # the 36 convs run as Winograd F(2x2,3x3) and execute 2.25x fewer MFMA FLOPs than that, so
-            # the fraction of the pipe actually busy is reported separately (mfma_executed_*).
+            # The roofline of the instruction that is issued: v_mfma_f32_32x32x16_f16 (dense fp16 MFMA peak 2516.6 TFLOP/s).
+            # achieved = fp16 MFMA FLOPs the matrix cores EXECUTE per second of conv time (for the fp32 path: three fp16
+            # MFMAs per fp32 product, padded tiles included) -> frac = busy fraction of the matrix pipe, always <= 1.
+            # algorithmic_tflops = direct-convolution 2*MAC FLOPs of SURVEY.md 8(d) per second, reported beside it.
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv3x3_split_f32 (3x3 stride-1 layers: fp32 operands as fp16 hi/lo halves, three fp16 MFMAs per "
-                                    "product, fp32 accumulate) + conv_igemm_f32 (stem, stride-2, 1x1: fp32 MFMA)" if precision == "f32" else
-                                    "conv_igemm_f16: fp16 MFMA implicit-GEMM conv (fp32 accumulate)") + ", all conv launches of a forward",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": measured_traffic(args.workload, precision),
-                         "mfma_executed_tflops": mfma_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
-                         "mfma_executed_frac": mfma_flops / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else 0.0,
+                         "kernel": ("conv3x3_split_f32 / conv3x3s2_split_f32 / conv_igemm_split_f32 / conv_stem5x5s2_pool_split: fp32 "
+                                    "operands as fp16 hi/lo halves, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate"
+                                    if precision == "f32" else
+                                    "conv_igemm_f16 / conv3x3_patch_f16: v_mfma_f32_32x32x16_f16 on fp16 operands, fp32 accumulate")
+                                   + "; all conv launches of a forward",
+                         "achieved": executed_f16, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": executed_f16 / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                         "algorithmic_tflops": algorithmic,
+                         "algorithmic_ceiling_tflops": PEAK_F16_MFMA_TFLOPS / (3.0 if precision == "f32" else 1.0),
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_sum_ms / max(n_launch, 1),
                          "lanes": n_lanes, "conv_busy_ms_per_step": conv_ms / args.steps,
-                         "launch_note": ("a launch = one conv layer of a forward; achieved = FLOPs / conv_busy time = the union over "
-                                         "both lanes of the timed conv stretches (two lanes run concurrently: a kernel shares the "
-                                         "machine with the other lane's, so avg_launch_us is longer than its solo duration and the "
-                                         "summed kernel time exceeds the wall time)") if n_lanes == 2 else
-                                        "a launch = one conv layer of a forward",
+                         "note": ("achieved = executed fp16-MFMA FLOPs / conv-busy time; conv-busy = the union over both lanes of the "
+                                  "timed conv stretches (HIP events on the launch streams; the two lanes run concurrently, so a "
+                                  "launch shares the machine with the other lane's and avg_launch_us is its duration as it ran); "
+                                  "traffic: not measurable inside the run -- PMC passes of this command are under profiles/"),
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }
+        if all_gather_us is not None:
+            line["all_gather_us"] = all_gather_us
         if precision == "f32":
-            line["roofline"]["frac_note"] = ("achieved counts the ALGORITHMIC fp32 FLOPs of the direct convolution (SURVEY.md 8d) against the "
-                                             "fp32 MFMA peak; the 3x3 stride-1 layers form each fp32 product from three fp16 MFMAs (16x the fp32 "
-                                             "rate), so frac can exceed 1 -- mfma_executed_* count executed MFMA work in fp32-rate equivalents "
-                                             "(an fp16 MFMA FLOP = 1/16): mfma_executed_frac is the busy fraction of the matrix pipe")
-            if line["roofline"]["traffic"] is not None:
-                line["roofline"]["traffic_note"] = ("HBM bytes per conv launch (incl. Infinity-Cache hits), PMC passes of this command: "
-                                                    "profiles/r01h_conv_hbm_traffic.json; the kernels are MFMA-bound")
-        if precision == "f32":
-            line["dtype_note"] = ("fp32 tensors and fp32 accumulation everywhere; the 3x3 convolutions multiply fp16 hi/lo halves of the fp32 "
-                                  "operands (three fp16 MFMAs per product, 22 significant bits), all other kernels are plain fp32")
+            line["dtype_note"] = ("fp32 tensors and fp32 accumulation everywhere; the convolutions multiply fp16 hi/lo halves of the fp32 "
+                                  "operands (three fp16 MFMAs per product, 22 significant bits: per-layer error vs fp64 as the exact-fp32 "
+                                  "kernels, 2e-5 of max|ref|), guarded against activations beyond the fp16 range (hp_net_status); "
+                                  "exact_fp32_kernels = the same job on fp32 MFMA only")
         if exact:
+            e_sec = exact[3] * 1e-3
+            e_exec = exact[7] / e_sec / 1e12 if e_sec > 0 else 0.0
             line["exact_fp32_kernels"] = {
                 "value": world * B * exact[1] / exact[0], "unit": line["unit"], "steps": exact[1], "ms_per_step": 1e3 * exact[0] / exact[1],
                 "max_abs_pose_diff_vs_default": exact[2],
-                "note": "same job with hp_conv_select_algo(WINOGRAD): fp32 MFMA only (Winograd F(2x2,3x3) / direct kernels); the default "
-                        "build forms the products of the 3x3 layers from three fp16 MFMAs on fp16 hi/lo halves of the fp32 operands with "
-                        "fp32 accumulation -- same stated tolerance vs fp64 (2e-5 of max|ref| per layer; DESIGN.md 4.1)"}
+                "roofline": {"bound": "mfma", "kernel": "conv3x3_wino8_f32 / conv3x3_patch_f32 / conv_igemm_f32: v_mfma_f32_16x16x4_f32 / "
+                                                        "v_mfma_f32_32x32x2_f32",
+                             "achieved": e_exec, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": e_exec / PEAK_F32_MFMA_TFLOPS,
+                             "algorithmic_tflops": exact[6] / e_sec / 1e12 if e_sec > 0 else 0.0,
+                             "note": "executed fp32 MFMA FLOPs (Winograd layers execute 2.25x fewer than the direct convolution)"},
+                "note": "same job with hp_net_set_conv_algo(WINOGRAD): every multiply an fp32 FMA on the fp32 matrix path"}
         if args.workload == "C2":
             line["stages"] = stage_rates(store, scene, images, K, TCO0, im_ids, device)
         if not args.no_cpu_baseline and args.workload == "C2":
-            base = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds)
+            base, cpu_poses = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds)
             line["cpu_baseline"] = base
             line["speedup_vs_cpu"] = line["value"] / base["value"]
+            # same-run CPU <-> GPU parity: the oracle's final poses of its sample vs the timed HIP path's
+            line["parity"] = pose_parity(poses[:B].cpu().numpy(), cpu_poses)
+            parity_failed = not line["parity"]["ok"]
             if not args.no_cpu_1thread:
-                line["cpu_baseline_1thread"] = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds / 2, cores=1)
+                line["cpu_baseline_1thread"] = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds / 2, cores=1)[0]
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if parity_failed:
+        sys.exit("bench.py: the HIP path's poses differ from the CPU oracle's beyond the stated tolerance (see \"parity\")")
 
 
 if __name__ == "__main__":
