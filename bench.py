@@ -438,7 +438,8 @@ def main():
         # matrix-pipe work in units of the instruction that dominates it.  net.cpp counts executed MFMA FLOPs (padded
         # tiles and the 3 MFMAs per product of the split scheme included) in fp32-MFMA-time equivalents: an fp16 MFMA
         # FLOP occupies the pipe 1/16 as long as an fp32 one.  fp16-rate units = x16.
-        executed_f16 = 16.0 * mfma_flops / sec / 1e12 if sec > 0 else 0.0
+        # fp16-rate units = x16 (the fp16 plan's count is in fp16 FLOPs already).
+        executed_f16 = (16.0 if precision == "f32" else 1.0) * mfma_flops / sec / 1e12 if sec > 0 else 0.0
         desc = {
             "C2": f"C2: CosyPose refiner, one 640x480 frame per GPU, {N_DET} detections x {N_HYP} hypotheses = {B} "
                   f"hypotheses/GPU, {N_ITERS} iterations, {args.arch}{' (WideResNet)' if 'resnet' in args.arch else ''} on 6x240x320",
@@ -479,6 +480,19 @@ def main():
                                   "traffic: not measurable inside the run -- PMC passes of this command are under profiles/"),
                          "conv_time_share": conv_ms * 1e-3 / elapsed},
         }
+        # what the matrix pipe SUSTAINS on this box (hp_probe_mfma_rate, measured now): gfx950 clocks to its power
+        # budget, so back-to-back fp16 MFMAs on random operands settle at ~1.6 GHz and ~2/3 of the nominal dense peak --
+        # the ceiling any dense fp16-MFMA kernel on real data is bound by
+        try:
+            sus_tf, sus_mhz = _ops.probe_mfma_rate(device, random_data=True)
+            nom_tf, nom_mhz = _ops.probe_mfma_rate(device, random_data=False)
+            line["roofline"]["sustained"] = {
+                "random_operands": {"tflops": sus_tf, "shader_mhz": sus_mhz}, "zero_operands": {"tflops": nom_tf, "shader_mhz": nom_mhz},
+                "frac_of_sustained": executed_f16 / sus_tf if sus_tf > 0 else None,
+                "note": "hp_probe_mfma_rate in this run: v_mfma_f32_32x32x16_f16 back to back on every SIMD, operands in registers; "
+                        "the power budget, not the issue rate, sets the clock (zeros reach the nominal peak)"}
+        except Exception as e:  # diagnostics only
+            line["roofline"]["sustained"] = {"error": str(e)}
         if all_gather_us is not None:
             line["all_gather_us"] = all_gather_us
         if precision == "f32":

@@ -67,6 +67,7 @@ struct ConvArgsH {
   int kh, kw;                 // filter size (selects the patch-staged 3x3 kernel)
   int tiles_m, tiles_n;       // filled by the launcher
   FastDiv fd_howo, fd_wo, fd_tn;  // by Ho*Wo, Wo, tiles_n (filled by the launcher; M < 2^31)
+  int no_tail_split;          // as ConvArgs::no_tail_split
 };
 
 // depthwise k x k conv + folded BN + swish (mbconv.hip)
@@ -104,6 +105,15 @@ bool conv_split_launchable(const ConvArgs& a);  // per launch: batch-dependent l
 size_t conv_split_weight_bytes(int cout, int cin);
 int conv_split_transform_weights(const float* d_w, void* d_ws, int cout, int cin, int Kpad, int stride, hipStream_t stream);
 int launch_conv_split(const ConvArgs& a, hipStream_t stream);
+// tail split-K planning of the one-workgroup-per-CU 3x3 kernels (conv_split.hip): T tiles, ncc splittable K units
+int conv_split_plan_tail(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_cu, hipStream_t stream);
+// ping-pong 3x3 / stride-1 kernel for Cout % 128 == 0 (conv_pp.hip): the two waves of a SIMD alternate between an
+// LDS / staging segment and an MFMA burst; fp32 (split-fp16 weights of conv_split_transform_weights) and fp16 modes
+bool conv_pp_split_applicable(const ConvArgs& a, int kh, int kw);
+int launch_conv_pp_split(const ConvArgs& a, hipStream_t stream);
+struct ConvArgsH;
+bool conv_pp_f16_applicable(const ConvArgsH& a);
+int launch_conv_pp_f16(const ConvArgsH& a, hipStream_t stream);
 // the same scheme for every other layer the generic kernel runs (stems, 1x1, odd 3x3): conv_igemm_split.hip
 size_t conv_igemm_split_weight_bytes(int rows_pad, int Kpad);
 int conv_igemm_split_transform_weights(const float* d_w, void* d_ws, int rows_pad, int Kpad, hipStream_t stream);

@@ -580,6 +580,7 @@ int launch_conv_f16(const ConvArgsH& a, hipStream_t stream) {
   if (a.x_bytes >= (1ll << 32) - 256 || a.w_bytes >= (1ll << 31))
     return fail(HP_ERR_ARG, "conv_igemm_f16: tensor too large for 32-bit buffer offsets (lower max_batch)");
   const bool pre = a.pre_scale != nullptr;
+  if (conv_pp_f16_applicable(a)) return launch_conv_pp_f16(a, stream);  // 3x3 s1, Cout % 128 == 0, Cin % 64 == 0: conv_pp.hip
   if (const int npc = patch_f16_npc(a, a.kh, a.kw)) return pre ? launch_patch<true>(a, npc, stream) : launch_patch<false>(a, npc, stream);
   if (a.Cout % 128 == 0) return pre ? launch_variant<128, true>(a, stream) : launch_variant<128, false>(a, stream);
   return pre ? launch_variant<64, true>(a, stream) : launch_variant<64, false>(a, stream);

@@ -242,6 +242,96 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
   load_b(0, cc_begin * 9 + 2);
   __syncthreads();
 
+#ifndef HP_SPLIT_OLD_TAP
+  // ---- software-pipelined tap body.  A tap is six groups of MT x NT MFMAs (hi.hi, hi.lo, lo.hi for each of the two
+  // 16-channel k-steps).  The fragments of group g + 1 are read BEFORE the MFMAs of group g are issued, the first
+  // group's fragments of the NEXT tap before the last group of this one, and the per-tap barrier sits between groups
+  // 4 and 5 (every B read of the tap has completed by then: the weight buffer may be overwritten, and the buffer of
+  // the next tap -- stored at the head of this one -- is visible).  With both waves of a SIMD in lockstep behind the
+  // barrier, an exposed LDS round trip at the head of every tap and one in its middle idled the matrix pipe for
+  // 15-25 % of the tap (the compiler clustered the reads in front of their first use); sched_barrier pins the order.
+  halfx8 pfa[MT], pfb[NT];  // q0 fragments of the tap about to run (prefetched)
+  auto a_base = [&](int tap, const _Float16* (&Ab)[MT]) {
+    const int d = (tap / 3 - 1) * W + (tap % 3 - 1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) Ab[i] = ((vmask[i] >> tap) & 1u) ? Afr[i] + d * LDH : Zfr;
+  };
+  auto rd_a = [&](halfx8 (&f)[MT], const _Float16* const (&Ab)[MT], int q) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) f[i] = *reinterpret_cast<const halfx8*>(Ab[i] + q * 16);
+  };
+  auto rd_b = [&](halfx8 (&f)[NT], int buf, int q) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) f[i] = *reinterpret_cast<const halfx8*>(Bfr + buf * BN * LDH + i * 32 * LDH + q * 16);
+  };
+  auto mm = [&](const halfx8 (&fa)[MT], const halfx8 (&fb)[NT]) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+  };
+#define HP_PIN() __builtin_amdgcn_sched_barrier(0)
+  auto prefetch_first = [&](int tap, int buf) {  // q0 fragments of `tap` (weights in LDS buffer `buf`)
+    const _Float16* Ab[MT];
+    a_base(tap, Ab);
+    rd_a(pfa, Ab, 0);
+    rd_b(pfb, buf, 0);
+  };
+  auto tap_step = [&](int tt, int cc, int tap, auto par) {
+    constexpr int Pb = decltype(par)::value;  // tt & 1: LDS weight buffer of this tap
+    const _Float16* Ab[MT];
+    a_base(tap, Ab);
+    const bool next_chunk = cc + 1 < ncc;
+    const bool swap = tap == 8 && next_chunk;  // the patch is replaced after this tap
+    halfx8 ah[MT], bh[NT], bl[NT], al[MT], ah1[MT], bh1[NT], bl1[NT], al1[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ah[i] = pfa[i];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) bh[i] = pfb[i];
+    rd_b(bl, Pb, 2);                       // group 1
+    store_b(1 - Pb, 1 - Pb);               // weights of tap tt+1 (register set (tt+1) & 1) ...
+    load_b(1 - Pb, tt + 3);                // ... and that set takes tap tt+3
+    HP_PIN();
+    mm(ah, bh);                            // group 0: hi.hi, k-step 0
+    HP_PIN();
+    rd_a(al, Ab, 2);                       // group 2
+    HP_PIN();
+    mm(ah, bl);                            // group 1: hi.lo
+    HP_PIN();
+    rd_a(ah1, Ab, 1);                      // group 3
+    rd_b(bh1, Pb, 1);
+    HP_PIN();
+    mm(al, bh);                            // group 2: lo.hi
+    HP_PIN();
+    rd_b(bl1, Pb, 3);                      // group 4
+#pragma unroll
+    for (int j = 0; j < NPC; ++j)          // next chunk's patch: one pass per tap (taps 0 .. NPC-1)
+      if (j == tap) load_patch(j, cc + 1 < ncc ? cc + 1 : cc);
+    HP_PIN();
+    mm(ah1, bh1);                          // group 3: hi.hi, k-step 1
+    HP_PIN();
+    rd_a(al1, Ab, 3);                      // group 5
+    HP_PIN();
+    mm(ah1, bl1);                          // group 4: hi.lo
+    HP_PIN();
+    __syncthreads();                       // every wave has finished the B reads of this tap and stored tap tt+1's weights
+    if (!swap) prefetch_first(tap == 8 ? 0 : tap + 1, 1 - Pb);
+    else rd_b(pfb, 1 - Pb, 0);
+    HP_PIN();
+    mm(al1, bh1);                          // group 5: lo.hi
+    HP_PIN();
+    if (swap) {  // every wave is done with this chunk's patch: swap in the next one
+      __syncthreads();
+      store_patch(cc + 1);
+      __syncthreads();
+      const _Float16* An[MT];
+      a_base(0, An);
+      rd_a(pfa, An, 0);
+    }
+  };
+#undef HP_PIN
+#else
   auto tap_step = [&](int tt, int cc, int tap, auto par) {
     constexpr int Pb = decltype(par)::value;  // tt & 1: LDS weight buffer of this tap
     const int d = (tap / 3 - 1) * W + (tap % 3 - 1);
@@ -343,6 +433,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
     }
 #endif
   };
+#endif
   // tap t of the item's chunk number rc uses weight buffer (rc + t) & 1: two chunks per loop iteration make
   // that a compile-time value
   auto chunk = [&](int cc, auto c0) {
@@ -354,6 +445,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
     tap_step(cc * 9 + 6, cc, 6, E{}); tap_step(cc * 9 + 7, cc, 7, O{}); tap_step(cc * 9 + 8, cc, 8, E{});
   };
   int cc = cc_begin;
+#ifndef HP_SPLIT_OLD_TAP
+  prefetch_first(0, 0);
+#endif
 #ifdef HP_SABL_NOLOOP
   cc = ncc;
 #endif
@@ -784,6 +878,10 @@ int launch_split_npc(const ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+int conv_split_plan_tail(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_cu, hipStream_t stream) {
+  return plan_tail_split(a, T, ncc, tile_floats, wg_per_cu, stream);
+}
+
 bool conv_split_applicable(const ConvArgs& a, int kh, int kw) {
   static const bool off = std::getenv("HP_CONV_NO_SPLIT") != nullptr;
   if (off || kh != 3 || kw != 3 || a.pad != 1 || a.Cin % CK != 0 || a.Cout % 64 != 0) return false;
@@ -814,6 +912,11 @@ int launch_conv_split(const ConvArgs& a, hipStream_t stream) {
   const bool pre = a.pre_scale != nullptr;
   if (a.stride == 2)
     return pre ? launch_split_s2_variant<4, 2, true, 3>(a, stream) : launch_split_s2_variant<4, 2, false, 3>(a, stream);
+  static const bool t128 = std::getenv("HP_SPLIT_128") != nullptr;  // experiment: 128 x 128 tiles, 4 waves, two workgroups per CU
+  if (t128 && a.Cout % 128 == 0 && SplitTile<2, 2>::npc(a.W) <= 7)
+    return pre ? launch_split_npc<2, 2, true>(a, stream) : launch_split_npc<2, 2, false>(a, stream);
+  // >= 128 output channels: the ping-pong kernel (conv_pp.hip) wherever its double-buffered patch fits the LDS
+  if (conv_pp_split_applicable(a, 3, 3)) return launch_conv_pp_split(a, stream);
   // (128 x 128 tiles in 4-wave workgroups, two per CU, measured 3-10 % slower than 256 x 128 on the >= 128-channel layers)
   if (a.Cout % 128 == 0) return pre ? launch_split_npc<4, 2, true>(a, stream) : launch_split_npc<4, 2, false>(a, stream);
   // 64-channel layers (60x80 maps, K = 18 taps): 256 x 64 tiles in 4-wave workgroups, TWO per CU -- with one 512 x 64

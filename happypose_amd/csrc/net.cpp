@@ -616,6 +616,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       a.H = L.H; a.W = L.W; a.Cin = L.cin16; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.cout;
       a.stride = L.stride; a.pad = L.pad; a.Kpad = L.Kpad16; a.ktiles = L.Kpad16 / 64; a.relu = L.relu;
       a.kh = L.kh; a.kw = L.kw;
+      a.no_tail_split = net->tail_split ? 0 : 1;
       a.x_bytes = (int64_t)batch * L.H * L.W * L.cin16 * 2;
       a.w_bytes = (int64_t)L.cout * L.Kpad16 * 2;
       if ((rc = prof_begin(op.conv))) return rc;

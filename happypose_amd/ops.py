@@ -408,6 +408,14 @@ def profile_mark_reference(device) -> None:
         check(lib().hp_profile_mark_reference(stream_ptr(device)), "hp_profile_mark_reference")
 
 
+def probe_mfma_rate(device, random_data: bool = True):
+    """``hp_probe_mfma_rate``: ``(TFLOP/s, shader MHz)`` the fp16 matrix pipe sustains on zero / random operands."""
+    tf, mhz = C.c_double(0), C.c_double(0)
+    with torch.cuda.device(device):
+        check(lib().hp_probe_mfma_rate(int(random_data), C.byref(tf), C.byref(mhz), stream_ptr(device)), "hp_probe_mfma_rate")
+    return tf.value, mhz.value
+
+
 CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2, "winograd-1wave": 3, "winograd": 4, "split": 5}
 
 

@@ -281,6 +281,12 @@ int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, do
 int hp_profile_mark_reference(void* stream);
 int hp_net_profile_intervals(hp_net* net, double* t0_ms, double* t1_ms, int cap);
 
+/* Diagnostics: the fp16 matrix-pipe rate this GPU SUSTAINS (back-to-back v_mfma_f32_32x32x16_f16 on every SIMD, operands
+ * in registers), chip-wide TFLOP/s and the shader clock it settles at.  gfx950 clocks to its power budget: zero operands
+ * reach the dense peak (~2.5 PFLOP/s at ~2.4 GHz), random fp16 operands -- what activations and weights are -- about two
+ * thirds of it at ~1.6 GHz.  bench.py reports the conv roofline against the nominal peak AND against this measurement. */
+int hp_probe_mfma_rate(int random_data, double* tflops, double* shader_mhz, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Depth refinement (run_depth_refiner=True): point-to-plane ICP between the depth rendered at
  * the predicted pose and the measured depth.  Replaces icp_refinement / ICPRefiner.refine_poses

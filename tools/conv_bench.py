@@ -29,4 +29,13 @@ for (h, w, cin, cout, k, s, p, pre) in shapes:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * k * k * cin
-    print(f"{h:3d}x{w:3d} {cin:4d}->{cout:4d} k{k} s{s} pre={int(pre)}  {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TFLOP/s")
+    extra = ""
+    try:  # diagnostics build (-DHP_PP_STAMPS): shader clock and cycles per tap inside the K loop of conv3x3_pp
+        import ctypes
+        fn = _ffi.lib().hp_debug_pp_stamps
+        buf = (ctypes.c_double * 8)()
+        if fn(buf) == 0 and buf[3] > 0:
+            extra = f"  clock {buf[0] / buf[1] * 100:6.0f} MHz  {buf[0] / buf[2]:7.0f} cycles/tap  ({buf[2] / buf[3]:.0f} taps/WG)  prologue {buf[4] / buf[3]:6.0f}  epilogue {buf[5] / buf[3]:6.0f} cycles/WG"
+    except AttributeError:
+        pass
+    print(f"{h:3d}x{w:3d} {cin:4d}->{cout:4d} k{k} s{s} pre={int(pre)}  {ms*1e3:8.1f} us  {fl/ms/1e9:6.1f} TFLOP/s{extra}")
