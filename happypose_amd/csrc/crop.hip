@@ -16,6 +16,8 @@
 // columns = 4-25 loads per channel instead of 64.  Pixels whose samples span more than 5
 // rows or columns (bin > 2.67 px: crop boxes wider than ~850 px) take the literal 16-sample
 // path.  The factorisation only re-associates the fp32 sum (<= 1e-6 relative).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hp {
@@ -228,6 +230,136 @@ __global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
   }
 }
 
+
+// ---- second-generation kernel: one workgroup = a 32 x 64 tile of output pixels.  The 16 x 16 kernel above spent most of
+// its ~600 vector instructions per pixel on (a) building the folded axis weights -- 32 lanes work, 224 wait, once per 256
+// pixels -- and (b) a fully predicated 5 x 5 x 4 tap loop although a typical crop (bin <= 1 source pixel) folds into 2-3
+// rows x 2-3 columns.  Here the folds of 32 rows + 64 columns are built once per 2048 pixels, a thread keeps its column
+// fold in registers and walks 8 rows, and the tap loops run to the TILE's largest span (workgroup-uniform bounds), the
+// channel count is a template parameter.  Same taps, same order of operations inside a pixel as above (and as
+// oracle/csrc/oracle.c up to the separable re-association stated in DESIGN.md).
+constexpr int kTR = 32, kTC = 64;
+
+template <int NC>
+__global__ __launch_bounds__(256) void crop_tile_kernel(CropArgs a) {
+  __shared__ Fold folds_y[kTR], folds_x[kTC];
+  __shared__ int span_max[2];
+  const int r = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.y * kTR, col0 = blockIdx.x * kTC;
+  const float* box = a.boxes + 4 * (int64_t)r;
+  const float x1 = box[0], y1 = box[1];
+  float roi_w = box[2] - x1, roi_h = box[3] - y1;
+  roi_w = roi_w < 1.0f ? 1.0f : roi_w;  // aligned=False
+  roi_h = roi_h < 1.0f ? 1.0f : roi_h;
+  const float bin_h = roi_h / (float)a.oh, bin_w = roi_w / (float)a.ow;
+  const int g = a.sr;
+  const float count = (float)(g * g);
+  const int H = a.H, W = a.W;
+  if (tid < 2) span_max[tid] = 0;
+  __syncthreads();
+  if (tid < kTR + kTC) {  // lanes 0-31: the tile's rows, 32-95: its columns
+    const bool is_x = tid >= kTR;
+    const int k = is_x ? tid - kTR : tid;
+    Axis t;
+    Fold f;
+    if (is_x) make_axis(x1, col0 + k, bin_w, g, W, t);
+    else make_axis(y1, row0 + k, bin_h, g, H, t);
+    fold_axis(t, g, f.first, f.span, f.w);
+    if (is_x) folds_x[k] = f; else folds_y[k] = f;
+    const bool inside = is_x ? col0 + k < a.ow : row0 + k < a.oh;
+    if (inside) atomicMax(&span_max[is_x ? 1 : 0], f.span);
+  }
+  __syncthreads();
+  const int nr_max = span_max[0], nc_max = span_max[1];
+  const bool separable = nr_max <= kSpan && nc_max <= kSpan;
+  const int tx = tid & (kTC - 1), tyg = tid / kTC;  // column of this thread, first of its rows
+  const int pw = col0 + tx;
+  if (pw >= a.ow) return;
+  const Fold fx = folds_x[tx];
+  const int c0 = fx.first, nc = fx.span;
+  const int im_id = a.im_ids[r];
+  const bool bad_id = (unsigned)im_id >= (unsigned)a.Bi;  // reads frame 0, writes zeros (see crop_kernel)
+  const float* img = a.images + (int64_t)(bad_id ? 0 : im_id) * a.C * H * W;
+  const int HW = H * W;
+  const float zn = (NC == 4 && a.depth_norm_mode != 0) ? a.depth_norm_z[r] : 1.0f;
+#pragma unroll 1
+  for (int k = 0; k < kTR / (256 / kTC); ++k) {
+    const int py = tyg + (256 / kTC) * k, ph = row0 + py;
+    if (ph >= a.oh) break;
+    const Fold fy = folds_y[py];
+    const int r0 = fy.first, nr = fy.span;
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+    float vacc = 0.0f;
+    if (separable) {
+      const int off0 = r0 * W + c0;
+#pragma unroll
+      for (int i = 0; i < kSpan; ++i) {  // unrolled (weights stay in registers); workgroup-uniform exit at the tile's span
+        if (i >= nr_max) break;
+        if (i < nr) {
+          const int off = off0 + i * W;
+          float racc[NC];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) racc[c] = 0.f;
+          float rv = 0.0f;
+#pragma unroll
+          for (int j = 0; j < kSpan; ++j) {
+            if (j >= nc_max) break;
+            if (j < nc) {
+              const float wj = fx.w[j];
+#pragma unroll
+              for (int c = 0; c < NC; ++c) {
+                const float v = img[c * HW + off + j];
+                racc[c] += wj * v;
+                if (c == 3) rv += wj * (v > 0.0f ? 1.0f : 0.0f);
+              }
+            }
+          }
+          const float wi = fy.w[i];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c] += wi * racc[c];
+          vacc += wi * rv;
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int c = 0; c < NC; ++c) {
+        float sacc = 0.0f, sv = 0.0f;
+        slow_pixel(img + (int64_t)c * HW, H, W, y1, x1, ph, pw, bin_h, bin_w, g, c == 3, sacc, sv);
+        acc[c] = sacc;
+        if (c == 3) vacc = sv;
+      }
+    }
+    float outv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float val = acc[c] / count;
+      if (c == 3) {
+        if (vacc / count < 0.99f) val = 0.0f;  // TB/lib3d/cropping.py:184-195
+        if (a.depth_norm_mode == 1) val = val / zn;
+        else if (a.depth_norm_mode == 2) val = fminf(fmaxf(val / zn, 0.0f), 2.0f) - 1.0f;
+        else if (a.depth_norm_mode == 3) val = fminf(fmaxf(val - zn, -2.0f), 2.0f);
+      }
+      outv[c] = bad_id ? 0.0f : val;
+    }
+    const int64_t obase = (int64_t)r * a.os.s_item + (int64_t)ph * a.os.s_row + (int64_t)pw * a.os.s_col;
+    typedef float float3v __attribute__((ext_vector_type(3)));
+    if (a.out_half) {  // strides count fp16 elements
+      _Float16* const o = reinterpret_cast<_Float16*>(a.out);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) o[obase + (int64_t)c * a.os.s_chan] = (_Float16)outv[c];
+    } else if (a.os.s_chan == 1 && NC == 3) {
+      *reinterpret_cast<float3v*>(reinterpret_cast<float*>(a.out) + obase) = float3v{outv[0], outv[1], outv[2]};
+    } else {
+      float* const o = reinterpret_cast<float*>(a.out);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) o[obase + (int64_t)c * a.os.s_chan] = outv[c];
+    }
+  }
+}
+
 }  // namespace hp
 
 namespace hp {
@@ -245,9 +377,16 @@ static int crop_launch(const float* d_images, int Bi, int C, int n_channels, int
   HP_REQUIRE(d_boxes && d_im_ids && d_out, "hp_crop_roi_align: null pointer");
   CropArgs a{d_images, Bi, C, n_channels, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio,
              d_out, out_half, *out_strides, d_depth_norm_z, depth_norm_mode};
-  dim3 grid((out_w + 15) / 16, (out_h + 15) / 16, n);
-  hipLaunchKernelGGL(crop_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-  return check_launch("crop_kernel");
+  static const bool old_kernel = std::getenv("HP_CROP_OLD") != nullptr;  // A/B: the 16 x 16 tile kernel
+  if (old_kernel) {
+    dim3 grid((out_w + 15) / 16, (out_h + 15) / 16, n);
+    hipLaunchKernelGGL(crop_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("crop_kernel");
+  }
+  dim3 grid((out_w + kTC - 1) / kTC, (out_h + kTR - 1) / kTR, n);
+  if (n_channels == 3) hipLaunchKernelGGL(crop_tile_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(crop_tile_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("crop_tile_kernel");
 }
 }  // namespace hp
 

@@ -144,15 +144,25 @@ __device__ __forceinline__ void tex_fetch(const uint8_t* tex, int tw, int th, fl
 
 struct TriSetup {
   float e0[3], e1[3], e2[3];
+  float z0, z1, z2;  // camera-space depth of the three corners
   float det;
   int x0, x1, y0, y1;  // inclusive pixel bbox clipped to the band; empty if x0 > x1
 };
 
+// the six 16-B records of a triangle's corners ({X, Y, Z, X/Z}, {Y/Z, ...} per vertex), loaded ahead of their use
+struct TriVerts { float4 p0, p1, p2; float v0, v1, v2; };
+__device__ __forceinline__ TriVerts load_tri_verts(const float4* xv, const int32_t* tri) {
+  TriVerts t;
+  t.p0 = xv[2 * tri[0]]; t.p1 = xv[2 * tri[1]]; t.p2 = xv[2 * tri[2]];
+  t.v0 = xv[2 * tri[0] + 1].x; t.v1 = xv[2 * tri[1] + 1].x; t.v2 = xv[2 * tri[2] + 1].x;
+  return t;
+}
+
 // Screen-space vertices + inclusive pixel bbox (clipped to the image).  Returns false when the
 // triangle is outside the clip range or the image.
-__device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const float4* xv, const int32_t* tri, float (&V0)[3],
+__device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const TriVerts& t, float (&V0)[3],
                                          float (&V1)[3], float (&V2)[3], int& x0, int& x1, int& y0, int& y1) {
-  const float4 p0 = xv[2 * tri[0]], p1 = xv[2 * tri[1]], p2 = xv[2 * tri[2]];
+  const float4 p0 = t.p0, p1 = t.p1, p2 = t.p2;
   V0[0] = p0.x; V0[1] = p0.y; V0[2] = p0.z;
   V1[0] = p1.x; V1[1] = p1.y; V1[2] = p1.z;
   V2[0] = p2.x; V2[1] = p2.y; V2[2] = p2.z;
@@ -161,7 +171,7 @@ __device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const float4* xv, 
   x0 = 0; x1 = a.w - 1; y0 = 0; y1 = a.h - 1;
   if (zmin > 1e-6f) {
     const float u0 = p0.w, u1 = p1.w, u2 = p2.w;  // X / Z, Y / Z: divided once per vertex and view
-    const float v0 = xv[2 * tri[0] + 1].x, v1 = xv[2 * tri[1] + 1].x, v2 = xv[2 * tri[2] + 1].x;
+    const float v0 = t.v0, v1 = t.v1, v2 = t.v2;
     float umin = fminf(u0, fminf(u1, u2)), umax = fmaxf(u0, fmaxf(u1, u2));
     float vmin = fminf(v0, fminf(v1, v2)), vmax = fmaxf(v0, fmaxf(v1, v2));
     if (!(umax >= 0.0f) || !(umin <= (float)a.w) || !(vmax >= 0.0f) || !(vmin <= (float)a.h)) return false;
@@ -174,10 +184,10 @@ __device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const float4* xv, 
 }
 
 // Returns false when the triangle cannot touch rows [row0, row1] of this view.
-__device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const float4* xv, const int32_t* tri, int row0,
+__device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const TriVerts& t, const int32_t* tri, int row0,
                                                int row1, TriSetup& s) {
   float V0[3], V1[3], V2[3];
-  if (!tri_bbox(a, xv, tri, V0, V1, V2, s.x0, s.x1, s.y0, s.y1)) return false;
+  if (!tri_bbox(a, t, V0, V1, V2, s.x0, s.x1, s.y0, s.y1)) return false;
   if (s.y0 < row0) s.y0 = row0;
   if (s.y1 > row1) s.y1 = row1;
   if (s.y0 > s.y1) return false;
@@ -186,6 +196,7 @@ __device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const float4
   edge_fn(V0, tri[0], V1, tri[1], s.e2);
   s.det = fmaf(V0[0], s.e0[0], fmaf(V0[1], s.e0[1], V0[2] * s.e0[2]));
   if (!(s.det != 0.0f) || !isfinite(s.det)) return false;
+  s.z0 = V0[2]; s.z1 = V1[2]; s.z2 = V2[2];
   return true;
 }
 
@@ -199,7 +210,8 @@ __device__ __forceinline__ void shade_pixel(const TriSetup& s, int i, int j, uin
   bool in_pos = (l0 >= 0.0f) & (l1 >= 0.0f) & (l2 >= 0.0f) & (sum > 0.0f);
   bool in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (sum < 0.0f);
   if (!(in_pos | in_neg)) return;
-  float Z = s.det / sum;
+  // depth = the vertex depths interpolated with the perspective-correct barycentrics (oracle.c explains why not det / sum)
+  float Z = fmaf(l0, s.z0, fmaf(l1, s.z1, l2 * s.z2)) / sum;
   if (!(Z >= kZNear) || !(Z <= kZFar)) return;
   unsigned long long key = ((unsigned long long)__float_as_uint(Z) << 32) | f;
   atomicMin(&zb[(i - row0) * w + j], key);
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
     int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
     float V0[3], V1[3], V2[3];
     int x0, x1, y0, y1;
-    if (tri_bbox(a, a.xverts + 2 * (int64_t)lv * a.max_verts, tri, V0, V1, V2, x0, x1, y0, y1)) {
+    if (tri_bbox(a, load_tri_verts(a.xverts + 2 * (int64_t)lv * a.max_verts, tri), V0, V1, V2, x0, x1, y0, y1)) {
       b0 = y0 / a.band_rows;
       b1 = y1 / a.band_rows;
     }
@@ -331,13 +343,17 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   const float4* xv = a.xverts + 2 * (int64_t)(lin / a.n_bands) * a.max_verts;
   const int32_t* fbase = a.faces + 3 * foff;
 
-  for (int p = tid; p < npix; p += kThreads) zb[p] = kKeyEmpty;
-  if (tid == 0) big_n = 0;
-  __syncthreads();
-
   // ---- coverage + depth: only the triangles binned to this band ----
   const int cnt = nf > 0 ? min(a.bin_count[lin], a.bin_cap) : 0;
   const int32_t* list = a.bin_list + (int64_t)lin * a.bin_cap;
+  // a band no triangle touches (40 % of the bands of the benchmark scenes) skips the z-buffer altogether: the resolve
+  // loop below sees every pixel empty and only streams the background out
+  const bool band_empty = cnt == 0;
+  if (!band_empty) {
+    for (int p = tid; p < npix; p += kThreads) zb[p] = kKeyEmpty;
+    if (tid == 0) big_n = 0;
+    __syncthreads();
+  }
   // the list entry and the corner indices of the NEXT triangle are fetched while this one is set up:
   // the loop is a chain of dependent gathers (list -> faces -> vertices), not arithmetic
 #ifdef HP_RABL_NO_COVER
@@ -345,18 +361,26 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
 #else
   const int cnt_loop = cnt;
 #endif
-  // two-deep: list entry two triangles ahead, corner indices one ahead (each needs the previous load)
-  int f1 = tid < cnt_loop ? list[tid] : 0;
-  int f2 = tid + kThreads < cnt_loop ? list[tid + kThreads] : 0;
+  // three-stage software pipeline over the dependent gathers list -> corner indices -> vertex records: while triangle k
+  // is rasterised, the vertex records of k + T, the corner indices of k + 2T and the list entry of k + 3T are in flight
+  // (every stage needs the previous stage's data of the same triangle); indices past the end read entry 0: harmless
+  int f0 = tid < cnt_loop ? list[tid] : 0;
+  int f1 = tid + kThreads < cnt_loop ? list[tid + kThreads] : 0;
+  int f2 = tid + 2 * kThreads < cnt_loop ? list[tid + 2 * kThreads] : 0;
+  int32_t tri0[3] = {fbase[3 * f0], fbase[3 * f0 + 1], fbase[3 * f0 + 2]};
   int32_t tri1[3] = {fbase[3 * f1], fbase[3 * f1 + 1], fbase[3 * f1 + 2]};
+  TriVerts tv0 = load_tri_verts(xv, tri0);
   for (int k = tid; k < cnt_loop; k += kThreads) {
-    const int f = f1;
-    const int32_t tri[3] = {tri1[0], tri1[1], tri1[2]};
+    const int f = f0;
+    const int32_t tri[3] = {tri0[0], tri0[1], tri0[2]};
+    const TriVerts tv = tv0;
+    f0 = f1; tri0[0] = tri1[0]; tri0[1] = tri1[1]; tri0[2] = tri1[2];
+    tv0 = load_tri_verts(xv, tri0);
     f1 = f2;
-    tri1[0] = fbase[3 * f1]; tri1[1] = fbase[3 * f1 + 1]; tri1[2] = fbase[3 * f1 + 2];  // f1 = 0 past the end: harmless
-    f2 = k + 2 * kThreads < cnt_loop ? list[k + 2 * kThreads] : 0;
+    tri1[0] = fbase[3 * f1]; tri1[1] = fbase[3 * f1 + 1]; tri1[2] = fbase[3 * f1 + 2];
+    f2 = k + 3 * kThreads < cnt_loop ? list[k + 3 * kThreads] : 0;
     TriSetup s;
-    if (!setup_triangle(a, xv, tri, row0, row1, s)) continue;
+    if (!setup_triangle(a, tv, tri, row0, row1, s)) continue;
     const int area = (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
     if (area > kBigArea) {
       int q = atomicAdd(&big_n, 1);
@@ -365,19 +389,19 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
     for (int i = s.y0; i <= s.y1; ++i)
       for (int j = s.x0; j <= s.x1; ++j) shade_pixel(s, i, j, (uint32_t)f, zb, row0, a.w);
   }
-  __syncthreads();
-  const int nbig = min(big_n, kBigQueue);
+  if (!band_empty) __syncthreads();
+  const int nbig = band_empty ? 0 : min(big_n, kBigQueue);
   for (int q = 0; q < nbig; ++q) {
     const int f = big_q[q];
     int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
     TriSetup s;
-    if (!setup_triangle(a, xv, tri, row0, row1, s)) continue;
+    if (!setup_triangle(a, load_tri_verts(xv, tri), tri, row0, row1, s)) continue;
     const int bw = s.x1 - s.x0 + 1;
     const int area = bw * (s.y1 - s.y0 + 1);
     for (int p = tid; p < area; p += kThreads)
       shade_pixel(s, s.y0 + p / bw, s.x0 + p % bw, (uint32_t)f, zb, row0, a.w);
   }
-  __syncthreads();
+  if (!band_empty) __syncthreads();
 
   // ---- resolve ----
   const int q8 = a.flags & HP_RASTER_QUANT8;
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
 
   for (int p = tid; p < npix; p += kThreads) {
     const int i = row0 + p / a.w, j = p % a.w;
-    const unsigned long long key = zb[p];
+    const unsigned long long key = band_empty ? kKeyEmpty : zb[p];
     float o_rgb[3] = {0.f, 0.f, 0.f}, o_n[3] = {0.f, 0.f, 0.f}, o_d = 0.0f;
 #ifdef HP_RABL_NO_SHADE
     if (key != kKeyEmpty && a.w < 0) {
