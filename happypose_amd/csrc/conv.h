@@ -136,6 +136,10 @@ inline bool conv_use_igemm_split(int kh, int Kpad) {
   return kh >= min_kh;
 }
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
+// nearest resize to (Ho, Wo) (stride_mode 0) or stride-2 subsampling (stride_mode 1), NHWC, C % 4 == 0
+int launch_resize_nearest(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, int stride_mode, hipStream_t stream);
+// (x - mean) / std per channel, NCHW [n,3,h,w] -> NHWC [n,h,w,4]
+int launch_normalize_nhwc4(const float* x, float* y, int n, int h, int w, const float* mean3, const float* std3, hipStream_t stream);
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream);
 int launch_dwconv(const DwArgs& a, hipStream_t stream);
 // squeeze-excitation: pooled [n][C] = mean over HW of y; gate [n][C] = sigmoid(W2 swish(W1 pooled + b1) + b2)

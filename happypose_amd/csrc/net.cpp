@@ -45,7 +45,9 @@ struct ConvLayer {
   std::string wname;       // e.g. "backbone.layer1.0.conv1.weight"
   std::string bn_after;    // BN folded into this conv ("" = none)
   std::string bn_before;   // BN + ReLU applied to the input as prologue ("" = none)
+  std::string bias_name;   // the convolution's own bias ("" = none; FPN convs), added to the folded-BN shift
   int cin_real, cin, cout, kh, kw, stride, pad, relu;
+  int cout_real = 0;       // rows of the parameter tensor when cout was rounded up to 4 (zero rows; 0 = cout)
   int H, W, Ho, Wo, Kpad;
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
   DevBuf w, w_wino, w_split, w_isplit, bias, lut, pre_scale, pre_shift;  // w_isplit: hi/lo halves for conv_igemm_split.hip  // w_wino: Winograd-transformed weights (3x3 s1 layers)
@@ -74,7 +76,7 @@ struct SeLayer {
   DevBuf w1, b1, w2, b2;
 };
 
-enum OpKind { OP_CONV, OP_MAXPOOL, OP_HEAD, OP_DW, OP_SE };
+enum OpKind { OP_CONV, OP_MAXPOOL, OP_HEAD, OP_DW, OP_SE, OP_RESIZE /* nearest to (Ho, Wo); C = stride mode flag in conv */ };
 struct Op { OpKind kind; int conv = -1; int in_buf = -1, out_buf = -1; int H = 0, W = 0, C = 0, Ho = 0, Wo = 0; };
 
 }  // namespace
@@ -99,6 +101,8 @@ struct Net {
   DevBuf fc_w, fc_b, pose_w, pose_b, logit_w, logit_b;
   int pose_dim = 0, n_logits = 0;
   int feat_H = 0, feat_W = 0;
+  struct FeatureMap { int buf, H, W, C; };
+  std::vector<FeatureMap> feature_maps;  // detector backbone: the FPN levels ('0', '1', '2', '3', 'pool'), arena slots
   double flops_per_sample = 0.0;
   bool profiling = false;
   std::vector<EventPair> ev_pending, ev_pool;  // conv-launch event pairs (profiling only)
@@ -314,16 +318,114 @@ int build_graph_efficientnet(Net& n) {
   return HP_OK;
 }
 
+// ---- ResNet-50 + FPN, the backbone of the Mask-RCNN detector (MP/models/mask_rcnn.py:22-42:
+//      torchvision resnet_fpn_backbone("resnet50"): models/resnet.py Bottleneck (stride on the 3x3 conv), BatchNorm2d in
+//      eval mode, ops/feature_pyramid_network.py with LastLevelMaxPool).  State-dict keys as the reference's
+//      DetectorMaskRCNN registers them: backbone.body.*, backbone.fpn.inner_blocks.N.0.*, backbone.fpn.layer_blocks.N.0.*.
+//      Arena slots: 0 stem, 1 pooled stem, 2..4 block scratch (t1, t2, downsample), 5/6 ping-pong block outputs,
+//      7..10 = C2..C5, 11..14 lateral sums, 15 upsampled, 16..19 = P2..P5, 20 = pool.
+int build_graph_r50fpn(Net& n) {
+  n.convs.clear(); n.ops.clear(); n.buf_floats_per_sample.clear(); n.flops_per_sample = 0.0; n.feature_maps.clear();
+  const std::string bb = "backbone.body.";
+  int c = add_conv(n, bb + "conv1.weight", bb + "bn1", "", n.n_inputs, 64, 7, 2, 3, 1, n.h, n.w, -1, 0, -1);
+  int H = n.convs[c]->Ho, W = n.convs[c]->Wo;
+  want(n, 0, (size_t)H * W * 64);
+  Op mp; mp.kind = OP_MAXPOOL; mp.in_buf = 0; mp.out_buf = 1; mp.H = H; mp.W = W; mp.C = 64;
+  mp.Ho = (H + 2 - 3) / 2 + 1; mp.Wo = (W + 2 - 3) / 2 + 1;
+  n.ops.push_back(mp);
+  H = mp.Ho; W = mp.Wo;
+  want(n, 1, (size_t)H * W * 64);
+  int cur = 1, inpl = 64;
+  int level_buf[4], level_H[4], level_W[4];
+  for (int li = 0; li < 4; ++li) {
+    const int planes = kPlanes[li], outc = planes * 4;
+    for (int b = 0; b < kLayers34[li]; ++b) {  // ResNet-50 has the [3, 4, 6, 3] layout of ResNet-34
+      const int stride = (b == 0 && li > 0) ? 2 : 1;
+      const bool ds = b == 0;
+      const std::string p = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(b);
+      const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+      const bool last = b == kLayers34[li] - 1;
+      const int o = last ? 7 + li : (cur == 5 ? 6 : 5);
+      want(n, 2, (size_t)H * W * planes);
+      want(n, 3, (size_t)Ho * Wo * planes);
+      want(n, o, (size_t)Ho * Wo * outc);
+      add_conv(n, p + ".conv1.weight", p + ".bn1", "", inpl, planes, 1, 1, 0, 1, H, W, cur, 2, -1);
+      add_conv(n, p + ".conv2.weight", p + ".bn2", "", planes, planes, 3, stride, 1, 1, H, W, 2, 3, -1);
+      int res = cur;
+      if (ds) {
+        want(n, 4, (size_t)Ho * Wo * outc);
+        add_conv(n, p + ".downsample.0.weight", p + ".downsample.1", "", inpl, outc, 1, stride, 0, 0, H, W, cur, 4, -1);
+        res = 4;
+      }
+      add_conv(n, p + ".conv3.weight", p + ".bn3", "", planes, outc, 1, 1, 0, 1, Ho, Wo, 3, o, res);
+      cur = o; inpl = outc; H = Ho; W = Wo;
+    }
+    level_buf[li] = cur; level_H[li] = H; level_W[li] = W;
+  }
+  // FPN (ops/feature_pyramid_network.py: FeaturePyramidNetwork.forward)
+  const std::string fp = "backbone.fpn.";
+  int last_inner = -1;
+  for (int li = 3; li >= 0; --li) {
+    const int Hl = level_H[li], Wl = level_W[li], cin = kPlanes[li] * 4;
+    const std::string ib = fp + "inner_blocks." + std::to_string(li) + ".0";
+    int res = -1;
+    if (last_inner >= 0) {  // top-down: nearest upsampling of the coarser lateral sum to this level's size
+      Op up; up.kind = OP_RESIZE; up.in_buf = last_inner; up.out_buf = 15; up.H = level_H[li + 1]; up.W = level_W[li + 1]; up.C = 256;
+      up.Ho = Hl; up.Wo = Wl; up.conv = 0;
+      n.ops.push_back(up);
+      want(n, 15, (size_t)Hl * Wl * 256);
+      res = 15;
+    }
+    const int inner = 11 + li;
+    want(n, inner, (size_t)Hl * Wl * 256);
+    int ci = add_conv(n, ib + ".weight", "", "", cin, 256, 1, 1, 0, 0, Hl, Wl, level_buf[li], inner, res);
+    n.convs[ci]->bias_name = ib + ".bias";
+    const std::string lb = fp + "layer_blocks." + std::to_string(li) + ".0";
+    want(n, 16 + li, (size_t)Hl * Wl * 256);
+    int co = add_conv(n, lb + ".weight", "", "", 256, 256, 3, 1, 1, 0, Hl, Wl, inner, 16 + li, -1);
+    n.convs[co]->bias_name = lb + ".bias";
+    last_inner = inner;
+  }
+  // LastLevelMaxPool: max_pool2d(P5, 1, 2, 0)
+  Op sp; sp.kind = OP_RESIZE; sp.in_buf = 19; sp.out_buf = 20; sp.H = level_H[3]; sp.W = level_W[3]; sp.C = 256;
+  sp.Ho = (level_H[3] - 1) / 2 + 1; sp.Wo = (level_W[3] - 1) / 2 + 1; sp.conv = 1;
+  n.ops.push_back(sp);
+  want(n, 20, (size_t)sp.Ho * sp.Wo * 256);
+  for (int li = 0; li < 4; ++li) n.feature_maps.push_back({16 + li, level_H[li], level_W[li], 256});
+  n.feature_maps.push_back({20, sp.Ho, sp.Wo, 256});
+  // RPN head on every level, shared weights (torchvision models/detection/rpn.py: RPNHead: conv 3x3 + ReLU, then
+  // cls_logits 1x1 -> 3 anchors and bbox_pred 1x1 -> 12 deltas): maps 5..9 = objectness [h][w][4] (channel 3 is padding),
+  // maps 10..14 = deltas [h][w][12].  Slot 21 = the shared 3x3 output, 22.. = per-level outputs.
+  const std::string rp = "rpn.head.";
+  for (int l = 0; l < 5; ++l) {
+    const Net::FeatureMap fm = n.feature_maps[l];
+    want(n, 21, (size_t)fm.H * fm.W * 256);
+    int c0 = add_conv(n, rp + "conv.0.0.weight", "", "", 256, 256, 3, 1, 1, 1, fm.H, fm.W, fm.buf, 21, -1);
+    n.convs[c0]->bias_name = rp + "conv.0.0.bias";
+    want(n, 22 + l, (size_t)fm.H * fm.W * 4);
+    int c1 = add_conv(n, rp + "cls_logits.weight", "", "", 256, 4, 1, 1, 0, 0, fm.H, fm.W, 21, 22 + l, -1);
+    n.convs[c1]->bias_name = rp + "cls_logits.bias"; n.convs[c1]->cout_real = 3;
+    want(n, 27 + l, (size_t)fm.H * fm.W * 12);
+    int c2 = add_conv(n, rp + "bbox_pred.weight", "", "", 256, 12, 1, 1, 0, 0, fm.H, fm.W, 21, 27 + l, -1);
+    n.convs[c2]->bias_name = rp + "bbox_pred.bias";
+  }
+  for (int l = 0; l < 5; ++l) n.feature_maps.push_back({22 + l, n.feature_maps[l].H, n.feature_maps[l].W, 4});
+  for (int l = 0; l < 5; ++l) n.feature_maps.push_back({27 + l, n.feature_maps[l].H, n.feature_maps[l].W, 12});
+  n.feat_H = sp.Ho; n.feat_W = sp.Wo; n.n_features = 256;
+  return HP_OK;
+}
+
 int pack_conv(Net& n, ConvLayer& L) {
   const std::vector<float>* w;
-  const size_t numel = (size_t)L.cout * L.cin_real * L.kh * L.kw;
+  const int rows = L.cout_real ? L.cout_real : L.cout;
+  const size_t numel = (size_t)rows * L.cin_real * L.kh * L.kw;
   int rc = need(n, L.wname, numel, &w);
   if (rc) return rc;
   std::vector<float> scale, shift;
   if (!L.bn_after.empty() && (rc = bn_affine(n, L.bn_after, L.cout, scale, shift))) return rc;
   std::vector<float> packed((size_t)L.cout_pad * L.Kpad, 0.f);  // rows padded to whole 64-wide tiles
   const int run = (L.kw * L.cin + 3) / 4 * 4;  // run mode: floats per filter row (30 -> 32)
-  for (int o = 0; o < L.cout; ++o) {
+  for (int o = 0; o < rows; ++o) {
     const float s = scale.empty() ? 1.f : scale[o];
     for (int ci = 0; ci < L.cin_real; ++ci)
       for (int y = 0; y < L.kh; ++y)
@@ -351,6 +453,12 @@ int pack_conv(Net& n, ConvLayer& L) {
       if ((rc = conv_igemm_split_transform_weights((const float*)L.w.p, L.w_isplit.p, L.cout_pad, L.Kpad, nullptr))) return rc;
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
     }
+  }
+  if (!L.bias_name.empty()) {  // the convolution's own bias (no BN on these layers, or added to its shift)
+    const std::vector<float>* b;
+    if ((rc = need(n, L.bias_name, rows, &b))) return rc;
+    if (shift.empty()) shift.assign(L.cout, 0.f);
+    for (int o = 0; o < rows; ++o) shift[o] += (*b)[o];
   }
   if (!shift.empty()) {
     shift.resize(L.cout_pad, 0.f);  // read by whole tiles
@@ -462,13 +570,14 @@ struct hp_net : hp::Net {};
 using namespace hp;
 
 extern "C" hp_net* hp_net_create(int arch, int n_inputs, int h, int w) {
-  if (arch < 0 || arch > HP_ARCH_EFFICIENTNET_B3 || n_inputs < 1 || h < 32 || w < 32) {
+  if (arch < 0 || arch > HP_ARCH_RESNET50_FPN || n_inputs < 1 || h < 32 || w < 32) {
     set_error("hp_net_create: bad architecture / input shape");
     return nullptr;
   }
   hp_net* n = new hp_net();
   n->arch = arch; n->n_inputs = n_inputs; n->c_pad = (n_inputs + 3) / 4 * 4; n->h = h; n->w = w;
-  if ((arch == HP_ARCH_EFFICIENTNET_B3 ? build_graph_efficientnet(*n) : build_graph(*n)) != HP_OK) {
+  if ((arch == HP_ARCH_EFFICIENTNET_B3 ? build_graph_efficientnet(*n) : arch == HP_ARCH_RESNET50_FPN ? build_graph_r50fpn(*n)
+                                                                                                    : build_graph(*n)) != HP_OK) {
     delete n;
     return nullptr;
   }
@@ -506,7 +615,8 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   int rc = conv_setup_once();
   if (rc) return rc;
   const bool f16 = net->precision == HP_PRECISION_F16;
-  HP_REQUIRE(!(f16 && net->arch == HP_ARCH_EFFICIENTNET_B3), "hp_net_finalize: no fp16 plan for EfficientNet");
+  HP_REQUIRE(!(f16 && (net->arch == HP_ARCH_EFFICIENTNET_B3 || net->arch == HP_ARCH_RESNET50_FPN)),
+             "hp_net_finalize: no fp16 plan for EfficientNet / the detector backbone");
   for (auto& D : net->dws)
     if ((rc = pack_dw(*net, *D))) return rc;
   for (auto& S : net->ses)
@@ -710,6 +820,11 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
                           (const float*)S.w1.p, (const float*)S.b1.p, (const float*)S.w2.p, (const float*)S.b2.p, batch, S.HW,
                           S.C, S.Cse, stream)))
         return rc;
+    } else if (op.kind == OP_RESIZE) {
+      if ((rc = prof_end(true))) return rc;
+      if ((rc = launch_resize_nearest((const float*)net->bufs[op.in_buf].p, (float*)net->bufs[op.out_buf].p, batch, op.H, op.W,
+                                      op.C, op.Ho, op.Wo, op.conv, stream)))
+        return rc;
     } else if (op.kind == OP_MAXPOOL && f16) {
       if ((rc = prof_end(true))) return rc;
       if ((rc = launch_maxpool_f16(net->bufs[op.in_buf].p, net->bufs[op.out_buf].p, batch, op.H, op.W, op.C, op.Ho,
@@ -747,6 +862,8 @@ extern "C" int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d
   HP_REQUIRE(d_x, "hp_net_forward: null input");
   HP_REQUIRE(!d_pose || net->pose_dim > 0, "hp_net_forward: network has no pose head");
   HP_REQUIRE(!d_logits || net->n_logits > 0, "hp_net_forward: network has no logits head");
+  HP_REQUIRE(net->feature_maps.empty() || (batch <= net->max_batch && !d_pose && !d_logits && !d_features),
+             "hp_net_forward: a feature-pyramid network takes at most max_batch images and has no heads (hp_net_feature_map)");
   hipStream_t st = (hipStream_t)stream;
   const size_t in_stride = (size_t)net->h * net->w * net->c_pad;
   for (int b0 = 0; b0 < batch; b0 += net->max_batch) {
@@ -758,6 +875,36 @@ extern "C" int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d
     if (rc) return rc;
   }
   return HP_OK;
+}
+
+extern "C" int hp_net_n_feature_maps(const hp_net* net) { return net ? (int)net->feature_maps.size() : HP_ERR_ARG; }
+
+extern "C" int hp_net_feature_map(const hp_net* net, int index, const float** d_ptr, int* h, int* w, int* c) {
+  HP_REQUIRE(net && net->finalized, "hp_net_feature_map: network not finalized");
+  HP_REQUIRE(index >= 0 && index < (int)net->feature_maps.size(), "hp_net_feature_map: no such feature map");
+  const auto& f = net->feature_maps[index];
+  if (d_ptr) *d_ptr = (const float*)net->bufs[f.buf].p;
+  if (h) *h = f.H;
+  if (w) *w = f.W;
+  if (c) *c = f.C;
+  return HP_OK;
+}
+
+extern "C" int hp_net_copy_feature_map(const hp_net* net, int index, int batch, float* d_dst, void* stream) {
+  HP_REQUIRE(net && net->finalized && d_dst, "hp_net_copy_feature_map: bad argument");
+  HP_REQUIRE(index >= 0 && index < (int)net->feature_maps.size(), "hp_net_copy_feature_map: no such feature map");
+  HP_REQUIRE(batch >= 0 && batch <= net->max_batch, "hp_net_copy_feature_map: batch exceeds max_batch");
+  const auto& f = net->feature_maps[index];
+  HP_CHECK_HIP(hipMemcpyAsync(d_dst, net->bufs[f.buf].p, (size_t)batch * f.H * f.W * f.C * sizeof(float), hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream));
+  return HP_OK;
+}
+
+extern "C" int hp_detector_preprocess(const float* d_images, int n, int h, int w, const float* h_mean3, const float* h_std3,
+                                      float* d_x_nhwc4, void* stream) {
+  HP_REQUIRE(d_images && d_x_nhwc4 && h_mean3 && h_std3 && n >= 0 && h > 0 && w > 0, "hp_detector_preprocess: bad argument");
+  if (n == 0) return HP_OK;
+  return launch_normalize_nhwc4(d_images, d_x_nhwc4, n, h, w, h_mean3, h_std3, (hipStream_t)stream);
 }
 
 extern "C" int hp_net_input_channels_f16(const hp_net* net) {

@@ -34,6 +34,37 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* x, float* 
   *reinterpret_cast<float4*>(y + ((int64_t)row * Wo + ow) * C + 4 * c4) = m;
 }
 
+// ---- nearest-neighbour resize (F.interpolate(size=..., mode="nearest"): src = min(floor(dst * in / out), in - 1)) and
+// the stride-2 subsampling max_pool2d(x, 1, 2, 0) of the FPN (torchvision ops/feature_pyramid_network.py:
+// FeaturePyramidNetwork.forward top-down pathway, LastLevelMaxPool), NHWC, 4 channels per lane
+__global__ __launch_bounds__(256) void resize_nearest_nhwc(const float* x, float* y, int H, int W, int C, int Ho, int Wo,
+                                                           int stride_mode, FastDiv fd_c4, FastDiv fd_ho) {
+  const int C4 = C / 4;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Wo * C4) return;
+  const int ow = fdiv(t, fd_c4), c4 = t - ow * C4;
+  const int row = blockIdx.y, img = fdiv(row, fd_ho), oh = row - img * Ho;
+  int ih, iw;
+  if (stride_mode) { ih = 2 * oh; iw = 2 * ow; }
+  else {
+    ih = (int)floorf((float)oh * ((float)H / (float)Ho)); ih = ih < H - 1 ? ih : H - 1;
+    iw = (int)floorf((float)ow * ((float)W / (float)Wo)); iw = iw < W - 1 ? iw : W - 1;
+  }
+  *reinterpret_cast<float4*>(y + ((int64_t)row * Wo + ow) * C + 4 * c4) =
+      *reinterpret_cast<const float4*>(x + (((int64_t)img * H + ih) * W + iw) * C + 4 * c4);
+}
+
+// ---- detector pre-processing: GeneralizedRCNNTransform.normalize ((image - mean) / std per channel,
+// torchvision models/detection/transform.py) + NCHW [b,3,h,w] -> NHWC [b,h,w,4] (pad channel 0)
+__global__ __launch_bounds__(256) void normalize_nchw_to_nhwc4(const float* x, float* y, int64_t hw, int64_t total,
+                                                               float m0, float m1, float m2, float s0, float s1, float s2) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int64_t img = t / hw, p = t - img * hw;
+  const float* src = x + img * 3 * hw + p;
+  *reinterpret_cast<float4*>(y + 4 * t) = make_float4((src[0] - m0) / s0, (src[hw] - m1) / s1, (src[2 * hw] - m2) / s2, 0.f);
+}
+
 // ---- head: spatial mean -> [fc 512x512 + bias] -> pose / logits linear heads -----------
 // one workgroup per sample; features [HW][C] NHWC.
 template <typename T>
@@ -80,6 +111,19 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
       else { if (a.logit_out) a.logit_out[(int64_t)b * a.n_logits + oo] = s + a.logit_b[oo]; }
     }
   }
+}
+
+int launch_resize_nearest(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, int stride_mode, hipStream_t stream) {
+  hipLaunchKernelGGL(resize_nearest_nhwc, dim3((Wo * (C / 4) + 255) / 256, n * Ho), dim3(256), 0, stream, x, y, H, W, C, Ho, Wo,
+                     stride_mode, make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)Ho));
+  return check_launch("resize_nearest_nhwc");
+}
+
+int launch_normalize_nhwc4(const float* x, float* y, int n, int h, int w, const float* mean3, const float* std3, hipStream_t stream) {
+  const int64_t hw = (int64_t)h * w, total = hw * n;
+  hipLaunchKernelGGL(normalize_nchw_to_nhwc4, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, hw, total,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  return check_launch("normalize_nchw_to_nhwc4");
 }
 
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream) {

@@ -20,8 +20,8 @@ from .mesh_store import MeshDataBase, PackedMeshes, RigidObjectDataset, sample_p
 DEPTH_NORM = {None: 0, "none": 0, "tCR_scale": 1, "tCR_scale_clamp_center": 2, "tCR_center_clamp": 3}
 MULTIVIEW = {"TCO": (0, 1), "1view_TCO": (0, 1), "TCO+front_1view": (1, 2),
              "TCO+front_3views": (3, 4), "TCO+front_5views": (5, 6)}
-ARCH = {"vanilla_resnet34": 0, "resnet34": 1, "resnet18": 2, "efficientnet-b3": 3}
-N_FEATURES = {"vanilla_resnet34": 512, "resnet34": 512, "resnet18": 512, "efficientnet-b3": 1536}
+ARCH = {"vanilla_resnet34": 0, "resnet34": 1, "resnet18": 2, "efficientnet-b3": 3, "resnet50-fpn": 4}
+N_FEATURES = {"vanilla_resnet34": 512, "resnet34": 512, "resnet18": 512, "efficientnet-b3": 1536, "resnet50-fpn": 256}
 
 
 def _np_ptr(a):
@@ -351,6 +351,19 @@ class Net:
             check(lib().hp_net_forward(self.handle, ptr(x), b, ptr(pose), ptr(logits), ptr(feats),
                                        stream_ptr(self.device)), "hp_net_forward")
         return pose, logits, feats
+
+    def feature_maps(self, batch: int):
+        """Feature-pyramid networks (``resnet50-fpn``): the output maps of the last ``forward`` as NHWC tensors
+        ``[batch, h, w, c]`` (``hp_net_copy_feature_map``)."""
+        outs = []
+        for i in range(lib().hp_net_n_feature_maps(self.handle)):
+            h, w, c = C.c_int(0), C.c_int(0), C.c_int(0)
+            check(lib().hp_net_feature_map(self.handle, i, None, C.byref(h), C.byref(w), C.byref(c)), "hp_net_feature_map")
+            t = torch.empty((batch, h.value, w.value, c.value), dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                check(lib().hp_net_copy_feature_map(self.handle, i, batch, ptr(t), stream_ptr(self.device)), "hp_net_copy_feature_map")
+            outs.append(t)
+        return outs
 
     def set_profiling(self, on: bool):
         check(lib().hp_net_set_profiling(self.handle, int(on)), "hp_net_set_profiling")

@@ -202,6 +202,11 @@ int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxe
 #define HP_ARCH_WIDE_RESNET34 1
 #define HP_ARCH_WIDE_RESNET18 2
 #define HP_ARCH_EFFICIENTNET_B3 3 /* CP/models/efficientnet.py (CosyPose's released checkpoints): features [b,1536] */
+/* ResNet-50 + FPN, the backbone of the Mask-RCNN detector (MP/models/mask_rcnn.py:22-42 -> torchvision
+ * resnet_fpn_backbone("resnet50")); parameters by the names DetectorMaskRCNN registers ("backbone.body.layer1.0.conv1.weight",
+ * "backbone.fpn.inner_blocks.0.0.weight", ...).  No heads: hp_net_forward(net, x, batch <= max_batch, NULL, NULL, NULL) fills
+ * the five pyramid levels, read back with hp_net_feature_map. */
+#define HP_ARCH_RESNET50_FPN 4
 
 typedef struct hp_net hp_net;
 
@@ -221,6 +226,20 @@ int hp_net_precision(const hp_net* net);
 int hp_net_finalize(hp_net* net, int max_batch);
 int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d_pose, float* d_logits,
                    float* d_features, void* stream);
+/* Feature-pyramid networks (HP_ARCH_RESNET50_FPN): number of output maps ('0', '1', '2', '3', 'pool' of torchvision's
+ * BackboneWithFPN) and the map itself -- NHWC [batch][h][w][c] fp32 in the network's arena, valid until the next forward. */
+int hp_net_n_feature_maps(const hp_net* net);
+int hp_net_feature_map(const hp_net* net, int index, const float** d_ptr, int* h, int* w, int* c);
+/* ... or copied (device to device, asynchronously on `stream`) into caller-owned memory [batch][h][w][c].  For
+ * HP_ARCH_RESNET50_FPN maps 0..4 are the pyramid levels, 5..9 the RPN objectness logits of those levels ([h][w][4], 3 anchors
+ * + one padding channel) and 10..14 the RPN box deltas ([h][w][12]) (torchvision models/detection/rpn.py: RPNHead, keys
+ * "rpn.head.conv.0.0.*", "rpn.head.cls_logits.*", "rpn.head.bbox_pred.*"). */
+int hp_net_copy_feature_map(const hp_net* net, int index, int batch, float* d_dst, void* stream);
+/* GeneralizedRCNNTransform.normalize of the detector (torchvision models/detection/transform.py: (image - mean) / std per
+ * channel; MaskRCNN defaults mean (0.485, 0.456, 0.406), std (0.229, 0.224, 0.225)) fused with the layout change the conv
+ * stack wants: d_images NCHW [n][3][h][w] in [0,1] (ObservationTensor.images[:, :3]) -> d_x NHWC [n][h][w][4], pad channel 0. */
+int hp_detector_preprocess(const float* d_images, int n, int h, int w, const float* h_mean3, const float* h_std3,
+                           float* d_x_nhwc4, void* stream);
 /* fp16 plan only: the input already in fp16, NHWC [batch][h][w][hp_net_input_channels_f16()] with the
  * channels past n_inputs zero (hp_crop_roi_align_f16 / hp_rasterize with HP_RASTER_OUT_F16 write it):
  * saves the fp32 -> fp16 conversion pass of hp_net_forward (5 % of a coarse-scoring step). */

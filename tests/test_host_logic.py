@@ -259,3 +259,21 @@ def test_legacy_keys_and_config_defaults_golden(golden_dir):
         # fields only this implementation adds are defaults the reference reads from TrainingConfig
         assert set(got) - set(want) <= {"views_inplane_rotations", "depth_normalization_type", "backbone_str", "renderer",
                                         "render_normals", "render_depth", "input_depth"}
+
+
+def test_detector_oracle_shapes():
+    """oracle/detector.py (torchvision ResNet-50 + FPN + RPN head restated): key list / parameter count of the reference's
+    DetectorMaskRCNN backbone and the pyramid geometry on a small image."""
+    from happypose_amd.synthetic import named_weights
+    from oracle import detector as od
+
+    s = od.param_shapes()
+    assert len(s) == 340 and s["backbone.body.layer4.2.conv3.weight"] == (2048, 512, 1, 1)
+    assert s["backbone.fpn.inner_blocks.3.0.weight"] == (256, 2048, 1, 1) and s["rpn.head.bbox_pred.bias"] == (12,)
+    n_par = sum(int(np.prod(v)) for k, v in s.items() if not k.endswith("num_batches_tracked"))
+    assert abs(n_par / 1e6 - 27.5) < 0.1  # 23.5 M (ResNet-50 without fc) + 3.3 M (FPN) + 0.6 M (RPN head)
+    with torch.no_grad():
+        out = od.backbone_fpn_rpn(torch.rand(1, 3, 64, 96), named_weights(s, seed=1))
+    assert [tuple(f.shape[-2:]) for f in out["features"]] == [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    assert all(o.shape[1] == 3 for o in out["objectness"]) and all(d.shape[1] == 12 for d in out["deltas"])
+    assert all(torch.isfinite(f).all() for f in out["features"])
