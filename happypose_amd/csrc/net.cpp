@@ -58,6 +58,7 @@ struct ConvLayer {
   // fp16 plan: cin rounded to 8, K to 64; packed halves, LUT per 8-half chunk, prologue in halves
   int cin16 = 0, Kpad16 = 0;
   DevBuf w16, lut16, pre_scale16, pre_shift16;
+  DevBuf w_stem7;          // 7x7 stems followed by the max-pool: weights packed for conv_stem7.hip (fp32 or fp16 plan)
 };
 
 // one timed stretch of conv launches: a single launch (per-layer table, HP_PROFILE_LAYERS) or a run of
@@ -454,6 +455,16 @@ int pack_conv(Net& n, ConvLayer& L) {
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
     }
   }
+  if (conv_stem7_applicable(L.kh, L.kw, L.stride, L.pad, L.cin, L.cout, L.relu, 0) && !L.run_mode && L.bn_before.empty()) {
+    std::vector<float> wf(numel);
+    for (int o = 0; o < L.cout; ++o) {
+      const float sc = scale.empty() ? 1.f : scale[o];
+      for (size_t i = 0; i < (size_t)L.cin_real * 49; ++i) wf[(size_t)o * L.cin_real * 49 + i] = (*w)[(size_t)o * L.cin_real * 49 + i] * sc;
+    }
+    std::vector<unsigned char> pk(conv_stem7_pack_weights(wf.data(), L.cin_real, L.cin, 0, nullptr));
+    conv_stem7_pack_weights(wf.data(), L.cin_real, L.cin, 0, pk.data());
+    if ((rc = L.w_stem7.upload(pk.data(), pk.size()))) return rc;
+  }
   if (!L.bias_name.empty()) {  // the convolution's own bias (no BN on these layers, or added to its shift)
     const std::vector<float>* b;
     if ((rc = need(n, L.bias_name, rows, &b))) return rc;
@@ -541,6 +552,16 @@ int pack_conv_f16(Net& n, ConvLayer& L) {
               (_Float16)((*w)[(((size_t)o * L.cin_real + ci) * L.kh + y) * L.kw + x] * s);
   }
   if ((rc = L.w16.upload(packed.data(), packed.size() * 2))) return rc;
+  if (conv_stem7_applicable(L.kh, L.kw, L.stride, L.pad, L.cin16, L.cout, L.relu, 1) && L.bn_before.empty()) {
+    std::vector<float> wf(numel);
+    for (int o = 0; o < L.cout; ++o) {
+      const float sc = scale.empty() ? 1.f : scale[o];
+      for (size_t i = 0; i < (size_t)L.cin_real * 49; ++i) wf[(size_t)o * L.cin_real * 49 + i] = (*w)[(size_t)o * L.cin_real * 49 + i] * sc;
+    }
+    std::vector<unsigned char> pk(conv_stem7_pack_weights(wf.data(), L.cin_real, L.cin16, 1, nullptr));
+    conv_stem7_pack_weights(wf.data(), L.cin_real, L.cin16, 1, pk.data());
+    if ((rc = L.w_stem7.upload(pk.data(), pk.size()))) return rc;
+  }
   if (!shift.empty() && (rc = L.bias.upload(shift.data(), shift.size() * 4))) return rc;
   if (!L.bn_before.empty()) {
     std::vector<float> ps, pb;
@@ -730,8 +751,20 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       a.x_bytes = (int64_t)batch * L.H * L.W * L.cin16 * 2;
       a.w_bytes = (int64_t)L.cout * L.Kpad16 * 2;
       if ((rc = prof_begin(op.conv))) return rc;
-      if ((rc = launch_conv_f16(a, stream))) return rc;
-      prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout * L.Kpad16);
+      const Op* next16 = op_index < (int)net->ops.size() ? &net->ops[op_index] : nullptr;
+      if (L.w_stem7.p && !no_fuse && next16 && next16->kind == OP_MAXPOOL && next16->in_buf == L.out_buf && next16->H == L.Ho &&
+          next16->W == L.Wo) {
+        // stem + ReLU + max-pool in one launch (conv_stem7.hip): the conv map is never written
+        ConvArgs s7{};
+        s7.x = (const float*)a.x; s7.w = (const float*)L.w_stem7.p; s7.bias = a.bias; s7.y = (float*)net->bufs[next16->out_buf].p;
+        s7.M = a.M; s7.H = L.H; s7.W = L.W; s7.Cin = L.cin16; s7.Ho = L.Ho; s7.Wo = L.Wo; s7.Cout = L.cout; s7.relu = L.relu;
+        if ((rc = launch_conv_stem7_pool(s7, 1, stream))) return rc;
+        pool_fused = true;
+        prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, 2.0 * (double)a.M * (256.0 / 192.0) * L.cout * 7 * 112);
+      } else {
+        if ((rc = launch_conv_f16(a, stream))) return rc;
+        prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout * L.Kpad16);
+      }
       if ((rc = prof_end(false))) return rc;
     } else if (op.kind == OP_CONV) {
       ConvLayer& L = *net->convs[op.conv];
@@ -760,7 +793,18 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       // FLOPs the matrix cores actually execute (padded tiles / K included): 16 multiplies per
       // 2x2 output tile, cin and cout for the Winograd layers, M x Cout x Kpad otherwise
       const bool wino_ok = algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINOGRAD_1WAVE || algo == HP_CONV_ALGO_WINOGRAD;
-      if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_split.p && conv_split_launchable(a)) {
+      const Op* next7 = op_index < (int)net->ops.size() ? &net->ops[op_index] : nullptr;
+      if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_stem7.p && !no_fuse && next7 && next7->kind == OP_MAXPOOL &&
+          next7->in_buf == L.out_buf && next7->H == L.Ho && next7->W == L.Wo) {
+        // MegaPose stem + ReLU + max-pool in one launch, the input region of a pooled tile staged once per channel slab
+        a.w = (const float*)L.w_stem7.p;
+        a.y = (float*)net->bufs[next7->out_buf].p;
+        a.status = net->d_status;
+        rc = launch_conv_stem7_pool(a, 0, stream);
+        pool_fused = true;
+        const int sc = L.cin % 8 == 0 ? 8 : 4, ks = (7 * sc + 15) / 16;
+        mfma_flops = 3.0 / 16.0 * 2.0 * (double)a.M * (256.0 / 192.0) * L.cout * (L.cin / sc) * 7.0 * ks * 16.0;
+      } else if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_split.p && conv_split_launchable(a)) {
         a.w = (const float*)L.w_split.p;
         a.status = net->d_status;
         rc = launch_conv_split(a, stream);
@@ -825,6 +869,9 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       if ((rc = launch_resize_nearest((const float*)net->bufs[op.in_buf].p, (float*)net->bufs[op.out_buf].p, batch, op.H, op.W,
                                       op.C, op.Ho, op.Wo, op.conv, stream)))
         return rc;
+    } else if (op.kind == OP_MAXPOOL && pool_fused) {
+      pool_fused = false;
+      if ((rc = prof_end(true))) return rc;
     } else if (op.kind == OP_MAXPOOL && f16) {
       if ((rc = prof_end(true))) return rc;
       if ((rc = launch_maxpool_f16(net->bufs[op.in_buf].p, net->bufs[op.out_buf].p, batch, op.H, op.W, op.C, op.Ho,
