@@ -355,7 +355,7 @@ int conv_igemm_split_transform_weights(const float* d_w, void* d_ws, int rows_pa
 // tiles, variant 1: 64-wide); a.pre_scale needs a.pre_shift (no squeeze-excitation gate), no swish
 bool conv_igemm_split_launchable(const ConvArgs& a) {
   static const bool off = std::getenv("HP_CONV_NO_SPLIT") != nullptr;
-  return !off && (a.pre_shift || !a.pre_scale) && a.relu != HP_ACT_SWISH && a.Kpad % 32 == 0;
+  return !off && (a.pre_shift || !a.pre_scale) && a.Kpad % 32 == 0;
 }
 
 int launch_conv_igemm_split(const ConvArgs& a, int variant, hipStream_t stream) {

@@ -449,7 +449,7 @@ int pack_conv(Net& n, ConvLayer& L) {
       if ((rc = L.w_split.alloc(conv_split_weight_bytes(L.cout, L.cin)))) return rc;
       if ((rc = conv_split_transform_weights((const float*)L.w.p, L.w_split.p, L.cout, L.cin, L.Kpad, L.stride, nullptr))) return rc;
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
-    } else if (L.relu != HP_ACT_SWISH && !L.se && L.Kpad % 32 == 0) {
+    } else if (!L.se && L.Kpad % 32 == 0) {  // swish layers too (the shared epilogue applies it); not the SE-gated projections
       if ((rc = L.w_isplit.alloc(conv_igemm_split_weight_bytes(L.cout_pad, L.Kpad)))) return rc;
       if ((rc = conv_igemm_split_transform_weights((const float*)L.w.p, L.w_isplit.p, L.cout_pad, L.Kpad, nullptr))) return rc;
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
