@@ -59,6 +59,8 @@ _PROTOS = {
                                         c_f32p, C.c_int, c_i32p, c_i32p, C.c_int, c_f32p, C.c_void_p]),
     "hp_net_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "hp_net_destroy": (None, [C.c_void_p]),
+    "hp_net_add_conv": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p] + [C.c_int] * 11),
+    "hp_net_add_output": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "hp_net_input_channels_padded": (C.c_int, [C.c_void_p]),
     "hp_net_set_param": (C.c_int, [C.c_void_p, C.c_char_p, c_f32p, C.c_int64]),
     "hp_net_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
@@ -85,6 +87,14 @@ _PROTOS = {
     "hp_conv_select_algo": (C.c_int, [C.c_int]),
     "hp_net_profile_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "hp_rpn_decode": (C.c_int, [c_f32p, c_i32p, C.c_int, c_f32p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float,
+                                C.c_float, C.c_float, c_f32p, c_f32p, c_u8p, C.c_void_p]),
+    "hp_nms": (C.c_int, [c_f32p, c_i32p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "hp_roi_align_levels": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int,
+                                      C.c_int, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_void_p]),
+    "hp_box_postprocess": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p,
+                                     c_f32p, C.c_void_p]),
+    "hp_paste_masks": (C.c_int, [c_f32p, C.c_int, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "hp_icp_refine": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 c_f32p, c_f32p, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p, C.c_void_p, c_f32p,
                                 C.c_void_p]),

@@ -591,18 +591,47 @@ struct hp_net : hp::Net {};
 using namespace hp;
 
 extern "C" hp_net* hp_net_create(int arch, int n_inputs, int h, int w) {
-  if (arch < 0 || arch > HP_ARCH_RESNET50_FPN || n_inputs < 1 || h < 32 || w < 32) {
+  if (arch < 0 || arch > HP_ARCH_CUSTOM || n_inputs < 1 || h < (arch == HP_ARCH_CUSTOM ? 1 : 32) || w < (arch == HP_ARCH_CUSTOM ? 1 : 32)) {
     set_error("hp_net_create: bad architecture / input shape");
     return nullptr;
   }
   hp_net* n = new hp_net();
   n->arch = arch; n->n_inputs = n_inputs; n->c_pad = (n_inputs + 3) / 4 * 4; n->h = h; n->w = w;
+  if (arch == HP_ARCH_CUSTOM) return n;  // the caller describes the graph: hp_net_add_conv / hp_net_add_output
   if ((arch == HP_ARCH_EFFICIENTNET_B3 ? build_graph_efficientnet(*n) : arch == HP_ARCH_RESNET50_FPN ? build_graph_r50fpn(*n)
                                                                                                     : build_graph(*n)) != HP_OK) {
     delete n;
     return nullptr;
   }
   return n;
+}
+
+// ---- HP_ARCH_CUSTOM: a feed-forward graph of convolutions described by the caller (the detector's RoI heads) ----
+extern "C" int hp_net_add_conv(hp_net* net, const char* weight_name, const char* bias_name, int cin, int cout, int k, int stride,
+                               int pad, int act, int H, int W, int in_slot, int out_slot, int res_slot) {
+  HP_REQUIRE(net && net->arch == HP_ARCH_CUSTOM && !net->finalized, "hp_net_add_conv: needs an unfinalized HP_ARCH_CUSTOM network");
+  HP_REQUIRE(weight_name && cin >= 1 && cout >= 1 && k >= 1 && (stride == 1 || stride == 2) && pad >= 0 && H >= 1 && W >= 1,
+             "hp_net_add_conv: bad layer geometry");
+  HP_REQUIRE(act >= HP_ACT_NONE && act <= HP_ACT_RELU, "hp_net_add_conv: activation must be none or ReLU");
+  HP_REQUIRE(in_slot >= -1 && in_slot < 32 && out_slot >= 0 && out_slot < 32 && res_slot >= -1 && res_slot < 32 && out_slot != in_slot &&
+                 out_slot != res_slot, "hp_net_add_conv: bad arena slots");
+  HP_REQUIRE(in_slot >= 0 || (cin == net->n_inputs && H == net->h && W == net->w), "hp_net_add_conv: the first layer must match the network input");
+  HP_REQUIRE((H + 2 * pad - k) / stride + 1 >= 1 && (W + 2 * pad - k) / stride + 1 >= 1, "hp_net_add_conv: empty output");
+  const int cout4 = (cout + 3) / 4 * 4;  // rows rounded up to 4 (zero rows): outputs are read as [.., cout4]
+  const int c = add_conv(*net, weight_name, "", "", cin, cout4, k, stride, pad, act, H, W, in_slot, out_slot, res_slot);
+  ConvLayer& L = *net->convs[c];
+  if (cout4 != cout) L.cout_real = cout;
+  if (bias_name && bias_name[0]) L.bias_name = bias_name;
+  want(*net, out_slot, (size_t)L.Ho * L.Wo * cout4);
+  return HP_OK;
+}
+
+extern "C" int hp_net_add_output(hp_net* net, int slot, int H, int W, int C) {
+  HP_REQUIRE(net && net->arch == HP_ARCH_CUSTOM && !net->finalized, "hp_net_add_output: needs an unfinalized HP_ARCH_CUSTOM network");
+  HP_REQUIRE(slot >= 0 && slot < (int)net->buf_floats_per_sample.size() && (size_t)H * W * C <= net->buf_floats_per_sample[slot],
+             "hp_net_add_output: no such slot / shape larger than the slot");
+  net->feature_maps.push_back({slot, H, W, C});
+  return HP_OK;
 }
 
 extern "C" void hp_net_destroy(hp_net* net) {

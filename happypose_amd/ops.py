@@ -412,6 +412,47 @@ class Net:
         return list(zip(list(a), list(b)))
 
 
+class GraphNet(Net):
+    """``HP_ARCH_CUSTOM``: a feed-forward graph of convolutions described layer by layer (the detector's RoI heads).
+    ``layers``: dicts ``weight, bias, cin, cout, k, stride, pad, relu, H, W, src, dst, res`` in execution order
+    (``src = -1`` = the network input, arena slots 0..31); ``outputs``: ``(slot, H, W, C)`` read back by
+    :meth:`Net.feature_maps` (``C`` rounded up to 4)."""
+
+    def __init__(self, c_in: int, h: int, w: int, layers, outputs, state_dict, max_batch: int, device="cuda"):
+        self.device = torch.device(device)
+        self.arch, self.n_inputs, self.h, self.w, self.precision = "custom", c_in, h, w, "f32"
+        self.n_features = self.pose_dim = self.n_logits = 0
+        with torch.cuda.device(self.device):
+            self._h = lib().hp_net_create(5, c_in, h, w)
+            if not self._h:
+                raise _ffi.HipLibraryError("hp_net_create: " + lib().hp_last_error().decode())
+            for L in layers:
+                check(lib().hp_net_add_conv(self.handle, L["weight"].encode(), (L.get("bias") or "").encode(), L["cin"], L["cout"], L["k"],
+                                            L.get("stride", 1), L.get("pad", 0), int(L.get("relu", False)), L["H"], L["W"], L["src"],
+                                            L["dst"], L.get("res", -1)), f"hp_net_add_conv({L['weight']})")
+            for slot, oh, ow, oc in outputs:
+                check(lib().hp_net_add_output(self.handle, slot, oh, ow, (oc + 3) // 4 * 4), "hp_net_add_output")
+            for name, value in state_dict.items():
+                arr = value.detach().cpu().numpy() if isinstance(value, torch.Tensor) else np.asarray(value)
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+                check(lib().hp_net_set_param(self.handle, name.encode(), _np_ptr(arr), arr.size), f"hp_net_set_param({name})")
+            check(lib().hp_net_finalize(self.handle, max_batch), "hp_net_finalize")
+        self.c_pad = lib().hp_net_input_channels_padded(self.handle)
+        self.max_batch = max_batch
+        self.flops_per_sample = lib().hp_net_flops_per_sample(self.handle)
+
+    def run(self, x: torch.Tensor):
+        """``x [n,h,w,c_in]`` NHWC fp32 -> list of output maps ``[n,oh,ow,oc4]`` (chunks of ``max_batch``)."""
+        n = x.shape[0]
+        outs = None
+        for s in range(0, n, self.max_batch):
+            xb = x[s:s + self.max_batch].contiguous()
+            self.forward(xb, want_pose=False)
+            maps = self.feature_maps(xb.shape[0])
+            outs = [[m] for m in maps] if outs is None else [o + [m] for o, m in zip(outs, maps)]
+        return [torch.cat(o) for o in outs] if outs is not None else []
+
+
 STATUS_NONFINITE, STATUS_EXACT_ONLY = 1, 2
 
 

@@ -208,10 +208,21 @@ int hp_tco_init_autodepth(const hp_mesh_store* store, int n, const float* d_boxe
  * the five pyramid levels, read back with hp_net_feature_map. */
 #define HP_ARCH_RESNET50_FPN 4
 
+/* A feed-forward graph of convolutions the CALLER describes (the detector's RoI heads: fully connected layers are 7x7 /
+ * 1x1 convolutions on [n][7][7][256], the mask head 3x3 convolutions on [n][14][14][256]).  hp_net_create(HP_ARCH_CUSTOM,
+ * c_in, h, w), then hp_net_add_conv per layer in execution order (arena slots 0..31; in_slot -1 = the network input;
+ * weight [cout][cin][k][k] and optional bias [cout] by parameter name; act 0 none / 1 ReLU; res_slot >= 0 adds that slot
+ * before the activation), hp_net_add_output for every slot to read back, hp_net_set_param, hp_net_finalize, hp_net_forward
+ * (heads NULL), hp_net_copy_feature_map.  Output channel counts are rounded up to 4 (zero rows). */
+#define HP_ARCH_CUSTOM 5
+
 typedef struct hp_net hp_net;
 
 hp_net* hp_net_create(int arch, int n_inputs, int h, int w);
 void hp_net_destroy(hp_net* net);
+int hp_net_add_conv(hp_net* net, const char* weight_name, const char* bias_name, int cin, int cout, int k, int stride, int pad,
+                    int act, int H, int W, int in_slot, int out_slot, int res_slot);
+int hp_net_add_output(hp_net* net, int slot, int H, int W, int C);
 int hp_net_input_channels_padded(const hp_net* net);
 int hp_net_set_param(hp_net* net, const char* name, const float* h_data, int64_t numel);
 /* Arithmetic of the conv stack, to be chosen before hp_net_finalize:
@@ -322,6 +333,39 @@ int hp_icp_refine(int n, int B, int H, int W, const float* d_depth_rendered, con
                   const float* d_TCO, int n_iterations, int n_min_points, float tolerance,
                   float depth_delta_thresh, float* d_TCO_out, int32_t* d_retval, float* d_residual,
                   void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Detector stages that are not convolutions (the reference's Detector.get_detections, MP/inference/detector.py:34-156, runs
+ * torchvision's MaskRCNN.forward; file references below are torchvision 0.14.1, pinned by the reference's pyproject.toml).
+ * The dense networks are hp_net objects: HP_ARCH_RESNET50_FPN (backbone + FPN + RPN head) and two HP_ARCH_CUSTOM graphs
+ * (box head, mask head).
+ *  hp_rpn_decode: for the n anchors a pyramid level's top-k selected (d_anchor_idx = (y * map_w + x) * 3 + a, objectness
+ *    logits gathered alongside): AnchorGenerator.grid_anchors (anchor_utils.py), BoxCoder.decode with weights (1,1,1,1) and
+ *    the log(1000/16) clamp (_utils.py), clip_boxes_to_image, remove_small_boxes(min_size) as a validity flag, sigmoid
+ *    (rpn.py: RegionProposalNetwork.filter_proposals).  d_deltas_map = that level's [h][map_w][12] map of ONE image.
+ *  hp_nms: boxes sorted by decreasing score; h_keep[i] = 1 when box i survives greedy suppression (IoU > threshold) inside its
+ *    group (ops/boxes.py: batched_nms).  Pairwise masks on the device, greedy pass on the host: SYNCHRONISES `stream`.
+ *  hp_roi_align_levels: MultiScaleRoIAlign (ops/poolers.py): level k = floor(4 + log2(sqrt(area) / 224) + 1e-6) clamped to
+ *    [k_min, k_min + n_levels), then roi_align(aligned=False) with spatial_scale h_scales[level] on that NHWC map
+ *    [n_img][h][w][C]; d_rois [K][5] = image index, x1, y1, x2, y2 (image coordinates); d_out [K][out][out][C].
+ *  hp_box_postprocess: softmax over n_classes + BoxCoder.decode with weights (10,10,5,5) per class + clip
+ *    (roi_heads.py: postprocess_detections); d_scores [n][n_classes], d_boxes [n][n_classes][4].
+ *  hp_paste_masks: maskrcnn_inference + paste_masks_in_image (roi_heads.py): sigmoid of channel d_labels[k] of the mask
+ *    logits [n][14][14][2][2][ld] (the mask head's 2x2 deconvolution kept as four 1x1 convolutions), padding 1, box expanded
+ *    and truncated to integers, bilinear resize (align_corners=False) to the box, pasted into d_out [n][H][W] (0 elsewhere).
+ * ---------------------------------------------------------------------------------- */
+int hp_rpn_decode(const float* d_objectness, const int32_t* d_anchor_idx, int n, const float* d_deltas_map, int map_w,
+                  int n_anchors, const float* h_base_anchors /* [3][4] */, int stride_h, int stride_w, float im_h, float im_w,
+                  float min_size, float* d_boxes, float* d_scores, uint8_t* d_valid, void* stream);
+int hp_nms(const float* d_boxes, const int32_t* d_group, int n, float iou_threshold, uint8_t* h_keep, void* stream);
+int hp_roi_align_levels(const float* const* h_feat_ptrs, const int* h_heights, const int* h_widths, const float* h_scales,
+                        int n_levels, int k_min, int C, const float* d_rois, int K, int out_size, int sampling_ratio, float* d_out,
+                        int32_t* d_levels /* [K] or NULL */, void* stream);
+int hp_box_postprocess(const float* d_class_logits, int ld_logits, const float* d_box_regression, int ld_regression,
+                       const float* d_proposals, int n, int n_classes, float im_h, float im_w, float* d_scores, float* d_boxes,
+                       void* stream);
+int hp_paste_masks(const float* d_mask_logits, int ld, const int32_t* d_labels, const float* d_boxes, int n, int H, int W,
+                   float* d_out, void* stream);
 
 /* Single layer entry (used by the parity tests of the conv kernels themselves):
  * y[n][ho][wo][cout] = act( conv(x_act, w) + bias + residual ),   act = relu: 0 none, 1 ReLU, 2 swish
