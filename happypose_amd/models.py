@@ -230,7 +230,7 @@ def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Op
         n_rendered_views=cfg.n_rendered_views, views_inplane_rotations=cfg.views_inplane_rotations,
         multiview_type=mv, render_normals=cfg.render_normals, render_depth=cfg.render_depth,
         input_depth=cfg.input_depth, predict_rendered_views_logits=cfg.predict_rendered_views_logits,
-        remove_TCO_rendering=False, predict_pose_update=cfg.predict_pose_update,
+        remove_TCO_rendering=cfg.remove_TCO_rendering, predict_pose_update=cfg.predict_pose_update,
         depth_normalization_type=cfg.depth_normalization_type)
     model.cfg = model.config = cfg
     return model

@@ -176,8 +176,14 @@ class PosePredictor(_RenderAndCompare):
                  n_rendered_views: int = 1, input_depth: bool = False, render_depth: bool = False,
                  depth_normalization_type: Optional[str] = None):
         self._setup(backbone, renderer, mesh_db, render_size)
-        if views_inplane_rotations or remove_TCO_rendering:
-            raise NotImplementedError("views_inplane_rotations / remove_TCO_rendering (unused by the released models)")
+        # views_inplane_rotations only reaches make_TCO_multiview from the training loss
+        # (MP/training/megapose_forward_loss.py:122); forward_refiner / forward_coarse never pass it
+        # (MP/models/pose_rigid.py:578-584), so at inference the flag is stored and has no effect -- same here.
+        self.views_inplane_rotations = views_inplane_rotations
+        # remove_TCO_rendering is read by forward_refiner only (forward_coarse renders the hypothesis itself,
+        # MP/models/pose_rigid.py:483-532): coarse models may carry it, refiners without the TCO view are not built
+        if remove_TCO_rendering and predict_pose_update:
+            raise NotImplementedError("refiner with remove_TCO_rendering (unused by the released models)")
         # legacy names (MP/training/pose_models_cfg.py:48-53)
         multiview_type = {"front_3views": "TCO+front_3views", "front_5views": "TCO+front_5views",
                           "front_1view": "TCO+front_1view"}.get(multiview_type, multiview_type)

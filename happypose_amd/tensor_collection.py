@@ -1,100 +1,117 @@
-"""Result containers of the path: named tensors + a pandas ``infos`` frame.
+"""Result containers of the path: a table of rows whose columns are batched tensors, optionally
+with a pandas ``infos`` frame holding the non-tensor columns.
 
-API-compatible with the reference's ``TensorCollection`` /
-``PandasTensorCollection`` / ``concatenate`` / ``filter_top_pose_estimates``
-(``TB/utils/tensor_collection.py:28-230``): tensors are reachable as attributes,
-``coll[ids]`` indexes every tensor and ``infos.iloc`` together and re-numbers the
-index, ``len(coll) == len(coll.infos)``.  The file-based multi-rank gather of the
-reference (``:166-187``) is replaced by ``happypose_amd.distributed.gather_poses``
-(one RCCL all-gather); ``gather_distributed`` is kept as a thin wrapper.
+Drop-in for the names the reference's callers use (``TensorCollection``,
+``PandasTensorCollection``, ``concatenate``, ``filter_top_pose_estimates``;
+``TB/utils/tensor_collection.py:28-230``): tensors are reachable as attributes, ``coll[ids]``
+selects the same rows of every tensor and of ``infos`` and renumbers the frame,
+``len(coll) == len(coll.infos)``.  The implementation is organised differently: both classes
+are one row table (``_RowTable``) whose operations are expressed as *map every column* /
+*rebuild with new columns*, the conversions (``cuda``, ``half`` ...) are generated from a table, and
+the multi-rank gather goes through one all-gather (``happypose_amd.distributed``) instead of the
+reference's rank files (``:166-187``).
 """
 
 from __future__ import annotations
 
-from typing import Dict, List
+from typing import Callable, Dict, List, Optional
 
 import pandas as pd
 import torch
 
+_CONVERSIONS = {"cuda": "cuda", "cpu": "cpu", "float": torch.float, "double": torch.double, "half": torch.half}
 
-class TensorCollection:
-    def __init__(self, **tensors):
-        object.__setattr__(self, "_tensors", {})
-        for name, value in tensors.items():
-            self.register_tensor(name, value)
 
-    # -- registry -----------------------------------------------------------------
-    def register_tensor(self, name: str, tensor) -> None:
-        self._tensors[name] = tensor
+class _RowTable:
+    """Columns (name -> tensor with the rows on dim 0) plus optional per-row ``infos``."""
 
-    def delete_tensor(self, name: str) -> None:
-        del self._tensors[name]
+    _has_infos = False
 
+    def _init_columns(self, tensors: Dict[str, torch.Tensor]) -> None:
+        # the column dict lives in __dict__ directly so that __setattr__ can tell columns from
+        # ordinary attributes
+        self.__dict__["_tensors"] = dict(tensors)
+
+    # -- columns ------------------------------------------------------------------
     @property
     def tensors(self) -> Dict[str, torch.Tensor]:
-        return self._tensors
+        return self.__dict__["_tensors"]
+
+    def register_tensor(self, name: str, tensor) -> None:
+        self.tensors[name] = tensor
+
+    def delete_tensor(self, name: str) -> None:
+        self.tensors.pop(name)
 
     @property
     def device(self):
-        return next(iter(self._tensors.values())).device
+        for t in self.tensors.values():
+            return t.device
+        raise ValueError("empty collection has no device")
 
-    # -- attribute access ---------------------------------------------------------
     def __getattr__(self, name):
-        tensors = self.__dict__.get("_tensors")
-        if tensors is not None and name in tensors:
-            return tensors[name]
-        raise AttributeError(name)
+        # only called when normal lookup fails: columns read as attributes
+        cols = self.__dict__.get("_tensors")
+        if cols is None or name not in cols:
+            raise AttributeError(name)
+        return cols[name]
 
     def __setattr__(self, name, value):
-        if "_tensors" not in self.__dict__:
+        cols = self.__dict__.get("_tensors")
+        if cols is None:
             raise ValueError("Please call __init__")
-        if name in self._tensors:
-            self._tensors[name] = value
+        if name in cols:
+            cols[name] = value
         else:
-            object.__setattr__(self, name, value)
+            self.__dict__[name] = value
 
-    def __getitem__(self, ids):
-        return TensorCollection(**{k: v[ids] for k, v in self._tensors.items()})
+    # -- the two primitives everything else is written with ------------------------------
+    def _rebuild(self, tensors: Dict[str, torch.Tensor], infos: Optional[pd.DataFrame] = None):
+        if self._has_infos:
+            return type(self)(self.infos if infos is None else infos, **tensors)
+        return type(self)(**tensors)
 
-    def __repr__(self):
-        rows = "".join(f"    {k}: {tuple(t.shape)} {t.dtype} {t.device},\n" for k, t in self._tensors.items())
-        return f"{type(self).__name__}(\n{rows})"
+    def _mapped(self, fn: Callable[[torch.Tensor], torch.Tensor]) -> Dict[str, torch.Tensor]:
+        return {name: fn(t) for name, t in self.tensors.items()}
 
-    # -- pickling -----------------------------------------------------------------
-    def __getstate__(self):
-        return {"tensors": self._tensors}
-
-    def __setstate__(self, state):
-        self.__init__(**state["tensors"])
-
-    # -- device / dtype -----------------------------------------------------------
+    # -- conversions (in place, like the reference; they return self for chaining) ---------
     def to(self, torch_attr):
-        for k, v in self._tensors.items():
-            self._tensors[k] = v.to(torch_attr)
+        self.tensors.update(self._mapped(lambda t: t.to(torch_attr)))
         return self
 
-    def cuda(self):
-        return self.to("cuda")
-
-    def cpu(self):
-        return self.to("cpu")
-
-    def float(self):
-        return self.to(torch.float)
-
-    def double(self):
-        return self.to(torch.double)
-
-    def half(self):
-        return self.to(torch.half)
-
     def clone(self):
-        return TensorCollection(**{k: v.clone() for k, v in self._tensors.items()})
+        return self._rebuild(self._mapped(torch.clone), self.infos.copy() if self._has_infos else None)
+
+    def _describe_columns(self) -> str:
+        return "".join(f"    {n}: {tuple(t.shape)} {t.dtype} {t.device},\n" for n, t in self.tensors.items())
 
 
-class PandasTensorCollection(TensorCollection):
+for _name, _target in _CONVERSIONS.items():
+    setattr(_RowTable, _name, (lambda target: lambda self: self.to(target))(_target))
+
+
+class TensorCollection(_RowTable):
+    def __init__(self, **tensors):
+        self._init_columns(tensors)
+
+    def __getitem__(self, ids):
+        return self._rebuild(self._mapped(lambda t: t[ids]))
+
+    def __repr__(self):
+        return f"{type(self).__name__}(\n{self._describe_columns()})"
+
+    def __getstate__(self):
+        return {"tensors": self.tensors}
+
+    def __setstate__(self, state):
+        self._init_columns(state["tensors"])
+
+
+class PandasTensorCollection(_RowTable):
+    _has_infos = True
+
     def __init__(self, infos: pd.DataFrame, **tensors):
-        super().__init__(**tensors)
+        self._init_columns(tensors)
         self.infos = infos.reset_index(drop=True)
         self.meta = {}
 
@@ -102,60 +119,51 @@ class PandasTensorCollection(TensorCollection):
         return len(self.infos)
 
     def __getitem__(self, ids):
-        if isinstance(ids, torch.Tensor):
-            pos = ids.cpu().numpy()
-        else:
-            pos = ids
-        infos = self.infos.iloc[pos].reset_index(drop=True)
-        return PandasTensorCollection(infos, **{k: v[ids] for k, v in self._tensors.items()})
+        rows = ids.cpu().numpy() if isinstance(ids, torch.Tensor) else ids
+        return self._rebuild(self._mapped(lambda t: t[ids]), self.infos.iloc[rows])
 
     def merge_df(self, df, *args, **kwargs):
-        infos = self.infos.merge(df, how="left", *args, **kwargs)
-        assert len(infos) == len(self.infos)
-        return PandasTensorCollection(infos=infos, **self._tensors)
-
-    def clone(self):
-        return PandasTensorCollection(self.infos.copy(), **{k: v.clone() for k, v in self._tensors.items()})
+        merged = self.infos.merge(df, how="left", *args, **kwargs)
+        if len(merged) != len(self.infos):
+            raise AssertionError("merge_df must keep one row per entry")
+        return self._rebuild(self.tensors, merged)
 
     def __repr__(self):
-        rows = "".join(f"    {k}: {tuple(t.shape)} {t.dtype} {t.device},\n" for k, t in self._tensors.items())
-        return f"{type(self).__name__}(\n{rows}{'-' * 40}\n    infos:\n{self.infos!r}\n)"
+        return f"{type(self).__name__}(\n{self._describe_columns()}{'-' * 40}\n    infos:\n{self.infos!r}\n)"
 
     def __getstate__(self):
-        state = super().__getstate__()
-        state["infos"] = self.infos
-        state["meta"] = self.meta
-        return state
+        return {"tensors": self.tensors, "infos": self.infos, "meta": self.meta}
 
     def __setstate__(self, state):
-        self.__init__(state["infos"], **state["tensors"])
-        self.meta = state["meta"]
+        self._init_columns(state["tensors"])
+        self.infos, self.meta = state["infos"], state["meta"]
 
     def gather_distributed(self, tmp_dir=None):
-        """Reference signature (``TB/utils/tensor_collection.py:166-187``); the rank
-        files are gone -- tensors travel through one all-gather."""
+        """Reference signature (``TB/utils/tensor_collection.py:166-187``); ``tmp_dir`` is unused --
+        the rows travel through one all-gather instead of per-rank files."""
         from .distributed import gather_collection
 
         return gather_collection(self)
 
 
 def concatenate(datas: List[PandasTensorCollection]) -> PandasTensorCollection:
-    """``TB/utils/tensor_collection.py:28-42``: drop empty parts, stack the rest."""
-    datas = [d for d in datas if len(d) > 0]
-    if not datas:
+    """Stack collections row-wise, ignoring empty ones (``TB/utils/tensor_collection.py:28-42``)."""
+    parts = [d for d in datas if len(d)]
+    if not parts:
         return PandasTensorCollection(infos=pd.DataFrame())
-    assert all(type(d) is type(datas[0]) for d in datas)
-    infos = pd.concat([d.infos for d in datas], axis=0, sort=False).reset_index(drop=True)
-    tensors = {k: torch.cat([getattr(d, k) for d in datas], dim=0) for k in datas[0].tensors}
-    return PandasTensorCollection(infos=infos, **tensors)
+    head = parts[0]
+    if any(type(d) is not type(head) for d in parts):
+        raise AssertionError("concatenate needs collections of one type")
+    frame = pd.concat([d.infos for d in parts], axis=0, sort=False)
+    columns = {name: torch.cat([d.tensors[name] for d in parts], dim=0) for name in head.tensors}
+    return PandasTensorCollection(infos=frame, **columns)
 
 
 def filter_top_pose_estimates(data_TCO: PandasTensorCollection, top_K: int, group_cols: List[str],
                               filter_field: str, ascending: bool = False) -> PandasTensorCollection:
-    """Keep the ``top_K`` rows per group ranked by ``filter_field``; the output is in
-    sorted (not input) order, exactly like the reference's
-    ``sort_values().groupby().head()`` (``TB/utils/tensor_collection.py:201-230``,
-    pinned by golden G8 including the tie case)."""
-    df = data_TCO.infos
-    kept = df.sort_values(filter_field, ascending=ascending).groupby(group_cols).head(top_K)
-    return data_TCO[kept.index.tolist()]
+    """Keep the ``top_K`` rows of each group ranked by ``filter_field``.  The result is in ranked
+    (not input) order, as the reference's ``sort_values().groupby().head()`` leaves it
+    (``TB/utils/tensor_collection.py:201-230``; golden G8 pins this including the tie case)."""
+    ranked = data_TCO.infos.sort_values(filter_field, ascending=ascending)
+    keep = ranked.groupby(group_cols).head(top_K).index
+    return data_TCO[list(keep)]

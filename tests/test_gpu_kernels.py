@@ -606,3 +606,49 @@ def test_efficientnet_b3_backbone_golden_g9(dev, golden_dir):
     xin3[..., :6] = torch.as_tensor(x3, device=dev).permute(0, 2, 3, 1)
     _, _, f3 = net.forward(xin3, want_pose=False, want_features=True)
     assert torch.equal(f3[:2], feats) and torch.equal(f3[2], feats[0])
+
+
+# ------------------------------------------------------------------- dispatcher registration
+def test_torch_ops_match_ctypes_path(dev, scene_store):
+    """``torch.ops.happypose_amd.*`` are the same C-ABI calls behind dispatcher schemas: bit-identical results."""
+    from happypose_amd import ops, torch_ops
+    from happypose_amd.synthetic import predictor_weights
+    from oracle import backbones as ob
+
+    o = torch.ops.happypose_amd
+    rs = np.random.RandomState(0)
+    img = torch.as_tensor(rs.rand(2, 3, 120, 160).astype(np.float32), device=dev)
+    boxes = torch.as_tensor(np.array([[10.3, 8.2, 120.7, 100.1], [-5, -4, 90, 70.5], [0, 0, 160, 120]], np.float32), device=dev)
+    ids = torch.as_tensor(np.array([0, 1, 1], np.int32), device=dev)
+    assert torch.equal(o.crop_roi_align(img, boxes, ids, 60, 80), ops.crop_roi_align(img, boxes, ids, (60, 80)))
+
+    T = torch.as_tensor(_poses(3, seed=2), device=dev)
+    K = torch.as_tensor(np.tile(np.array([[150.0, 0, 80], [0, 150.0, 60], [0, 0, 1]], np.float32), (3, 1, 1)), device=dev)
+    obj = torch.as_tensor(np.array([0, 1, 2], np.int32), device=dev)
+    st = torch_ops.ticket(scene_store)
+    got = o.rasterize(st, obj, T, K, 120, 160, True, True)
+    ref = ops.rasterize(scene_store, obj, T, K, (120, 160), render_normals=True, render_depth=True)
+    assert len(got) == 3 and all(torch.equal(a, b) for a, b in zip(got, ref[:3]))
+
+    prep = o.pose_prep(st, T, K, torch.arange(3, dtype=torch.int32, device=dev), obj, 120, 160, 60, 80, "TCO+front_3views", True)
+    ref = ops.pose_prep(scene_store, T, K, torch.arange(3, dtype=torch.int32), obj, (120, 160), (60, 80), "TCO+front_3views", True)
+    for a, k in zip(prep, ("TCO", "tCR", "TCV_O", "boxes_rend", "boxes_crop", "K_crop")):
+        assert torch.equal(a, ref[k]), k
+    pose9 = torch.as_tensor(rs.randn(3, 9).astype(np.float32) * 0.1, device=dev)
+    assert torch.equal(o.pose_update(prep[0], prep[5][:, 0].contiguous(), pose9, prep[1]),
+                       ops.pose_update(prep[0], prep[5][:, 0].contiguous(), pose9, prep[1]))
+
+    w = predictor_weights(ob.predictor_param_shapes("resnet18", 6, pose_dim=9), seed=3, update_scale=0.05)
+    net = ops.Net("resnet18", 6, w, max_batch=2, device=dev)
+    xin = net.new_input(2)
+    xin[..., :6] = torch.as_tensor(rs.rand(2, 240, 320, 6).astype(np.float32), device=dev)
+    (pose,) = o.net_forward(torch_ops.ticket(net), xin)
+    assert torch.equal(pose, net.forward(xin)[0])
+
+    x = torch.as_tensor(rs.randn(2, 12, 16, 32).astype(np.float32), device=dev)
+    wt = torch.as_tensor(rs.randn(64, 3, 3, 32).astype(np.float32) * 0.05, device=dev)
+    assert torch.equal(o.conv2d_nhwc(x, wt, 1, 1, act=1), ops.conv2d_nhwc(x, wt, 1, 1, relu=True))
+    with pytest.raises(ValueError):
+        o.net_forward(10 ** 9, xin)  # not a live ticket
+    with pytest.raises(NotImplementedError):
+        o.pose_update(prep[0].cpu(), prep[5][:, 0].cpu().contiguous(), pose9.cpu(), prep[1].cpu())  # no CPU kernels

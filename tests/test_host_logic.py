@@ -277,3 +277,22 @@ def test_detector_oracle_shapes():
     assert [tuple(f.shape[-2:]) for f in out["features"]] == [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
     assert all(o.shape[1] == 3 for o in out["objectness"]) and all(d.shape[1] == 12 for d in out["deltas"])
     assert all(torch.isfinite(f).all() for f in out["features"])
+
+
+def test_torch_ops_registered_with_shape_functions():
+    """``torch.ops.happypose_amd.*`` exist, their Meta kernels give the output shapes, and there is no CPU kernel."""
+    from happypose_amd import torch_ops
+
+    o = torch.ops.happypose_amd
+    for name in torch_ops.OPS:
+        assert hasattr(o, name), name
+    m = lambda *s, **k: torch.empty(*s, device="meta", **k)
+    i32 = dict(dtype=torch.int32)
+    assert o.crop_roi_align(m(2, 3, 48, 64), m(5, 4), m(5, **i32), 24, 32).shape == (5, 3, 24, 32)
+    assert o.pose_update(m(5, 4, 4), m(5, 3, 3), m(5, 9)).shape == (5, 4, 4)
+    assert [t.shape[1] for t in o.rasterize(0, m(5, **i32), m(5, 4, 4), m(5, 3, 3), 24, 32, True, True)] == [3, 3, 1]
+    prep = o.pose_prep(0, m(5, 4, 4), m(2, 3, 3), m(5, **i32), m(5, **i32), 48, 64, 24, 32, "TCO+front_3views")
+    assert prep[2].shape == (5, 4, 4, 4) and prep[5].shape == (5, 4, 3, 3)
+    assert o.conv2d_nhwc(m(2, 8, 8, 16), m(32, 3, 3, 16), 2, 1).shape == (2, 4, 4, 32)
+    with pytest.raises(NotImplementedError):
+        o.pose_update(torch.eye(4)[None], torch.eye(3)[None], torch.zeros(1, 9))
