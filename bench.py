@@ -226,8 +226,10 @@ def pose_parity(gpu_poses: np.ndarray, cpu_poses: np.ndarray) -> dict:
     n = len(cpu_poses)
     A, B = np.asarray(gpu_poses[:n], np.float64), np.asarray(cpu_poses, np.float64)
     dt = np.linalg.norm(A[:, :3, 3] - B[:, :3, 3], axis=1)
-    R = A[:, :3, :3] @ np.swapaxes(B[:, :3, :3], 1, 2)
-    ang = np.arccos(np.clip((np.trace(R, axis1=1, axis2=2) - 1) / 2, -1, 1))
+    # geodesic angle through the chord: ||R_A - R_B||_F = 2 sqrt(2) sin(theta / 2).  (arccos of the trace has a floor of
+    # ~sqrt(2 * 1e-7) = 5e-4 rad on fp32 matrices -- it reported 8e-4 rad for poses that agree to 1e-6)
+    chord = np.linalg.norm(A[:, :3, :3] - B[:, :3, :3], axis=(1, 2))
+    ang = 2.0 * np.arcsin(np.clip(chord / (2.0 * np.sqrt(2.0)), 0.0, 1.0))
     ok = bool(np.isfinite(A).all() and dt.max() <= T_TOL and ang.max() <= R_TOL)
     return {"hypotheses_compared": n, "iterations": N_ITERS, "max_dt_m": float(dt.max()), "max_dR_rad": float(ang.max()),
             "tol": {"dt_m": T_TOL, "dR_rad": R_TOL}, "ok": ok}

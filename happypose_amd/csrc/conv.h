@@ -74,6 +74,7 @@ struct ConvArgsH {
 struct DwArgs {
   const float* x; const float* w /* [k*k][C], BN scale folded */; const float* bias /* [C] BN shift */; float* y;
   int n, H, W, C, Ho, Wo, k, stride, pad_t, pad_l;
+  float* pool_partial;  // or null: [n][dwconv_pool_strips(Ho)][C] sums of the outputs (squeeze-excitation pooling)
 };
 
 struct HeadArgs {
@@ -147,10 +148,13 @@ int launch_resize_nearest(const float* x, float* y, int n, int H, int W, int C, 
 int launch_normalize_nhwc4(const float* x, float* y, int n, int h, int w, const float* mean3, const float* std3, hipStream_t stream);
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream);
 int launch_dwconv(const DwArgs& a, hipStream_t stream);
+bool dwconv_pools(const DwArgs& a);   // the launch can also write a.pool_partial
+int dwconv_pool_strips(int Ho);       // partial sums per image it writes
 // squeeze-excitation: pooled [n][C] = mean over HW of y; gate [n][C] = sigmoid(W2 swish(W1 pooled + b1) + b2)
 int se_partial_floats(int n, int C);  // workspace of launch_se
 int launch_se(const float* y, float* partial, float* pooled, float* sq, float* gate, const float* w1, const float* b1,
               const float* w2t /* expand weights transposed to [Cse][C] */, const float* b2, int n, int HW, int C, int Cse,
+              int n_partials /* > 0: partial already holds [n][n_partials][C] sums (launch_dwconv), 0: pool y here */,
               hipStream_t stream);
 int launch_conv_f16(const ConvArgsH& a, hipStream_t stream);
 int launch_cast_pad_f16(const float* x, void* y, int64_t pixels, int c_in, int c_out, hipStream_t stream);

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void split_weights_generic_kernel(const float*
 // written or re-read.  Conv pixels outside the map do not take part in the max (PyTorch pads with -inf).
 constexpr int kPoolRows = 3, kPoolCols = 8, kPoolCW = 2 * kPoolCols + 1, kPoolCH = 2 * kPoolRows + 1;
 
-template <int BN, bool PRE, int NBUF, bool POOL>
+// PRE: 0 none, 1 BN + ReLU on the input (pre_scale / pre_shift [Cin]), 2 squeeze-excitation gate (pre_scale [n][Cin],
+// EfficientNet projections: the gated input is formed in fp32 and then split, as the exact kernels form it)
+template <int BN, int PRE, int NBUF, bool POOL>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3 - NBUF), 2 * (3 - NBUF)))) void conv_igemm_split_f32(ConvArgs a) {
   constexpr int MT = 2, NT = BN / 64;  // 4 waves 2 x 2, wave tile 64 x BN/2
   constexpr int NA = 4, NB = BN / 32;  // staged 16-B pieces per thread and K-tile
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
   // per staged row (output pixel): input origin and offset
   const float* xrow[NA];
   int ih0[NA], iw0[NA];
+  int gate_off[NA];  // PRE == 2: image index * Cin of each staged row
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
       const int rem = (int)m - img * HoWo;
       oh = fdiv(rem, a.fd_wo); ow = rem - oh * a.Wo;
     }
+    gate_off[i] = live ? img * a.Cin : 0;
     if (live) {
       ih0[i] = oh * a.stride - a.pad;
       iw0[i] = ow * a.stride - a.pad;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
 
   // staged K-tile in registers; two sets, so that the loads of K-tile t+2 are in flight while t is multiplied and
   // t+1 is written to LDS (these launches are latency-bound: a dozen MFMAs per K-tile and wave)
-  struct Stage { floatx4 ra[NA]; halfx8 rbw[NB]; floatx4 ps, pb; unsigned ok; };
+  struct Stage { floatx4 ra[NA]; halfx8 rbw[NB]; floatx4 ps, pb; floatx4 g[PRE == 2 ? NA : 1]; unsigned ok; };
   auto issue = [&](int t, Stage& st) {
     const int4 e = a.lut[t * 8 + kc];  // {offset, kh, kw, channel}; kh < 0 marks K padding
     st.ok = 0;
@@ -162,17 +166,23 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) st.rbw[i] = *reinterpret_cast<const halfx8*>(wrow[i] + (size_t)t * 64);
-    if (PRE) {
+    if (PRE == 1) {
       const int c = e.y >= 0 ? e.w : 0;
       st.ps = *reinterpret_cast<const floatx4*>(a.pre_scale + c);
       st.pb = *reinterpret_cast<const floatx4*>(a.pre_shift + c);
+    }
+    if (PRE == 2) {
+      const int c = e.y >= 0 ? e.w : 0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) st.g[PRE == 2 ? i : 0] = *reinterpret_cast<const floatx4*>(a.pre_scale + gate_off[i] + c);
     }
   };
   auto store = [&](int buf, const Stage& st) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       floatx4 v = st.ra[i];
-      if (PRE) v = __builtin_elementwise_max(v * st.ps + st.pb, floatx4{0.f, 0.f, 0.f, 0.f});
+      if (PRE == 1) v = __builtin_elementwise_max(v * st.ps + st.pb, floatx4{0.f, 0.f, 0.f, 0.f});
+      if (PRE == 2) v = v * st.g[PRE == 2 ? i : 0];
       if (!((st.ok >> i) & 1u)) v = floatx4{0.f, 0.f, 0.f, 0.f};
       const halfx4 hi = __builtin_convertvector(v, halfx4);
       const halfx4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), halfx4);
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
   conv_report_nonfinite(a, pool_chk);
 }
 
-template <int BN, bool PRE, int NBUF>
+template <int BN, int PRE, int NBUF>
 int launch_igs_pool(ConvArgs args, hipStream_t stream) {
   static bool opted = false;
   if (!opted) {
@@ -316,7 +326,7 @@ int launch_igs_pool(ConvArgs args, hipStream_t stream) {
   return check_launch("conv_igemm_split_f32<pool>");
 }
 
-template <int BN, bool PRE, int NBUF>
+template <int BN, int PRE, int NBUF>
 int launch_igs(ConvArgs args, hipStream_t stream) {
   static bool opted = false;
   if (!opted) {
@@ -352,17 +362,24 @@ int conv_igemm_split_transform_weights(const float* d_w, void* d_ws, int rows_pa
 }
 
 // a.w = weights split by conv_igemm_split_transform_weights over cout_pad rows (variant 0: cout_pad % 128 == 0 -> 128-wide
-// tiles, variant 1: 64-wide); a.pre_scale needs a.pre_shift (no squeeze-excitation gate), no swish
+// tiles, variant 1: 64-wide); a.pre_scale with a.pre_shift = BN + ReLU prologue, a.pre_scale alone = squeeze-excitation gate
 bool conv_igemm_split_launchable(const ConvArgs& a) {
   static const bool off = std::getenv("HP_CONV_NO_SPLIT") != nullptr;
-  return !off && (a.pre_shift || !a.pre_scale) && a.Kpad % 32 == 0;
+  static const bool no_gate = std::getenv("HP_NO_SPLIT_GATE") != nullptr;
+  if (a.pre_scale && !a.pre_shift && (no_gate || a.Cin % 4)) return false;
+  return !off && a.Kpad % 32 == 0;
+}
+
+template <int BN, int NBUF>
+static int launch_igs_pre(const ConvArgs& a, hipStream_t stream) {
+  if (!a.pre_scale) return launch_igs<BN, 0, NBUF>(a, stream);
+  return a.pre_shift ? launch_igs<BN, 1, NBUF>(a, stream) : launch_igs<BN, 2, NBUF>(a, stream);
 }
 
 int launch_conv_igemm_split(const ConvArgs& a, int variant, hipStream_t stream) {
-  const bool pre = a.pre_scale != nullptr;
-  if (variant == 0) return pre ? launch_igs<128, true, 2>(a, stream) : launch_igs<128, false, 2>(a, stream);
-  if (a.ktiles <= 8) return pre ? launch_igs<64, true, 1>(a, stream) : launch_igs<64, false, 1>(a, stream);
-  return pre ? launch_igs<64, true, 2>(a, stream) : launch_igs<64, false, 2>(a, stream);
+  if (variant == 0) return launch_igs_pre<128, 2>(a, stream);
+  if (a.ktiles <= 8) return launch_igs_pre<64, 1>(a, stream);
+  return launch_igs_pre<64, 2>(a, stream);
 }
 
 // conv + ReLU + 3x3 / stride-2 / pad-1 max-pool in one launch (a.y = the pooled map [n][Hp][Wp][Cout]); 64-wide tiles only
@@ -373,6 +390,6 @@ bool conv_igemm_split_pool_launchable(const ConvArgs& a, int cout_pad) {
          a.ktiles <= 8;
 }
 
-int launch_conv_igemm_split_pool(const ConvArgs& a, hipStream_t stream) { return launch_igs_pool<64, false, 1>(a, stream); }
+int launch_conv_igemm_split_pool(const ConvArgs& a, hipStream_t stream) { return launch_igs_pool<64, 0, 1>(a, stream); }
 
 }  // namespace hp

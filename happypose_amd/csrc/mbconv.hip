@@ -11,6 +11,8 @@
 // in the bounds test.
 #include "conv.h"
 
+#include <cstdlib>
+
 namespace hp {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -54,6 +56,82 @@ __global__ __launch_bounds__(256) void dwconv_swish_nhwc(DwArgs a) {
   *reinterpret_cast<floatx4*>(a.y + (((int64_t)img * a.Ho + oh) * a.Wo + ow) * a.C + c) = swish4(acc);
 }
 
+// Strip kernel: a workgroup owns R output rows of one image for up to 256 channel quads.  A lane keeps ONE channel quad
+// (its k*k weights stay in registers) and walks the columns of the strip; per column it streams the (R-1)*S+K input
+// rows once and feeds every output row they reach, so an output costs ((R-1)*S+K)*K/R quad loads instead of K*K
+// (k5: 10 vs 25 -- the one-output-per-lane kernel above is bound by the L1 request rate, not by HBM).  The FMA order
+// per output is the same (dy, dx ascending), so the conv result is bit-identical.  The lanes also sum what they store:
+// the per-(image, strip, channel) sums are the squeeze-excitation pooling partials (se_pool_kernel re-read the whole
+// tensor for them); lanes of one channel quad meet in LDS in a fixed order (reproducible).
+constexpr int kDwRows = 4;
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_strip_kernel(DwArgs a) {
+  constexpr int R = kDwRows, NR = (R - 1) * S + K;
+  __shared__ floatx4 red[256];
+  const int C4 = a.C >> 2;
+  const int cq0 = blockIdx.x * 256;
+  const int nq = C4 - cq0 < 256 ? C4 - cq0 : 256;
+  const int nph = 256 / nq;
+  const int tid = threadIdx.x;
+  const int ph = tid / nq, q = tid - ph * nq;
+  const int img = blockIdx.z, strip = blockIdx.y, oh0 = strip * R;
+  const int c = 4 * (cq0 + q);
+  floatx4 psum = {0.f, 0.f, 0.f, 0.f};
+  if (ph < nph) {
+    floatx4 w[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) w[t] = *reinterpret_cast<const floatx4*>(a.w + t * a.C + c);
+    const floatx4 bias = *reinterpret_cast<const floatx4*>(a.bias + c);
+    const int ih0 = oh0 * S - a.pad_t;
+    const float* const ximg = a.x + (int64_t)img * a.H * a.W * a.C + c;
+    float* const yimg = a.y + (int64_t)img * a.Ho * a.Wo * a.C + c;
+    for (int ow = ph; ow < a.Wo; ow += nph) {
+      floatx4 acc[R];
+#pragma unroll
+      for (int o = 0; o < R; ++o) acc[o] = bias;
+      const int iw0 = ow * S - a.pad_l;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int ih = ih0 + r;
+        const bool rok = (unsigned)ih < (unsigned)a.H;
+        floatx4 xv[K];
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          const int iw = iw0 + dx;
+          const bool ok = rok && (unsigned)iw < (unsigned)a.W;
+          xv[dx] = ok ? *reinterpret_cast<const floatx4*>(ximg + ((int64_t)ih * a.W + iw) * a.C) : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+          const int dy = r - o * S;  // compile-time after unrolling
+          if (dy >= 0 && dy < K) {
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(xv[dx][e], w[dy * K + dx][e], acc[o][e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < R; ++o) {
+        if (oh0 + o < a.Ho) {
+          const floatx4 v = swish4(acc[o]);
+          *reinterpret_cast<floatx4*>(yimg + ((int64_t)(oh0 + o) * a.Wo + ow) * a.C) = v;
+          psum += v;
+        }
+      }
+    }
+  }
+  red[tid] = psum;
+  __syncthreads();
+  if (tid < nq && a.pool_partial) {
+    floatx4 sum = red[tid];
+    for (int p = 1; p < nph; ++p) sum += red[p * nq + tid];
+    *reinterpret_cast<floatx4*>(a.pool_partial + ((int64_t)img * gridDim.y + strip) * a.C + 4 * (cq0 + tid)) = sum;
+  }
+}
+
 // sums over the pixels of each (image, channel) in kSeStrips strips: block = 64 channels x 4 pixel
 // lanes of one strip, fixed summation order (pixel lanes stride the strip, then a 4-way LDS sum; the
 // strips are added in order by se_gate_kernel) -> bitwise reproducible, and enough blocks to fill
@@ -81,12 +159,12 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const float* y, float* par
 //   se_mean_kernel:   pooled[n][c]  = sum of the strip partials / HW            (fixed order)
 //   se_reduce_kernel: sq[n][j]      = swish(W1[j] . pooled[n] + b1[j])          one wave per (n, j)
 //   se_expand_kernel: gate[n][c]    = sigmoid(W2t[.][c] . sq[n] + b2[c])        W2 transposed: coalesced
-__global__ __launch_bounds__(256) void se_mean_kernel(const float* partial, float* pooled, int HW, int C, int total) {
+__global__ __launch_bounds__(256) void se_mean_kernel(const float* partial, float* pooled, int HW, int C, int total, int n_partials) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int img = idx / C, c = idx - img * C;
   float s = 0.f;
-  for (int st = 0; st < kSeStrips; ++st) s += partial[((int64_t)img * kSeStrips + st) * C + c];
+  for (int st = 0; st < n_partials; ++st) s += partial[((int64_t)img * n_partials + st) * C + c];
   pooled[idx] = s / (float)HW;
 }
 
@@ -117,7 +195,20 @@ __global__ __launch_bounds__(256) void se_expand_kernel(const float* sq, const f
 
 }  // namespace
 
+int dwconv_pool_strips(int Ho) { return (Ho + kDwRows - 1) / kDwRows; }
+
+// a.pool_partial (or null) receives [n][dwconv_pool_strips(Ho)][C] sums of the outputs (strip kernel only)
 int launch_dwconv(const DwArgs& a, hipStream_t stream) {
+  static const bool old_kernel = std::getenv("HP_DW_OLD") != nullptr;
+  if (!old_kernel && (a.stride == 1 || a.stride == 2) && (a.k == 3 || a.k == 5) && a.n < 65536) {
+    const dim3 grid((unsigned)((a.C / 4 + 255) / 256), (unsigned)dwconv_pool_strips(a.Ho), (unsigned)a.n);
+    if (a.k == 3 && a.stride == 1) hipLaunchKernelGGL((dwconv_strip_kernel<3, 1>), grid, dim3(256), 0, stream, a);
+    else if (a.k == 3) hipLaunchKernelGGL((dwconv_strip_kernel<3, 2>), grid, dim3(256), 0, stream, a);
+    else if (a.stride == 1) hipLaunchKernelGGL((dwconv_strip_kernel<5, 1>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((dwconv_strip_kernel<5, 2>), grid, dim3(256), 0, stream, a);
+    return check_launch("dwconv_strip_kernel");
+  }
+  if (a.pool_partial) return fail(HP_ERR_ARG, "dwconv: pooled sums need the strip kernel");
   const int64_t total = (int64_t)a.n * a.Ho * a.Wo * (a.C / 4);
   const dim3 grid((unsigned)((total + 255) / 256));
   if (a.k == 3) hipLaunchKernelGGL(dwconv_swish_nhwc<3>, grid, dim3(256), 0, stream, a);
@@ -126,16 +217,25 @@ int launch_dwconv(const DwArgs& a, hipStream_t stream) {
   return check_launch("dwconv_swish_nhwc");
 }
 
+bool dwconv_pools(const DwArgs& a) {
+  static const bool old_kernel = std::getenv("HP_DW_OLD") != nullptr;
+  return !old_kernel && (a.stride == 1 || a.stride == 2) && (a.k == 3 || a.k == 5) && a.n < 65536;
+}
+
 int se_partial_floats(int n, int C) { return n * kSeStrips * C; }
 
-// w2t = the expand weights transposed to [Cse][C]; sq = workspace [n][Cse]
+// w2t = the expand weights transposed to [Cse][C]; sq = workspace [n][Cse].  n_partials > 0: `partial` already holds
+// [n][n_partials][C] sums written by the depthwise kernel (no pooling pass); 0: pool y here.
 int launch_se(const float* y, float* partial, float* pooled, float* sq, float* gate, const float* w1, const float* b1,
-              const float* w2t, const float* b2, int n, int HW, int C, int Cse, hipStream_t stream) {
+              const float* w2t, const float* b2, int n, int HW, int C, int Cse, int n_partials, hipStream_t stream) {
   if (Cse > 128) return fail(HP_ERR_ARG, "squeeze-excitation: more than 128 squeezed channels");
-  hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, n, kSeStrips), dim3(256), 0, stream, y, partial, HW, C);
-  int rc = check_launch("se_pool_kernel");
-  if (rc) return rc;
-  hipLaunchKernelGGL(se_mean_kernel, dim3((n * C + 255) / 256), dim3(256), 0, stream, partial, pooled, HW, C, n * C);
+  int rc;
+  if (n_partials <= 0) {
+    hipLaunchKernelGGL(se_pool_kernel, dim3((C + 63) / 64, n, kSeStrips), dim3(256), 0, stream, y, partial, HW, C);
+    if ((rc = check_launch("se_pool_kernel"))) return rc;
+    n_partials = kSeStrips;
+  }
+  hipLaunchKernelGGL(se_mean_kernel, dim3((n * C + 255) / 256), dim3(256), 0, stream, partial, pooled, HW, C, n * C, n_partials);
   if ((rc = check_launch("se_mean_kernel"))) return rc;
   hipLaunchKernelGGL(se_reduce_kernel, dim3((Cse + 3) / 4, n), dim3(256), 0, stream, pooled, w1, b1, sq, C, Cse);
   if ((rc = check_launch("se_reduce_kernel"))) return rc;

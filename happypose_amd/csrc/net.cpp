@@ -449,7 +449,7 @@ int pack_conv(Net& n, ConvLayer& L) {
       if ((rc = L.w_split.alloc(conv_split_weight_bytes(L.cout, L.cin)))) return rc;
       if ((rc = conv_split_transform_weights((const float*)L.w.p, L.w_split.p, L.cout, L.cin, L.Kpad, L.stride, nullptr))) return rc;
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
-    } else if (!L.se && L.Kpad % 32 == 0) {  // swish layers too (the shared epilogue applies it); not the SE-gated projections
+    } else if (L.Kpad % 32 == 0) {  // swish layers and the SE-gated projections too (gate applied while staging)
       if ((rc = L.w_isplit.alloc(conv_igemm_split_weight_bytes(L.cout_pad, L.Kpad)))) return rc;
       if ((rc = conv_igemm_split_transform_weights((const float*)L.w.p, L.w_isplit.p, L.cout_pad, L.Kpad, nullptr))) return rc;
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
@@ -754,8 +754,10 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
   const int net_algo = net->exact_only ? HP_CONV_ALGO_WINOGRAD : (net->algo >= 0 ? net->algo : conv_algo());
   int op_index = 0;
   bool pool_fused = false;  // the stem wrote the pooled map itself: skip the max-pool op that follows it
+  int dw_partials = 0;      // > 0: the depthwise launch left this many pooling partials per image for the SE op after it
   static const bool no_fuse = std::getenv("HP_NO_POOL_FUSION") != nullptr;
-  for (const Op& op : net->ops) {
+  for (size_t oi = 0; oi < net->ops.size(); ++oi) {
+    const Op& op = net->ops[oi];
     if (sync_ops) {
       HP_CHECK_HIP(hipDeviceSynchronize());
       std::fprintf(stderr, "[hp net] op %d kind %d conv %d (everything before it has completed)\n", op_index, (int)op.kind, op.conv);
@@ -884,6 +886,13 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       d.y = (float*)net->bufs[D.out_buf].p;
       d.n = batch; d.H = D.H; d.W = D.W; d.C = D.C; d.Ho = D.Ho; d.Wo = D.Wo; d.k = D.k; d.stride = D.stride;
       d.pad_t = d.pad_l = D.pad;
+      // the squeeze-excitation that follows pools this output: let the depthwise launch sum what it stores
+      dw_partials = 0;
+      if (oi + 1 < net->ops.size() && net->ops[oi + 1].kind == OP_SE && net->ses[net->ops[oi + 1].conv]->in_buf == D.out_buf &&
+          dwconv_pools(d) && dwconv_pool_strips(D.Ho) <= 32) {
+        d.pool_partial = (float*)net->se_partial.p;
+        dw_partials = dwconv_pool_strips(D.Ho);
+      }
       if ((rc = launch_dwconv(d, stream))) return rc;
     } else if (op.kind == OP_SE) {
       if ((rc = prof_end(true))) return rc;
@@ -891,8 +900,9 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       if ((rc = launch_se((const float*)net->bufs[S.in_buf].p, (float*)net->se_partial.p, (float*)net->se_pooled.p, (float*)net->se_sq.p,
                           (float*)net->se_gate.p,
                           (const float*)S.w1.p, (const float*)S.b1.p, (const float*)S.w2.p, (const float*)S.b2.p, batch, S.HW,
-                          S.C, S.Cse, stream)))
+                          S.C, S.Cse, dw_partials, stream)))
         return rc;
+      dw_partials = 0;
     } else if (op.kind == OP_RESIZE) {
       if ((rc = prof_end(true))) return rc;
       if ((rc = launch_resize_nearest((const float*)net->bufs[op.in_buf].p, (float*)net->bufs[op.out_buf].p, batch, op.H, op.W,

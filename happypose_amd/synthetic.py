@@ -158,7 +158,13 @@ def named_weights(shapes: Dict[str, Tuple[int, ...]], seed: int = 0,
             if name.endswith("conv2.weight"):
                 w = w * 0.25  # keeps the residual stream O(1) through 16 blocks
             if name.endswith("_project_conv.weight"):
-                w = w * 0.3  # same for the 26 MBConv blocks of EfficientNet-b3
+                # EfficientNet-b3: blocks with an identity skip keep the stream O(1) with a small branch (0.3); the first
+                # block of a stage has no skip and must carry the signal itself (1.25 balances the 0.5 SE gate and the
+                # swish gain: with 0.3 everywhere the output was input-independent to 6 digits and a golden on it blind
+                # to everything but the last blocks' biases)
+                stem = name[: -len("_project_conv.weight")]
+                c_in = shapes[stem + "_expand_conv.weight"][1] if stem + "_expand_conv.weight" in shapes else shape[1]
+                w = w * (0.3 if c_in == shape[0] else 1.25)
             out[name] = w.astype(np.float32)
     return out
 
