@@ -77,6 +77,19 @@ struct DwArgs {
   float* pool_partial;  // or null: [n][dwconv_pool_strips(Ho)][C] sums of the outputs (squeeze-excitation pooling)
 };
 
+// expansion 1x1 + BN + swish + depthwise k x k + BN + swish in one launch (mbconv_front.hip)
+struct FrontArgs {
+  const float* x;          // block input NHWC [n][H][W][Cin]
+  const void* w_split;     // the expansion's weights as conv_igemm_split_transform_weights leaves them (rows_pad x Kpad)
+  const float* bias_e;     // [Cexp] folded BN shift of the expansion
+  const float* w_dw;       // [k*k][Cexp] depthwise weights, BN scale folded
+  const float* bias_d;     // [Cexp]
+  float* y;                // depthwise output NHWC [n][Ho][Wo][Cexp]
+  float* pool_partial;     // [n][mbconv_front_tiles][Cexp] sums of y (squeeze-excitation pooling partials)
+  unsigned* status;        // non-finite guard word or null
+  int n, H, W, Cin, Cexp, Ho, Wo, k, stride, pad_t, pad_l, Kpad, rows_pad;
+};
+
 struct HeadArgs {
   int x_is_half;   // features are fp16 (fp16 plan) instead of fp32
   const void* x;   // NHWC [b][HW][C]
@@ -148,6 +161,9 @@ int launch_resize_nearest(const float* x, float* y, int n, int H, int W, int C, 
 int launch_normalize_nhwc4(const float* x, float* y, int n, int h, int w, const float* mean3, const float* std3, hipStream_t stream);
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream);
 int launch_dwconv(const DwArgs& a, hipStream_t stream);
+bool mbconv_front_applicable(int cin, int kpad, int cexp, int k, int stride);
+int mbconv_front_tiles(int Ho, int Wo, int stride);
+int launch_mbconv_front(const FrontArgs& a, hipStream_t stream);
 bool dwconv_pools(const DwArgs& a);   // the launch can also write a.pool_partial
 int dwconv_pool_strips(int Ho);       // partial sums per image it writes
 // squeeze-excitation: pooled [n][C] = mean over HW of y; gate [n][C] = sigmoid(W2 swish(W1 pooled + b1) + b2)

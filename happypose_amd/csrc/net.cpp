@@ -675,7 +675,10 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
     if ((rc = net->se_pooled.alloc((size_t)max_batch * net->se_max_c * 4))) return rc;
     if ((rc = net->se_gate.alloc((size_t)max_batch * net->se_max_c * 4))) return rc;
     if ((rc = net->se_sq.alloc((size_t)max_batch * 128 * 4))) return rc;
-    if ((rc = net->se_partial.alloc((size_t)se_partial_floats(max_batch, net->se_max_c) * 4))) return rc;
+    size_t part = (size_t)se_partial_floats(max_batch, net->se_max_c);
+    for (auto& D : net->dws)  // the fused front launch leaves one partial per tile of its output
+      part = std::max(part, (size_t)max_batch * mbconv_front_tiles(D->Ho, D->Wo, D->stride) * D->C);
+    if ((rc = net->se_partial.alloc(part * 4))) return rc;
   }
   for (auto& L : net->convs)
     if ((rc = f16 ? pack_conv_f16(*net, *L) : pack_conv(*net, *L))) return rc;
@@ -754,6 +757,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
   const int net_algo = net->exact_only ? HP_CONV_ALGO_WINOGRAD : (net->algo >= 0 ? net->algo : conv_algo());
   int op_index = 0;
   bool pool_fused = false;  // the stem wrote the pooled map itself: skip the max-pool op that follows it
+  bool front_fused = false; // the expansion conv ran the depthwise conv after it too (mbconv_front.hip): skip that op
   int dw_partials = 0;      // > 0: the depthwise launch left this many pooling partials per image for the SE op after it
   static const bool no_fuse = std::getenv("HP_NO_POOL_FUSION") != nullptr;
   for (size_t oi = 0; oi < net->ops.size(); ++oi) {
@@ -825,6 +829,28 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       // 2x2 output tile, cin and cout for the Winograd layers, M x Cout x Kpad otherwise
       const bool wino_ok = algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINOGRAD_1WAVE || algo == HP_CONV_ALGO_WINOGRAD;
       const Op* next7 = op_index < (int)net->ops.size() ? &net->ops[op_index] : nullptr;
+      // MBConv front: expansion + depthwise (+ SE pooling sums) in one launch, the expanded tensor stays on the CU
+      const DwLayer* fdw = nullptr;
+      if (oi + 2 < net->ops.size() && net->ops[oi + 1].kind == OP_DW && net->ops[oi + 2].kind == OP_SE && L.w_isplit.p && L.kh == 1 &&
+          L.relu == HP_ACT_SWISH && !L.se && L.res_buf < 0 && !a.pre_scale && conv_use_split(algo, L.H, L.W, L.cin, L.cout)) {
+        const DwLayer& D = *net->dws[net->ops[oi + 1].conv];
+        if (D.in_buf == L.out_buf && D.C == L.cout && net->ses[net->ops[oi + 2].conv]->in_buf == D.out_buf &&
+            mbconv_front_applicable(L.cin, L.Kpad, L.cout, D.k, D.stride))
+          fdw = &D;
+      }
+      if (fdw) {
+        FrontArgs f{};
+        f.x = a.x; f.w_split = L.w_isplit.p; f.bias_e = a.bias; f.w_dw = (const float*)fdw->w.p; f.bias_d = (const float*)fdw->bias.p;
+        f.y = (float*)net->bufs[fdw->out_buf].p; f.pool_partial = (float*)net->se_partial.p; f.status = net->d_status;
+        f.n = batch; f.H = L.H; f.W = L.W; f.Cin = L.cin; f.Cexp = L.cout; f.Ho = fdw->Ho; f.Wo = fdw->Wo; f.k = fdw->k;
+        f.stride = fdw->stride; f.pad_t = f.pad_l = fdw->pad; f.Kpad = L.Kpad; f.rows_pad = L.cout_pad;
+        rc = launch_mbconv_front(f, stream);
+        front_fused = true;
+        dw_partials = mbconv_front_tiles(fdw->Ho, fdw->Wo, fdw->stride);
+        const int th = fdw->stride == 1 ? 8 : 4, tw = fdw->stride == 1 ? 16 : 8;
+        const int rows = (((th - 1) * fdw->stride + fdw->k) * ((tw - 1) * fdw->stride + fdw->k) + 31) / 32 * 32;
+        mfma_flops = 2.0 * (double)batch * dw_partials * rows * ((L.cout + 31) / 32 * 32) * L.Kpad * 3.0 / 16.0;
+      } else
       if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_stem7.p && !no_fuse && next7 && next7->kind == OP_MAXPOOL &&
           next7->in_buf == L.out_buf && next7->H == L.Ho && next7->W == L.Wo) {
         // MegaPose stem + ReLU + max-pool in one launch, the input region of a pooled tile staged once per channel slab
@@ -878,6 +904,9 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       if (rc) return rc;
       prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, mfma_flops);
       if ((rc = prof_end(false))) return rc;
+    } else if (op.kind == OP_DW && front_fused) {
+      front_fused = false;  // the expansion's launch wrote this depthwise output (and the pooling partials) already
+      if ((rc = prof_end(true))) return rc;
     } else if (op.kind == OP_DW) {
       if ((rc = prof_end(true))) return rc;
       const DwLayer& D = *net->dws[op.conv];
