@@ -311,6 +311,9 @@ def main():
                     help="refiner workloads (C2, C3): 2 = two half-batch chains on two streams (TwoLanePredictor)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16"],
                     help="conv arithmetic (default: f32, the reference's; f16 for C5 as BASELINE.json names it)")
+    ap.add_argument("--graphs", default="off", choices=["on", "off"],
+                    help="replay the refiner step as a captured hipGraph (happypose_amd.graphs).  Measured: within 2 %% of the "
+                         "eager path on C2 and C3 -- the steps are bound by the GPU, not by the host's launch rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-1thread", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -365,17 +368,36 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
+    graphs = args.workload != "C5" and args.graphs == "on"
+    if graphs:  # part of the set-up, like building the network plan: eager call, then capture
+        model.use_graphs = True
+        step(); step()
     for _ in range(args.warmup):
         step()
-    model.backbone.set_profiling(True)
-    fence()
     from happypose_amd import ops as _ops
+    if not graphs:  # HIP events around the conv stretches of the timed steps themselves
+        model.backbone.set_profiling(True)
+    fence()
     _ops.profile_mark_reference(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         poses = step()
     fence()
     elapsed = time.perf_counter() - t0
+    instrumented_ms = None
+    if graphs:
+        # events cannot be recorded inside a replayed graph: the per-launch timing of the roofline comes from the same K
+        # steps run once more eagerly (the launches are identical; only the host's part differs), reported beside it
+        model.backbone.set_profiling(True)  # also drops the captured graphs (ops.graph_epoch)
+        step()
+        model.backbone.profile_collect(); model.backbone.profile_intervals()
+        fence()
+        _ops.profile_mark_reference(device)
+        t_i = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        instrumented_ms = 1e3 * (time.perf_counter() - t_i) / args.steps
     def conv_profile():
         """(union ms, sum ms, launches, algorithmic FLOPs, matrix-pipe FLOPs in fp32-MFMA-time equivalents) of the conv
         launches timed since profiling was switched on.  Union = the time during which ANY conv kernel was running: with
@@ -457,7 +479,8 @@ def main():
             "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
-            "config": {"workload": desc + (", two half-batch lanes on two streams" if n_lanes == 2 else ""),
+            "config": {"workload": desc + (", two half-batch lanes on two streams" if n_lanes == 2 else "") +
+                       (", the 5-iteration step replayed as one captured hipGraph" if graphs else ""),
                        "hypotheses_per_gpu": B, "iterations": N_ITERS if args.workload != "C5" else 1,
                        "parallelism": f"hypothesis-shard x{world}"},
             # The roofline of the instruction that is issued: v_mfma_f32_32x32x16_f16 (dense fp16 MFMA peak 2516.6 TFLOP/s).
@@ -480,8 +503,12 @@ def main():
                                   "timed conv stretches (HIP events on the launch streams; the two lanes run concurrently, so a "
                                   "launch shares the machine with the other lane's and avg_launch_us is its duration as it ran); "
                                   "traffic: not measurable inside the run -- PMC passes of this command are under profiles/"),
-                         "conv_time_share": conv_ms * 1e-3 / elapsed},
+                         "conv_time_share": conv_ms * 1e-3 / (elapsed if instrumented_ms is None else instrumented_ms * 1e-3 * args.steps)},
         }
+        if instrumented_ms is not None:
+            line["roofline"]["timed_in"] = ("a second, eager pass of the same %d steps (%.2f ms/step): HIP events cannot be recorded inside "
+                                            "a replayed graph; `value` is the graph-replayed pass" % (args.steps, instrumented_ms))
+            line["eager_ms_per_step"] = instrumented_ms
         # what the matrix pipe SUSTAINS on this box (hp_probe_mfma_rate, measured now): gfx950 clocks to its power
         # budget, so back-to-back fp16 MFMAs on random operands settle at ~1.6 GHz and ~2/3 of the nominal dense peak --
         # the ceiling any dense fp16-MFMA kernel on real data is bound by

@@ -98,6 +98,7 @@ struct HeadArgs {
   const float* pose_w; const float* pose_b; int pose_dim;
   const float* logit_w; const float* logit_b; int n_logits;
   float* pose_out; float* logit_out; float* features;
+  float* ws_pool; float* ws_fc;   // [batch][C] workspaces of the fc path (three launches)
 };
 
 // variant 0: 128x128 block tile, variant 1: 128x64 (Cout == 64)

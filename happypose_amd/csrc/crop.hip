@@ -81,9 +81,10 @@ __device__ __forceinline__ void fold_axis(const Axis& ax, int g, int& first, int
   }
 }
 
-// Literal 16-sample evaluation (torchvision's loop) for strongly down-sampling crops; rolled
-// loops and no inlining so that it does not cost the common path registers.
-__device__ __noinline__ void slow_pixel(const float* plane, int H, int W, float y1, float x1, int ph, int pw,
+// Literal 16-sample evaluation (torchvision's loop) for strongly down-sampling crops; rolled loops so that it does
+// not cost the common path registers.  Inlined: a real call needs a stack, and a kernel with scratch memory cannot be
+// replayed from a captured hipGraph on this ROCm (second replay faults) -- see happypose_amd/graphs.py.
+__device__ __forceinline__ void slow_pixel(const float* plane, int H, int W, float y1, float x1, int ph, int pw,
                                         float bin_h, float bin_w, int g, bool want_valid, float& acc, float& vacc) {
 #pragma unroll 1
   for (int iy = 0; iy < g; ++iy) {
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void crop_tile_kernel(CropArgs a) {
         }
       }
     } else {
-#pragma unroll 1
+#pragma unroll  // unrolled: a runtime channel index would put acc[] in scratch memory
       for (int c = 0; c < NC; ++c) {
         float sacc = 0.0f, sv = 0.0f;
         slow_pixel(img + (int64_t)c * HW, H, W, y1, x1, ph, pw, bin_h, bin_w, g, c == 3, sacc, sv);

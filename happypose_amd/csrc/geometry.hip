@@ -114,30 +114,41 @@ __global__ __launch_bounds__(kT) void pose_prep_kernel(PrepArgs a) {
   __shared__ float red[4][4];
   const int i = blockIdx.x / a.n_views, v = blockIdx.x % a.n_views;
   const int tid = threadIdx.x;
-  float Tin[16], T[16], TV[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) Tin[k] = a.TCO_in[16 * (int64_t)i + k];
-  if (a.normalize) normalize_T_dev(Tin, T);
-  else {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) T[k] = Tin[k];
-  }
-  view_pose(T, v, TV);
+  // The pose chain (normalize_T, the double-precision look-at of the extra views, P = K @ TV) is evaluated by lane 0
+  // ONLY and the projection matrix handed to the other lanes through LDS.  Every lane used to evaluate it for itself:
+  // redundant, and -- measured -- not reproducible: with conv launches of another stream sharing the CUs, single
+  // lanes sporadically (~1 launch in 500) came out of the fp64 look-at with a different P than lane 0, their points
+  // projected a few pixels off and K_crop of that view changed by up to 100 px (two-lane MegaPose refiner; found by
+  // the graph-replay test).  One evaluation per view also makes "all lanes agree" true by construction.
+  __shared__ float Psh[12];
+  float T[16], TV[16], K[9], P[12];
+  const int im_id = a.im_ids[i], ob_id = a.obj_ids[i];
   // an image / object id outside the tables never leaves them: the hypothesis reads row 0 and its outputs are NaN
   // (the reference's indexing would raise; a device-side check cannot, and NaN poses render as zero images)
-  const int im_id = a.im_ids[i], ob_id = a.obj_ids[i];
   const bool bad_id = (unsigned)im_id >= (unsigned)a.n_images || (unsigned)ob_id >= (unsigned)a.n_obj;
-  const float* Kp = a.K + 9 * (int64_t)(bad_id ? 0 : im_id);
-  float K[9];
+  if (tid == 0) {
+    float Tin[16];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) K[k] = Kp[k];
-  // P = K @ TV[:3]  (TB/lib3d/camera_geometry.py:52)
-  float P[12];
+    for (int k = 0; k < 16; ++k) Tin[k] = a.TCO_in[16 * (int64_t)i + k];
+    if (a.normalize) normalize_T_dev(Tin, T);
+    else {
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+      for (int k = 0; k < 16; ++k) T[k] = Tin[k];
+    }
+    view_pose(T, v, TV);
+    const float* Kp = a.K + 9 * (int64_t)(bad_id ? 0 : im_id);
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      P[4 * r + c] = fmaf(K[3 * r + 2], TV[8 + c], fmaf(K[3 * r + 1], TV[4 + c], K[3 * r] * TV[c]));
+    for (int k = 0; k < 9; ++k) K[k] = Kp[k];
+    // P = K @ TV[:3]  (TB/lib3d/camera_geometry.py:52)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        Psh[4 * r + c] = fmaf(K[3 * r + 2], TV[8 + c], fmaf(K[3 * r + 1], TV[4 + c], K[3 * r] * TV[c]));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 12; ++k) P[k] = Psh[k];
 
   const int32_t* ids = v == 0 ? a.ids_main : a.ids_extra;
   const int npts = v == 0 ? a.n_main : a.n_extra;
@@ -200,6 +211,7 @@ __global__ __launch_bounds__(kT) void pose_prep_kernel(PrepArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) a.TCV_O[16 * ((int64_t)i * a.n_views + v) + k] = TV[k];
   }
+
   if (v == 0) {
     if (a.TCO_out) {
 #pragma unroll

@@ -100,6 +100,7 @@ struct Net {
   std::vector<size_t> buf_floats_per_sample;  // arena slot sizes
   std::vector<DevBuf> bufs;
   DevBuf fc_w, fc_b, pose_w, pose_b, logit_w, logit_b;
+  DevBuf head_ws;  // fc path of the head: 2 x [max_batch][512] floats
   int pose_dim = 0, n_logits = 0;
   int feat_H = 0, feat_W = 0;
   struct FeatureMap { int buf, H, W, C; };
@@ -688,6 +689,7 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
     if ((rc = net->fc_w.upload(v->data(), v->size() * 4))) return rc;
     if ((rc = need(*net, "backbone.fc.bias", 512, &v))) return rc;
     if ((rc = net->fc_b.upload(v->data(), v->size() * 4))) return rc;
+    if ((rc = net->head_ws.alloc((size_t)2 * max_batch * 512 * 4))) return rc;
   }
   net->pose_dim = net->n_logits = 0;
   if ((v = find(*net, "pose_fc.weight"))) {
@@ -963,6 +965,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       h.logit_w = (const float*)net->logit_w.p; h.logit_b = (const float*)net->logit_b.p;
       h.n_logits = d_logits ? net->n_logits : 0;
       h.pose_out = d_pose; h.logit_out = d_logits; h.features = d_features;
+      h.ws_pool = (float*)net->head_ws.p; h.ws_fc = h.ws_pool ? h.ws_pool + (size_t)net->max_batch * 512 : nullptr;
       if ((rc = launch_head(h, batch, stream))) return rc;
     }
   }

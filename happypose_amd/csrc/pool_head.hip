@@ -72,72 +72,70 @@ __device__ __forceinline__ float4 load4(const _Float16* p) {
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
-// ---- head: spatial mean -> [fc 512x512 + bias] -> pose / logits linear heads -----------
-// one workgroup per sample; features [HW][C] NHWC.
+// spatial mean of x [HW][C] into feat[C] (LDS); part = LDS scratch [2048].
+// channel quads x G groups of positions, 4 independent loads in flight per lane: the mean is a chain of HW dependent
+// loads otherwise (47 us per launch for 10 MB).  Partial sums meet in LDS in a fixed order (deterministic).
 template <typename T>
-__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
-  __shared__ float feat[2048];   // C <= 2048 (512 ResNets, 1536 EfficientNet-b3)
-  __shared__ float feat2[512];   // fc output (torchvision ResNet only, C = 512)
-  __shared__ float part[2048];   // partial spatial sums, [G][C] with G * C <= 2048
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const T* x = reinterpret_cast<const T*>(a.x) + (int64_t)b * a.HW * a.C;
-  if ((a.C & 3) == 0) {
-    // channel quads x G groups of positions, 8 independent loads in flight per lane: the mean is a chain of HW dependent
-    // loads otherwise (47 us per launch for 10 MB).  Partial sums meet in LDS in a fixed order (deterministic).
-    const int nq = a.C >> 2;
+__device__ __forceinline__ void head_pool_t(const T* x, int HW, int C, float* feat, float* part) {
+  const int tid = threadIdx.x;
+  if ((C & 3) == 0) {
+    const int nq = C >> 2;
     const int G = nq < 256 ? 256 / nq : 1;
     for (int q = tid; q < nq * G; q += 256) {
       const int g = q / nq, c4 = q - g * nq;
       float4 s[4] = {};
       int p = g;
-      for (; p + 3 * G < a.HW; p += 4 * G) {
+      for (; p + 3 * G < HW; p += 4 * G) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float4 v = load4(x + (int64_t)(p + u * G) * a.C + 4 * c4);
+          const float4 v = load4(x + (int64_t)(p + u * G) * C + 4 * c4);
           s[u].x += v.x; s[u].y += v.y; s[u].z += v.z; s[u].w += v.w;
         }
       }
-      for (; p < a.HW; p += G) {
-        const float4 v = load4(x + (int64_t)p * a.C + 4 * c4);
+      for (; p < HW; p += G) {
+        const float4 v = load4(x + (int64_t)p * C + 4 * c4);
         s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
       }
-      float* dst = part + g * a.C + 4 * c4;
+      float* dst = part + g * C + 4 * c4;
       dst[0] = (s[0].x + s[1].x) + (s[2].x + s[3].x); dst[1] = (s[0].y + s[1].y) + (s[2].y + s[3].y);
       dst[2] = (s[0].z + s[1].z) + (s[2].z + s[3].z); dst[3] = (s[0].w + s[1].w) + (s[2].w + s[3].w);
     }
     __syncthreads();
-    for (int c = tid; c < a.C; c += 256) {
+    for (int c = tid; c < C; c += 256) {
       float s = part[c];
-      for (int g = 1; g < G; ++g) s += part[g * a.C + c];
-      feat[c] = s / (float)a.HW;
+      for (int g = 1; g < G; ++g) s += part[g * C + c];
+      feat[c] = s / (float)HW;
     }
   } else {
-    for (int c = tid; c < a.C; c += 256) {
+    for (int c = tid; c < C; c += 256) {
       float s = 0.f;
-      for (int p = 0; p < a.HW; ++p) s += (float)x[(int64_t)p * a.C + c];
-      feat[c] = s / (float)a.HW;
+      for (int p = 0; p < HW; ++p) s += (float)x[(int64_t)p * C + c];
+      feat[c] = s / (float)HW;
     }
   }
-  __syncthreads();
-  const float* f = feat;
-  if (a.fc_w) {  // torchvision ResNet: avgpool -> fc (MP/models/torchvision_resnet.py:337-341)
-    // one wave per output row, lanes stride the features: the weight row is read as coalesced 256-B pieces (a thread
-    // per output row read 512 rows 2 KB apart: 90 us per launch, 3 % of a MegaPose refiner step)
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int o = wave; o < a.C; o += 4) {
-      const float* w = a.fc_w + (int64_t)o * a.C;
-      float s = 0.f;
-      for (int c = lane; c < a.C; c += 64) s = fmaf(w[c], feat[c], s);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (lane == 0) feat2[o] = s + a.fc_b[o];
-    }
-    __syncthreads();
-    f = feat2;
+}
+
+// ---- head: spatial mean -> [fc 512x512 + bias] -> pose / logits linear heads -----------
+// features [HW][C] NHWC.  Without the fc (CosyPose WideResNet, EfficientNet) one workgroup per sample does everything.
+// With it (torchvision ResNet, MP/models/torchvision_resnet.py:337-341) the work is three launches: a workgroup per
+// sample re-read the 1 MB fc matrix once per sample through four waves -- 450 us per forward, 10 % of a MegaPose
+// refiner step -- so the fc runs as one wave per OUTPUT row over all samples (the row stays in registers).
+__device__ __forceinline__ void head_pool(const HeadArgs& a, int b, float* feat, float* part) {
+  const int tid = threadIdx.x;
+  if (a.x_is_half) {
+    const _Float16* x = reinterpret_cast<const _Float16*>(a.x) + (int64_t)b * a.HW * a.C;
+    head_pool_t(x, a.HW, a.C, feat, part);
+  } else {
+    const float* x = reinterpret_cast<const float*>(a.x) + (int64_t)b * a.HW * a.C;
+    head_pool_t(x, a.HW, a.C, feat, part);
   }
+  (void)tid;
+}
+
+// linear heads from LDS features f[C]: one wave per output row, lanes stride the features
+__device__ __forceinline__ void head_linear(const HeadArgs& a, int b, const float* f) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (a.features) for (int c = tid; c < a.C; c += 256) a.features[(int64_t)b * a.C + c] = f[c];
-  // linear heads: one wave per output row, lanes stride the 512 features
-  const int lane = tid & 63, wave = tid >> 6;
   for (int o = wave; o < a.pose_dim + a.n_logits; o += 4) {
     const bool is_pose = o < a.pose_dim;
     const int oo = is_pose ? o : o - a.pose_dim;
@@ -151,6 +149,54 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
       else { if (a.logit_out) a.logit_out[(int64_t)b * a.n_logits + oo] = s + a.logit_b[oo]; }
     }
   }
+}
+
+// no fc: everything per sample
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+  __shared__ float feat[2048];   // C <= 2048 (512 ResNets, 1536 EfficientNet-b3)
+  __shared__ float part[2048];   // partial spatial sums, [G][C] with G * C <= 2048
+  head_pool(a, blockIdx.x, feat, part);
+  __syncthreads();
+  head_linear(a, blockIdx.x, feat);
+}
+
+// fc path, launch 1: pooled features -> ws_pool [b][C]
+__global__ __launch_bounds__(256) void head_pool_kernel(HeadArgs a) {
+  __shared__ float feat[2048];
+  __shared__ float part[2048];
+  head_pool(a, blockIdx.x, feat, part);
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += 256) a.ws_pool[(int64_t)blockIdx.x * a.C + c] = feat[c];
+}
+
+// fc path, launch 2: ws_fc[b][o] = fc_w[o] . ws_pool[b] + fc_b[o]; one wave per output row o (C == 512: 8 weights per
+// lane in registers), looping over the samples; the summation order per (b, o) is the lanes' strided partial sums and a
+// butterfly, as in the one-launch kernel
+__global__ __launch_bounds__(256) void head_fc_kernel(HeadArgs a, int batch) {
+  const int lane = threadIdx.x & 63, o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= a.C) return;
+  const float* w = a.fc_w + (int64_t)o * a.C;
+  float wr[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wr[j] = w[lane + 64 * j];
+  const float bo = a.fc_b[o];
+  for (int b = 0; b < batch; ++b) {
+    const float* f = a.ws_pool + (int64_t)b * a.C;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = fmaf(wr[j], f[lane + 64 * j], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) a.ws_fc[(int64_t)b * a.C + o] = s + bo;
+  }
+}
+
+// fc path, launch 3: linear heads on ws_fc
+__global__ __launch_bounds__(256) void head_linear_kernel(HeadArgs a) {
+  __shared__ float f[2048];
+  for (int c = threadIdx.x; c < a.C; c += 256) f[c] = a.ws_fc[(int64_t)blockIdx.x * a.C + c];
+  __syncthreads();
+  head_linear(a, blockIdx.x, f);
 }
 
 int launch_resize_nearest(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, int stride_mode, hipStream_t stream) {
@@ -175,9 +221,19 @@ int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho,
 }
 
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream) {
-  if (a.x_is_half) hipLaunchKernelGGL(head_kernel<_Float16>, dim3(batch), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(head_kernel<float>, dim3(batch), dim3(256), 0, stream, a);
-  return check_launch("head_kernel");
+  if (a.C > 2048) return fail(HP_ERR_ARG, "head: more than 2048 features");
+  if (!a.fc_w) {
+    hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(256), 0, stream, a);
+    return check_launch("head_kernel");
+  }
+  if (a.C != 512 || !a.ws_pool || !a.ws_fc) return fail(HP_ERR_ARG, "head: the fc path needs 512 features and its workspaces");
+  hipLaunchKernelGGL(head_pool_kernel, dim3(batch), dim3(256), 0, stream, a);
+  int rc = check_launch("head_pool_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(head_fc_kernel, dim3(a.C / 4), dim3(256), 0, stream, a, batch);
+  if ((rc = check_launch("head_fc_kernel"))) return rc;
+  hipLaunchKernelGGL(head_linear_kernel, dim3(batch), dim3(256), 0, stream, a);
+  return check_launch("head_linear_kernel");
 }
 
 

@@ -242,6 +242,11 @@ __device__ __forceinline__ ViewXform load_view(const RasterArgs& a, int view) {
 __global__ __launch_bounds__(256) void raster_xform_kernel(RasterArgs a) {
   const int lv = blockIdx.y, view = a.view0 + lv;
   const int v = blockIdx.x * 256 + threadIdx.x;
+  // the band counters of this view start at zero for the binning pass that follows in stream order (a
+  // hipMemsetAsync did this: captured in a hipGraph, the memset node is skipped from the second replay on --
+  // counters kept growing past the lists)
+  if (blockIdx.x == 0)
+    for (int b = threadIdx.x; b < a.n_bands; b += 256) a.bin_count[(int64_t)lv * a.n_bands + b] = 0;
   const int item = view / a.views_per_item;
   const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
   if (v >= (int)ob[1]) return;
@@ -602,7 +607,6 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
     const int nv = n - v0 < chunk ? n - v0 : chunk;
     a.view0 = v0;
     a.n = nv;
-    HP_CHECK_HIP(hipMemsetAsync(ms->bin_count, 0, (size_t)nv * a.n_bands * sizeof(int32_t), st));
     hipLaunchKernelGGL(raster_xform_kernel, dim3((a.max_verts + 255) / 256, nv), dim3(256), 0, st, a);
     hipLaunchKernelGGL(raster_bin_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
     const int total = nv * a.n_bands;

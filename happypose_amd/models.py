@@ -211,12 +211,16 @@ def _two_lanes(make, renderer: BatchRenderer, max_batch: int):
 
 
 def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Optional[Dict] = None,
-                      max_batch: int = 128, precision: str = "f32", n_lanes: int = 1) -> PosePredictor:
+                      max_batch: int = 128, precision: str = "f32", n_lanes: int = 1, graphs: bool = False) -> PosePredictor:
     """MegaPose predictor (``MP/training/pose_models_cfg.py:89-142``).  ``state_dict`` holds the
     reference's keys (``backbone.*``, ``pose_fc.*``, ``views_logits_head.*``).  ``n_lanes=2``: the refiner's
-    ``forward`` runs two half-batch chains on two streams (:class:`TwoLanePredictor`)."""
+    ``forward`` runs two half-batch chains on two streams (:class:`TwoLanePredictor`).  ``graphs=True``: ``forward`` is
+    captured once per call signature and replayed as a hipGraph (``happypose_amd.graphs``; pays off when the launches
+    are shorter than the host's launch rate: refiner batches of <= 64)."""
     if n_lanes == 2:
-        return _two_lanes(lambda r, mb: create_model_pose(cfg, r, mesh_db, state_dict, mb, precision), renderer, max_batch)
+        model = _two_lanes(lambda r, mb: create_model_pose(cfg, r, mesh_db, state_dict, mb, precision), renderer, max_batch)
+        model.use_graphs = graphs
+        return model
     assert n_lanes == 1
     cfg = check_update_config(cfg)
     assert state_dict is not None, "weights are required (no training path here)"
@@ -233,16 +237,20 @@ def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Op
         remove_TCO_rendering=cfg.remove_TCO_rendering, predict_pose_update=cfg.predict_pose_update,
         depth_normalization_type=cfg.depth_normalization_type)
     model.cfg = model.config = cfg
+    model.use_graphs = graphs
     return model
 
 
 def create_pose_model_cosypose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Optional[Dict] = None,
-                               max_batch: int = 128, precision: str = "f32", n_lanes: int = 1) -> CosyPosePosePredictor:
+                               max_batch: int = 128, precision: str = "f32", n_lanes: int = 1,
+                               graphs: bool = False) -> CosyPosePosePredictor:
     """``CP/training/pose_models_cfg.py:30-53`` (6 input channels; ``n_pose_dims`` = 9).  ``n_lanes`` as in
     :func:`create_model_pose`."""
     if n_lanes == 2:
-        return _two_lanes(lambda r, mb: create_pose_model_cosypose(cfg, r, mesh_db, state_dict, mb, precision), renderer,
-                          max_batch)
+        model = _two_lanes(lambda r, mb: create_pose_model_cosypose(cfg, r, mesh_db, state_dict, mb, precision), renderer,
+                           max_batch)
+        model.use_graphs = graphs
+        return model
     assert n_lanes == 1
     d = dict(cfg) if isinstance(cfg, dict) else dict(vars(cfg))
     d.setdefault("init_method", "v0")  # check_update_config, :24-27
@@ -253,6 +261,7 @@ def create_pose_model_cosypose(cfg, renderer: BatchRenderer, mesh_db=None, state
     model = CosyPosePosePredictor(backbone=net, renderer=renderer, mesh_db=mesh_db, render_size=(240, 320),
                                   pose_dim=cfg.n_pose_dims)
     model.cfg = model.config = cfg
+    model.use_graphs = graphs
     return model
 
 

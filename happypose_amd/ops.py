@@ -24,6 +24,21 @@ ARCH = {"vanilla_resnet34": 0, "resnet34": 1, "resnet18": 2, "efficientnet-b3": 
 N_FEATURES = {"vanilla_resnet34": 512, "resnet34": 512, "resnet18": 512, "efficientnet-b3": 1536, "resnet50-fpn": 256}
 
 
+_GRAPH_EPOCH = 0
+
+
+def graph_epoch() -> int:
+    """Bumped whenever something changes WHICH kernels a forward launches (conv algorithm, profiling events, the
+    non-finite guard switching a network to its exact kernels): captured hipGraphs of an older epoch are stale
+    (``happypose_amd.graphs``)."""
+    return _GRAPH_EPOCH
+
+
+def bump_graph_epoch() -> None:
+    global _GRAPH_EPOCH
+    _GRAPH_EPOCH += 1
+
+
 def _np_ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -281,6 +296,8 @@ def tco_init_autodepth(store: MeshStore, boxes: torch.Tensor, K: torch.Tensor, i
 class Net:
     """``hp_net``: backbone + heads with BN folded, on one device."""
 
+    profiling = False  # set_profiling(True): conv stretches are timed with HIP events (no graph capture then)
+
     def __init__(self, arch: str, n_inputs: int, state_dict: Dict[str, "np.ndarray | torch.Tensor"],
                  max_batch: int = 128, device="cuda", h: int = 240, w: int = 320, precision: str = "f32"):
         """``precision``: ``"f32"`` (the reference's arithmetic) or ``"f16"`` (fp16 weights and
@@ -367,11 +384,14 @@ class Net:
 
     def set_profiling(self, on: bool):
         check(lib().hp_net_set_profiling(self.handle, int(on)), "hp_net_set_profiling")
+        self.profiling = bool(on)
+        bump_graph_epoch()  # event records change the launch sequence a captured graph holds
 
     def set_conv_algo(self, name: Optional[str] = None):
         """Kernel families THIS network may use (``hp_net_set_conv_algo``; names of :data:`CONV_ALGOS`);
         ``None`` returns it to the process-wide default."""
         check(lib().hp_net_set_conv_algo(self.handle, -1 if name is None else CONV_ALGOS[name]), "hp_net_set_conv_algo")
+        bump_graph_epoch()
 
     def set_tail_split(self, on: bool):
         """K-slicing of the tail tiles of this network's conv launches (``hp_net_set_tail_split``): off while a
@@ -387,6 +407,8 @@ class Net:
         sp = stream_ptr(self.device) if stream is None else C.c_void_p(stream.cuda_stream)
         with torch.cuda.device(self.device):
             check(lib().hp_net_status(self.handle, sp, C.byref(flags)), "hp_net_status")
+        if flags.value:
+            bump_graph_epoch()  # the network switched kernels: captured graphs still hold the old ones
         return flags.value
 
     def profile_collect(self):
@@ -480,6 +502,7 @@ def select_conv_algo(name: str = "auto") -> None:
     with the one-wave-per-SIMD schedule of that kernel, ``direct`` = no Winograd, ``igemm`` = the
     generic implicit-GEMM kernel only (``hp_conv_select_algo``)."""
     check(lib().hp_conv_select_algo(CONV_ALGOS[name]), "hp_conv_select_algo")
+    bump_graph_epoch()
 
 
 def conv2d_nhwc(x, w_packed, stride, pad, bias=None, residual=None, pre_scale=None, pre_shift=None, relu=False):

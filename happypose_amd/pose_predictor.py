@@ -104,6 +104,11 @@ class _RenderAndCompare:
         self.keep_pixels = False
         self.debug = False
         self._x: Optional[torch.Tensor] = None
+        # hipGraph replay of forward() (happypose_amd.graphs): off unless asked for -- the first two calls of a
+        # signature run eagerly / capture, and callers that time single launches want the eager path
+        self.use_graphs = False
+        self._graphs = None
+        self._graph_epoch = -1
 
     def eval(self):
         return self
@@ -133,6 +138,23 @@ class _RenderAndCompare:
             im_ids = torch.as_tensor(im_ids).to(device=self.device, dtype=torch.int32)
             assert im_ids.shape == (bsz,)
         return im_ids, self.store.ids_of(labels)
+
+    def _run_refine(self, consts, inputs, fn):
+        """``fn(*inputs)`` eagerly, or through the graph cache when ``use_graphs`` is set and nothing in the call
+        resists capture (kept pixels are large and change what is launched; profiling records events)."""
+        if not self.use_graphs or self.keep_pixels or self.debug or self._profiling():
+            return fn(*inputs)
+        from .graphs import GraphCache
+
+        if self._graphs is None or self._graph_epoch != ops.graph_epoch():
+            self._graphs, self._graph_epoch = GraphCache(self.device), ops.graph_epoch()
+        return self._graphs.run(consts, inputs, fn, keepalive=self._graph_keepalive)
+
+    def _profiling(self) -> bool:
+        return bool(self.backbone.profiling)
+
+    def _graph_keepalive(self):
+        return [self._x]
 
     def numerics_status(self) -> int:
         """Guard flags of the backbone (``ops.Net.status``; synchronises the current stream): non-zero bit 0 means
@@ -224,10 +246,16 @@ class PosePredictor(_RenderAndCompare):
         assert images.dim() == 4 and images.shape[1] >= self._n_img, "images must be [B,C,H,W] with C>=3 (4 if input_depth)"
         per_hyp = im_ids is None
         im_ids, obj_ids = self._ids(images, K, labels, im_ids)
-        labels = list(labels)
-        outputs: Dict[str, PosePredictorOutput] = {}
         TCO_input = TCO.to(self.device, torch.float32)
-        for n in range(n_iterations):
+        recs = self._run_refine((n_iterations,), [images, K, im_ids, obj_ids, TCO_input],
+                                lambda *t: self._refine_device(*t, n_iterations=n_iterations))
+        return self._build_outputs(recs, list(labels), K, per_hyp, im_ids)
+
+    def _refine_device(self, images, K, im_ids, obj_ids, TCO_input, *, n_iterations: int):
+        """The device program of ``forward``: only launches on tensors (capturable as a hipGraph).  One record per
+        iteration."""
+        recs = []
+        for _ in range(n_iterations):
             prep, x, pose, logits, render_time = self._one_pass(
                 images, K, im_ids, obj_ids, TCO_input, n_img_channels=self._n_img,
                 multiview_type=self.multiview_type, normalize=True, render_normals=self.render_normals,
@@ -238,22 +266,29 @@ class PosePredictor(_RenderAndCompare):
                 TCO_output = ops.pose_update(TCO_norm, prep["K_crop"], pose, prep["tCR"])
             else:
                 TCO_output = TCO_norm.clone()
-            net_out = {}
-            if pose is not None:
-                net_out["pose"] = pose
-            if logits is not None:
-                net_out["renderings_logits"] = logits
             images_crop, renders = self._pixels(x, self._n_img, self._n_single_render_channels * self.n_rendered_views)
-            Kb = K if per_hyp else K[im_ids.long()]
-            outputs[f"iteration={n + 1}"] = PosePredictorOutput(
-                renders=renders, images_crop=images_crop, TCO_input=TCO_norm, TCO_output=TCO_output,
-                TCV_O_input=prep["TCV_O"], tCR=prep["tCR"], labels=labels, K=Kb, K_crop=prep["K_crop"][:, 0],
-                KV_crop=prep["K_crop"], network_outputs=net_out, boxes_rend=prep["boxes_rend"],
-                boxes_crop=prep["boxes_crop"],
-                renderings_logits=logits if logits is not None else torch.empty(
-                    bsz, self.n_rendered_views, dtype=torch.float32, device=self.device),
-                timing_dict={"render": render_time})
+            recs.append(dict(TCO_input=TCO_norm, TCO_output=TCO_output, TCV_O=prep["TCV_O"], tCR=prep["tCR"],
+                             KV_crop=prep["K_crop"], boxes_rend=prep["boxes_rend"], boxes_crop=prep["boxes_crop"],
+                             pose=pose, logits=logits, images_crop=images_crop, renders=renders, render_time=render_time))
             TCO_input = TCO_output
+        return recs
+
+    def _build_outputs(self, recs, labels, K, per_hyp, im_ids) -> Dict[str, PosePredictorOutput]:
+        outputs: Dict[str, PosePredictorOutput] = {}
+        Kb = K if per_hyp else K[im_ids.long()]
+        for n, r in enumerate(recs):
+            net_out = {}
+            if r["pose"] is not None:
+                net_out["pose"] = r["pose"]
+            if r["logits"] is not None:
+                net_out["renderings_logits"] = r["logits"]
+            outputs[f"iteration={n + 1}"] = PosePredictorOutput(
+                renders=r["renders"], images_crop=r["images_crop"], TCO_input=r["TCO_input"], TCO_output=r["TCO_output"],
+                TCV_O_input=r["TCV_O"], tCR=r["tCR"], labels=labels, K=Kb, K_crop=r["KV_crop"][:, 0],
+                KV_crop=r["KV_crop"], network_outputs=net_out, boxes_rend=r["boxes_rend"], boxes_crop=r["boxes_crop"],
+                renderings_logits=r["logits"] if r["logits"] is not None else torch.empty(
+                    len(labels), self.n_rendered_views, dtype=torch.float32, device=self.device),
+                timing_dict={"render": r["render_time"]})
         return outputs
 
     __call__ = forward
@@ -306,22 +341,35 @@ class CosyPosePosePredictor(_RenderAndCompare):
         assert TCO.shape == (bsz, 4, 4)
         per_hyp = im_ids is None
         im_ids, obj_ids = self._ids(images, K, labels, im_ids)
-        labels = list(labels)
-        outputs: Dict[str, PosePredictorOutput] = {}
         TCO_input = TCO.to(self.device, torch.float32)
-        for n in range(n_iterations):
+        recs = self._run_refine((n_iterations,), [images, K, im_ids, obj_ids, TCO_input],
+                                lambda *t: self._refine_device(*t, n_iterations=n_iterations))
+        return self._build_outputs(recs, list(labels), K, per_hyp, im_ids)
+
+    def _refine_device(self, images, K, im_ids, obj_ids, TCO_input, *, n_iterations: int):
+        """The device program of ``forward`` (see ``PosePredictor._refine_device``)."""
+        recs = []
+        for _ in range(n_iterations):
             prep, x, pose, _, render_time = self._one_pass(
                 images, K, im_ids, obj_ids, TCO_input, n_img_channels=3, multiview_type="TCO", normalize=False,
                 render_normals=False, render_depth=False, depth_mode=0, want_pose=True, want_logits=False)
             TCO_output = ops.pose_update(TCO_input, prep["K_crop"], pose, None)
             images_crop, renders = self._pixels(x, 3, 3)
-            Kb = K if per_hyp else K[im_ids.long()]
-            outputs[f"iteration={n + 1}"] = PosePredictorOutput(
-                renders=renders, images_crop=images_crop, TCO_input=TCO_input, TCO_output=TCO_output,
-                TCV_O_input=prep["TCV_O"], tCR=prep["tCR"], labels=labels, K=Kb, K_crop=prep["K_crop"][:, 0],
-                KV_crop=prep["K_crop"], network_outputs={"pose": pose}, boxes_rend=prep["boxes_rend"],
-                boxes_crop=prep["boxes_crop"], timing_dict={"render": render_time})
+            recs.append(dict(TCO_input=TCO_input, TCO_output=TCO_output, TCV_O=prep["TCV_O"], tCR=prep["tCR"],
+                             KV_crop=prep["K_crop"], boxes_rend=prep["boxes_rend"], boxes_crop=prep["boxes_crop"],
+                             pose=pose, images_crop=images_crop, renders=renders, render_time=render_time))
             TCO_input = TCO_output
+        return recs
+
+    def _build_outputs(self, recs, labels, K, per_hyp, im_ids) -> Dict[str, PosePredictorOutput]:
+        outputs: Dict[str, PosePredictorOutput] = {}
+        Kb = K if per_hyp else K[im_ids.long()]
+        for n, r in enumerate(recs):
+            outputs[f"iteration={n + 1}"] = PosePredictorOutput(
+                renders=r["renders"], images_crop=r["images_crop"], TCO_input=r["TCO_input"], TCO_output=r["TCO_output"],
+                TCV_O_input=r["TCV_O"], tCR=r["tCR"], labels=labels, K=Kb, K_crop=r["KV_crop"][:, 0],
+                KV_crop=r["KV_crop"], network_outputs={"pose": r["pose"]}, boxes_rend=r["boxes_rend"],
+                boxes_crop=r["boxes_crop"], timing_dict={"render": r["render_time"]})
         return outputs
 
     __call__ = forward
@@ -426,9 +474,12 @@ class TwoLanePredictor:
         self.device = lanes[0].device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in lanes]
         self.backbone = _LaneBackbones([l.backbone for l in lanes])
+        self.use_graphs = False  # hipGraph replay of forward() (happypose_amd.graphs)
+        self._graphs = None
+        self._graph_epoch = -1
 
     def __getattr__(self, name):
-        if name in ("lanes", "streams", "backbone", "device"):  # not set yet: no recursion through lanes[0]
+        if name in ("lanes", "streams", "backbone", "device", "use_graphs", "_graphs", "_graph_epoch"):  # not set yet: no recursion through lanes[0]
             raise AttributeError(name)
         return getattr(self.lanes[0], name)
 
@@ -449,9 +500,18 @@ class TwoLanePredictor:
         """``kw``: what the lanes' ``forward`` takes beyond this (MegaPose: ``random_ambient_light``)."""
         bsz = len(labels)
         if bsz < self.MIN_BATCH:
+            self.lanes[0].use_graphs = self.use_graphs
             return self.lanes[0].forward(images, K, labels, TCO, n_iterations=n_iterations, im_ids=im_ids, **kw)
+        assert not kw.get("random_ambient_light", False), "random_ambient_light is a training-time augmentation"
         labels = list(labels)
         h = bsz // 2
+        lane0 = self.lanes[0]
+        assert TCO.shape == (bsz, 4, 4) and K.dim() == 3 and K.shape[1:] == (3, 3) and images.dim() == 4
+        per_hyp = im_ids is None  # the reference's calling convention: images / K already gathered per hypothesis
+        im_ids, obj_ids = lane0._ids(images, K, labels, im_ids)
+        TCO_input = TCO.to(self.device, torch.float32)
+        # one chain per lane on its own stream; with use_graphs each lane replays ITS OWN captured graph there (a single
+        # graph holding both chains is executed as one serial node order by this runtime: the lanes would not overlap)
         cur = torch.cuda.current_stream(self.device)
         parts = []
         # the other lane fills the CUs a partially filled round of tiles leaves idle: K-slicing those tiles would only
@@ -459,12 +519,15 @@ class TwoLanePredictor:
         self.backbone.set_tail_split(False)  # per network: other predictors are not affected
         try:
             for lane, stream, sl in zip(self.lanes, self.streams, (slice(0, h), slice(h, bsz))):
-                per_hyp = im_ids is None  # the reference's calling convention: images / K already gathered per hypothesis
+                lane.use_graphs = self.use_graphs
                 stream.wait_stream(cur)
                 with torch.cuda.stream(stream):
-                    parts.append(lane.forward(images[sl] if per_hyp else images, K[sl] if per_hyp else K, labels[sl], TCO[sl],
-                                              n_iterations=n_iterations,
-                                              im_ids=None if per_hyp else torch.as_tensor(im_ids)[sl], **kw))
+                    n_l = sl.stop - sl.start
+                    ids_l = torch.arange(n_l, dtype=torch.int32, device=self.device) if per_hyp else im_ids[sl]
+                    img_l, K_l = (images[sl], K[sl]) if per_hyp else (images, K)
+                    recs = lane._run_refine((n_iterations,), [img_l, K_l, ids_l, obj_ids[sl], TCO_input[sl]],
+                                            lambda *t, lane=lane: lane._refine_device(*t, n_iterations=n_iterations))
+                    parts.append(lane._build_outputs(recs, labels[sl], K_l, per_hyp, None if per_hyp else ids_l))
         finally:
             self.backbone.set_tail_split(True)
         for stream in self.streams:

@@ -705,3 +705,93 @@ def test_index_guards(dev, world):
     init = ops.tco_init_autodepth(store, bx, K, torch.zeros(2, dtype=torch.int32, device=dev), obj[:2].to(dev),
                                   box_ids=torch.tensor([0, 4], dtype=torch.int32, device=dev)).cpu().numpy()
     assert np.isfinite(init[0]).all() and np.isnan(init[1]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# hipGraph replay of forward() (happypose_amd.graphs): the captured step must reproduce the eager one bit for bit
+# (same kernels, same order, same buffers), on new inputs, with results that survive the next replay.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("flavour,lanes", [("cosypose", 1), ("cosypose", 2), ("megapose", 2)])
+def test_graph_replay_matches_eager(dev, world, flavour, lanes):
+    from happypose_amd.models import create_model_pose, create_pose_model_cosypose
+    from happypose_amd.synthetic import make_scene
+
+    renderer = world["renderer"]
+    scenes = [make_scene(n_detections=6, n_hypotheses=8, n_objects=len(renderer.store.labels), seed=s, with_depth=True)
+              for s in (9, 10, 11)]
+    if flavour == "cosypose":
+        w = _weights("resnet18", 6, seed=3)
+        make = lambda g: create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=w, max_batch=48,  # noqa: E731
+                                                    n_lanes=lanes, graphs=g)
+        chans = 3
+    else:
+        w = _weights("vanilla_resnet34", 32, seed=4)
+        cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+                   render_depth=True, input_depth=True, predict_pose_update=True, depth_augmentation=False,
+                   depth_normalization_type="tCR_scale_clamp_center")
+        make = lambda g: create_model_pose(cfg, renderer, state_dict=w, max_batch=48, n_lanes=lanes, graphs=g)  # noqa: E731
+        chans = 4
+    eager, graphed = make(False), make(True)
+    kept = []
+    for i, sc in enumerate(scenes):  # call 1 eager, call 2 captures + replays, call 3 replays
+        labels = [renderer.store.labels[j] for j in sc["hyp_obj_ids"]]
+        args = (torch.as_tensor(sc["images"][:, :chans].copy(), device=dev), torch.as_tensor(sc["K"], device=dev), labels,
+                torch.as_tensor(sc["TCO_hyp"], device=dev))
+        im_ids = torch.zeros(len(labels), dtype=torch.int32)
+        a = eager.forward(*args, n_iterations=3, im_ids=im_ids)
+        b = graphed.forward(*args, n_iterations=3, im_ids=im_ids)
+        for k in a:
+            for f in ("TCO_output", "TCO_input", "K_crop", "KV_crop", "boxes_crop", "boxes_rend", "tCR", "TCV_O_input"):
+                assert torch.equal(getattr(a[k], f), getattr(b[k], f)), (i, k, f)
+            assert torch.equal(a[k].network_outputs["pose"], b[k].network_outputs["pose"])
+            assert a[k].labels == b[k].labels
+        kept.append((a["iteration=3"].TCO_output.clone(), b["iteration=3"].TCO_output))
+    caches = [graphed._graphs] if lanes == 1 else [l._graphs for l in graphed.lanes]  # two lanes: a graph per lane
+    assert all(c is not None and c.replays == 2 for c in caches)
+    for ref, got in kept:  # outputs of earlier replays were not overwritten by later ones
+        assert torch.equal(ref, got)
+    # per-hypothesis calling convention (the reference's) is another signature: captured separately
+    sc = scenes[0]
+    labels = [renderer.store.labels[j] for j in sc["hyp_obj_ids"]]
+    n = len(labels)
+    imgs = torch.as_tensor(sc["images"][:1, :chans].copy(), device=dev).expand(n, -1, -1, -1).contiguous()
+    Ks = torch.as_tensor(sc["K"][:1], device=dev).expand(n, -1, -1).contiguous()
+    T0 = torch.as_tensor(sc["TCO_hyp"], device=dev)
+    ref = eager.forward(imgs, Ks, labels, T0, n_iterations=2)["iteration=2"].TCO_output
+    for _ in range(3):
+        got = graphed.forward(imgs, Ks, labels, T0, n_iterations=2)["iteration=2"].TCO_output
+        assert torch.equal(ref, got)
+    # anything that changes the launches drops the captured graphs
+    graphed.backbone.set_profiling(True)
+    graphed.forward(imgs, Ks, labels, T0, n_iterations=2)
+    graphed.backbone.set_profiling(False)
+    got = graphed.forward(imgs, Ks, labels, T0, n_iterations=2)["iteration=2"].TCO_output
+    assert torch.equal(ref, got)
+
+
+def test_two_lane_megapose_is_reproducible(dev, world):
+    """Regression: with the two lanes' launches sharing the CUs, the extra views' K_crop of hp_pose_prep sporadically
+    changed by up to 100 px (every lane evaluated the fp64 look-at for itself and single lanes disagreed with lane 0;
+    now lane 0 evaluates it once and the block shares the projection matrix).  Same inputs -> same bits, every time."""
+    from happypose_amd.models import create_model_pose
+    from happypose_amd.synthetic import make_scene
+
+    renderer = world["renderer"]
+    w = _weights("vanilla_resnet34", 32, seed=4)
+    cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+               render_depth=True, input_depth=True, predict_pose_update=True, depth_augmentation=False,
+               depth_normalization_type="tCR_scale_clamp_center")
+    m = create_model_pose(cfg, renderer, state_dict=w, max_batch=48, n_lanes=2)
+    sc = make_scene(n_detections=6, n_hypotheses=8, n_objects=len(renderer.store.labels), seed=9, with_depth=True)
+    labels = [renderer.store.labels[j] for j in sc["hyp_obj_ids"]]
+    args = (torch.as_tensor(sc["images"][:, :4].copy(), device=dev), torch.as_tensor(sc["K"], device=dev), labels,
+            torch.as_tensor(sc["TCO_hyp"], device=dev))
+    im_ids = torch.zeros(len(labels), dtype=torch.int32)
+    fields = ("TCO_output", "KV_crop", "TCV_O_input", "boxes_crop")
+    ref = m.forward(*args, n_iterations=3, im_ids=im_ids)
+    ref = {k: {f: getattr(v, f).clone() for f in fields} for k, v in ref.items()}
+    for run in range(40):
+        out = m.forward(*args, n_iterations=3, im_ids=im_ids)
+        for k in out:
+            for f in fields:
+                assert torch.equal(ref[k][f], getattr(out[k], f)), (run, k, f)
