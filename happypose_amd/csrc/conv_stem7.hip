@@ -45,8 +45,30 @@ constexpr int BN = 64, BMR = 256, LDC = BN + 4;
 template <int MODE, int SC>
 struct Stem7 {
   static constexpr int KS = (7 * SC + 15) / 16;          // k-steps of 16 per (slab, kh) step
-  static constexpr int ROWP = ((IPX + 2) * SC + 7) / 8 * 8 + 8;  // halves per staged row (16-B multiple): 2 pixels of slack
-                                                                 // for the last k-step + 16 B against bank conflicts
+  // Staged row layout.  SC = 4: [pixel][4] -- consecutive conv pixels (consecutive lanes of an A fragment, 2 input pixels
+  // apart) are 16 B apart: conflict-free 16-B reads.  With [pixel][SC] the lane stride is 32 B (SC = 8) / 64 B (SC = 16):
+  // 2- / 4-way bank conflicts on every A fragment (the fp16 stem ran at a twelfth of its MFMA time).  SC >= 8 therefore
+  // stores a row as two planes of 8-half chunks, [plane][position][8]: SC = 8: plane = pixel parity, position = pixel / 2
+  // (lanes < 32 of k-step kk read pixel 2 dc + 2 kk, lanes >= 32 the odd pixel after it); SC = 16: plane = channel half
+  // (the lane's k half), position = parity * HP + pixel / 2 (k-step kk = pixel 2 dc + kk).  Either way a fragment is
+  // row + hsel * plane pitch + (dc + f(kk)) * 8 halves: 16 B from lane to lane.
+  static constexpr bool DEINT = SC >= 8;
+  static constexpr int HP = (IPX + 3) / 2;               // positions per pixel parity (2 pixels of slack for the last k-step)
+  static constexpr int NPOS = SC == 16 ? 2 * HP : HP;    // positions per plane
+  static constexpr int ROWP = DEINT ? 2 * NPOS * 8 + 8   // halves per staged row (16-B multiple; + 16 B between rows)
+                                    : ((IPX + 2) * SC + 7) / 8 * 8 + 8;
+  // half offset of the 8-half (SC >= 8) or SC-half chunk `q` of staged pixel cc inside its row
+  static constexpr __host__ __device__ int pix_off(int cc, int q) {
+    if (SC == 16) return q * NPOS * 8 + ((cc & 1) * HP + (cc >> 1)) * 8;
+    if (SC == 8) return (cc & 1) * NPOS * 8 + (cc >> 1) * 8 + 4 * q;  // q: 4-half piece of the pixel's 8 channels
+    return cc * SC + 4 * q;
+  }
+  // half offset of k-step kk relative to the fragment base of a conv pixel
+  static constexpr __host__ __device__ int kstep_off(int kk) {
+    if (SC == 16) return ((kk & 1) * HP + (kk >> 1)) * 8;
+    if (SC == 8) return kk * 8;
+    return 16 * kk;
+  }
   static constexpr int PLANE = IR * ROWP + 16;           // halves per plane
   static constexpr int NPLANES = MODE == MODE_SPLIT ? 2 : 1;
   static constexpr int WROW = (NPLANES * KS * 16 + 31) / 32 * 32;  // halves per cout and step: [hi k-steps | lo k-steps], padded
@@ -81,15 +103,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int H = a.H, W = a.W, Cin = a.Cin;
   const int NS = Cin / SC, nsteps = NS * 7;
 
-  // zero the slack columns of every staged row once (read by the last k-step against zero weights: must be finite)
-  for (int i = tid; i < IR * (ROWP - IPX * SC); i += kThreads) {
-    const int rr = i / (ROWP - IPX * SC), j = i - rr * (ROWP - IPX * SC);
-    Ahi[rr * ROWP + IPX * SC + j] = (_Float16)0.f;
-    if (MODE == MODE_SPLIT) Alo[rr * ROWP + IPX * SC + j] = (_Float16)0.f;
-  }
-  for (int i = tid; i < 16; i += kThreads) {
-    Ahi[IR * ROWP + i] = (_Float16)0.f;
-    if (MODE == MODE_SPLIT) Alo[IR * ROWP + i] = (_Float16)0.f;
+  // zero the staged planes once: the slack positions are read by the last k-step against zero weights (must be finite)
+  {
+    const s7_halfx8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < S::NPLANES * PLANE / 8; i += kThreads) *reinterpret_cast<s7_halfx8*>(Ahi + 8 * i) = z8;
+    __syncthreads();
   }
 
   // ---- staging helpers
@@ -114,8 +132,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
           const int px = idx / PPT, q = idx - px * PPT, rr = px / IPX, cc = px - rr * IPX;
           const s7_halfx4 hi = __builtin_convertvector(v[k], s7_halfx4);
           const s7_halfx4 lo = __builtin_convertvector(v[k] - __builtin_convertvector(hi, s7_floatx4), s7_halfx4);
-          *reinterpret_cast<s7_halfx4*>(Ahi + rr * ROWP + cc * SC + 4 * q) = hi;
-          *reinterpret_cast<s7_halfx4*>(Alo + rr * ROWP + cc * SC + 4 * q) = lo;
+          *reinterpret_cast<s7_halfx4*>(Ahi + rr * ROWP + S::pix_off(cc, q)) = hi;
+          *reinterpret_cast<s7_halfx4*>(Alo + rr * ROWP + S::pix_off(cc, q)) = lo;
         }
       }
     } else {
@@ -134,7 +152,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int idx = tid + k * kThreads;
         if (idx < NPIECE) {
           const int px = idx / PPT, q = idx - px * PPT, rr = px / IPX, cc = px - rr * IPX;
-          *reinterpret_cast<s7_halfx8*>(Ahi + rr * ROWP + cc * SC + 8 * q) = v[k];
+          *reinterpret_cast<s7_halfx8*>(Ahi + rr * ROWP + (SC == 16 ? S::pix_off(cc, q) : cc * SC + 8 * q)) = v[k];
         }
       }
     }
@@ -167,7 +185,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     int r = wave * 64 + mt * 32 + frow;
     r = r < CH * CW ? r : CH * CW - 1;  // rows past the tile repeat its last pixel; they are never read back
     const int dr = r / CW, dc = r - dr * CW;
-    abase[mt] = 2 * dr * ROWP + 2 * dc * SC + 8 * hsel;
+    abase[mt] = S::DEINT ? 2 * dr * ROWP + hsel * S::NPOS * 8 + dc * 8 : 2 * dr * ROWP + 2 * dc * SC + 8 * hsel;
   }
   const _Float16* const Bfr = Bs + frow * LDB + 8 * hsel;
 
@@ -199,8 +217,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         s7_halfx8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          ah[mt] = *reinterpret_cast<const s7_halfx8*>(Ahi + abase[mt] + kh * ROWP + 16 * kk);
-          if (MODE == MODE_SPLIT) al[mt] = *reinterpret_cast<const s7_halfx8*>(Alo + abase[mt] + kh * ROWP + 16 * kk);
+          ah[mt] = *reinterpret_cast<const s7_halfx8*>(Ahi + abase[mt] + kh * ROWP + S::kstep_off(kk));
+          if (MODE == MODE_SPLIT) al[mt] = *reinterpret_cast<const s7_halfx8*>(Alo + abase[mt] + kh * ROWP + S::kstep_off(kk));
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {

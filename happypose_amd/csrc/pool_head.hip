@@ -169,18 +169,21 @@ __global__ __launch_bounds__(256) void head_pool_kernel(HeadArgs a) {
   for (int c = threadIdx.x; c < a.C; c += 256) a.ws_pool[(int64_t)blockIdx.x * a.C + c] = feat[c];
 }
 
+constexpr int kFcSamples = 64;  // samples per workgroup of head_fc_kernel (batch 576: 9 x 128 workgroups instead of 128)
+
 // fc path, launch 2: ws_fc[b][o] = fc_w[o] . ws_pool[b] + fc_b[o]; one wave per output row o (C == 512: 8 weights per
 // lane in registers), looping over the samples; the summation order per (b, o) is the lanes' strided partial sums and a
 // butterfly, as in the one-launch kernel
 __global__ __launch_bounds__(256) void head_fc_kernel(HeadArgs a, int batch) {
   const int lane = threadIdx.x & 63, o = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (o >= a.C) return;
+  const int b0 = blockIdx.y * kFcSamples, b1 = b0 + kFcSamples < batch ? b0 + kFcSamples : batch;  // samples of this workgroup
   const float* w = a.fc_w + (int64_t)o * a.C;
   float wr[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) wr[j] = w[lane + 64 * j];
   const float bo = a.fc_b[o];
-  for (int b = 0; b < batch; ++b) {
+  for (int b = b0; b < b1; ++b) {
     const float* f = a.ws_pool + (int64_t)b * a.C;
     float s = 0.f;
 #pragma unroll
@@ -230,7 +233,7 @@ int launch_head(const HeadArgs& a, int batch, hipStream_t stream) {
   hipLaunchKernelGGL(head_pool_kernel, dim3(batch), dim3(256), 0, stream, a);
   int rc = check_launch("head_pool_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(head_fc_kernel, dim3(a.C / 4), dim3(256), 0, stream, a, batch);
+  hipLaunchKernelGGL(head_fc_kernel, dim3(a.C / 4, (batch + kFcSamples - 1) / kFcSamples), dim3(256), 0, stream, a, batch);
   if ((rc = check_launch("head_fc_kernel"))) return rc;
   hipLaunchKernelGGL(head_linear_kernel, dim3(batch), dim3(256), 0, stream, a);
   return check_launch("head_linear_kernel");
