@@ -76,6 +76,8 @@ _PROTOS = {
     "hp_net_copy_feature_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "hp_detector_preprocess": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), c_f32p,
                                          C.c_void_p]),
+    "hp_detector_preprocess_resize": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.POINTER(C.c_float), C.POINTER(C.c_float), c_f32p, C.c_void_p]),
     "hp_net_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_conv_occupancy": (C.c_int, [C.c_int]),
     "hp_probe_mfma_rate": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),

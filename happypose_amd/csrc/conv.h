@@ -160,6 +160,9 @@ int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho,
 int launch_resize_nearest(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, int stride_mode, hipStream_t stream);
 // (x - mean) / std per channel, NCHW [n,3,h,w] -> NHWC [n,h,w,4]
 int launch_normalize_nhwc4(const float* x, float* y, int n, int h, int w, const float* mean3, const float* std3, hipStream_t stream);
+// bilinear resize [n,3,hi,wi] -> [ho,wo] (align_corners = False), (v - mean) / std, into the top-left of a zeroed NHWC4 canvas [n,hp,wp,4]
+int launch_normalize_resize_nhwc4(const float* x, float* y, int n, int hi, int wi, int ho, int wo, int hp, int wp, const float* mean3,
+                                  const float* std3, hipStream_t stream);
 int launch_head(const HeadArgs& a, int batch, hipStream_t stream);
 int launch_dwconv(const DwArgs& a, hipStream_t stream);
 bool mbconv_front_applicable(int cin, int kpad, int cexp, int k, int stride);

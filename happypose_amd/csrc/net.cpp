@@ -1025,6 +1025,16 @@ extern "C" int hp_detector_preprocess(const float* d_images, int n, int h, int w
   return launch_normalize_nhwc4(d_images, d_x_nhwc4, n, h, w, h_mean3, h_std3, (hipStream_t)stream);
 }
 
+extern "C" int hp_detector_preprocess_resize(const float* d_images, int n, int h_in, int w_in, int h_out, int w_out, int h_pad,
+                                             int w_pad, const float* h_mean3, const float* h_std3, float* d_x_nhwc4,
+                                             void* stream) {
+  HP_REQUIRE(d_images && d_x_nhwc4 && h_mean3 && h_std3 && n >= 0 && h_in > 0 && w_in > 0 && h_out > 0 && w_out > 0 &&
+                 h_pad >= h_out && w_pad >= w_out, "hp_detector_preprocess_resize: bad argument");
+  if (n == 0) return HP_OK;
+  return launch_normalize_resize_nhwc4(d_images, d_x_nhwc4, n, h_in, w_in, h_out, w_out, h_pad, w_pad, h_mean3, h_std3,
+                                       (hipStream_t)stream);
+}
+
 extern "C" int hp_net_input_channels_f16(const hp_net* net) {
   return net && net->finalized && net->precision == HP_PRECISION_F16 ? net->convs[0]->cin16 : HP_ERR_ARG;
 }

@@ -54,6 +54,42 @@ __global__ __launch_bounds__(256) void resize_nearest_nhwc(const float* x, float
       *reinterpret_cast<const float4*>(x + (((int64_t)img * H + ih) * W + iw) * C + 4 * c4);
 }
 
+// ---- detector pre-processing with GeneralizedRCNNTransform.resize: bilinear, align_corners = False, the scale
+// recomputed from the sizes (torch upsample_bilinear2d: src = (dst + 0.5) * in / out - 0.5, clamped at 0; the neighbour
+// index clamped at in - 1), then (v - mean) / std; pixels of the padded canvas outside [0, ho) x [0, wo) are zero
+// (batch_images pads the NORMALISED image with zeros).  torchvision normalises first and interpolates after; both are
+// affine per channel, so the order only moves the rounding.
+__global__ __launch_bounds__(256) void normalize_resize_nchw_to_nhwc4(const float* x, float* y, int n, int hi, int wi, int ho, int wo,
+                                                                      int hp, int wp, float m0, float m1, float m2, float s0,
+                                                                      float s1, float s2) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)n * hp * wp;
+  if (t >= total) return;
+  const int px = (int)(t % wp);
+  const int64_t r = t / wp;
+  const int py = (int)(r % hp), img = (int)(r / hp);
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (py < ho && px < wo) {
+    const float sy = (float)hi / (float)ho, sx = (float)wi / (float)wo;
+    float fy = sy * ((float)py + 0.5f) - 0.5f, fx = sx * ((float)px + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const int64_t plane = (int64_t)hi * wi;
+    const float* src = x + (int64_t)img * 3 * plane;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* pc = src + c * plane;
+      v[c] = hy * (hx * pc[(int64_t)y0 * wi + x0] + lx * pc[(int64_t)y0 * wi + x1]) +
+             ly * (hx * pc[(int64_t)y1 * wi + x0] + lx * pc[(int64_t)y1 * wi + x1]);
+    }
+    o = make_float4((v[0] - m0) / s0, (v[1] - m1) / s1, (v[2] - m2) / s2, 0.f);
+  }
+  *reinterpret_cast<float4*>(y + 4 * t) = o;
+}
+
 // ---- detector pre-processing: GeneralizedRCNNTransform.normalize ((image - mean) / std per channel,
 // torchvision models/detection/transform.py) + NCHW [b,3,h,w] -> NHWC [b,h,w,4] (pad channel 0)
 __global__ __launch_bounds__(256) void normalize_nchw_to_nhwc4(const float* x, float* y, int64_t hw, int64_t total,
@@ -213,6 +249,14 @@ int launch_normalize_nhwc4(const float* x, float* y, int n, int h, int w, const 
   hipLaunchKernelGGL(normalize_nchw_to_nhwc4, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, hw, total,
                      mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
   return check_launch("normalize_nchw_to_nhwc4");
+}
+
+int launch_normalize_resize_nhwc4(const float* x, float* y, int n, int hi, int wi, int ho, int wo, int hp, int wp, const float* mean3,
+                                  const float* std3, hipStream_t stream) {
+  const int64_t total = (int64_t)n * hp * wp;
+  hipLaunchKernelGGL(normalize_resize_nchw_to_nhwc4, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, n, hi, wi,
+                     ho, wo, hp, wp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  return check_launch("normalize_resize_nchw_to_nhwc4");
 }
 
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream) {

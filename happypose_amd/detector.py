@@ -70,31 +70,55 @@ def base_anchors(size: float) -> np.ndarray:
     return np.round(np.stack([-ws, -hs, ws, hs], 1) / np.float32(2)).astype(np.float32)
 
 
+def transform_sizes(image_size, min_size: Optional[int] = None, max_size: Optional[int] = None):
+    """``GeneralizedRCNNTransform.resize`` + ``batch_images`` (torchvision models/detection/transform.py) for one image
+    size: ``(resized (h, w), padded (h, w))``.  The scale is formed in float32 exactly as torchvision's tensor expression
+    forms it (``min(min_size / min(h, w), max_size / max(h, w))``), the resized size is ``floor(size * scale)``
+    (``F.interpolate(..., recompute_scale_factor=True)``), the canvas is that rounded up to a multiple of 32."""
+    h, w = int(image_size[0]), int(image_size[1])
+    min_size = min(h, w) if min_size is None else min_size
+    max_size = max(h, w) if max_size is None else max_size
+    # torchvision divides a Python float by a 0-dim float32 tensor: Tensor.__rtruediv__ = reciprocal(tensor) * scalar, two
+    # float32 roundings (320 / 500 -> 0.64000005, not the correctly rounded 0.63999999: 300 x 500 becomes 192 x 320, not 191 x 319)
+    rdiv = lambda num, den: np.float32(np.float32(1.0) / np.float32(den)) * np.float32(num)  # noqa: E731
+    scale = float(min(rdiv(min_size, min(h, w)), rdiv(max_size, max(h, w))))
+    hr, wr = int(np.floor(float(h) * scale)), int(np.floor(float(w) * scale))
+    return (hr, wr), ((hr + 31) // 32 * 32, (wr + 31) // 32 * 32)
+
+
 class DetectorBackbone:
     """ResNet-50 + FPN + RPN head on the device.  ``state_dict``: the reference checkpoint's keys
-    (``backbone.body.*``, ``backbone.fpn.*``, ``rpn.head.*``); input size is fixed at construction (the reference
-    resizes every image to ``input_resize``, ``MP/models/mask_rcnn.py:25,39-40``)."""
+    (``backbone.body.*``, ``backbone.fpn.*``, ``rpn.head.*``).  The image size is fixed at construction (the plan is built for
+    it); ``min_size`` / ``max_size`` are the reference's ``input_resize`` (``MP/models/mask_rcnn.py:25,39-40``: images are
+    resized so that the short side is ``min(input_resize)``, capped by ``max(input_resize)`` on the long side)."""
 
-    def __init__(self, state_dict: Dict, input_size=(480, 640), max_batch: int = 1, device="cuda"):
+    def __init__(self, state_dict: Dict, input_size=(480, 640), max_batch: int = 1, device="cuda", min_size: Optional[int] = None,
+                 max_size: Optional[int] = None):
         self.device = torch.device(device)
-        self.h, self.w = input_size
-        assert self.h % 32 == 0 and self.w % 32 == 0, "input size must be a multiple of 32 (GeneralizedRCNNTransform pads to that)"
+        self.in_h, self.in_w = int(input_size[0]), int(input_size[1])              # images as handed over
+        (self.rh, self.rw), (self.h, self.w) = transform_sizes(input_size, min_size, max_size)  # resized; padded canvas = the plan
         sd = {k: v for k, v in modernise_keys(state_dict).items() if k.startswith(("backbone.", "rpn.head."))}
         self.net = ops.Net("resnet50-fpn", 3, sd, max_batch=max_batch, device=self.device, h=self.h, w=self.w)
         self.max_batch = max_batch
 
     @torch.no_grad()
     def forward_nhwc(self, images: torch.Tensor) -> List[torch.Tensor]:
-        """``images [b,3,h,w]`` fp32 in [0,1] -> the 15 NHWC maps (5 pyramid levels, 5 objectness ``[..,4]``, 5 deltas ``[..,12]``)."""
+        """``images [b,3,H,W]`` fp32 in [0,1] -> the 15 NHWC maps (5 pyramid levels, 5 objectness ``[..,4]``, 5 deltas ``[..,12]``)
+        of the resized, normalised, zero-padded images."""
         b = images.shape[0]
-        assert images.shape[1:] == (3, self.h, self.w) and images.dtype == torch.float32 and b <= self.max_batch
+        assert images.shape[1:] == (3, self.in_h, self.in_w) and images.dtype == torch.float32 and b <= self.max_batch
         images = images.to(self.device).contiguous()
         x = torch.empty((b, self.h, self.w, 4), dtype=torch.float32, device=self.device)
         mean = (C.c_float * 3)(*IMAGE_MEAN)
         std = (C.c_float * 3)(*IMAGE_STD)
         with torch.cuda.device(self.device):
-            check(lib().hp_detector_preprocess(ptr(images), b, self.h, self.w, mean, std, ptr(x), stream_ptr(self.device)),
-                  "hp_detector_preprocess")
+            if (self.in_h, self.in_w) == (self.h, self.w):
+                check(lib().hp_detector_preprocess(ptr(images), b, self.h, self.w, mean, std, ptr(x), stream_ptr(self.device)),
+                      "hp_detector_preprocess")
+            else:
+                check(lib().hp_detector_preprocess_resize(ptr(images), b, self.in_h, self.in_w, self.rh, self.rw, self.h, self.w,
+                                                          mean, std, ptr(x), stream_ptr(self.device)),
+                      "hp_detector_preprocess_resize")
         self.net.forward(x, want_pose=False)
         return self.net.feature_maps(b)
 
@@ -114,13 +138,15 @@ class MaskRCNN:
     torchvision's ``MaskRCNN.forward`` (masks ``[n,1,H,W]`` probabilities)."""
 
     def __init__(self, state_dict: Dict, num_classes: int, input_size=(480, 640), max_batch: int = 1, device="cuda",
-                 rpn_pre_nms_top_n: int = 1000, rpn_post_nms_top_n: int = 1000, rpn_nms_thresh: float = 0.7,
+                 min_size: Optional[int] = None, max_size: Optional[int] = None, rpn_pre_nms_top_n: int = 1000, rpn_post_nms_top_n: int = 1000, rpn_nms_thresh: float = 0.7,
                  box_score_thresh: float = 0.05, box_nms_thresh: float = 0.5, box_detections_per_img: int = 100):
         sd = modernise_keys(state_dict)
         self.device = torch.device(device)
         self.num_classes = num_classes
-        self.size = tuple(input_size)
-        self.backbone = DetectorBackbone(sd, input_size, max_batch, device)
+        self.orig_size = (int(input_size[0]), int(input_size[1]))      # images as handed over; boxes / masks are returned in it
+        self.backbone = DetectorBackbone(sd, input_size, max_batch, device, min_size, max_size)
+        self.size = (self.backbone.rh, self.backbone.rw)               # the resized image: what boxes are clipped to
+        self.padded = (self.backbone.h, self.backbone.w)               # the canvas the network runs on
         self.cfg = dict(pre=rpn_pre_nms_top_n, post=rpn_post_nms_top_n, rpn_nms=rpn_nms_thresh, score=box_score_thresh,
                         nms=box_nms_thresh, dets=box_detections_per_img)
         c4 = (num_classes + 3) // 4 * 4
@@ -200,7 +226,7 @@ class MaskRCNN:
             base = (C.c_float * 12)(*self._base[l].reshape(-1).tolist())
             delta_map = delta_map.contiguous()
             with torch.cuda.device(dev):
-                check(lib().hp_rpn_decode(ptr(top), ptr(idx32), k, ptr(delta_map), gw, 3, base, H // gh, W // gw,
+                check(lib().hp_rpn_decode(ptr(top), ptr(idx32), k, ptr(delta_map), gw, 3, base, self.padded[0] // gh, self.padded[1] // gw,
                                           C.c_float(H), C.c_float(W), C.c_float(1e-3), ptr(boxes), ptr(scores), ptr(valid),
                                           stream_ptr(dev)), "hp_rpn_decode")
             boxes_l.append(boxes); scores_l.append(scores); valid_l.append(valid.bool()); lvl_l.append(torch.full((k,), l, device=dev, dtype=torch.int32))
@@ -244,14 +270,21 @@ class MaskRCNN:
             keep = self._nms(bx, lb, self.cfg["nms"])
             bx, sc, lb = bx[keep][: self.cfg["dets"]], sc[keep][: self.cfg["dets"]], lb[keep][: self.cfg["dets"]]
             nd = bx.shape[0]
-            masks = torch.zeros((nd, 1, H, W), dtype=torch.float32, device=dev)
+            OH, OW = self.orig_size
+            masks = torch.zeros((nd, 1, OH, OW), dtype=torch.float32, device=dev)
+            ml = None
             if nd:
                 mrois = torch.cat([torch.full((nd, 1), float(b), device=dev), bx], 1)
                 mp = self._roi_align(maps, mrois, 14)                                    # [nd,14,14,256]
                 ml = self.mask_net.run(mp)[0]                                            # [nd,14,56,c4] = (i, (j, a, b), class)
+            if (OH, OW) != (H, W):  # GeneralizedRCNNTransform.postprocess: resize_boxes back to the image as handed over
+                rh = torch.tensor(float(OH), dtype=torch.float32) / torch.tensor(float(H), dtype=torch.float32)
+                rw = torch.tensor(float(OW), dtype=torch.float32) / torch.tensor(float(W), dtype=torch.float32)
+                bx = bx * torch.stack([rw, rh, rw, rh]).to(dev)
+            if nd:
                 lab32, ml, bx = lb.to(torch.int32).contiguous(), ml.contiguous(), bx.contiguous()
                 with torch.cuda.device(dev):
-                    check(lib().hp_paste_masks(ptr(ml), ml.shape[-1], ptr(lab32), ptr(bx), nd, H, W, ptr(masks),
+                    check(lib().hp_paste_masks(ptr(ml), ml.shape[-1], ptr(lab32), ptr(bx), nd, OH, OW, ptr(masks),
                                                stream_ptr(dev)), "hp_paste_masks")
             results.append(dict(boxes=bx, labels=lb, scores=sc, masks=masks))
             inter.append(dict(proposals=props, proposal_scores=pscores, pooled=pooled, class_logits=cls[:, : self.num_classes],

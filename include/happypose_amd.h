@@ -251,6 +251,12 @@ int hp_net_copy_feature_map(const hp_net* net, int index, int batch, float* d_ds
  * stack wants: d_images NCHW [n][3][h][w] in [0,1] (ObservationTensor.images[:, :3]) -> d_x NHWC [n][h][w][4], pad channel 0. */
 int hp_detector_preprocess(const float* d_images, int n, int h, int w, const float* h_mean3, const float* h_std3,
                            float* d_x_nhwc4, void* stream);
+/* The same with GeneralizedRCNNTransform.resize + batch_images in front (torchvision models/detection/transform.py:
+ * _resize_image_and_masks = F.interpolate(bilinear, align_corners=False, recompute_scale_factor=True); batch_images pads
+ * to a multiple of 32 with zeros): images [n,3,h_in,w_in] -> resized to [h_out,w_out], normalised, written into the
+ * top-left of the zeroed canvas [n,h_pad,w_pad,4].  The caller computes the sizes (happypose_amd/detector.py). */
+int hp_detector_preprocess_resize(const float* d_images, int n, int h_in, int w_in, int h_out, int w_out, int h_pad, int w_pad,
+                                  const float* h_mean3, const float* h_std3, float* d_x_nhwc4, void* stream);
 /* fp16 plan only: the input already in fp16, NHWC [batch][h][w][hp_net_input_channels_f16()] with the
  * channels past n_inputs zero (hp_crop_roi_align_f16 / hp_rasterize with HP_RASTER_OUT_F16 write it):
  * saves the fp32 -> fp16 conversion pass of hp_net_forward (5 % of a coarse-scoring step). */

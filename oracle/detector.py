@@ -79,12 +79,12 @@ def normalize(images: torch.Tensor) -> torch.Tensor:
     return (images - mean) / std
 
 
-def backbone_fpn_rpn(images: torch.Tensor, state_dict) -> Dict[str, List[torch.Tensor]]:
-    """images ``[b,3,h,w]`` in [0,1] -> ``dict(features=[5 x [b,256,h_l,w_l]], objectness=[5 x [b,3,h_l,w_l]],
-    deltas=[5 x [b,12,h_l,w_l]])``."""
+def backbone_fpn_rpn(images: torch.Tensor, state_dict, normalized: bool = False) -> Dict[str, List[torch.Tensor]]:
+    """images ``[b,3,h,w]`` in [0,1] (or already normalised / resized / padded by :func:`transform`) ->
+    ``dict(features=[5 x [b,256,h_l,w_l]], objectness=[5 x [b,3,h_l,w_l]], deltas=[5 x [b,12,h_l,w_l]])``."""
     sd = {k: torch.as_tensor(np.asarray(v)) for k, v in state_dict.items()}
     b = "backbone.body."
-    x = normalize(images)
+    x = images if normalized else normalize(images)
     x = F.relu(_bn(F.conv2d(x, sd[b + "conv1.weight"], stride=2, padding=3), sd, b + "bn1"))
     x = F.max_pool2d(x, 3, 2, 1)
     feats = []
@@ -220,8 +220,11 @@ def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, t
 
 
 def rpn_proposals(objectness: List[torch.Tensor], deltas: List[torch.Tensor], image_size, pre_nms_top_n=1000, post_nms_top_n=1000,
-                  nms_thresh=0.7, min_size=1e-3, score_thresh=0.0):
-    """``RegionProposalNetwork.forward`` (eval) for image 0 of the batch: maps ``[b,3,h,w]`` / ``[b,12,h,w]``."""
+                  nms_thresh=0.7, min_size=1e-3, score_thresh=0.0, padded_size=None):
+    """``RegionProposalNetwork.forward`` (eval): maps ``[b,3,h,w]`` / ``[b,12,h,w]``.  ``image_size`` = the (resized) image the
+    boxes are clipped to; ``padded_size`` = the batched canvas the anchor strides come from (AnchorGenerator.forward uses
+    ``image_list.tensors.shape[-2:]``); default: no padding."""
+    padded_size = image_size if padded_size is None else padded_size
     out = []
     for b in range(objectness[0].shape[0]):
         boxes_l, scores_l, lvl_l = [], [], []
@@ -231,7 +234,7 @@ def rpn_proposals(objectness: List[torch.Tensor], deltas: List[torch.Tensor], im
             dl = d[b].view(A, 4, gh, gw).permute(2, 3, 0, 1).reshape(-1, 4)
             k = min(pre_nms_top_n, ob.numel())
             top, idx = ob.topk(k)
-            anchors = level_anchors(image_size, (gh, gw), ANCHOR_SIZES[l][0])
+            anchors = level_anchors(padded_size, (gh, gw), ANCHOR_SIZES[l][0])
             prop = decode(dl[idx], anchors[idx], (1.0, 1.0, 1.0, 1.0)).view(-1, 4)
             boxes_l.append(prop); scores_l.append(torch.sigmoid(top)); lvl_l.append(torch.full((k,), l, dtype=torch.int64))
         boxes, scores, lvl = torch.cat(boxes_l), torch.cat(scores_l), torch.cat(lvl_l)
@@ -322,13 +325,37 @@ def paste_masks(mask_prob: torch.Tensor, boxes: torch.Tensor, image_size, paddin
     return torch.stack(res)[:, None] if res else torch.zeros((0, 1, im_h, im_w))
 
 
-def maskrcnn_forward(images: torch.Tensor, state_dict):
-    """``DetectorMaskRCNN.forward`` in eval mode on images that already have the network's input size (no resize / padding
-    in GeneralizedRCNNTransform): list of ``dict(boxes, labels, scores, masks [n,1,H,W])`` per image + the intermediates."""
+def transform(images: torch.Tensor, min_size: int, max_size: int):
+    """``GeneralizedRCNNTransform.forward`` for a batch of equally sized images: normalize, ``_resize_image_and_masks``
+    (``F.interpolate(bilinear, align_corners=False, recompute_scale_factor=True)`` with the float32 scale torchvision
+    forms), ``batch_images`` (zero padding to a multiple of 32) -> ``(canvas [b,3,hp,wp], resized (h, w))``."""
+    h, w = images.shape[-2:]
+    x = normalize(images)
+    im_shape = torch.tensor([h, w])
+    scale = torch.min(float(min_size) / torch.min(im_shape).to(torch.float32), float(max_size) / torch.max(im_shape).to(torch.float32))
+    x = F.interpolate(x, scale_factor=scale.item(), mode="bilinear", recompute_scale_factor=True, align_corners=False)
+    hr, wr = x.shape[-2:]
+    hp, wp = (hr + 31) // 32 * 32, (wr + 31) // 32 * 32
+    canvas = x.new_zeros((x.shape[0], 3, hp, wp))
+    canvas[:, :, :hr, :wr] = x
+    return canvas, (hr, wr)
+
+
+def maskrcnn_forward(images: torch.Tensor, state_dict, min_size=None, max_size=None):
+    """``DetectorMaskRCNN.forward`` in eval mode: list of ``dict(boxes, labels, scores, masks [n,1,H,W])`` per image (in the
+    coordinates of the images as handed over) + the intermediates.  ``min_size`` / ``max_size``: the transform's resize
+    (default: the image's own sides -> no resize, no padding: images that already have the network's input size)."""
     sd = {k: torch.as_tensor(np.asarray(v)) for k, v in state_dict.items()}
-    image_size = tuple(images.shape[-2:])
-    dense = backbone_fpn_rpn(images, state_dict)
-    props = rpn_proposals(dense["objectness"], dense["deltas"], image_size)
+    orig_size = tuple(images.shape[-2:])
+    if min_size is None and max_size is None:
+        image_size = padded = orig_size
+        dense = backbone_fpn_rpn(images, state_dict)
+    else:
+        canvas, image_size = transform(images, min(orig_size) if min_size is None else min_size,
+                                       max(orig_size) if max_size is None else max_size)
+        padded = tuple(canvas.shape[-2:])
+        dense = backbone_fpn_rpn(canvas, state_dict, normalized=True)
+    props = rpn_proposals(dense["objectness"], dense["deltas"], image_size, padded_size=padded)
     boxes_per_image = [p[0] for p in props]
     pooled, _ = multiscale_roi_align(dense["features"], boxes_per_image, image_size, 7)
     cls, reg = box_head(pooled, sd)
@@ -338,11 +365,15 @@ def maskrcnn_forward(images: torch.Tensor, state_dict):
         bx, sc, lb = postprocess_detections(cls[start:start + n], reg[start:start + n], pb, image_size)
         start += n
         mp, _ = multiscale_roi_align(dense["features"], [torch.zeros((0, 4))] * b + [bx], image_size, 14) if len(bx) else (torch.zeros((0, 256, 14, 14)), None)
+        if image_size != orig_size:  # GeneralizedRCNNTransform.postprocess -> resize_boxes
+            rh = torch.tensor(orig_size[0], dtype=torch.float32) / torch.tensor(image_size[0], dtype=torch.float32)
+            rw = torch.tensor(orig_size[1], dtype=torch.float32) / torch.tensor(image_size[1], dtype=torch.float32)
+            bx = bx * torch.stack([rw, rh, rw, rh])
         if len(bx):
             ml = mask_head(mp, sd)
             prob = ml.sigmoid()[torch.arange(len(bx)), lb][:, None]
-            masks = paste_masks(prob, bx, image_size)
+            masks = paste_masks(prob, bx, orig_size)
         else:
-            masks = torch.zeros((0, 1, *image_size))
+            masks = torch.zeros((0, 1, *orig_size))
         results.append(dict(boxes=bx, labels=lb, scores=sc, masks=masks))
     return results, dict(dense=dense, proposals=props, pooled=pooled, class_logits=cls, box_regression=reg)

@@ -201,6 +201,55 @@ def test_maskrcnn_end_to_end_vs_oracle(dev):
     assert len(d1) <= NC - 1 and (d1.infos.score > 0.5).all()
 
 
+@pytest.mark.parametrize("size,min_size,max_size", [((300, 500), 240, 320), ((360, 400), 200, 400)])
+def test_maskrcnn_transform_resize_vs_oracle(dev, size, min_size, max_size):
+    """GeneralizedRCNNTransform.resize + batch_images in front and resize_boxes / paste at the original size behind:
+    images that do not arrive at ``input_resize`` (300 x 500 -> 192 x 320, no padding; 360 x 400 -> 200 x 222 on a
+    224 x 224 canvas).  The resized, normalised canvas is checked first (hp_detector_preprocess_resize vs F.interpolate),
+    then the detections in the coordinates of the image as handed over."""
+    from happypose_amd.detector import MaskRCNN, transform_sizes
+    from oracle import detector as od
+
+    NC = 4
+    w = _weights(NC)
+    model = MaskRCNN(w, NC, input_size=size, max_batch=1, device=dev, min_size=min_size, max_size=max_size)
+    images = torch.as_tensor(np.random.RandomState(7).uniform(0, 1, size=(1, 3, *size)).astype(np.float32))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        canvas, resized = od.transform(images, min_size, max_size)
+        ref, inter = od.maskrcnn_forward(images, w, min_size=min_size, max_size=max_size)
+    assert (tuple(resized), tuple(canvas.shape[-2:])) == transform_sizes(size, min_size, max_size) == (model.size, model.padded)
+    # the pre-processing kernel alone: run the backbone's first step by hand
+    import ctypes as C
+
+    from happypose_amd._ffi import check, lib, ptr, stream_ptr
+    from happypose_amd.detector import IMAGE_MEAN, IMAGE_STD
+
+    x = torch.empty((1, *model.padded, 4), dtype=torch.float32, device=dev)
+    img_d = images.to(dev).contiguous()
+    check(lib().hp_detector_preprocess_resize(ptr(img_d), 1, size[0], size[1], resized[0], resized[1], model.padded[0], model.padded[1],
+                                              (C.c_float * 3)(*IMAGE_MEAN), (C.c_float * 3)(*IMAGE_STD), ptr(x), stream_ptr(dev)),
+          "hp_detector_preprocess_resize")
+    np.testing.assert_allclose(x[..., :3].permute(0, 3, 1, 2).cpu().numpy(), canvas.numpy(), rtol=0, atol=2e-5)
+    assert float(x[..., 3].abs().max()) == 0.0
+
+    out, mine = model.forward(images.to(dev), return_intermediates=True)
+    assert abs(len(mine[0]["proposals"]) - len(inter["proposals"][0][0])) <= 5
+    r, g = ref[0], out[0]
+    assert abs(len(g["boxes"]) - len(r["boxes"])) <= 2 and len(r["boxes"]) >= 3
+    assert g["masks"].shape[-2:] == tuple(size) == tuple(r["masks"].shape[-2:])
+    iou = _iou(r["boxes"].numpy(), g["boxes"].cpu().numpy())
+    matched = 0
+    for i in range(len(r["boxes"])):
+        j = int(iou[i].argmax())
+        if iou[i, j] > 0.98 and int(g["labels"][j]) == int(r["labels"][i]) and abs(float(g["scores"][j]) - float(r["scores"][i])) < 2e-3:
+            matched += 1
+            a, b_ = g["masks"][j, 0].cpu().numpy() > 0.8, r["masks"][i, 0].numpy() > 0.8
+            assert (a != b_).mean() < 2e-3
+    assert matched >= len(r["boxes"]) - 1, (matched, len(r["boxes"]))
+    assert float(g["boxes"][:, 2].max()) <= size[1] + 1e-3 and float(g["boxes"][:, 3].max()) <= size[0] + 1e-3
+
+
 def test_run_inference_pipeline_with_detector(dev):
     """run_detector=True (MP/inference/pose_estimator.py:559-566): detections come from the Mask-RCNN detector and feed the
     coarse / refiner stages; labels are mapped through label_to_category_id like the reference's Detector."""
