@@ -169,7 +169,7 @@ bool mbconv_front_applicable(int cin, int kpad, int cexp, int k, int stride);
 int mbconv_front_tiles(int Ho, int Wo, int stride);
 int launch_mbconv_front(const FrontArgs& a, hipStream_t stream);
 bool dwconv_pools(const DwArgs& a);   // the launch can also write a.pool_partial
-int dwconv_pool_strips(int Ho);       // partial sums per image it writes
+int dwconv_pool_strips(int Ho, int k, int stride);  // partial sums per image it writes
 // squeeze-excitation: pooled [n][C] = mean over HW of y; gate [n][C] = sigmoid(W2 swish(W1 pooled + b1) + b2)
 int se_partial_floats(int n, int C);  // workspace of launch_se
 int launch_se(const float* y, float* partial, float* pooled, float* sq, float* gate, const float* w1, const float* b1,

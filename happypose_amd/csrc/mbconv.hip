@@ -63,11 +63,14 @@ __global__ __launch_bounds__(256) void dwconv_swish_nhwc(DwArgs a) {
 // per output is the same (dy, dx ascending), so the conv result is bit-identical.  The lanes also sum what they store:
 // the per-(image, strip, channel) sums are the squeeze-excitation pooling partials (se_pool_kernel re-read the whole
 // tensor for them); lanes of one channel quad meet in LDS in a fixed order (reproducible).
-constexpr int kDwRows = 4;
+// output rows per strip: 8 on the maps with >= 30 rows (input rows re-read by neighbouring strips: (R-1)S+K for R outputs), 4 on
+// the small maps, where strips are what fills the GPU
+// (5x5 / stride 2 stays at 4: 11 + 4 input rows x 5 quads beside 25 taps spill at 8)
+__host__ __device__ constexpr int dw_rows(int Ho, int k, int stride) { return Ho >= 30 && !(k == 5 && stride == 2) ? 8 : 4; }
 
-template <int K, int S>
+template <int K, int S, int R>
 __global__ __launch_bounds__(256) void dwconv_strip_kernel(DwArgs a) {
-  constexpr int R = kDwRows, NR = (R - 1) * S + K;
+  constexpr int NR = (R - 1) * S + K;
   __shared__ floatx4 red[256];
   const int C4 = a.C >> 2;
   const int cq0 = blockIdx.x * 256;
@@ -195,17 +198,20 @@ __global__ __launch_bounds__(256) void se_expand_kernel(const float* sq, const f
 
 }  // namespace
 
-int dwconv_pool_strips(int Ho) { return (Ho + kDwRows - 1) / kDwRows; }
+int dwconv_pool_strips(int Ho, int k, int stride) { return (Ho + dw_rows(Ho, k, stride) - 1) / dw_rows(Ho, k, stride); }
 
 // a.pool_partial (or null) receives [n][dwconv_pool_strips(Ho)][C] sums of the outputs (strip kernel only)
 int launch_dwconv(const DwArgs& a, hipStream_t stream) {
   static const bool old_kernel = std::getenv("HP_DW_OLD") != nullptr;
   if (!old_kernel && (a.stride == 1 || a.stride == 2) && (a.k == 3 || a.k == 5) && a.n < 65536) {
-    const dim3 grid((unsigned)((a.C / 4 + 255) / 256), (unsigned)dwconv_pool_strips(a.Ho), (unsigned)a.n);
-    if (a.k == 3 && a.stride == 1) hipLaunchKernelGGL((dwconv_strip_kernel<3, 1>), grid, dim3(256), 0, stream, a);
-    else if (a.k == 3) hipLaunchKernelGGL((dwconv_strip_kernel<3, 2>), grid, dim3(256), 0, stream, a);
-    else if (a.stride == 1) hipLaunchKernelGGL((dwconv_strip_kernel<5, 1>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((dwconv_strip_kernel<5, 2>), grid, dim3(256), 0, stream, a);
+    const dim3 grid((unsigned)((a.C / 4 + 255) / 256), (unsigned)dwconv_pool_strips(a.Ho, a.k, a.stride), (unsigned)a.n);
+#define HP_DW(K_, S_)                                                                                                        \
+  if (a.k == K_ && a.stride == S_) {                                                                                        \
+    if (dw_rows(a.Ho, K_, S_) == 8) hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 8>), grid, dim3(256), 0, stream, a);            \
+    else hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 4>), grid, dim3(256), 0, stream, a);                               \
+  }
+    HP_DW(3, 1) HP_DW(3, 2) HP_DW(5, 1) HP_DW(5, 2)
+#undef HP_DW
     return check_launch("dwconv_strip_kernel");
   }
   if (a.pool_partial) return fail(HP_ERR_ARG, "dwconv: pooled sums need the strip kernel");

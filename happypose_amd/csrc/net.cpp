@@ -920,9 +920,9 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       // the squeeze-excitation that follows pools this output: let the depthwise launch sum what it stores
       dw_partials = 0;
       if (oi + 1 < net->ops.size() && net->ops[oi + 1].kind == OP_SE && net->ses[net->ops[oi + 1].conv]->in_buf == D.out_buf &&
-          dwconv_pools(d) && dwconv_pool_strips(D.Ho) <= 32) {
+          dwconv_pools(d) && dwconv_pool_strips(D.Ho, D.k, D.stride) <= 32) {
         d.pool_partial = (float*)net->se_partial.p;
-        dw_partials = dwconv_pool_strips(D.Ho);
+        dw_partials = dwconv_pool_strips(D.Ho, D.k, D.stride);
       }
       if ((rc = launch_dwconv(d, stream))) return rc;
     } else if (op.kind == OP_SE) {
