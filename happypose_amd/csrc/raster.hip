@@ -43,6 +43,24 @@ constexpr float kZNear = 0.1f;
 constexpr float kZFar = 10.0f;
 constexpr unsigned long long kKeyEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kBandPixels = HP_RASTER_BAND_PIXELS;  // LDS z-buffer of a band, 8 B per pixel
+// HP_RASTER_MSAA4 (the reference's framebuffer state, see oracle.c HP_R_MSAA4): five keys per pixel -- the four colour
+// samples of the standard 4x pattern and the pixel centre (depth / mask stay centre-sampled) -- in a 50-KB z-buffer:
+// 4 rows of 320 pixels per band, three 512-thread workgroups per CU (12800 keys / one workgroup per CU: 1.4x slower).
+// The coverage pass tests 5 samples on a bounding box that grows by the sample spread: ~10x its single-sample work,
+// 3.6x the whole rasteriser (128 views: 240 -> 880 us)
+constexpr int kSamplesMsaa = 5;
+#ifndef HP_RASTER_BAND_KEYS_MSAA
+#define HP_RASTER_BAND_KEYS_MSAA 6400
+#endif
+constexpr int kBandKeysMsaa = HP_RASTER_BAND_KEYS_MSAA;
+__device__ __forceinline__ float sample_x(int ns, int sm) {
+  const float sx[5] = {0.375f, 0.875f, 0.125f, 0.625f, 0.5f};
+  return ns == 1 ? 0.5f : sx[sm];
+}
+__device__ __forceinline__ float sample_y(int ns, int sm) {
+  const float sy[5] = {0.125f, 0.375f, 0.625f, 0.875f, 0.5f};
+  return ns == 1 ? 0.5f : sy[sm];
+}
 constexpr int kBigQueue = 512;
 constexpr int kBigArea = 128;  // bbox pixels above which a triangle is walked cooperatively
 constexpr int kThreads = HP_RASTER_THREADS;  // band kernel
@@ -71,6 +89,7 @@ struct RasterArgs {
   hp_strides cs, ds;
   int n, views_per_item, n_lights, h, w, flags, depth_norm_mode;
   int band_rows, n_bands;
+  int msaa;             // 1: five keys per pixel (HP_RASTER_MSAA4 and a colour / normal output), 0: the centre only
   float depth_max;
   // per-(view, band) triangle lists built by raster_bin_kernel
   int32_t* bin_count;   // [chunk views][n_bands]
@@ -177,6 +196,9 @@ __device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const TriVerts& t,
     if (!(umax >= 0.0f) || !(umin <= (float)a.w) || !(vmax >= 0.0f) || !(vmin <= (float)a.h)) return false;
     float xa = ceilf(umin - 0.5f), xb = floorf(umax - 0.5f);
     float ya = ceilf(vmin - 0.5f), yb = floorf(vmax - 0.5f);
+    if (a.msaa) {  // some sample of pixel j inside [umin, umax]: offsets run from 0.125 to 0.875
+      xa = ceilf(umin - 0.875f); xb = floorf(umax - 0.125f); ya = ceilf(vmin - 0.875f); yb = floorf(vmax - 0.125f);
+    }
     x0 = xa < 0.0f ? 0 : (int)xa; x1 = xb > (float)(a.w - 1) ? a.w - 1 : (int)xb;
     y0 = ya < 0.0f ? 0 : (int)ya; y1 = yb > (float)(a.h - 1) ? a.h - 1 : (int)yb;
   }
@@ -200,21 +222,25 @@ __device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const TriVer
   return true;
 }
 
+template <int NS>
 __device__ __forceinline__ void shade_pixel(const TriSetup& s, int i, int j, uint32_t f,
                                             unsigned long long* zb, int row0, int w) {
-  const float pv = (float)i + 0.5f, pu = (float)j + 0.5f;
-  float l0 = fmaf(s.e0[0], pu, fmaf(s.e0[1], pv, s.e0[2]));
-  float l1 = fmaf(s.e1[0], pu, fmaf(s.e1[1], pv, s.e1[2]));
-  float l2 = fmaf(s.e2[0], pu, fmaf(s.e2[1], pv, s.e2[2]));
-  float sum = l0 + l1 + l2;
-  bool in_pos = (l0 >= 0.0f) & (l1 >= 0.0f) & (l2 >= 0.0f) & (sum > 0.0f);
-  bool in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (sum < 0.0f);
-  if (!(in_pos | in_neg)) return;
-  // depth = the vertex depths interpolated with the perspective-correct barycentrics (oracle.c explains why not det / sum)
-  float Z = fmaf(l0, s.z0, fmaf(l1, s.z1, l2 * s.z2)) / sum;
-  if (!(Z >= kZNear) || !(Z <= kZFar)) return;
-  unsigned long long key = ((unsigned long long)__float_as_uint(Z) << 32) | f;
-  atomicMin(&zb[(i - row0) * w + j], key);
+#pragma unroll
+  for (int sm = 0; sm < NS; ++sm) {
+    const float pv = (float)i + sample_y(NS, sm), pu = (float)j + sample_x(NS, sm);
+    float l0 = fmaf(s.e0[0], pu, fmaf(s.e0[1], pv, s.e0[2]));
+    float l1 = fmaf(s.e1[0], pu, fmaf(s.e1[1], pv, s.e1[2]));
+    float l2 = fmaf(s.e2[0], pu, fmaf(s.e2[1], pv, s.e2[2]));
+    float sum = l0 + l1 + l2;
+    bool in_pos = (l0 >= 0.0f) & (l1 >= 0.0f) & (l2 >= 0.0f) & (sum > 0.0f);
+    bool in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (sum < 0.0f);
+    if (!(in_pos | in_neg)) continue;
+    // depth = the vertex depths interpolated with the perspective-correct barycentrics (oracle.c explains why not det / sum)
+    float Z = fmaf(l0, s.z0, fmaf(l1, s.z1, l2 * s.z2)) / sum;
+    if (!(Z >= kZNear) || !(Z <= kZFar)) continue;
+    unsigned long long key = ((unsigned long long)__float_as_uint(Z) << 32) | f;
+    atomicMin(&zb[((i - row0) * w + j) * NS + sm], key);
+  }
 }
 
 struct ViewXform { float T[12], Kv[9]; bool finite; };
@@ -310,8 +336,84 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
   }
 }
 
+// One fragment-shader invocation: colour and normal code of triangle f at the CENTRE of pixel (i, j) (attributes
+// extrapolated when the centre lies outside the triangle: multisampled edge pixels) -- oracle.c shade_centre.
+struct ShadeCtx {
+  const float* T; const float* Kv; const float* amb; const float4* xv; const int32_t* fbase;
+  int64_t voff, toff; int tw, th, view, q8;
+};
+__device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx& cx, int f, int i, int j, float* o_rgb, float* o_n) {
+  const float* T = cx.T; const float* Kv = cx.Kv; const float* amb = cx.amb; const float4* xv = cx.xv;
+  const int32_t* fbase = cx.fbase;
+  const int64_t voff = cx.voff, toff = cx.toff;
+  const int tw = cx.tw, th = cx.th, view = cx.view, q8 = cx.q8;
+  int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
+  float e0[3], e1[3], e2[3];
+  const float4 q0 = xv[2 * tri[0]], q1 = xv[2 * tri[1]], q2 = xv[2 * tri[2]];
+  const float V0[3] = {q0.x, q0.y, q0.z}, V1[3] = {q1.x, q1.y, q1.z}, V2[3] = {q2.x, q2.y, q2.z};
+  edge_fn(V1, tri[1], V2, tri[2], e0);
+  edge_fn(V2, tri[2], V0, tri[0], e1);
+  edge_fn(V0, tri[0], V1, tri[1], e2);
+  const float pu = (float)j + 0.5f, pv = (float)i + 0.5f;
+  float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
+  float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
+  float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
+  float sum = l0 + l1 + l2;
+  float b0 = l0 / sum, b1 = l1 / sum, b2 = l2 / sum;
+  const float Z = fmaf(l0, V0[2], fmaf(l1, V1[2], l2 * V2[2])) / sum;  // = the key's depth when the centre is covered
+  const int64_t g0 = voff + tri[0], g1 = voff + tri[1], g2 = voff + tri[2];
+  float alb[3];
+  if (toff >= 0) {
+    const float2 t0 = *reinterpret_cast<const float2*>(a.uvs + 2 * g0);
+    const float2 t1 = *reinterpret_cast<const float2*>(a.uvs + 2 * g1);
+    const float2 t2 = *reinterpret_cast<const float2*>(a.uvs + 2 * g2);
+    float tu = fmaf(b0, t0.x, fmaf(b1, t1.x, b2 * t2.x));
+    float tv = fmaf(b0, t0.y, fmaf(b1, t1.y, b2 * t2.y));
+    tex_fetch(a.tex + toff, tw, th, tu, tv, alb);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      alb[c] = fmaf(b0, (float)a.colors[4 * g0 + c],
+                    fmaf(b1, (float)a.colors[4 * g1 + c], b2 * (float)a.colors[4 * g2 + c])) / 255.0f;
+  }
+  float no[3], nc[3];
+  const float4 n0 = a.normals4[g0], n1 = a.normals4[g1], n2 = a.normals4[g2];
+  no[0] = fmaf(b0, n0.x, fmaf(b1, n1.x, b2 * n2.x));
+  no[1] = fmaf(b0, n0.y, fmaf(b1, n1.y, b2 * n2.y));
+  no[2] = fmaf(b0, n0.z, fmaf(b1, n1.z, b2 * n2.z));
+  nc[0] = fmaf(T[0], no[0], fmaf(T[1], no[1], T[2] * no[2]));
+  nc[1] = fmaf(T[4], no[0], fmaf(T[5], no[1], T[6] * no[2]));
+  nc[2] = fmaf(T[8], no[0], fmaf(T[9], no[1], T[10] * no[2]));
+  float nn = sqrtf(fmaf(nc[0], nc[0], fmaf(nc[1], nc[1], nc[2] * nc[2])));
+  if (nn > 0.0f) { nc[0] /= nn; nc[1] /= nn; nc[2] /= nn; }
+  float lit[3] = {amb[0], amb[1], amb[2]};
+  if (a.n_lights > 0) {
+    float py = (pv - Kv[5]) * Z / Kv[4];
+    float px = ((pu - Kv[2]) * Z - Kv[1] * py) / Kv[0];
+    for (int l = 0; l < a.n_lights; ++l) {
+      const float* lp = a.light_pos + 3 * ((int64_t)view * a.n_lights + l);
+      const float* lc = a.light_col + 3 * ((int64_t)view * a.n_lights + l);
+      float lx = fmaf(T[0], lp[0], fmaf(T[1], lp[1], fmaf(T[2], lp[2], T[3]))) - px;
+      float ly = fmaf(T[4], lp[0], fmaf(T[5], lp[1], fmaf(T[6], lp[2], T[7]))) - py;
+      float lz = fmaf(T[8], lp[0], fmaf(T[9], lp[1], fmaf(T[10], lp[2], T[11]))) - Z;
+      float ln = sqrtf(fmaf(lx, lx, fmaf(ly, ly, lz * lz)));
+      float ndl = ln > 0.0f ? fmaf(nc[0], lx, fmaf(nc[1], ly, nc[2] * lz)) / ln : 0.0f;
+      if (ndl > 0.0f) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lit[c] = fmaf(lc[c], ndl, lit[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o_rgb[c] = quant8(alb[c] * lit[c], q8);
+  o_n[0] = quant8(normal_code(nc[0]), q8);
+  o_n[1] = quant8(normal_code(-nc[1]), q8);
+  o_n[2] = quant8(normal_code(-nc[2]), q8);
+}
+
+template <int NS>
 __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
-  __shared__ unsigned long long zb[kBandPixels];
+  __shared__ unsigned long long zb[NS == 1 ? kBandPixels : kBandKeysMsaa];
   __shared__ int big_q[kBigQueue];
   __shared__ int big_n;
 
@@ -355,7 +457,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   // loop below sees every pixel empty and only streams the background out
   const bool band_empty = cnt == 0;
   if (!band_empty) {
-    for (int p = tid; p < npix; p += kThreads) zb[p] = kKeyEmpty;
+    for (int p = tid; p < npix * NS; p += kThreads) zb[p] = kKeyEmpty;
     if (tid == 0) big_n = 0;
     __syncthreads();
   }
@@ -392,7 +494,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
       if (q < kBigQueue) { big_q[q] = f; continue; }
     }
     for (int i = s.y0; i <= s.y1; ++i)
-      for (int j = s.x0; j <= s.x1; ++j) shade_pixel(s, i, j, (uint32_t)f, zb, row0, a.w);
+      for (int j = s.x0; j <= s.x1; ++j) shade_pixel<NS>(s, i, j, (uint32_t)f, zb, row0, a.w);
   }
   if (!band_empty) __syncthreads();
   const int nbig = band_empty ? 0 : min(big_n, kBigQueue);
@@ -404,7 +506,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
     const int bw = s.x1 - s.x0 + 1;
     const int area = bw * (s.y1 - s.y0 + 1);
     for (int p = tid; p < area; p += kThreads)
-      shade_pixel(s, s.y0 + p / bw, s.x0 + p % bw, (uint32_t)f, zb, row0, a.w);
+      shade_pixel<NS>(s, s.y0 + p / bw, s.x0 + p % bw, (uint32_t)f, zb, row0, a.w);
   }
   if (!band_empty) __syncthreads();
 
@@ -416,79 +518,58 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   const int64_t dbase = (int64_t)item * a.ds.s_item + (int64_t)(view % a.views_per_item) * a.ds.s_view;
   const float zn = a.depth_norm_z ? a.depth_norm_z[item] : 1.0f;
 
+  const ShadeCtx cx{T, Kv, amb, xv, fbase, voff, toff, tw, th, view, q8};
   for (int p = tid; p < npix; p += kThreads) {
     const int i = row0 + p / a.w, j = p % a.w;
-    const unsigned long long key = band_empty ? kKeyEmpty : zb[p];
+    const unsigned long long key = band_empty ? kKeyEmpty : zb[p * NS + (NS - 1)];  // the pixel centre
     float o_rgb[3] = {0.f, 0.f, 0.f}, o_n[3] = {0.f, 0.f, 0.f}, o_d = 0.0f;
-#ifdef HP_RABL_NO_SHADE
-    if (key != kKeyEmpty && a.w < 0) {
-#else
     if (key != kKeyEmpty) {
-#endif
-      const int f = (int)(key & 0xFFFFFFFFull);
-      int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
-      float e0[3], e1[3], e2[3];
-      const float4 q0 = xv[2 * tri[0]], q1 = xv[2 * tri[1]], q2 = xv[2 * tri[2]];
-      const float V0[3] = {q0.x, q0.y, q0.z}, V1[3] = {q1.x, q1.y, q1.z}, V2[3] = {q2.x, q2.y, q2.z};
-      edge_fn(V1, tri[1], V2, tri[2], e0);
-      edge_fn(V2, tri[2], V0, tri[0], e1);
-      edge_fn(V0, tri[0], V1, tri[1], e2);
-      const float pu = (float)j + 0.5f, pv = (float)i + 0.5f;
-      float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
-      float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
-      float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
-      float sum = l0 + l1 + l2;
-      float b0 = l0 / sum, b1 = l1 / sum, b2 = l2 / sum;
-      float Z = __uint_as_float((uint32_t)(key >> 32));
-      const int64_t g0 = voff + tri[0], g1 = voff + tri[1], g2 = voff + tri[2];
-      float alb[3];
-      if (toff >= 0) {
-        const float2 t0 = *reinterpret_cast<const float2*>(a.uvs + 2 * g0);
-        const float2 t1 = *reinterpret_cast<const float2*>(a.uvs + 2 * g1);
-        const float2 t2 = *reinterpret_cast<const float2*>(a.uvs + 2 * g2);
-        float tu = fmaf(b0, t0.x, fmaf(b1, t1.x, b2 * t2.x));
-        float tv = fmaf(b0, t0.y, fmaf(b1, t1.y, b2 * t2.y));
-        tex_fetch(a.tex + toff, tw, th, tu, tv, alb);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          alb[c] = fmaf(b0, (float)a.colors[4 * g0 + c],
-                        fmaf(b1, (float)a.colors[4 * g1 + c], b2 * (float)a.colors[4 * g2 + c])) / 255.0f;
-      }
-      float no[3], nc[3];
-      const float4 n0 = a.normals4[g0], n1 = a.normals4[g1], n2 = a.normals4[g2];
-      no[0] = fmaf(b0, n0.x, fmaf(b1, n1.x, b2 * n2.x));
-      no[1] = fmaf(b0, n0.y, fmaf(b1, n1.y, b2 * n2.y));
-      no[2] = fmaf(b0, n0.z, fmaf(b1, n1.z, b2 * n2.z));
-      nc[0] = fmaf(T[0], no[0], fmaf(T[1], no[1], T[2] * no[2]));
-      nc[1] = fmaf(T[4], no[0], fmaf(T[5], no[1], T[6] * no[2]));
-      nc[2] = fmaf(T[8], no[0], fmaf(T[9], no[1], T[10] * no[2]));
-      float nn = sqrtf(fmaf(nc[0], nc[0], fmaf(nc[1], nc[1], nc[2] * nc[2])));
-      if (nn > 0.0f) { nc[0] /= nn; nc[1] /= nn; nc[2] /= nn; }
-      float lit[3] = {amb[0], amb[1], amb[2]};
-      if (a.n_lights > 0) {
-        float py = (pv - Kv[5]) * Z / Kv[4];
-        float px = ((pu - Kv[2]) * Z - Kv[1] * py) / Kv[0];
-        for (int l = 0; l < a.n_lights; ++l) {
-          const float* lp = a.light_pos + 3 * ((int64_t)view * a.n_lights + l);
-          const float* lc = a.light_col + 3 * ((int64_t)view * a.n_lights + l);
-          float lx = fmaf(T[0], lp[0], fmaf(T[1], lp[1], fmaf(T[2], lp[2], T[3]))) - px;
-          float ly = fmaf(T[4], lp[0], fmaf(T[5], lp[1], fmaf(T[6], lp[2], T[7]))) - py;
-          float lz = fmaf(T[8], lp[0], fmaf(T[9], lp[1], fmaf(T[10], lp[2], T[11]))) - Z;
-          float ln = sqrtf(fmaf(lx, lx, fmaf(ly, ly, lz * lz)));
-          float ndl = ln > 0.0f ? fmaf(nc[0], lx, fmaf(nc[1], ly, nc[2] * lz)) / ln : 0.0f;
-          if (ndl > 0.0f) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) lit[c] = fmaf(lc[c], ndl, lit[c]);
-          }
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) o_rgb[c] = quant8(alb[c] * lit[c], q8);
-      o_n[0] = quant8(normal_code(nc[0]), q8);
-      o_n[1] = quant8(normal_code(-nc[1]), q8);
-      o_n[2] = quant8(normal_code(-nc[2]), q8);
+      const float Z = __uint_as_float((uint32_t)(key >> 32));
       o_d = Z > a.depth_max ? 0.0f : Z;
+    }
+    if (NS == 1) {
+#ifdef HP_RABL_NO_SHADE
+      if (key != kKeyEmpty && a.w < 0)
+#else
+      if (key != kKeyEmpty)
+#endif
+        shade_centre(a, cx, (int)(key & 0xFFFFFFFFull), i, j, o_rgb, o_n);
+    } else if (!band_empty) {
+      // mean over the four samples of the colour their triangle has at the pixel centre; one invocation per pixel and triangle
+      int cf[4];
+      float crgb[4][3], cn[4][3];
+      int ncached = 0;
+      float a_rgb[3] = {0.f, 0.f, 0.f}, a_n[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sm = 0; sm < 4; ++sm) {
+        const unsigned long long ks = zb[p * NS + sm];
+        if (ks == kKeyEmpty) continue;  // the clear colour
+        const int f = (int)(ks & 0xFFFFFFFFull);
+        int k = ncached;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < ncached && cf[q] == f) k = q;
+        if (k == ncached) {
+          float r3[3], n3[3];
+          shade_centre(a, cx, f, i, j, r3, n3);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q == ncached) {
+              cf[q] = f;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { crgb[q][c] = r3[c]; cn[q][c] = n3[c]; }
+            }
+          ++ncached;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q == k) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a_rgb[c] += crgb[q][c]; a_n[c] += cn[q][c]; }
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { o_rgb[c] = quant8(a_rgb[c] * 0.25f, q8); o_n[c] = quant8(a_n[c] * 0.25f, q8); }
     }
     const int64_t co = cbase + (int64_t)i * a.cs.s_row + (int64_t)j * a.cs.s_col;
     // channel-interleaved destinations (NHWC slices of the network input): one 12-B store per pixel
@@ -564,7 +645,11 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   if (depth_strides) a.ds = *depth_strides;
   a.n = n; a.views_per_item = views_per_item; a.n_lights = n_lights; a.h = h; a.w = w;
   a.flags = flags; a.depth_norm_mode = depth_norm_mode;
-  a.band_rows = kBandPixels / w;
+  a.msaa = (flags & HP_RASTER_MSAA4) && (d_rgb || d_nrm) ? 1 : 0;  // depth-only renders have nothing to multisample
+  if (a.msaa)
+    HP_REQUIRE(kSamplesMsaa * w <= kBandKeysMsaa && (h + kBandKeysMsaa / (kSamplesMsaa * w) - 1) / (kBandKeysMsaa / (kSamplesMsaa * w)) <= kMaxBands,
+               "hp_rasterize: resolution too large for HP_RASTER_MSAA4");
+  a.band_rows = a.msaa ? kBandKeysMsaa / (kSamplesMsaa * w) : kBandPixels / w;
   a.n_bands = (h + a.band_rows - 1) / a.band_rows;
   a.depth_max = kZNear / (1.0f - (1.0f - 1e-3f) * (kZFar - kZNear) / kZFar);
   // Views are processed in chunks so that the per-(view, band) triangle lists stay within a
@@ -610,7 +695,8 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
     hipLaunchKernelGGL(raster_xform_kernel, dim3((a.max_verts + 255) / 256, nv), dim3(256), 0, st, a);
     hipLaunchKernelGGL(raster_bin_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
     const int total = nv * a.n_bands;
-    hipLaunchKernelGGL(raster_kernel, dim3(8 * ((total + 7) / 8)), dim3(kThreads), 0, st, a);
+    if (a.msaa) hipLaunchKernelGGL(raster_kernel<kSamplesMsaa>, dim3(8 * ((total + 7) / 8)), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL(raster_kernel<1>, dim3(8 * ((total + 7) / 8)), dim3(kThreads), 0, st, a);
   }
   return check_launch("raster_kernel");
 }

@@ -63,8 +63,13 @@ class BatchRenderer:
     ``split_objects`` are accepted for signature compatibility and ignored."""
 
     def __init__(self, asset_dataset: RigidObjectDataset, n_workers: int = 8, preload_cache: bool = True,
-                 split_objects: bool = False, device="cuda", store: Optional[ops.MeshStore] = None):
+                 split_objects: bool = False, device="cuda", store: Optional[ops.MeshStore] = None, msaa: bool = False):
+        """``msaa``: render colour / normals with 4x multisampling, the framebuffer state of the reference's Panda3D
+        renderer (``TB/renderer/panda3d_scene_renderer.py:70-71``; semantics in ``oracle/csrc/oracle.c`` ``HP_R_MSAA4``).
+        Off by default: the sample pattern is implementation-defined in OpenGL and cannot be pinned here, and the
+        single-sample renders are what every parity number of this repository was measured on."""
         assert n_workers >= 1
+        self.msaa = bool(msaa)
         self._object_dataset = asset_dataset
         self.store = store if store is not None else ops.MeshStore(asset_dataset, device)
         self.device = self.store.device
@@ -108,7 +113,7 @@ class BatchRenderer:
         rgb, nrm, dep, msk = ops.rasterize(
             self.store, self.store.ids_of(labels), TCO.detach(), K, tuple(resolution),
             render_normals=render_normals, render_depth=render_depth,
-            render_binary_mask=render_binary_mask, ambient=amb, light_pos=pos, light_col=col)
+            render_binary_mask=render_binary_mask, ambient=amb, light_pos=pos, light_col=col, msaa=self.msaa)
         return BatchRenderOutput(rgbs=rgb, normals=nrm, depths=dep, binary_masks=msk)
 
     def stop(self) -> None:

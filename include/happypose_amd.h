@@ -90,6 +90,11 @@ const float* hp_mesh_store_points(const hp_mesh_store* store);
 /* d_rgb / d_nrm / d_depth point at fp16 tensors (strides in fp16 elements): views rendered straight into
  * the input of an fp16 network plan (hp_net_forward_f16in).  The mask stays uint8. */
 #define HP_RASTER_OUT_F16 16
+/* 4x multisampled colour / normal buffers, the framebuffer state of the reference's renderer
+ * (TB/renderer/panda3d_scene_renderer.py:70-71 "framebuffer-multisample 1 / multisamples 4"): coverage and depth per
+ * sample (standard 4x pattern), one shading per pixel and triangle at the pixel centre, 8-bit resolve = mean of the four
+ * samples.  Depth and mask stay sampled at the pixel centre.  Ignored by depth-only renders. */
+#define HP_RASTER_MSAA4 32
 
 typedef struct {
   int64_t s_item, s_view, s_chan, s_row, s_col;

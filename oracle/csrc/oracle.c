@@ -97,6 +97,17 @@ void hp_oracle_roi_align(const float* images, int Bi, int C, int H, int W,
 #define HP_R_DEPTH 2
 #define HP_R_MASK 4
 #define HP_R_QUANT8 8 /* emulate the 8-bit framebuffer: round(c*255)/255 */
+#define HP_R_MSAA4 32 /* 4x multisampling of the colour / normal buffers (the reference's framebuffer state:
+                       * TB/renderer/panda3d_scene_renderer.py:70-71 "framebuffer-multisample 1 / multisamples 4", buffers made
+                       * from FrameBufferProperties.getDefault(), TB/renderer/types.py:207).  OpenGL semantics: coverage and
+                       * depth are evaluated per SAMPLE, the fragment is shaded ONCE per pixel and primitive at the pixel
+                       * centre (attributes extrapolated when the centre lies outside the primitive; no centroid qualifier in
+                       * Panda3D's default shaders) and the 8-bit colour written to the samples it covers; the resolve
+                       * averages the four samples (background = the clear colour 0) back into an 8-bit value.  Sample
+                       * positions: the standard 4x pattern every current implementation uses (D3D's, also Mesa's and the
+                       * vendors' GL): (0.375, 0.125), (0.875, 0.375), (0.125, 0.625), (0.625, 0.875).  NOT pinned: the sample
+                       * positions are implementation-defined in OpenGL and Panda3D is absent here.  Depth and mask are
+                       * left at the pixel centre (a fifth, non-averaged sample): every consumer back-projects pixel centres. */
 
 typedef struct {
   const float* verts;    /* [Vtot][3] metres, object frame */
@@ -172,6 +183,72 @@ static inline void tex_fetch(const uint8_t* tex, int tw, int th, float u, float 
  * NCHW (sc=h*w, sr=w, sp=1) and NHWC slices are both expressible.  Any output pointer may
  * be NULL.  mask is uint8 with the same (sv, sr, sp) strides divided by... its own strides.
  */
+/* One fragment-shader invocation: colour and normal code of triangle f at the CENTRE of pixel (i, j) -- albedo (texture or
+ * vertex colours) x (ambient + Lambert point lights), eye-space normal code; perspective-correct barycentrics from the
+ * edge functions (extrapolated when the centre lies outside the triangle: multisampled edge pixels). */
+static void shade_centre(const hp_oracle_meshes* M, const float* sv3, const float* T, const float* Kv, const float* amb,
+                         int n_lights, const float* light_pos, const float* light_col, int view, int64_t voff, int64_t foff,
+                         int64_t toff, int tw, int th, int64_t f, int i, int j, int q8, float* o_rgb, float* o_n) {
+  const int32_t* tri = M->faces + 3 * (foff + f);
+  const float* V0 = sv3 + 3 * tri[0];
+  const float* V1 = sv3 + 3 * tri[1];
+  const float* V2 = sv3 + 3 * tri[2];
+  float e0[3], e1[3], e2[3];
+  edge_fn(V1, tri[1], V2, tri[2], e0);
+  edge_fn(V2, tri[2], V0, tri[0], e1);
+  edge_fn(V0, tri[0], V1, tri[1], e2);
+  const float pu = (float)j + 0.5f, pv = (float)i + 0.5f;
+  float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
+  float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
+  float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
+  float s = l0 + l1 + l2;
+  float b0 = l0 / s, b1 = l1 / s, b2 = l2 / s; /* perspective-correct barycentrics */
+  const float Z = fmaf(l0, V0[2], fmaf(l1, V1[2], l2 * V2[2])) / s; /* the depth the coverage pass stored for a covered centre */
+  const int64_t g0 = voff + tri[0], g1 = voff + tri[1], g2 = voff + tri[2];
+  /* albedo */
+  float alb[3];
+  if (toff >= 0) {
+    float tu = fmaf(b0, M->uvs[2 * g0], fmaf(b1, M->uvs[2 * g1], b2 * M->uvs[2 * g2]));
+    float tv = fmaf(b0, M->uvs[2 * g0 + 1], fmaf(b1, M->uvs[2 * g1 + 1], b2 * M->uvs[2 * g2 + 1]));
+    tex_fetch(M->tex + toff, tw, th, tu, tv, alb);
+  } else {
+    for (int c = 0; c < 3; ++c)
+      alb[c] = fmaf(b0, (float)M->colors[4 * g0 + c],
+                    fmaf(b1, (float)M->colors[4 * g1 + c], b2 * (float)M->colors[4 * g2 + c])) / 255.0f;
+  }
+  /* interpolated object-space normal -> camera (OpenCV) frame, unit length */
+  float no[3], nc[3];
+  for (int c = 0; c < 3; ++c)
+    no[c] = fmaf(b0, M->normals[3 * g0 + c], fmaf(b1, M->normals[3 * g1 + c], b2 * M->normals[3 * g2 + c]));
+  nc[0] = fmaf(T[0], no[0], fmaf(T[1], no[1], T[2] * no[2]));
+  nc[1] = fmaf(T[4], no[0], fmaf(T[5], no[1], T[6] * no[2]));
+  nc[2] = fmaf(T[8], no[0], fmaf(T[9], no[1], T[10] * no[2]));
+  float nn = sqrtf(fmaf(nc[0], nc[0], fmaf(nc[1], nc[1], nc[2] * nc[2])));
+  if (nn > 0.0f) { nc[0] /= nn; nc[1] /= nn; nc[2] /= nn; }
+  /* lighting: ambient + Lambert point lights (no attenuation) */
+  float lit[3] = {amb[0], amb[1], amb[2]};
+  if (n_lights > 0) {
+    /* camera-space position of the surface point */
+    float py = (pv - Kv[5]) * Z / Kv[4];
+    float px = ((pu - Kv[2]) * Z - Kv[1] * py) / Kv[0];
+    for (int l = 0; l < n_lights; ++l) {
+      const float* lp = light_pos + 3 * ((size_t)view * n_lights + l);
+      const float* lc = light_col + 3 * ((size_t)view * n_lights + l);
+      float lx = fmaf(T[0], lp[0], fmaf(T[1], lp[1], fmaf(T[2], lp[2], T[3]))) - px;
+      float ly = fmaf(T[4], lp[0], fmaf(T[5], lp[1], fmaf(T[6], lp[2], T[7]))) - py;
+      float lz = fmaf(T[8], lp[0], fmaf(T[9], lp[1], fmaf(T[10], lp[2], T[11]))) - Z;
+      float ln = sqrtf(fmaf(lx, lx, fmaf(ly, ly, lz * lz)));
+      float ndl = ln > 0.0f ? fmaf(nc[0], lx, fmaf(nc[1], ly, nc[2] * lz)) / ln : 0.0f;
+      if (ndl > 0.0f) for (int c = 0; c < 3; ++c) lit[c] = fmaf(lc[c], ndl, lit[c]);
+    }
+  }
+  for (int c = 0; c < 3; ++c) o_rgb[c] = quant8(alb[c] * lit[c], q8);
+  /* eye-normal colour code; Panda/GL eye space is (x right, y up, z backward) */
+  o_n[0] = quant8(normal_code(nc[0]), q8);
+  o_n[1] = quant8(normal_code(-nc[1]), q8);
+  o_n[2] = quant8(normal_code(-nc[2]), q8);
+}
+
 void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_ids,
                          const float* TCO, const float* K, const float* ambient,
                          int n_lights, const float* light_pos, const float* light_col,
@@ -182,7 +259,10 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
   const float depth_max = Z_NEAR / (1.0f - (1.0f - 1e-3f) * (Z_FAR - Z_NEAR) / Z_FAR);
 #pragma omp parallel
   {
-    uint64_t* zbuf = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)h * w);
+    const int msaa = (flags & HP_R_MSAA4) && (rgb || nrm);
+    const int ns = msaa ? 5 : 1;                 /* keys per pixel: 4 colour samples + the centre, or the centre alone */
+    static const float SX[5] = {0.375f, 0.875f, 0.125f, 0.625f, 0.5f}, SY[5] = {0.125f, 0.375f, 0.625f, 0.875f, 0.5f};
+    uint64_t* zbuf = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)h * w * ns);
     float* sv3 = NULL; size_t sv_cap = 0;
 #pragma omp for schedule(dynamic, 1)
     for (int view = 0; view < n; ++view) {
@@ -194,7 +274,7 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
       const int64_t* ob = M->obj + 8 * obj_ids[view];
       const int64_t voff = ob[0], nv = ob[1], foff = ob[2], nf = ob[3], toff = ob[4];
       const int tw = (int)ob[5], th = (int)ob[6];
-      for (size_t p = 0; p < (size_t)h * w; ++p) zbuf[p] = KEY_EMPTY;
+      for (size_t p = 0; p < (size_t)h * w * ns; ++p) zbuf[p] = KEY_EMPTY;
       if ((size_t)nv * 3 > sv_cap) { sv_cap = (size_t)nv * 3; sv3 = (float*)realloc(sv3, sv_cap * 4); }
 
       if (finite) {
@@ -232,103 +312,75 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
             /* pixel centre j+0.5 in [umin, umax]  <=>  j in [ceil(umin-0.5), floor(umax-0.5)] */
             float a = ceilf(umin - 0.5f), b = floorf(umax - 0.5f);
             float c = ceilf(vmin - 0.5f), d = floorf(vmax - 0.5f);
+            if (msaa) { /* some sample of pixel j inside [umin, umax]: the offsets run from 0.125 to 0.875 */
+              a = ceilf(umin - 0.875f); b = floorf(umax - 0.125f); c = ceilf(vmin - 0.875f); d = floorf(vmax - 0.125f);
+            }
             x0 = a < 0.0f ? 0 : (int)a; x1 = b > (float)(w - 1) ? w - 1 : (int)b;
             y0 = c < 0.0f ? 0 : (int)c; y1 = d > (float)(h - 1) ? h - 1 : (int)d;
           }
           for (int i = y0; i <= y1; ++i) {
-            const float pv = (float)i + 0.5f;
             for (int j = x0; j <= x1; ++j) {
-              const float pu = (float)j + 0.5f;
-              float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
-              float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
-              float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
-              float s = l0 + l1 + l2;
-              int in_pos = (l0 >= 0.0f) & (l1 >= 0.0f) & (l2 >= 0.0f) & (s > 0.0f);
-              int in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (s < 0.0f);
-              if (!(in_pos | in_neg)) continue;
-              /* camera-space depth: affine over the 3-D triangle, i.e. linear in the perspective-correct barycentrics
-               * l_i / s.  (Z = det / s is the same number algebraically, but det -- a 3x3 determinant of homogeneous
-               * pixel coordinates ~1e2 whose value is ~area * z^3 ~ 0.1 -- cancels to ~5e-4 relative in fp32 on
-               * pixel-sized triangles: 0.1 mm of depth noise at 0.4 m.  Interpolating the vertex depths is accurate to
-               * ~1e-7 m, the precision class of the 24-bit depth buffer the reference reads back,
-               * TB/renderer/utils.py:46-60.) */
-              float Z = fmaf(l0, V0[2], fmaf(l1, V1[2], l2 * V2[2])) / s;
-              if (!(Z >= Z_NEAR) || !(Z <= Z_FAR)) continue;
-              uint64_t key = ((uint64_t)f2u(Z) << 32) | (uint32_t)f;
-              uint64_t* zp = zbuf + (size_t)i * w + j;
-              if (key < *zp) *zp = key;
+              for (int sm = 0; sm < ns; ++sm) {
+                const int slot = msaa ? sm : 4;  /* single-sample mode: the centre only */
+                const float pv = (float)i + SY[slot], pu = (float)j + SX[slot];
+                float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
+                float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
+                float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
+                float s = l0 + l1 + l2;
+                int in_pos = (l0 >= 0.0f) & (l1 >= 0.0f) & (l2 >= 0.0f) & (s > 0.0f);
+                int in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (s < 0.0f);
+                if (!(in_pos | in_neg)) continue;
+                /* camera-space depth: affine over the 3-D triangle, i.e. linear in the perspective-correct barycentrics
+                 * l_i / s.  (Z = det / s is the same number algebraically, but det -- a 3x3 determinant of homogeneous
+                 * pixel coordinates ~1e2 whose value is ~area * z^3 ~ 0.1 -- cancels to ~5e-4 relative in fp32 on
+                 * pixel-sized triangles: 0.1 mm of depth noise at 0.4 m.  Interpolating the vertex depths is accurate to
+                 * ~1e-7 m, the precision class of the 24-bit depth buffer the reference reads back,
+                 * TB/renderer/utils.py:46-60.) */
+                float Z = fmaf(l0, V0[2], fmaf(l1, V1[2], l2 * V2[2])) / s;
+                if (!(Z >= Z_NEAR) || !(Z <= Z_FAR)) continue;
+                uint64_t key = ((uint64_t)f2u(Z) << 32) | (uint32_t)f;
+                uint64_t* zp = zbuf + ((size_t)i * w + j) * ns + sm;
+                if (key < *zp) *zp = key;
+              }
             }
           }
         }
       }
 
-      /* resolve: attributes of the nearest triangle at every covered pixel */
+      /* resolve: attributes of the nearest triangle at every covered pixel (single sample), or the mean over the four
+       * samples of the colours their triangles have at the pixel centre (HP_R_MSAA4) */
       const float* amb = ambient + 3 * view;
+      const int q8 = flags & HP_R_QUANT8;
       for (int i = 0; i < h; ++i)
         for (int j = 0; j < w; ++j) {
-          const uint64_t key = zbuf[(size_t)i * w + j];
+          const uint64_t* keys = zbuf + ((size_t)i * w + j) * ns;
+          const uint64_t ckey = keys[ns - 1]; /* the pixel centre */
           float o_rgb[3] = {0, 0, 0}, o_n[3] = {0, 0, 0}, o_d = 0.0f;
-          if (key != KEY_EMPTY) {
-            const int64_t f = (int64_t)(key & 0xFFFFFFFFull);
-            const int32_t* tri = M->faces + 3 * (foff + f);
-            const float* V0 = sv3 + 3 * tri[0];
-            const float* V1 = sv3 + 3 * tri[1];
-            const float* V2 = sv3 + 3 * tri[2];
-            float e0[3], e1[3], e2[3];
-            edge_fn(V1, tri[1], V2, tri[2], e0);
-            edge_fn(V2, tri[2], V0, tri[0], e1);
-            edge_fn(V0, tri[0], V1, tri[1], e2);
-            const float pu = (float)j + 0.5f, pv = (float)i + 0.5f;
-            float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
-            float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
-            float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
-            float s = l0 + l1 + l2;
-            float b0 = l0 / s, b1 = l1 / s, b2 = l2 / s; /* perspective-correct barycentrics */
-            float Z = u2f((uint32_t)(key >> 32));
-            const int64_t g0 = voff + tri[0], g1 = voff + tri[1], g2 = voff + tri[2];
-            /* albedo */
-            float alb[3];
-            if (toff >= 0) {
-              float tu = fmaf(b0, M->uvs[2 * g0], fmaf(b1, M->uvs[2 * g1], b2 * M->uvs[2 * g2]));
-              float tv = fmaf(b0, M->uvs[2 * g0 + 1], fmaf(b1, M->uvs[2 * g1 + 1], b2 * M->uvs[2 * g2 + 1]));
-              tex_fetch(M->tex + toff, tw, th, tu, tv, alb);
-            } else {
-              for (int c = 0; c < 3; ++c)
-                alb[c] = fmaf(b0, (float)M->colors[4 * g0 + c],
-                              fmaf(b1, (float)M->colors[4 * g1 + c], b2 * (float)M->colors[4 * g2 + c])) / 255.0f;
-            }
-            /* interpolated object-space normal -> camera (OpenCV) frame, unit length */
-            float no[3], nc[3];
-            for (int c = 0; c < 3; ++c)
-              no[c] = fmaf(b0, M->normals[3 * g0 + c], fmaf(b1, M->normals[3 * g1 + c], b2 * M->normals[3 * g2 + c]));
-            nc[0] = fmaf(T[0], no[0], fmaf(T[1], no[1], T[2] * no[2]));
-            nc[1] = fmaf(T[4], no[0], fmaf(T[5], no[1], T[6] * no[2]));
-            nc[2] = fmaf(T[8], no[0], fmaf(T[9], no[1], T[10] * no[2]));
-            float nn = sqrtf(fmaf(nc[0], nc[0], fmaf(nc[1], nc[1], nc[2] * nc[2])));
-            if (nn > 0.0f) { nc[0] /= nn; nc[1] /= nn; nc[2] /= nn; }
-            /* lighting: ambient + Lambert point lights (no attenuation) */
-            float lit[3] = {amb[0], amb[1], amb[2]};
-            if (n_lights > 0) {
-              /* camera-space position of the surface point */
-              float py = (pv - Kv[5]) * Z / Kv[4];
-              float px = ((pu - Kv[2]) * Z - Kv[1] * py) / Kv[0];
-              for (int l = 0; l < n_lights; ++l) {
-                const float* lp = light_pos + 3 * ((size_t)view * n_lights + l);
-                const float* lc = light_col + 3 * ((size_t)view * n_lights + l);
-                float lx = fmaf(T[0], lp[0], fmaf(T[1], lp[1], fmaf(T[2], lp[2], T[3]))) - px;
-                float ly = fmaf(T[4], lp[0], fmaf(T[5], lp[1], fmaf(T[6], lp[2], T[7]))) - py;
-                float lz = fmaf(T[8], lp[0], fmaf(T[9], lp[1], fmaf(T[10], lp[2], T[11]))) - Z;
-                float ln = sqrtf(fmaf(lx, lx, fmaf(ly, ly, lz * lz)));
-                float ndl = ln > 0.0f ? fmaf(nc[0], lx, fmaf(nc[1], ly, nc[2] * lz)) / ln : 0.0f;
-                if (ndl > 0.0f) for (int c = 0; c < 3; ++c) lit[c] = fmaf(lc[c], ndl, lit[c]);
-              }
-            }
-            for (int c = 0; c < 3; ++c) o_rgb[c] = quant8(alb[c] * lit[c], flags & HP_R_QUANT8);
-            /* eye-normal colour code; Panda/GL eye space is (x right, y up, z backward) */
-            o_n[0] = quant8(normal_code(nc[0]), flags & HP_R_QUANT8);
-            o_n[1] = quant8(normal_code(-nc[1]), flags & HP_R_QUANT8);
-            o_n[2] = quant8(normal_code(-nc[2]), flags & HP_R_QUANT8);
+          if (ckey != KEY_EMPTY) {
+            const float Z = u2f((uint32_t)(ckey >> 32));
             o_d = Z > depth_max ? 0.0f : Z;
+          }
+          if (!msaa) {
+            if (ckey != KEY_EMPTY)
+              shade_centre(M, sv3, T, Kv, amb, n_lights, light_pos, light_col, view, voff, foff, toff, tw, th,
+                           (int64_t)(ckey & 0xFFFFFFFFull), i, j, q8, o_rgb, o_n);
+          } else {
+            int64_t cf[4]; float crgb[4][3], cn[4][3]; int ncached = 0;
+            float a_rgb[3] = {0, 0, 0}, a_n[3] = {0, 0, 0};
+            for (int sm = 0; sm < 4; ++sm) {
+              if (keys[sm] == KEY_EMPTY) continue; /* the clear colour: 0 */
+              const int64_t f = (int64_t)(keys[sm] & 0xFFFFFFFFull);
+              int k = 0;
+              while (k < ncached && cf[k] != f) ++k;
+              if (k == ncached) { /* one fragment-shader invocation per pixel and primitive */
+                cf[k] = f;
+                shade_centre(M, sv3, T, Kv, amb, n_lights, light_pos, light_col, view, voff, foff, toff, tw, th, f, i, j, q8,
+                             crgb[k], cn[k]);
+                ++ncached;
+              }
+              for (int c = 0; c < 3; ++c) { a_rgb[c] += crgb[k][c]; a_n[c] += cn[k][c]; }
+            }
+            for (int c = 0; c < 3; ++c) { o_rgb[c] = quant8(a_rgb[c] * 0.25f, q8); o_n[c] = quant8(a_n[c] * 0.25f, q8); }
           }
           const int64_t base = (int64_t)view * sv + (int64_t)i * sr + (int64_t)j * sp;
           if (rgb) for (int c = 0; c < 3; ++c) rgb[base + c * sc] = o_rgb[c];

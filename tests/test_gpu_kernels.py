@@ -83,6 +83,42 @@ def test_rasterizer_vs_oracle(dev, scene_store):
     _compare_renders(gpu, ref)
 
 
+def test_rasterizer_msaa4_vs_oracle(dev, scene_store):
+    """HP_RASTER_MSAA4 (the reference's framebuffer state): per-sample coverage / depth, one shading per pixel and
+    triangle at the pixel centre, 8-bit resolve.  Against the oracle's definition, and against the single-sample render:
+    depth and mask are unchanged (centre-sampled), colours only change where samples of a pixel see different triangles."""
+    from happypose_amd import ops
+    from oracle import native
+
+    n = 12
+    T = _poses(n, 5)
+    K = np.tile(np.array([[900.0, 0, 160], [0, 900.0, 120], [0, 0, 1]], np.float32), (n, 1, 1))
+    K[:, 0, 2] += np.linspace(-20, 20, n)
+    obj = (np.arange(n) % 3).astype(np.int32)
+    args = (scene_store, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), (240, 320))
+    gpu = ops.rasterize(*args, render_normals=True, render_depth=True, render_binary_mask=True, msaa=True)
+    one = ops.rasterize(*args, render_normals=True, render_depth=True, render_binary_mask=True)
+    ref = native.rasterize(scene_store.packed, obj, T, K, (240, 320), True, True, True, msaa=True)
+    assert torch.equal(gpu[2], one[2]) and torch.equal(gpu[3], one[3])
+    rgb, nrm = gpu[0].cpu().numpy(), gpu[1].cpu().numpy()
+    # a sample whose edge function is within fp32 round-off of zero may fall on the other side: the pixel then differs by
+    # one sample's share (<= 1/4 of the colour); everything else matches to the 8-bit step
+    for got, want in ((rgb, ref["rgbs"]), (nrm, ref["normals"])):
+        d = np.abs(got - want).max(1)
+        assert (d > 1.5 / 255).mean() < 5e-4, (d > 1.5 / 255).mean()
+        assert d.max() <= 0.5 + 1e-6
+    changed = np.abs(rgb - one[0].cpu().numpy()).max(1) > 0
+    cov = ref["depths"][:, 0] > 0
+    assert 0.02 < changed[cov].mean() < 0.6                       # edges and multi-triangle pixels only
+    edge = (~cov) & changed                                        # uncovered centres that still collect samples
+    assert edge.sum() > 100 and np.allclose(rgb * 255, np.round(rgb * 255), atol=1e-3)
+    # NHWC slices of a network input
+    x = torch.zeros((n, 240, 320, 8), device=dev)
+    Tv, Kv = torch.as_tensor(T, device=dev)[:, None].contiguous(), torch.as_tensor(K, device=dev)[:, None].contiguous()
+    ops.rasterize_into(scene_store, x, 3, torch.as_tensor(obj), Tv, Kv, False, False, msaa=True)
+    assert torch.equal(x[..., 3:6].permute(0, 3, 1, 2), gpu[0])
+
+
 def test_rasterizer_reference_test_scene(dev, golden_dir):
     """Scene and structural asserts of the reference's renderer test
     (tests/test_batch_renderer_panda3d.py:43-69,105-122,166-179) on its own asset."""
