@@ -62,7 +62,12 @@ extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float
   // validate the descriptor table: kernels index with it unchecked
   for (int o = 0; o < n_obj; ++o) {
     const int64_t* r = h_obj + 8 * o;
-    const bool tex_ok = r[4] < 0 || (r[5] > 0 && r[6] > 0 && r[4] + 4 * r[5] * r[6] <= tex_bytes && h_tex);
+    int64_t chain = 0;  // bytes of level 0 and the mip levels stored behind it (entry 7 = number of levels, 0 / 1 = level 0 only)
+    for (int64_t k = 0, w = r[5], h = r[6]; r[4] >= 0 && k < (r[7] > 0 ? r[7] : 1) && w > 0 && h > 0; ++k) {
+      chain += 4 * w * h;
+      w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1;
+    }
+    const bool tex_ok = r[4] < 0 || (r[5] > 0 && r[6] > 0 && r[7] >= 0 && r[7] <= 32 && r[4] + chain <= tex_bytes && h_tex);
     if (r[0] < 0 || r[1] <= 0 || r[0] + r[1] > n_verts_total || r[2] < 0 || r[3] <= 0 ||
         r[2] + r[3] > n_faces_total || !tex_ok) {
       set_error("hp_mesh_store_create: object descriptor " + std::to_string(o) + " out of range");

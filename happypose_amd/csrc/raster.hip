@@ -161,6 +161,49 @@ __device__ __forceinline__ void tex_fetch(const uint8_t* tex, int tw, int th, fl
   }
 }
 
+// bilinear fetch of mip level `lvl` (level k is max(1, tw >> k) x max(1, th >> k), stored behind the levels before it)
+__device__ __forceinline__ void tex_fetch_level(const uint8_t* tex, int tw, int th, int lvl, float u, float v, float* rgb) {
+  size_t off = 0;
+  int w = tw, h = th;
+  for (int k = 0; k < lvl; ++k) { off += (size_t)4 * w * h; w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; }
+  tex_fetch(tex + off, w, h, u, v, rgb);
+}
+
+// trilinear + anisotropic fetch (HP_RASTER_TEX_ANISO; oracle.c tex_fetch_aniso, same operations in the same order)
+__device__ __forceinline__ void tex_fetch_aniso(const uint8_t* tex, int tw, int th, int nlev, float u, float v, float ux,
+                                                float vx, float uy, float vy, float* rgb) {
+  const float px = sqrtf(fmaf(ux * (float)tw, ux * (float)tw, vx * (float)th * (vx * (float)th)));
+  const float py = sqrtf(fmaf(uy * (float)tw, uy * (float)tw, vy * (float)th * (vy * (float)th)));
+  const bool along_x = px >= py;
+  const float pmax = along_x ? px : py, pmin = along_x ? py : px;
+  float nf = pmin > 0.0f ? ceilf(pmax / pmin) : 16.0f;
+  if (!(nf >= 1.0f)) nf = 1.0f;
+  if (nf > 16.0f) nf = 16.0f;
+  const int N = (int)nf;
+  float lod = pmax > 0.0f ? log2f(pmax / nf) : 0.0f;
+  if (!(lod > 0.0f)) lod = 0.0f;
+  if (lod > (float)(nlev - 1)) lod = (float)(nlev - 1);
+  const int l0 = (int)lod;
+  const float fl = lod - (float)l0;
+  const float du = along_x ? ux : uy, dv = along_x ? vx : vy;
+  float acc[3] = {0.0f, 0.0f, 0.0f};
+  for (int i = 1; i <= N; ++i) {
+    const float t = (float)i / (float)(N + 1) - 0.5f;
+    const float su = fmaf(t, du, u), sv = fmaf(t, dv, v);
+    float c0[3], c1[3];
+    tex_fetch_level(tex, tw, th, l0, su, sv, c0);
+    if (fl > 0.0f && l0 + 1 < nlev) {
+      tex_fetch_level(tex, tw, th, l0 + 1, su, sv, c1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) c0[c] = fmaf(fl, c1[c] - c0[c], c0[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += c0[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rgb[c] = acc[c] / (float)N;
+}
+
 struct TriSetup {
   float e0[3], e1[3], e2[3];
   float z0, z1, z2;  // camera-space depth of the three corners
@@ -340,7 +383,7 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
 // extrapolated when the centre lies outside the triangle: multisampled edge pixels) -- oracle.c shade_centre.
 struct ShadeCtx {
   const float* T; const float* Kv; const float* amb; const float4* xv; const int32_t* fbase;
-  int64_t voff, toff; int tw, th, view, q8;
+  int64_t voff, toff; int tw, th, view, q8, nlev, aniso;
 };
 __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx& cx, int f, int i, int j, float* o_rgb, float* o_n) {
   const float* T = cx.T; const float* Kv = cx.Kv; const float* amb = cx.amb; const float4* xv = cx.xv;
@@ -369,7 +412,19 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
     const float2 t2 = *reinterpret_cast<const float2*>(a.uvs + 2 * g2);
     float tu = fmaf(b0, t0.x, fmaf(b1, t1.x, b2 * t2.x));
     float tv = fmaf(b0, t0.y, fmaf(b1, t1.y, b2 * t2.y));
-    tex_fetch(a.tex + toff, tw, th, tu, tv, alb);
+    if (cx.aniso && cx.nlev > 1) {
+      // screen-space derivatives of the perspective-correct barycentrics: b_i = l_i / sum, l_i affine in (x, y)
+      const float sx = e0[0] + e1[0] + e2[0], sy = e0[1] + e1[1] + e2[1];
+      const float bx[3] = {(e0[0] - b0 * sx) / sum, (e1[0] - b1 * sx) / sum, (e2[0] - b2 * sx) / sum};
+      const float by[3] = {(e0[1] - b0 * sy) / sum, (e1[1] - b1 * sy) / sum, (e2[1] - b2 * sy) / sum};
+      const float ux = fmaf(bx[0], t0.x, fmaf(bx[1], t1.x, bx[2] * t2.x));
+      const float vx = fmaf(bx[0], t0.y, fmaf(bx[1], t1.y, bx[2] * t2.y));
+      const float uy = fmaf(by[0], t0.x, fmaf(by[1], t1.x, by[2] * t2.x));
+      const float vy = fmaf(by[0], t0.y, fmaf(by[1], t1.y, by[2] * t2.y));
+      tex_fetch_aniso(a.tex + toff, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
+    } else {
+      tex_fetch(a.tex + toff, tw, th, tu, tv, alb);
+    }
   } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -518,7 +573,8 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   const int64_t dbase = (int64_t)item * a.ds.s_item + (int64_t)(view % a.views_per_item) * a.ds.s_view;
   const float zn = a.depth_norm_z ? a.depth_norm_z[item] : 1.0f;
 
-  const ShadeCtx cx{T, Kv, amb, xv, fbase, voff, toff, tw, th, view, q8};
+  const ShadeCtx cx{T, Kv, amb, xv, fbase, voff, toff, tw, th, view, q8, (int)ob[7] > 0 ? (int)ob[7] : 1,
+                    (a.flags & HP_RASTER_TEX_ANISO) != 0};
   for (int p = tid; p < npix; p += kThreads) {
     const int i = row0 + p / a.w, j = p % a.w;
     const unsigned long long key = band_empty ? kKeyEmpty : zb[p * NS + (NS - 1)];  // the pixel centre

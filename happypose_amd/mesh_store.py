@@ -194,13 +194,36 @@ class MeshDataBase:
         return BatchedMeshes(new_infos, np.array(labels), pts)
 
 
+def mip_chain(tex: np.ndarray):
+    """Levels 1.. of an RGBA8 texture ``[h,w,4]`` as ``glGenerateMipmap`` builds them: each level halves the previous one
+    (``max(1, floor(n / 2))`` per side) with a 2 x 2 box filter, rounded to nearest in 8 bit; a side that is already 1
+    averages 2 x 1.  Returned without level 0."""
+    levels, cur = [], np.ascontiguousarray(tex, np.uint8)
+    while cur.shape[0] > 1 or cur.shape[1] > 1:
+        h, w = cur.shape[0], cur.shape[1]
+        nh, nw = max(1, h // 2), max(1, w // 2)
+        c = cur.astype(np.uint16)
+        r0 = c[0:2 * nh:2] if h > 1 else c
+        r1 = c[1:2 * nh:2] if h > 1 else c
+        a = r0[:, 0:2 * nw:2] if w > 1 else r0
+        b = r0[:, 1:2 * nw:2] if w > 1 else r0
+        cc = r1[:, 0:2 * nw:2] if w > 1 else r1
+        d = r1[:, 1:2 * nw:2] if w > 1 else r1
+        cur = ((a + b + cc + d + 2) >> 2).astype(np.uint8)
+        levels.append(cur)
+    return levels
+
+
 class PackedMeshes:
     """Flat layout consumed by the rasteriser (HIP and oracle).
 
     ``verts [Vtot,3] f32`` (metres), ``normals [Vtot,3] f32``, ``uvs [Vtot,2] f32``,
     ``colors [Vtot,4] u8``, ``faces [Ftot,3] i32`` (ids local to the object),
     ``tex`` RGBA8 pool, ``obj [n_obj,8] i64`` = (vert_off, n_verts, face_off, n_faces,
-    tex_off | -1, tex_w, tex_h, 0), ``radius [n_obj] f32`` = bounding radius (m)."""
+    tex_off | -1, tex_w, tex_h, n_mip_levels), ``radius [n_obj] f32`` = bounding radius (m).  A texture is stored as its
+    level 0 followed by its mip chain (:func:`mip_chain`; level ``k`` is ``max(1, w >> k) x max(1, h >> k)``): the
+    bilinear level-0 fetch ignores the chain, ``HP_RASTER_TEX_ANISO`` (the reference's ``texture-minfilter mipmap`` +
+    ``texture-anisotropic-degree 16``) walks it."""
 
     def __init__(self, object_ds: RigidObjectDataset):
         self.labels = [o.label for o in object_ds.list_objects]
@@ -223,9 +246,11 @@ class PackedMeshes:
             faces.append(np.asarray(m.faces, np.int32))
             if m.texture is not None and m.uvs is not None:
                 t = np.ascontiguousarray(m.texture, np.uint8)
-                rows.append((voff, nv, foff, nf, toff, t.shape[1], t.shape[0], 0))
-                tex.append(t.reshape(-1))
-                toff += t.size
+                chain = mip_chain(t)
+                rows.append((voff, nv, foff, nf, toff, t.shape[1], t.shape[0], 1 + len(chain)))
+                for lvl in [t] + chain:
+                    tex.append(lvl.reshape(-1))
+                    toff += lvl.size
             else:
                 rows.append((voff, nv, foff, nf, -1, 0, 0, 0))
             radius.append(float(np.linalg.norm(v, axis=1).max()) if nv else 0.0)

@@ -120,9 +120,10 @@ def rasterize(store: MeshStore, obj_ids: torch.Tensor, TCO: torch.Tensor, K: tor
               resolution: Tuple[int, int], render_normals=False, render_depth=False,
               render_binary_mask=False, ambient: Optional[torch.Tensor] = None,
               light_pos: Optional[torch.Tensor] = None, light_col: Optional[torch.Tensor] = None,
-              quant8: bool = True, msaa: bool = False):
+              quant8: bool = True, msaa: bool = False, aniso: bool = False):
     """NCHW outputs shaped like ``BatchRenderOutput`` (TB/renderer/types.py:45-56).  ``msaa``: 4x multisampled colour /
-    normal buffers (``HP_RASTER_MSAA4``, the reference renderer's framebuffer state)."""
+    normal buffers (``HP_RASTER_MSAA4``), ``aniso``: mip-mapped trilinear + anisotropic-16 texture filtering
+    (``HP_RASTER_TEX_ANISO``) -- the reference renderer's framebuffer / texture state."""
     dev = store.device
     n = TCO.shape[0]
     assert TCO.shape == (n, 4, 4) and K.shape == (n, 3, 3)
@@ -146,7 +147,7 @@ def rasterize(store: MeshStore, obj_ids: torch.Tensor, TCO: torch.Tensor, K: tor
     cs, ds = nchw_strides(3, h, w), nchw_strides(1, h, w)
     with torch.cuda.device(dev):
         check(lib().hp_rasterize(store.handle, n, 1, ptr(obj_ids), ptr(TCO), ptr(K), ptr(ambient), n_lights,
-                                 ptr(light_pos), ptr(light_col), h, w, (8 if quant8 else 0) | (32 if msaa else 0), ptr(rgb), ptr(nrm),
+                                 ptr(light_pos), ptr(light_col), h, w, (8 if quant8 else 0) | (32 if msaa else 0) | (64 if aniso else 0), ptr(rgb), ptr(nrm),
                                  C.byref(cs), ptr(dep), C.byref(ds), ptr(msk), None, 0, stream_ptr(dev)),
               "hp_rasterize")
     return rgb, nrm, dep, (msk.bool() if msk is not None else None)
@@ -155,7 +156,7 @@ def rasterize(store: MeshStore, obj_ids: torch.Tensor, TCO: torch.Tensor, K: tor
 def rasterize_into(store: MeshStore, x: torch.Tensor, chan0: int, obj_ids: torch.Tensor,
                    TCV_O: torch.Tensor, KV: torch.Tensor, render_normals: bool, render_depth: bool,
                    depth_norm_z: Optional[torch.Tensor] = None, depth_norm_mode: int = 0,
-                   ambient: Optional[torch.Tensor] = None, msaa: bool = False) -> None:
+                   ambient: Optional[torch.Tensor] = None, msaa: bool = False, aniso: bool = False) -> None:
     """Render ``V`` views per hypothesis straight into channel slices of the NHWC network
     input ``x [b,h,w,c_pad]``: view ``v`` occupies channels ``chan0 + v*C_r ...`` in the
     reference's order rgb, normals, depth (MP/models/pose_rigid.py:437-453)."""
@@ -173,7 +174,7 @@ def rasterize_into(store: MeshStore, x: torch.Tensor, chan0: int, obj_ids: torch
     rgb_p = C.c_void_p(base)
     nrm_p = C.c_void_p(base + esz * 3) if render_normals else None
     dep_p = C.c_void_p(base + esz * (6 if render_normals else 3)) if render_depth else None
-    flags = 8 | (16 if x.dtype == torch.float16 else 0) | (32 if msaa else 0)
+    flags = 8 | (16 if x.dtype == torch.float16 else 0) | (32 if msaa else 0) | (64 if aniso else 0)
     with torch.cuda.device(dev):
         check(lib().hp_rasterize(store.handle, b * V, V, ptr(obj_ids), ptr(TCV_O), ptr(KV), ptr(ambient), 0,
                                  None, None, h, w, flags, rgb_p, nrm_p, C.byref(cs), dep_p, C.byref(cs), None,

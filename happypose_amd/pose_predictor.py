@@ -175,7 +175,7 @@ class _RenderAndCompare:
                            n_channels=n_img_channels)
         t0 = time.time()
         ops.rasterize_into(self.store, x, n_img_channels, obj_ids, prep["TCV_O"], prep["K_crop"],
-                           render_normals, render_depth, z, depth_mode, msaa=self.renderer.msaa)
+                           render_normals, render_depth, z, depth_mode, msaa=self.renderer.msaa, aniso=self.renderer.aniso)
         render_time = time.time() - t0
         pose, logits, _ = self.backbone.forward(x, want_pose=want_pose, want_logits=want_logits)
         return prep, x, pose, logits, render_time

@@ -63,13 +63,17 @@ class BatchRenderer:
     ``split_objects`` are accepted for signature compatibility and ignored."""
 
     def __init__(self, asset_dataset: RigidObjectDataset, n_workers: int = 8, preload_cache: bool = True,
-                 split_objects: bool = False, device="cuda", store: Optional[ops.MeshStore] = None, msaa: bool = False):
+                 split_objects: bool = False, device="cuda", store: Optional[ops.MeshStore] = None, msaa: bool = False,
+                 aniso: bool = False):
         """``msaa``: render colour / normals with 4x multisampling, the framebuffer state of the reference's Panda3D
         renderer (``TB/renderer/panda3d_scene_renderer.py:70-71``; semantics in ``oracle/csrc/oracle.c`` ``HP_R_MSAA4``).
         Off by default: the sample pattern is implementation-defined in OpenGL and cannot be pinned here, and the
-        single-sample renders are what every parity number of this repository was measured on."""
+        single-sample renders are what every parity number of this repository was measured on.  ``aniso``: the texture
+        state of the same file (``texture-minfilter mipmap``, ``texture-anisotropic-degree 16``): trilinear over the mip
+        chain + up to 16 probes along the footprint's major axis (``HP_R_TEX_ANISO``); off by default for the same reason."""
         assert n_workers >= 1
         self.msaa = bool(msaa)
+        self.aniso = bool(aniso)
         self._object_dataset = asset_dataset
         self.store = store if store is not None else ops.MeshStore(asset_dataset, device)
         self.device = self.store.device
@@ -113,7 +117,7 @@ class BatchRenderer:
         rgb, nrm, dep, msk = ops.rasterize(
             self.store, self.store.ids_of(labels), TCO.detach(), K, tuple(resolution),
             render_normals=render_normals, render_depth=render_depth,
-            render_binary_mask=render_binary_mask, ambient=amb, light_pos=pos, light_col=col, msaa=self.msaa)
+            render_binary_mask=render_binary_mask, ambient=amb, light_pos=pos, light_col=col, msaa=self.msaa, aniso=self.aniso)
         return BatchRenderOutput(rgbs=rgb, normals=nrm, depths=dep, binary_masks=msk)
 
     def stop(self) -> None:

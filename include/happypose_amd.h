@@ -95,6 +95,11 @@ const float* hp_mesh_store_points(const hp_mesh_store* store);
  * sample (standard 4x pattern), one shading per pixel and triangle at the pixel centre, 8-bit resolve = mean of the four
  * samples.  Depth and mask stay sampled at the pixel centre.  Ignored by depth-only renders. */
 #define HP_RASTER_MSAA4 32
+/* Texture filtering of the reference's renderer (TB/renderer/panda3d_scene_renderer.py:68-69 "texture-minfilter mipmap",
+ * "texture-anisotropic-degree 16"): trilinear over the mip chain the store keeps behind level 0 (obj row entry 7 = number
+ * of levels) + up to 16 probes along the major axis of the pixel footprint (EXT_texture_filter_anisotropic's sketch).
+ * Default (flag clear): bilinear on level 0. */
+#define HP_RASTER_TEX_ANISO 64
 
 typedef struct {
   int64_t s_item, s_view, s_chan, s_row, s_col;

@@ -97,6 +97,12 @@ void hp_oracle_roi_align(const float* images, int Bi, int C, int H, int W,
 #define HP_R_DEPTH 2
 #define HP_R_MASK 4
 #define HP_R_QUANT8 8 /* emulate the 8-bit framebuffer: round(c*255)/255 */
+#define HP_R_TEX_ANISO 64 /* texture filtering of the reference's renderer (TB/renderer/panda3d_scene_renderer.py:68-69:
+                           * "texture-minfilter mipmap", "texture-anisotropic-degree 16"): trilinear over the mip chain the
+                           * store keeps behind level 0 + anisotropic sampling as EXT_texture_filter_anisotropic sketches
+                           * it -- Px, Py = lengths of the texel-space derivatives along screen x / y, N = min(ceil(Pmax / Pmin),
+                           * 16) probes along the major axis at LOD log2(Pmax / N), averaged.  NOT pinned: the extension
+                           * leaves the footprint to the implementation and Panda3D is absent. */
 #define HP_R_MSAA4 32 /* 4x multisampling of the colour / normal buffers (the reference's framebuffer state:
                        * TB/renderer/panda3d_scene_renderer.py:70-71 "framebuffer-multisample 1 / multisamples 4", buffers made
                        * from FrameBufferProperties.getDefault(), TB/renderer/types.py:207).  OpenGL semantics: coverage and
@@ -176,6 +182,46 @@ static inline void tex_fetch(const uint8_t* tex, int tw, int th, float u, float 
   }
 }
 
+/* bilinear fetch of mip level `lvl` (level k is max(1, tw >> k) x max(1, th >> k), stored behind the levels before it) */
+static inline void tex_fetch_level(const uint8_t* tex, int tw, int th, int lvl, float u, float v, float* rgb) {
+  size_t off = 0;
+  int w = tw, h = th;
+  for (int k = 0; k < lvl; ++k) { off += (size_t)4 * w * h; w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; }
+  tex_fetch(tex + off, w, h, u, v, rgb);
+}
+
+/* trilinear + anisotropic fetch (HP_R_TEX_ANISO): (ux, vx) / (uy, vy) = d(u, v) / d(screen x) / d(screen y) */
+static inline void tex_fetch_aniso(const uint8_t* tex, int tw, int th, int nlev, float u, float v, float ux, float vx,
+                                   float uy, float vy, float* rgb) {
+  const float px = sqrtf(fmaf(ux * (float)tw, ux * (float)tw, vx * (float)th * (vx * (float)th)));
+  const float py = sqrtf(fmaf(uy * (float)tw, uy * (float)tw, vy * (float)th * (vy * (float)th)));
+  const int along_x = px >= py;
+  const float pmax = along_x ? px : py, pmin = along_x ? py : px;
+  float nf = pmin > 0.0f ? ceilf(pmax / pmin) : 16.0f;
+  if (!(nf >= 1.0f)) nf = 1.0f;   /* NaN / zero footprints */
+  if (nf > 16.0f) nf = 16.0f;
+  const int N = (int)nf;
+  float lod = pmax > 0.0f ? log2f(pmax / nf) : 0.0f;
+  if (!(lod > 0.0f)) lod = 0.0f;  /* magnification: level 0 */
+  if (lod > (float)(nlev - 1)) lod = (float)(nlev - 1);
+  const int l0 = (int)lod;
+  const float fl = lod - (float)l0;
+  const float du = along_x ? ux : uy, dv = along_x ? vx : vy;
+  float acc[3] = {0.0f, 0.0f, 0.0f};
+  for (int i = 1; i <= N; ++i) {
+    const float t = (float)i / (float)(N + 1) - 0.5f;
+    const float su = fmaf(t, du, u), sv = fmaf(t, dv, v);
+    float c0[3], c1[3];
+    tex_fetch_level(tex, tw, th, l0, su, sv, c0);
+    if (fl > 0.0f && l0 + 1 < nlev) {
+      tex_fetch_level(tex, tw, th, l0 + 1, su, sv, c1);
+      for (int c = 0; c < 3; ++c) c0[c] = fmaf(fl, c1[c] - c0[c], c0[c]);
+    }
+    for (int c = 0; c < 3; ++c) acc[c] += c0[c];
+  }
+  for (int c = 0; c < 3; ++c) rgb[c] = acc[c] / (float)N;
+}
+
 /*
  * obj_ids [n]; TCO [n][16]; K [n][9]; ambient [n][3]; n_lights point lights per view:
  * light_pos [n][n_lights][3] (object frame, metres), light_col [n][n_lights][3].
@@ -188,7 +234,8 @@ static inline void tex_fetch(const uint8_t* tex, int tw, int th, float u, float 
  * edge functions (extrapolated when the centre lies outside the triangle: multisampled edge pixels). */
 static void shade_centre(const hp_oracle_meshes* M, const float* sv3, const float* T, const float* Kv, const float* amb,
                          int n_lights, const float* light_pos, const float* light_col, int view, int64_t voff, int64_t foff,
-                         int64_t toff, int tw, int th, int64_t f, int i, int j, int q8, float* o_rgb, float* o_n) {
+                         int64_t toff, int tw, int th, int nlev, int aniso, int64_t f, int i, int j, int q8, float* o_rgb,
+                         float* o_n) {
   const int32_t* tri = M->faces + 3 * (foff + f);
   const float* V0 = sv3 + 3 * tri[0];
   const float* V1 = sv3 + 3 * tri[1];
@@ -210,7 +257,19 @@ static void shade_centre(const hp_oracle_meshes* M, const float* sv3, const floa
   if (toff >= 0) {
     float tu = fmaf(b0, M->uvs[2 * g0], fmaf(b1, M->uvs[2 * g1], b2 * M->uvs[2 * g2]));
     float tv = fmaf(b0, M->uvs[2 * g0 + 1], fmaf(b1, M->uvs[2 * g1 + 1], b2 * M->uvs[2 * g2 + 1]));
-    tex_fetch(M->tex + toff, tw, th, tu, tv, alb);
+    if (aniso && nlev > 1) {
+      /* screen-space derivatives of the perspective-correct barycentrics: b_i = l_i / s, l_i affine in (x, y) */
+      const float sx = e0[0] + e1[0] + e2[0], sy = e0[1] + e1[1] + e2[1];
+      const float bx[3] = {(e0[0] - b0 * sx) / s, (e1[0] - b1 * sx) / s, (e2[0] - b2 * sx) / s};
+      const float by[3] = {(e0[1] - b0 * sy) / s, (e1[1] - b1 * sy) / s, (e2[1] - b2 * sy) / s};
+      const float ux = fmaf(bx[0], M->uvs[2 * g0], fmaf(bx[1], M->uvs[2 * g1], bx[2] * M->uvs[2 * g2]));
+      const float vx = fmaf(bx[0], M->uvs[2 * g0 + 1], fmaf(bx[1], M->uvs[2 * g1 + 1], bx[2] * M->uvs[2 * g2 + 1]));
+      const float uy = fmaf(by[0], M->uvs[2 * g0], fmaf(by[1], M->uvs[2 * g1], by[2] * M->uvs[2 * g2]));
+      const float vy = fmaf(by[0], M->uvs[2 * g0 + 1], fmaf(by[1], M->uvs[2 * g1 + 1], by[2] * M->uvs[2 * g2 + 1]));
+      tex_fetch_aniso(M->tex + toff, tw, th, nlev, tu, tv, ux, vx, uy, vy, alb);
+    } else {
+      tex_fetch(M->tex + toff, tw, th, tu, tv, alb);
+    }
   } else {
     for (int c = 0; c < 3; ++c)
       alb[c] = fmaf(b0, (float)M->colors[4 * g0 + c],
@@ -273,7 +332,8 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
       for (int i = 0; i < 9; ++i) finite &= isfinite(Kv[i]) ? 1 : 0;
       const int64_t* ob = M->obj + 8 * obj_ids[view];
       const int64_t voff = ob[0], nv = ob[1], foff = ob[2], nf = ob[3], toff = ob[4];
-      const int tw = (int)ob[5], th = (int)ob[6];
+      const int tw = (int)ob[5], th = (int)ob[6], nlev = (int)ob[7] > 0 ? (int)ob[7] : 1;
+      const int aniso = (flags & HP_R_TEX_ANISO) != 0;
       for (size_t p = 0; p < (size_t)h * w * ns; ++p) zbuf[p] = KEY_EMPTY;
       if ((size_t)nv * 3 > sv_cap) { sv_cap = (size_t)nv * 3; sv3 = (float*)realloc(sv3, sv_cap * 4); }
 
@@ -362,7 +422,7 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
           }
           if (!msaa) {
             if (ckey != KEY_EMPTY)
-              shade_centre(M, sv3, T, Kv, amb, n_lights, light_pos, light_col, view, voff, foff, toff, tw, th,
+              shade_centre(M, sv3, T, Kv, amb, n_lights, light_pos, light_col, view, voff, foff, toff, tw, th, nlev, aniso,
                            (int64_t)(ckey & 0xFFFFFFFFull), i, j, q8, o_rgb, o_n);
           } else {
             int64_t cf[4]; float crgb[4][3], cn[4][3]; int ncached = 0;
@@ -374,8 +434,8 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
               while (k < ncached && cf[k] != f) ++k;
               if (k == ncached) { /* one fragment-shader invocation per pixel and primitive */
                 cf[k] = f;
-                shade_centre(M, sv3, T, Kv, amb, n_lights, light_pos, light_col, view, voff, foff, toff, tw, th, f, i, j, q8,
-                             crgb[k], cn[k]);
+                shade_centre(M, sv3, T, Kv, amb, n_lights, light_pos, light_col, view, voff, foff, toff, tw, th, nlev, aniso, f, i,
+                             j, q8, crgb[k], cn[k]);
                 ++ncached;
               }
               for (int c = 0; c < 3; ++c) { a_rgb[c] += crgb[k][c]; a_n[c] += cn[k][c]; }

@@ -15,7 +15,7 @@ _DIR = Path(__file__).resolve().parent
 _LIB_PATH = _DIR / "_build" / "liboracle.so"
 _lib = None
 
-R_NORMALS, R_DEPTH, R_MASK, R_QUANT8, R_MSAA4 = 1, 2, 4, 8, 32
+R_NORMALS, R_DEPTH, R_MASK, R_QUANT8, R_MSAA4, R_TEX_ANISO = 1, 2, 4, 8, 32, 64
 
 
 def build(force: bool = False) -> Path:
@@ -85,8 +85,9 @@ def crop_images(images, boxes, im_ids, output_size=(240, 320)):
 
 def rasterize(meshes, obj_ids, TCO, K, resolution, render_normals=False, render_depth=False,
               render_binary_mask=False, ambient=None, light_pos=None, light_col=None,
-              quant8=True, msaa=False):
-    """``msaa``: 4x multisampled colour / normal buffers (``HP_R_MSAA4`` in oracle.c).
+              quant8=True, msaa=False, aniso=False):
+    """``msaa``: 4x multisampled colour / normal buffers (``HP_R_MSAA4`` in oracle.c); ``aniso``: mip-mapped trilinear +
+    anisotropic-16 texture filtering (``HP_R_TEX_ANISO``).
     Returns dict(rgbs [n,3,h,w], normals, depths [n,1,h,w], binary_masks bool) -- the
     shapes/dtypes of ``BatchRenderOutput`` (TB/renderer/types.py:45-56).
 
@@ -117,7 +118,8 @@ def rasterize(meshes, obj_ids, TCO, K, resolution, render_normals=False, render_
     M = _Meshes(*[_p(arrs[k]) for k in ("verts", "normals", "uvs", "colors", "faces", "tex", "obj")],
                 len(arrs["obj"]))
     flags = (R_NORMALS if render_normals else 0) | (R_DEPTH if render_depth else 0) | \
-        (R_MASK if render_binary_mask else 0) | (R_QUANT8 if quant8 else 0) | (R_MSAA4 if msaa else 0)
+        (R_MASK if render_binary_mask else 0) | (R_QUANT8 if quant8 else 0) | (R_MSAA4 if msaa else 0) | \
+        (R_TEX_ANISO if aniso else 0)
     if render_binary_mask:
         assert render_depth, "Binary mask can only be rendered if depth is rendered"
     rgb = np.empty((n, 3, h, w), np.float32)

@@ -296,3 +296,20 @@ def test_torch_ops_registered_with_shape_functions():
     assert o.conv2d_nhwc(m(2, 8, 8, 16), m(32, 3, 3, 16), 2, 1).shape == (2, 4, 4, 32)
     with pytest.raises(NotImplementedError):
         o.pose_update(torch.eye(4)[None], torch.eye(3)[None], torch.zeros(1, 9))
+
+
+def test_mip_chain_matches_box_filter():
+    """``mesh_store.mip_chain``: 2 x 2 box filter, rounded to nearest, halving down to 1 x 1; the packed texture pool holds
+    level 0 followed by the chain and the object row records the number of levels."""
+    from happypose_amd.mesh_store import PackedMeshes, mip_chain
+    from happypose_amd.synthetic import make_object_dataset
+
+    t = np.random.RandomState(0).randint(0, 256, size=(8, 4, 4)).astype(np.uint8)
+    ch = mip_chain(t)
+    assert [c.shape for c in ch] == [(4, 2, 4), (2, 1, 4), (1, 1, 4)]
+    ref = (t.astype(np.int32).reshape(4, 2, 2, 2, 4).sum((1, 3)) + 2) // 4
+    assert np.array_equal(ch[0], ref.astype(np.uint8))
+    assert np.array_equal(ch[1][:, 0], ((ch[0].astype(np.int32)[0::2].sum(1) + ch[0].astype(np.int32)[1::2].sum(1) + 2) // 4).astype(np.uint8))
+    pm = PackedMeshes(make_object_dataset(2, seed=1, tex_size=64))
+    assert pm.obj[0, 7] == 7 and pm.obj[1, 4] == sum(4 * (64 >> k) ** 2 for k in range(7))
+    assert pm.tex.size == 2 * pm.obj[1, 4]
