@@ -795,3 +795,41 @@ def test_two_lane_megapose_is_reproducible(dev, world):
         for k in out:
             for f in fields:
                 assert torch.equal(ref[k][f], getattr(out[k], f)), (run, k, f)
+
+
+@pytest.mark.parametrize("H,W,flavour", [(360, 500, "cosypose"), (720, 1280, "cosypose"), (350, 470, "megapose")])
+def test_refiners_on_other_frame_sizes_vs_oracle(dev, world, H, W, flavour):
+    """Frames that are not 640 x 480 (odd sizes, a portrait-ish aspect, HD): the crop box aspect rule, the roi_align
+    bounds and the K_crop chain depend on (H, W); poses against the oracle at T_TOL / R_TOL after 3 iterations."""
+    from happypose_amd.models import create_model_pose, create_pose_model_cosypose
+    from happypose_amd.synthetic import make_scene
+    from oracle.pipeline import OraclePredictor
+
+    store = world["store"]
+    sc = make_scene(n_detections=3, n_hypotheses=3, n_objects=3, seed=21, with_depth=True, H=H, W=W, f=0.9 * W)
+    B = len(sc["TCO_hyp"])
+    labels = _labels(world, sc["hyp_obj_ids"])
+    K = torch.as_tensor(sc["K"], device=dev)
+    im_ids = torch.zeros(B, dtype=torch.int32)
+    if flavour == "cosypose":
+        w = _weights("resnet18", 6, seed=1)
+        model = create_pose_model_cosypose(dict(backbone_str="resnet18"), world["renderer"], state_dict=w, max_batch=16)
+        images = sc["images"][:, :3].copy()
+        ora = OraclePredictor(w, store.packed, store.mesh_db.points, arch="resnet18", cosypose=True)
+    else:
+        w = _weights("vanilla_resnet34", 32, seed=4)
+        cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+                   render_depth=True, input_depth=True, predict_pose_update=True, depth_augmentation=False,
+                   depth_normalization_type="tCR_scale_clamp_center")
+        model = create_model_pose(cfg, world["renderer"], state_dict=w, max_batch=16)
+        images = sc["images"][:, :4].copy()
+        ora = OraclePredictor(w, store.packed, store.mesh_db.points, arch="vanilla_resnet34", n_views=4, multiview_type="TCO+front_3views",
+                              render_normals=True, render_depth=True, input_depth=True,
+                              depth_normalization_type="tCR_scale_clamp_center")
+    out = model.forward(torch.as_tensor(images, device=dev), K, labels, torch.as_tensor(sc["TCO_hyp"]), n_iterations=3, im_ids=im_ids)
+    ref = ora.forward(images, sc["K"], np.zeros(B, np.int32), sc["hyp_obj_ids"], sc["TCO_hyp"], 3)
+    for n in range(3):
+        o = out[f"iteration={n + 1}"]
+        dt, dr = _pose_err(o.TCO_output.cpu().numpy(), ref[n]["TCO_output"])
+        assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
+        np.testing.assert_allclose(o.boxes_crop.cpu().numpy(), ref[n]["boxes_crop"], rtol=1e-4, atol=5e-2)
