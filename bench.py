@@ -100,8 +100,8 @@ def bench_e2e(args, device, rank, world):
                 depth_augmentation=False)
     wc = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 9, pose_dim=0, n_views_logits=1), seed=0)
     wr = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 27), seed=1)
-    coarse = create_model_pose(ccfg, renderer, state_dict=wc, max_batch=576, precision=coarse_precision)
-    refiner = create_model_pose(rcfg, renderer, state_dict=wr, max_batch=64, precision="f32")
+    coarse = create_model_pose(ccfg, renderer, state_dict=wc, max_batch=576, precision=coarse_precision, n_lanes=args.lanes)
+    refiner = create_model_pose(rcfg, renderer, state_dict=wr, max_batch=64, precision="f32", n_lanes=args.lanes)
     est = PoseEstimator(refiner_model=refiner, coarse_model=coarse, bsz_objects=8, bsz_images=576, SO3_grid_size=576)
 
     # detections = bounding boxes of the projected objects (what a detector would hand over)

@@ -62,6 +62,8 @@ class _Entry:
 
 
 class GraphCache:
+    MAX_ENTRIES = 8  # signatures kept (least recently used dropped): an entry owns clones of its inputs and a graph pool
+
     def __init__(self, device):
         self.device = torch.device(device)
         self.entries: Dict[Tuple, _Entry] = {}
@@ -75,11 +77,14 @@ class GraphCache:
         ``keepalive()`` returns objects whose device memory the launches reference besides inputs and outputs
         (reused scratch buffers): the entry holds them so that a later reallocation cannot free them under the graph."""
         key = (consts, tuple((tuple(t.shape), t.dtype) for t in inputs))
-        e = self.entries.get(key)
+        e = self.entries.pop(key, None)
         cur = torch.cuda.current_stream(self.device)
         if e is None:
-            e = self.entries[key] = _Entry(self.device)
+            while len(self.entries) >= self.MAX_ENTRIES:
+                self.entries.pop(next(iter(self.entries)))  # dicts keep insertion order: the first key is the oldest use
+            e = _Entry(self.device)
             e.static_in = [t.clone() for t in inputs]
+        self.entries[key] = e  # (re-)inserted last = most recently used
         e.calls += 1
         for s, t in zip(e.static_in, inputs):
             if s.data_ptr() != t.data_ptr():
