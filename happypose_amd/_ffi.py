@@ -48,6 +48,10 @@ _PROTOS = {
                                c_i32p, c_i32p, C.c_int, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                C.c_void_p]),
+    "hp_pose_prep_views": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_i32p,
+                                     c_i32p, c_i32p, C.c_int, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                     C.c_void_p]),
     "hp_crop_roi_align": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, c_f32p, C.POINTER(Strides), c_f32p,
                                     C.c_int, C.c_void_p]),

@@ -108,11 +108,17 @@ struct PrepArgs {
   int b, n_views, normalize, im_h, im_w, crop_h, crop_w; float lamb;
   int n_images, n_obj;  // rows of K / objects of the store: an id outside them poisons the hypothesis (NaN outputs)
   float* TCO_out; float* tCR; float* TCV_O; float* boxes_rend; float* boxes_crop; float* K_crop;
+  // remove_TCO_rendering (TB/lib3d/multiview.py:189-236, MP/models/pose_rigid.py:609-611): the identity view is still
+  // evaluated (it defines TCO / tCR / the crop box / the crop's K) but is not one of the n_views rendered views: its K goes
+  // to K_crop_main, the look-at views fill slots 0..n_views-1 of TCV_O / K_crop with THEIR OWN 200-point crop intrinsics
+  int skip_tco; float* K_crop_main;
 };
 
 __global__ __launch_bounds__(kT) void pose_prep_kernel(PrepArgs a) {
   __shared__ float red[4][4];
-  const int i = blockIdx.x / a.n_views, v = blockIdx.x % a.n_views;
+  const int nvt = a.n_views + a.skip_tco;  // evaluated views: the rendered ones (+ the identity view when it is not rendered)
+  const int i = blockIdx.x / nvt, v = blockIdx.x % nvt;
+  const int slot = v - a.skip_tco;         // position among the rendered views, -1: the unrendered identity view
   const int tid = threadIdx.x;
   // The pose chain (normalize_T, the double-precision look-at of the extra views, P = K @ TV) is evaluated by lane 0
   // ONLY and the projection matrix handed to the other lanes through LDS.  Every lane used to evaluate it for itself:
@@ -192,24 +198,33 @@ __global__ __launch_bounds__(kT) void pose_prep_kernel(PrepArgs a) {
   float cy = K[5] + (ch - 1.0f) / 2.0f - ci;
   float ocx = cx - (cw - 1.0f) / 2.0f, ocy = cy - (ch - 1.0f) / 2.0f;
   float sx = fw / cw, sy = fh / ch;
-  float* Ko = a.K_crop + 9 * ((int64_t)i * a.n_views + v);
+  float Kn[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) Ko[k] = K[k];
-  Ko[0] = sx * K[0];
-  Ko[4] = sy * K[4];
-  Ko[2] = (fw - 1.0f) / 2.0f + sx * ocx;
-  Ko[5] = (fh - 1.0f) / 2.0f + sy * ocy;
+  for (int k = 0; k < 9; ++k) Kn[k] = K[k];
+  Kn[0] = sx * K[0];
+  Kn[4] = sy * K[4];
+  Kn[2] = (fw - 1.0f) / 2.0f + sx * ocx;
+  Kn[5] = (fh - 1.0f) / 2.0f + sy * ocy;
   if (bad_id) {
     const float nan = __builtin_nanf("");
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Ko[k] = nan;
+    for (int k = 0; k < 9; ++k) Kn[k] = nan;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { T[k] = nan; TV[k] = nan; }
     x1 = y1 = x2 = y2 = bx1 = by1 = bx2 = by2 = nan;
   }
-  if (a.TCV_O) {
+  if (slot >= 0) {
+    float* Ko = a.K_crop + 9 * ((int64_t)i * a.n_views + slot);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a.TCV_O[16 * ((int64_t)i * a.n_views + v) + k] = TV[k];
+    for (int k = 0; k < 9; ++k) Ko[k] = Kn[k];
+    if (a.TCV_O) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a.TCV_O[16 * ((int64_t)i * a.n_views + slot) + k] = TV[k];
+    }
+  }
+  if (v == 0 && a.K_crop_main) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.K_crop_main[9 * (int64_t)i + k] = Kn[k];
   }
 
   if (v == 0) {
@@ -321,6 +336,36 @@ __global__ __launch_bounds__(kT) void tco_init_kernel(InitArgs a) {
 
 }  // namespace hp
 
+static int pose_prep_impl(const hp_mesh_store* store, int b, int n_views, int multiview_type, int remove_tco,
+                          int normalize, const float* d_TCO_in, const float* d_K, int n_images,
+                          const int32_t* d_im_ids, const int32_t* d_obj_ids,
+                          const int32_t* d_point_ids_main, int n_points_main,
+                          const int32_t* d_point_ids_extra, int n_points_extra, int im_h,
+                          int im_w, int crop_h, int crop_w, float lamb, float* d_TCO_out,
+                          float* d_tCR, float* d_TCV_O, float* d_boxes_rend,
+                          float* d_boxes_crop, float* d_K_crop, float* d_K_crop_main, void* stream) {
+  using namespace hp;
+  HP_REQUIRE(store && store->points, "hp_pose_prep: mesh store has no point table");
+  HP_REQUIRE(b >= 0 && n_images >= 1, "hp_pose_prep: negative batch / no intrinsics");
+  const int nvt = n_views + (remove_tco ? 1 : 0);  // the identity view is evaluated either way
+  HP_REQUIRE((multiview_type == 0 && nvt == 1) || (multiview_type == 1 && nvt == 2) ||
+                 (multiview_type == 3 && nvt == 4) || (multiview_type == 5 && nvt == 6),
+             "hp_pose_prep: n_views does not match multiview_type");
+  HP_REQUIRE(!remove_tco || (n_views >= 2 && d_K_crop_main), "hp_pose_prep: remove_TCO_rendering needs >= 2 rendered views and d_K_crop_main");
+  if (b == 0) return HP_OK;
+  HP_REQUIRE(d_TCO_in && d_K && d_im_ids && d_obj_ids && d_K_crop, "hp_pose_prep: null input");
+  HP_REQUIRE(d_point_ids_main && n_points_main > 0 && n_points_main <= store->n_pad,
+             "hp_pose_prep: n_points must be in (0, n_pad]");
+  HP_REQUIRE(nvt == 1 || (d_point_ids_extra && n_points_extra > 0 && n_points_extra <= store->n_pad),
+             "hp_pose_prep: extra-view point ids missing");
+  PrepArgs a{store->points, store->n_pad, d_TCO_in, d_K, d_im_ids, d_obj_ids,
+             d_point_ids_main, n_points_main, d_point_ids_extra, n_points_extra,
+             b, n_views, normalize, im_h, im_w, crop_h, crop_w, lamb, n_images, store->n_obj,
+             d_TCO_out, d_tCR, d_TCV_O, d_boxes_rend, d_boxes_crop, d_K_crop, remove_tco ? 1 : 0, d_K_crop_main};
+  hipLaunchKernelGGL(pose_prep_kernel, dim3(b * nvt), dim3(kT), 0, (hipStream_t)stream, a);
+  return check_launch("pose_prep_kernel");
+}
+
 extern "C" int hp_pose_prep(const hp_mesh_store* store, int b, int n_views, int multiview_type,
                             int normalize, const float* d_TCO_in, const float* d_K, int n_images,
                             const int32_t* d_im_ids, const int32_t* d_obj_ids,
@@ -329,25 +374,22 @@ extern "C" int hp_pose_prep(const hp_mesh_store* store, int b, int n_views, int 
                             int im_w, int crop_h, int crop_w, float lamb, float* d_TCO_out,
                             float* d_tCR, float* d_TCV_O, float* d_boxes_rend,
                             float* d_boxes_crop, float* d_K_crop, void* stream) {
-  using namespace hp;
-  HP_REQUIRE(store && store->points, "hp_pose_prep: mesh store has no point table");
-  HP_REQUIRE(b >= 0 && n_images >= 1, "hp_pose_prep: negative batch / no intrinsics");
-  HP_REQUIRE((multiview_type == 0 && n_views == 1) || (multiview_type == 1 && n_views == 2) ||
-                 (multiview_type == 3 && n_views == 4) || (multiview_type == 5 && n_views == 6),
-             "hp_pose_prep: n_views does not match multiview_type");
-  if (b == 0) return HP_OK;
-  HP_REQUIRE(d_TCO_in && d_K && d_im_ids && d_obj_ids && d_K_crop, "hp_pose_prep: null input");
-  HP_REQUIRE(d_point_ids_main && n_points_main > 0 && n_points_main <= store->n_pad,
-             "hp_pose_prep: n_points must be in (0, n_pad]");
-  HP_REQUIRE(n_views == 1 || (d_point_ids_extra && n_points_extra > 0 && n_points_extra <= store->n_pad),
-             "hp_pose_prep: extra-view point ids missing");
-  if (b == 0) return HP_OK;
-  PrepArgs a{store->points, store->n_pad, d_TCO_in, d_K, d_im_ids, d_obj_ids,
-             d_point_ids_main, n_points_main, d_point_ids_extra, n_points_extra,
-             b, n_views, normalize, im_h, im_w, crop_h, crop_w, lamb, n_images, store->n_obj,
-             d_TCO_out, d_tCR, d_TCV_O, d_boxes_rend, d_boxes_crop, d_K_crop};
-  hipLaunchKernelGGL(pose_prep_kernel, dim3(b * n_views), dim3(kT), 0, (hipStream_t)stream, a);
-  return check_launch("pose_prep_kernel");
+  return pose_prep_impl(store, b, n_views, multiview_type, 0, normalize, d_TCO_in, d_K, n_images, d_im_ids, d_obj_ids,
+                        d_point_ids_main, n_points_main, d_point_ids_extra, n_points_extra, im_h, im_w, crop_h, crop_w, lamb,
+                        d_TCO_out, d_tCR, d_TCV_O, d_boxes_rend, d_boxes_crop, d_K_crop, nullptr, stream);
+}
+
+extern "C" int hp_pose_prep_views(const hp_mesh_store* store, int b, int n_views, int multiview_type, int remove_tco_rendering,
+                                  int normalize, const float* d_TCO_in, const float* d_K, int n_images,
+                                  const int32_t* d_im_ids, const int32_t* d_obj_ids,
+                                  const int32_t* d_point_ids_main, int n_points_main,
+                                  const int32_t* d_point_ids_extra, int n_points_extra, int im_h,
+                                  int im_w, int crop_h, int crop_w, float lamb, float* d_TCO_out,
+                                  float* d_tCR, float* d_TCV_O, float* d_boxes_rend,
+                                  float* d_boxes_crop, float* d_K_crop, float* d_K_crop_main, void* stream) {
+  return pose_prep_impl(store, b, n_views, multiview_type, remove_tco_rendering, normalize, d_TCO_in, d_K, n_images, d_im_ids,
+                        d_obj_ids, d_point_ids_main, n_points_main, d_point_ids_extra, n_points_extra, im_h, im_w, crop_h, crop_w,
+                        lamb, d_TCO_out, d_tCR, d_TCV_O, d_boxes_rend, d_boxes_crop, d_K_crop, d_K_crop_main, stream);
 }
 
 extern "C" int hp_pose_update(int b, const float* d_TCO, const float* d_K_crop, int k_stride,

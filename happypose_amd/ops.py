@@ -185,12 +185,18 @@ def rasterize_into(store: MeshStore, x: torch.Tensor, chan0: int, obj_ids: torch
 def pose_prep(store: MeshStore, TCO: torch.Tensor, K: torch.Tensor, im_ids: torch.Tensor,
               obj_ids: torch.Tensor, im_size: Tuple[int, int], crop_size: Tuple[int, int] = (240, 320),
               multiview_type: str = "TCO", normalize: bool = False, n_points: int = 2000,
-              n_points_extra: int = 200, lamb: float = 1.4):
-    """Returns ``dict(TCO, tCR, TCV_O [b,V,4,4], boxes_rend, boxes_crop, K_crop [b,V,3,3])``."""
+              n_points_extra: int = 200, lamb: float = 1.4, remove_TCO_rendering: bool = False):
+    """Returns ``dict(TCO, tCR, TCV_O [b,V,4,4], boxes_rend, boxes_crop, K_crop [b,V,3,3], K_crop_main [b,3,3])``.
+    ``K_crop_main`` is the K of the observed crop (``crop_inputs``): view 0 of ``K_crop`` unless
+    ``remove_TCO_rendering`` (the TCO view is then not among the ``V`` rendered views; every view carries the K of its
+    own 200-point crop, ``MP/models/pose_rigid.py:598-611``)."""
     dev = store.device
     b = TCO.shape[0]
     assert TCO.shape == (b, 4, 4) and K.dim() == 3 and K.shape[1:] == (3, 3)
     mv, V = MULTIVIEW[multiview_type]
+    if remove_TCO_rendering:
+        assert V >= 3, "remove_TCO_rendering needs a multi-view type with at least two look-at views"
+        V -= 1
     TCO, K = _f32(TCO, dev), _f32(K, dev)
     _check_ids(im_ids, K.shape[0], "pose_prep: im_ids -> K")
     _check_ids(obj_ids, len(store.labels), "pose_prep: obj_ids -> objects")
@@ -201,14 +207,24 @@ def pose_prep(store: MeshStore, TCO: torch.Tensor, K: torch.Tensor, im_ids: torc
                TCV_O=torch.empty((b, V, 4, 4), **f), boxes_rend=torch.empty((b, 4), **f),
                boxes_crop=torch.empty((b, 4), **f), K_crop=torch.empty((b, V, 3, 3), **f))
     ids_main = store.point_ids(n_points)
-    ids_extra = store.point_ids(n_points_extra) if V > 1 else None
+    multi = V > 1 or remove_TCO_rendering
+    ids_extra = store.point_ids(n_points_extra) if multi else None
     with torch.cuda.device(dev):
-        check(lib().hp_pose_prep(store.handle, b, V, mv, int(normalize), ptr(TCO), ptr(K), K.shape[0], ptr(im_ids),
-                                 ptr(obj_ids), ptr(ids_main), n_points, ptr(ids_extra),
-                                 n_points_extra if V > 1 else 0, im_size[0], im_size[1], crop_size[0],
-                                 crop_size[1], C.c_float(lamb), ptr(out["TCO"]), ptr(out["tCR"]),
-                                 ptr(out["TCV_O"]), ptr(out["boxes_rend"]), ptr(out["boxes_crop"]),
-                                 ptr(out["K_crop"]), stream_ptr(dev)), "hp_pose_prep")
+        if remove_TCO_rendering:
+            out["K_crop_main"] = torch.empty((b, 3, 3), **f)
+            check(lib().hp_pose_prep_views(store.handle, b, V, mv, 1, int(normalize), ptr(TCO), ptr(K), K.shape[0], ptr(im_ids),
+                                           ptr(obj_ids), ptr(ids_main), n_points, ptr(ids_extra), n_points_extra, im_size[0],
+                                           im_size[1], crop_size[0], crop_size[1], C.c_float(lamb), ptr(out["TCO"]),
+                                           ptr(out["tCR"]), ptr(out["TCV_O"]), ptr(out["boxes_rend"]), ptr(out["boxes_crop"]),
+                                           ptr(out["K_crop"]), ptr(out["K_crop_main"]), stream_ptr(dev)), "hp_pose_prep_views")
+        else:
+            check(lib().hp_pose_prep(store.handle, b, V, mv, int(normalize), ptr(TCO), ptr(K), K.shape[0], ptr(im_ids),
+                                     ptr(obj_ids), ptr(ids_main), n_points, ptr(ids_extra),
+                                     n_points_extra if multi else 0, im_size[0], im_size[1], crop_size[0],
+                                     crop_size[1], C.c_float(lamb), ptr(out["TCO"]), ptr(out["tCR"]),
+                                     ptr(out["TCV_O"]), ptr(out["boxes_rend"]), ptr(out["boxes_crop"]),
+                                     ptr(out["K_crop"]), stream_ptr(dev)), "hp_pose_prep")
+            out["K_crop_main"] = out["K_crop"][:, 0]
     return out
 
 

@@ -164,10 +164,11 @@ class _RenderAndCompare:
         return self.backbone.status()
 
     def _one_pass(self, images, K, im_ids, obj_ids, TCO_in, *, n_img_channels, multiview_type, normalize,
-                  render_normals, render_depth, depth_mode, want_pose, want_logits):
+                  render_normals, render_depth, depth_mode, want_pose, want_logits, remove_TCO_rendering=False):
         b = TCO_in.shape[0]
         prep = ops.pose_prep(self.store, TCO_in, K, im_ids, obj_ids, tuple(images.shape[-2:]),
-                             self.render_size, multiview_type=multiview_type, normalize=normalize)
+                             self.render_size, multiview_type=multiview_type, normalize=normalize,
+                             remove_TCO_rendering=remove_TCO_rendering)
         x = self._input_buffer(b)
         z = prep["tCR"][:, 2].contiguous() if depth_mode else None
         ops.crop_roi_align(images, prep["boxes_crop"], im_ids, self.render_size, out=x,
@@ -202,16 +203,18 @@ class PosePredictor(_RenderAndCompare):
         # (MP/training/megapose_forward_loss.py:122); forward_refiner / forward_coarse never pass it
         # (MP/models/pose_rigid.py:578-584), so at inference the flag is stored and has no effect -- same here.
         self.views_inplane_rotations = views_inplane_rotations
-        # remove_TCO_rendering is read by forward_refiner only (forward_coarse renders the hypothesis itself,
-        # MP/models/pose_rigid.py:483-532): coarse models may carry it, refiners without the TCO view are not built
-        if remove_TCO_rendering and predict_pose_update:
-            raise NotImplementedError("refiner with remove_TCO_rendering (unused by the released models)")
+        # remove_TCO_rendering: forward_refiner renders the look-at views only (MP/models/pose_rigid.py:578-611; with one
+        # rendered view make_TCO_multiview short-cuts to the TCO view and only the K of the render changes -- not built);
+        # forward_coarse renders the hypothesis itself either way (:483-532)
+        if remove_TCO_rendering and predict_pose_update and n_rendered_views < 2:
+            raise NotImplementedError("refiner with remove_TCO_rendering and a single rendered view")
         # legacy names (MP/training/pose_models_cfg.py:48-53)
         multiview_type = {"front_3views": "TCO+front_3views", "front_5views": "TCO+front_5views",
                           "front_1view": "TCO+front_1view"}.get(multiview_type, multiview_type)
         self.n_rendered_views = n_rendered_views
         self.multiview_type = multiview_type if n_rendered_views > 1 else "TCO"
-        if self.multiview_type not in ops.MULTIVIEW or ops.MULTIVIEW[self.multiview_type][1] != n_rendered_views:
+        self._skip_tco = bool(remove_TCO_rendering and predict_pose_update and n_rendered_views > 1)
+        if self.multiview_type not in ops.MULTIVIEW or ops.MULTIVIEW[self.multiview_type][1] != n_rendered_views + int(self._skip_tco):
             raise ValueError(multiview_type)
         self.input_depth = input_depth
         self.render_normals = render_normals
@@ -260,15 +263,18 @@ class PosePredictor(_RenderAndCompare):
                 images, K, im_ids, obj_ids, TCO_input, n_img_channels=self._n_img,
                 multiview_type=self.multiview_type, normalize=True, render_normals=self.render_normals,
                 render_depth=self.render_depth, depth_mode=self._depth_mode,
-                want_pose=self.predict_pose_update, want_logits=self.predict_rendered_views_logits)
+                want_pose=self.predict_pose_update, want_logits=self.predict_rendered_views_logits,
+                remove_TCO_rendering=self._skip_tco)
             TCO_norm = prep["TCO"]
             if self.predict_pose_update:
-                TCO_output = ops.pose_update(TCO_norm, prep["K_crop"], pose, prep["tCR"])
+                TCO_output = ops.pose_update(TCO_norm, prep["K_crop_main"].contiguous() if self._skip_tco else prep["K_crop"], pose,
+                                             prep["tCR"])
             else:
                 TCO_output = TCO_norm.clone()
             images_crop, renders = self._pixels(x, self._n_img, self._n_single_render_channels * self.n_rendered_views)
             recs.append(dict(TCO_input=TCO_norm, TCO_output=TCO_output, TCV_O=prep["TCV_O"], tCR=prep["tCR"],
-                             KV_crop=prep["K_crop"], boxes_rend=prep["boxes_rend"], boxes_crop=prep["boxes_crop"],
+                             KV_crop=prep["K_crop"], K_crop=prep["K_crop_main"] if self._skip_tco else None,
+                             boxes_rend=prep["boxes_rend"], boxes_crop=prep["boxes_crop"],
                              pose=pose, logits=logits, images_crop=images_crop, renders=renders, render_time=render_time))
             TCO_input = TCO_output
         return recs
@@ -284,7 +290,8 @@ class PosePredictor(_RenderAndCompare):
                 net_out["renderings_logits"] = r["logits"]
             outputs[f"iteration={n + 1}"] = PosePredictorOutput(
                 renders=r["renders"], images_crop=r["images_crop"], TCO_input=r["TCO_input"], TCO_output=r["TCO_output"],
-                TCV_O_input=r["TCV_O"], tCR=r["tCR"], labels=labels, K=Kb, K_crop=r["KV_crop"][:, 0],
+                TCV_O_input=r["TCV_O"], tCR=r["tCR"], labels=labels, K=Kb,
+                K_crop=r["K_crop"] if r.get("K_crop") is not None else r["KV_crop"][:, 0],
                 KV_crop=r["KV_crop"], network_outputs=net_out, boxes_rend=r["boxes_rend"], boxes_crop=r["boxes_crop"],
                 renderings_logits=r["logits"] if r["logits"] is not None else torch.empty(
                     len(labels), self.n_rendered_views, dtype=torch.float32, device=self.device),

@@ -144,6 +144,19 @@ int hp_pose_prep(const hp_mesh_store* store, int b, int n_views, int multiview_t
                  int crop_h, int crop_w, float lamb, float* d_TCO_out, float* d_tCR,
                  float* d_TCV_O, float* d_boxes_rend, float* d_boxes_crop, float* d_K_crop,
                  void* stream);
+/* The same with `remove_TCO_rendering` (TB/lib3d/multiview.py:189-236, MP/models/pose_rigid.py:609-611): the TCO view
+ * itself is not rendered.  n_views counts the RENDERED views (multiview_type 3 -> 3, 5 -> 5; >= 2); d_TCV_O / d_K_crop hold
+ * the look-at views only, each with the intrinsics of its own 200-point crop (compute_crops_multiview), and the K of the
+ * observed crop (crop_inputs; what hp_pose_update needs) goes to d_K_crop_main [b][9].  remove_tco_rendering = 0 behaves
+ * like hp_pose_prep (d_K_crop_main optional: a copy of view 0's K). */
+int hp_pose_prep_views(const hp_mesh_store* store, int b, int n_views, int multiview_type, int remove_tco_rendering,
+                       int normalize, const float* d_TCO_in, const float* d_K, int n_images,
+                       const int32_t* d_im_ids, const int32_t* d_obj_ids,
+                       const int32_t* d_point_ids_main, int n_points_main,
+                       const int32_t* d_point_ids_extra, int n_points_extra, int im_h, int im_w,
+                       int crop_h, int crop_w, float lamb, float* d_TCO_out, float* d_tCR,
+                       float* d_TCV_O, float* d_boxes_rend, float* d_boxes_crop, float* d_K_crop,
+                       float* d_K_crop_main, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Crop.  Replaces crop_images / torchvision.ops.roi_align(images, [k,x1,y1,x2,y2],

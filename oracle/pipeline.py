@@ -43,7 +43,7 @@ class OraclePredictor:
         self.points = np.asarray(points_table, np.float32)  # [n_obj, n_pad, 3]
         self.cfg = dict(arch="resnet34", n_views=1, multiview_type="TCO", render_normals=False,
                         render_depth=False, input_depth=False, depth_normalization_type=None,
-                        cosypose=False)
+                        cosypose=False, remove_TCO_rendering=False)
         self.cfg.update(cfg)
         self.render_size = (240, 320)
 
@@ -62,12 +62,14 @@ class OraclePredictor:
         TCO = TCO_in if c["cosypose"] else G.normalize_T(TCO_in)
         tCR = TCO[:, :3, 3].copy()
         V = c["n_views"]
-        TCV_O = G.make_TCO_multiview(TCO, tCR, c["multiview_type"], V) if V > 1 else TCO[:, None].copy()
+        skip = bool(c["remove_TCO_rendering"]) and V > 1  # forward_refiner: the look-at views only (pose_rigid.py:578-611)
+        TCV_O = G.make_TCO_multiview(TCO, tCR, c["multiview_type"], V, remove_TCO_rendering=skip) if V > 1 else TCO[:, None].copy()
         boxes_rend, boxes_crop, K_crop = self._crop_inputs(images, Kb, TCO, tCR, obj_ids, im_ids)
         images_crop = native.crop_images(np.ascontiguousarray(images[:, :n_img]), boxes_crop, im_ids, self.render_size)
         KV = np.zeros((b, V, 3, 3), np.float32)
-        KV[:, 0] = K_crop
-        for v in range(1, V):  # compute_crops_multiview: 200 points, boxes only
+        if not skip:
+            KV[:, 0] = K_crop
+        for v in range(1 if not skip else 0, V):  # compute_crops_multiview: 200 points, boxes only
             _, _, KV[:, v] = self._crop_inputs(images, Kb, TCV_O[:, v], TCV_O[:, v, :3, 3], obj_ids, im_ids, 200)
         r = native.rasterize(self.meshes, np.repeat(obj_ids, V), TCV_O.reshape(-1, 4, 4), KV.reshape(-1, 3, 3),
                              self.render_size, c["render_normals"], c["render_depth"])
