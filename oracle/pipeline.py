@@ -43,7 +43,7 @@ class OraclePredictor:
         self.points = np.asarray(points_table, np.float32)  # [n_obj, n_pad, 3]
         self.cfg = dict(arch="resnet34", n_views=1, multiview_type="TCO", render_normals=False,
                         render_depth=False, input_depth=False, depth_normalization_type=None,
-                        cosypose=False, remove_TCO_rendering=False)
+                        cosypose=False, remove_TCO_rendering=False, msaa=False, aniso=False)
         self.cfg.update(cfg)
         self.render_size = (240, 320)
 
@@ -72,7 +72,7 @@ class OraclePredictor:
         for v in range(1 if not skip else 0, V):  # compute_crops_multiview: 200 points, boxes only
             _, _, KV[:, v] = self._crop_inputs(images, Kb, TCV_O[:, v], TCV_O[:, v, :3, 3], obj_ids, im_ids, 200)
         r = native.rasterize(self.meshes, np.repeat(obj_ids, V), TCV_O.reshape(-1, 4, 4), KV.reshape(-1, 3, 3),
-                             self.render_size, c["render_normals"], c["render_depth"])
+                             self.render_size, c["render_normals"], c["render_depth"], msaa=c["msaa"], aniso=c["aniso"])
         parts = [r["rgbs"]]
         if c["render_normals"]:
             parts.append(r["normals"])

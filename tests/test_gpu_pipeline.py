@@ -864,3 +864,43 @@ def test_megapose_refiner_remove_tco_rendering_vs_oracle(dev, world):
         np.testing.assert_allclose(o.K_crop.cpu().numpy(), ref[n]["K_crop"], rtol=1e-4, atol=5e-2)
     # the first rendered view is the re-aimed camera, not the TCO view
     assert not torch.allclose(out["iteration=1"].TCV_O_input[:, 0], out["iteration=1"].TCO_input, atol=1e-4)
+
+
+def test_refiner_with_reference_render_state_vs_oracle(dev, world):
+    """``BatchRenderer(msaa=True, aniso=True)`` (the reference renderer's framebuffer / texture state) through the whole
+    MegaPose refiner: multi-view NHWC slices, normals and depth channels, against the oracle with the same switches."""
+    from happypose_amd.models import create_model_pose
+    from happypose_amd.renderer import BatchRenderer
+    from oracle.pipeline import OraclePredictor
+
+    sc, store = world["scene"], world["store"]
+    renderer = BatchRenderer(world["ds"], device=dev, store=store, msaa=True, aniso=True)
+    cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+               render_depth=True, input_depth=True, predict_pose_update=True, depth_augmentation=False,
+               depth_normalization_type="tCR_scale_clamp_center")
+    w = _weights("vanilla_resnet34", 32, seed=2)
+    model = create_model_pose(cfg, renderer, state_dict=w, max_batch=8)
+    model.keep_pixels = True
+    sel = np.arange(0, 12, 2)
+    images = torch.as_tensor(sc["images"], device=dev)
+    out = model.forward(images, torch.as_tensor(sc["K"], device=dev), _labels(world, sc["hyp_obj_ids"][sel]),
+                        torch.as_tensor(sc["TCO_hyp"][sel]), n_iterations=2, im_ids=torch.zeros(len(sel), dtype=torch.int32))
+    ora = OraclePredictor(w, store.packed, store.mesh_db.points, arch="vanilla_resnet34", n_views=4,
+                          multiview_type="TCO+front_3views", render_normals=True, render_depth=True, input_depth=True,
+                          depth_normalization_type="tCR_scale_clamp_center", msaa=True, aniso=True)
+    ref = ora.forward(sc["images"], sc["K"], np.zeros(len(sel), np.int32), sc["hyp_obj_ids"][sel], sc["TCO_hyp"][sel], 2)
+    for n in range(2):
+        o = out[f"iteration={n + 1}"]
+        dt, dr = _pose_err(o.TCO_output.cpu().numpy(), ref[n]["TCO_output"])
+        assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
+    # the renders of the first iteration differ from the default state's (the switches reach the predictor's raster call)
+    plain = create_model_pose(cfg, world["renderer"], state_dict=w, max_batch=8)
+    plain.keep_pixels = True
+    o2 = plain.forward(images, torch.as_tensor(sc["K"], device=dev), _labels(world, sc["hyp_obj_ids"][sel]),
+                       torch.as_tensor(sc["TCO_hyp"][sel]), n_iterations=1, im_ids=torch.zeros(len(sel), dtype=torch.int32))
+    r_on, r_off = out["iteration=1"].renders, o2["iteration=1"].renders
+    assert r_on.shape == r_off.shape == (len(sel), 28, 240, 320)
+    rgb_idx = [v * 7 + c for v in range(4) for c in range(3)]
+    dep_idx = [v * 7 + 6 for v in range(4)]
+    assert (r_on[:, rgb_idx] != r_off[:, rgb_idx]).float().mean() > 0.01
+    assert torch.equal(r_on[:, dep_idx], r_off[:, dep_idx])  # depth stays centre-sampled
