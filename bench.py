@@ -266,7 +266,8 @@ def stage_rates(store, scene, images, K, TCO0, im_ids, device, reps=20):
         return e0.elapsed_time(e1) / reps * 1e-3
 
     t_r = timeit(lambda: ops.rasterize_into(store, x, 3, obj, TCO0[:, None], Kc[:, None], False, False))
-    t_c = timeit(lambda: ops.crop_roi_align(images, prep["boxes_crop"], im_ids, out=x))
+    # as the predictors call it: the crop owns the pixel record and stores whole 32-B sectors (HP_CROP_FULL_RECORD8)
+    t_c = timeit(lambda: ops.crop_roi_align(images, prep["boxes_crop"], im_ids, out=x, n_channels=3, owns_record=True))
     return {
         "rasterize": {"views": B, "us": t_r * 1e6, "algorithmic_MB": raster_bytes / 1e6,
                       "GB/s": raster_bytes / t_r / 1e9, "frac_hbm_peak": raster_bytes / t_r / PEAK_HBM_BPS,

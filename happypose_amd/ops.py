@@ -231,7 +231,7 @@ def pose_prep(store: MeshStore, TCO: torch.Tensor, K: torch.Tensor, im_ids: torc
 def crop_roi_align(images: torch.Tensor, boxes: torch.Tensor, im_ids: torch.Tensor,
                    output_size=(240, 320), sampling_ratio: int = 4, out: Optional[torch.Tensor] = None,
                    depth_norm_z: Optional[torch.Tensor] = None, depth_norm_mode: int = 0,
-                   n_channels: Optional[int] = None) -> torch.Tensor:
+                   n_channels: Optional[int] = None, owns_record: bool = False) -> torch.Tensor:
     """``crop_images`` (TB/lib3d/cropping.py:155-197).  ``out=None`` -> NCHW ``[n,C,oh,ow]``;
     otherwise ``out`` is the NHWC network input ``[n,oh,ow,c_pad]`` and channels 0..C-1 are
     written."""
@@ -254,10 +254,15 @@ def crop_roi_align(images: torch.Tensor, boxes: torch.Tensor, im_ids: torch.Tens
         cp = out.shape[3]
         st = Strides(oh * ow * cp, 0, 1, ow * cp, cp)
     fn = lib().hp_crop_roi_align_f16 if res.dtype == torch.float16 else lib().hp_crop_roi_align
+    mode = depth_norm_mode if Cc == 4 else 0
+    # ``owns_record``: the caller promises that the rest of every pixel record may be zeroed (the rasteriser writes it
+    # afterwards): 8-float records are then stored as whole 32-B sectors (HP_CROP_FULL_RECORD8)
+    if owns_record and out is not None and res.dtype == torch.float32 and Cc == 3 and res.shape[3] == 8 and res.data_ptr() % 32 == 0:
+        mode |= 0x100
     with torch.cuda.device(dev):
         check(fn(ptr(images), Bi, Ct, Cc, H, W, ptr(boxes), ptr(im_ids), n, oh, ow,
                  sampling_ratio, ptr(res), C.byref(st),
-                 ptr(depth_norm_z), depth_norm_mode if Cc == 4 else 0, stream_ptr(dev)),
+                 ptr(depth_norm_z), mode, stream_ptr(dev)),
               "hp_crop_roi_align")
     return res
 

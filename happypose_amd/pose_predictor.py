@@ -173,7 +173,7 @@ class _RenderAndCompare:
         z = prep["tCR"][:, 2].contiguous() if depth_mode else None
         ops.crop_roi_align(images, prep["boxes_crop"], im_ids, self.render_size, out=x,
                            depth_norm_z=z, depth_norm_mode=depth_mode if n_img_channels == 4 else 0,
-                           n_channels=n_img_channels)
+                           n_channels=n_img_channels, owns_record=True)  # the rasteriser writes the rest of the record next
         t0 = time.time()
         ops.rasterize_into(self.store, x, n_img_channels, obj_ids, prep["TCV_O"], prep["K_crop"],
                            render_normals, render_depth, z, depth_mode, msaa=self.renderer.msaa, aniso=self.renderer.aniso)

@@ -293,6 +293,16 @@ def test_crop_vs_oracle(dev):
     assert np.all(o[..., 4:] == 0)
     e = ops.crop_roi_align(torch.as_tensor(img, device=dev), torch.zeros(0, 4), torch.zeros(0, dtype=torch.int32))
     assert e.shape == (0, 4, 240, 320)
+    # the crop as owner of an 8-float pixel record (HP_CROP_FULL_RECORD8): same three channels, the rest of the record zeroed
+    net_in = torch.full((6, 240, 320, 8), 7.0, device=dev)
+    ops.crop_roi_align(torch.as_tensor(img, device=dev), torch.as_tensor(boxes), torch.as_tensor(ids), out=net_in, n_channels=3,
+                       owns_record=True)
+    o = net_in.cpu().numpy()
+    np.testing.assert_allclose(o[..., :3], ref[:, :3].transpose(0, 2, 3, 1), rtol=1e-5, atol=1e-6)
+    assert np.all(o[..., 3:] == 0)
+    plain = torch.full((6, 240, 320, 8), 7.0, device=dev)
+    ops.crop_roi_align(torch.as_tensor(img, device=dev), torch.as_tensor(boxes), torch.as_tensor(ids), out=plain, n_channels=3)
+    assert torch.equal(plain[..., :3], net_in[..., :3]) and bool((plain[..., 3:] == 7.0).all())
 
 
 # -------------------------------------------------------------------------------- geometry
