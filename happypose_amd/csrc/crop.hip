@@ -29,7 +29,7 @@ struct CropArgs {
   const float* boxes; const int32_t* im_ids; int n, oh, ow, sr;
   void* out; int out_half; hp_strides os;  // fp32, or fp16 when the crop feeds an fp16 network input directly
   const float* depth_norm_z; int depth_norm_mode;
-  int full_record8;  // fp32 NHWC destination whose pixel record is exactly 8 floats starting at the crop's channel 0, 32-B aligned
+  int full_record8;  // fp32 NHWC destination, records of a multiple of 8 floats, 32-B aligned: the crop owns the first 8 floats
 };
 
 constexpr int kMaxSR = 4;
@@ -352,13 +352,14 @@ __global__ __launch_bounds__(256) void crop_tile_kernel(CropArgs a) {
       _Float16* const o = reinterpret_cast<_Float16*>(a.out);
 #pragma unroll
       for (int c = 0; c < NC; ++c) o[obase + (int64_t)c * a.os.s_chan] = (_Float16)outv[c];
-    } else if (a.os.s_chan == 1 && NC == 3 && a.full_record8) {
-      // CosyPose network input: the pixel record is 8 floats = one 32-B sector.  The crop runs first and writes the WHOLE
-      // record (its three channels + zeros; the rasteriser overwrites channels 3..5, the pad stays zero): a full-sector
-      // store instead of 12 B of it (a partial-sector write costs the memory system a read-modify-write)
+    } else if (a.os.s_chan == 1 && a.full_record8) {
+      // The crop runs first and owns the first 8 floats = the first 32-B sector of every pixel record (CosyPose: the whole
+      // record; MegaPose RGB-D: its four channels + the head of view 0's render): it writes the WHOLE sector (its channels +
+      // zeros; the rasteriser overwrites the rest afterwards, pads stay zero) -- a full-sector store instead of 12 / 16 B
+      // of it (a partial-sector write costs the memory system a read-modify-write)
       typedef float float4v __attribute__((ext_vector_type(4)));
       float* const o = reinterpret_cast<float*>(a.out) + obase;
-      *reinterpret_cast<float4v*>(o) = float4v{outv[0], outv[1], outv[2], 0.f};
+      *reinterpret_cast<float4v*>(o) = float4v{outv[0], outv[1], outv[2], NC == 4 ? outv[NC - 1] : 0.f};
       *reinterpret_cast<float4v*>(o + 4) = float4v{0.f, 0.f, 0.f, 0.f};
     } else if (a.os.s_chan == 1 && NC == 3) {
       *reinterpret_cast<float3v*>(reinterpret_cast<float*>(a.out) + obase) = float3v{outv[0], outv[1], outv[2]};
@@ -387,10 +388,10 @@ static int crop_launch(const float* d_images, int Bi, int C, int n_channels, int
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_crop_roi_align: depth_norm_z missing");
   if (n == 0) return HP_OK;
   HP_REQUIRE(d_boxes && d_im_ids && d_out, "hp_crop_roi_align: null pointer");
-  HP_REQUIRE(!full_record || (!out_half && n_channels == 3 && out_strides->s_chan == 1 && out_strides->s_col == 8 &&
-                              out_strides->s_row == 8 * (int64_t)out_w && out_strides->s_item == 8 * (int64_t)out_w * out_h &&
+  HP_REQUIRE(!full_record || (!out_half && out_strides->s_chan == 1 && out_strides->s_col >= 8 && out_strides->s_col % 8 == 0 &&
+                              out_strides->s_row % 8 == 0 && out_strides->s_item % 8 == 0 &&
                               (reinterpret_cast<uintptr_t>(d_out) & 31) == 0),
-             "hp_crop_roi_align: HP_CROP_FULL_RECORD8 needs a dense fp32 [n][oh][ow][8] destination, 3 channels, 32-B aligned");
+             "hp_crop_roi_align: HP_CROP_FULL_RECORD8 needs an fp32 NHWC destination whose pixel records are multiples of 8 floats, 32-B aligned");
   CropArgs a{d_images, Bi, C, n_channels, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio,
              d_out, out_half, *out_strides, d_depth_norm_z, depth_norm_mode, full_record ? 1 : 0};
   static const bool old_kernel = std::getenv("HP_CROP_OLD") != nullptr;  // A/B: the 16 x 16 tile kernel

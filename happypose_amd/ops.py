@@ -256,8 +256,8 @@ def crop_roi_align(images: torch.Tensor, boxes: torch.Tensor, im_ids: torch.Tens
     fn = lib().hp_crop_roi_align_f16 if res.dtype == torch.float16 else lib().hp_crop_roi_align
     mode = depth_norm_mode if Cc == 4 else 0
     # ``owns_record``: the caller promises that the rest of every pixel record may be zeroed (the rasteriser writes it
-    # afterwards): 8-float records are then stored as whole 32-B sectors (HP_CROP_FULL_RECORD8)
-    if owns_record and out is not None and res.dtype == torch.float32 and Cc == 3 and res.shape[3] == 8 and res.data_ptr() % 32 == 0:
+    # afterwards): the first 8 floats of every record are then stored as a whole 32-B sector (HP_CROP_FULL_RECORD8)
+    if owns_record and out is not None and res.dtype == torch.float32 and res.shape[3] % 8 == 0 and res.data_ptr() % 32 == 0:
         mode |= 0x100
     with torch.cuda.device(dev):
         check(fn(ptr(images), Bi, Ct, Cc, H, W, ptr(boxes), ptr(im_ids), n, oh, ow,
