@@ -348,7 +348,14 @@ __global__ __launch_bounds__(256) void crop_tile_kernel(CropArgs a) {
     }
     const int64_t obase = (int64_t)r * a.os.s_item + (int64_t)ph * a.os.s_row + (int64_t)pw * a.os.s_col;
     typedef float float3v __attribute__((ext_vector_type(3)));
-    if (a.out_half) {  // strides count fp16 elements
+    if (a.out_half && a.os.s_chan == 1 && a.full_record8) {
+      // fp16 network input (16-half records = one 32-B sector): same ownership rule, sixteen halves in two 16-B stores
+      typedef _Float16 halfx8v __attribute__((ext_vector_type(8)));
+      _Float16* const o = reinterpret_cast<_Float16*>(a.out) + obase;
+      const _Float16 z = (_Float16)0.f;
+      *reinterpret_cast<halfx8v*>(o) = halfx8v{(_Float16)outv[0], (_Float16)outv[1], (_Float16)outv[2], NC == 4 ? (_Float16)outv[NC - 1] : z, z, z, z, z};
+      *reinterpret_cast<halfx8v*>(o + 8) = halfx8v{z, z, z, z, z, z, z, z};
+    } else if (a.out_half) {  // strides count fp16 elements
       _Float16* const o = reinterpret_cast<_Float16*>(a.out);
 #pragma unroll
       for (int c = 0; c < NC; ++c) o[obase + (int64_t)c * a.os.s_chan] = (_Float16)outv[c];
@@ -388,10 +395,13 @@ static int crop_launch(const float* d_images, int Bi, int C, int n_channels, int
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_crop_roi_align: depth_norm_z missing");
   if (n == 0) return HP_OK;
   HP_REQUIRE(d_boxes && d_im_ids && d_out, "hp_crop_roi_align: null pointer");
-  HP_REQUIRE(!full_record || (!out_half && out_strides->s_chan == 1 && out_strides->s_col >= 8 && out_strides->s_col % 8 == 0 &&
-                              out_strides->s_row % 8 == 0 && out_strides->s_item % 8 == 0 &&
-                              (reinterpret_cast<uintptr_t>(d_out) & 31) == 0),
-             "hp_crop_roi_align: HP_CROP_FULL_RECORD8 needs an fp32 NHWC destination whose pixel records are multiples of 8 floats, 32-B aligned");
+  {
+    const int unit = out_half ? 16 : 8;  // elements per 32-B sector
+    HP_REQUIRE(!full_record || (out_strides->s_chan == 1 && out_strides->s_col >= unit && out_strides->s_col % unit == 0 &&
+                                out_strides->s_row % unit == 0 && out_strides->s_item % unit == 0 &&
+                                (reinterpret_cast<uintptr_t>(d_out) & 31) == 0),
+               "hp_crop_roi_align: HP_CROP_FULL_RECORD8 needs an NHWC destination whose pixel records are multiples of 32 B, 32-B aligned");
+  }
   CropArgs a{d_images, Bi, C, n_channels, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio,
              d_out, out_half, *out_strides, d_depth_norm_z, depth_norm_mode, full_record ? 1 : 0};
   static const bool old_kernel = std::getenv("HP_CROP_OLD") != nullptr;  // A/B: the 16 x 16 tile kernel

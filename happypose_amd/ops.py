@@ -257,7 +257,7 @@ def crop_roi_align(images: torch.Tensor, boxes: torch.Tensor, im_ids: torch.Tens
     mode = depth_norm_mode if Cc == 4 else 0
     # ``owns_record``: the caller promises that the rest of every pixel record may be zeroed (the rasteriser writes it
     # afterwards): the first 8 floats of every record are then stored as a whole 32-B sector (HP_CROP_FULL_RECORD8)
-    if owns_record and out is not None and res.dtype == torch.float32 and res.shape[3] % 8 == 0 and res.data_ptr() % 32 == 0:
+    if owns_record and out is not None and res.shape[3] % (8 if res.dtype == torch.float32 else 16) == 0 and res.data_ptr() % 32 == 0:
         mode |= 0x100
     with torch.cuda.device(dev):
         check(fn(ptr(images), Bi, Ct, Cc, H, W, ptr(boxes), ptr(im_ids), n, oh, ow,

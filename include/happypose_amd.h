@@ -167,8 +167,8 @@ int hp_pose_prep_views(const hp_mesh_store* store, int b, int n_views, int multi
  * n_channels (3 = rgb, 4 = rgbd) planes are cropped (a model without input_depth drops the
  * depth plane of an RGB-D observation, MP/models/pose_rigid.py:557-559).  Output
  * addressing as in hp_rasterize with views_per_item = 1 (s_view unused).
- * depth_norm_mode may carry HP_CROP_FULL_RECORD8: the destination is an fp32 NHWC tensor whose pixel records are
- * multiples of 8 floats (32-B aligned) and the crop owns the first 8 floats of each: its 3 / 4 channels AND zeros for the
+ * depth_norm_mode may carry HP_CROP_FULL_RECORD8: the destination is an NHWC tensor whose pixel records are
+ * multiples of 32 B (8 floats / 16 halves; 32-B aligned) and the crop owns the first 32 B of each: its 3 / 4 channels AND zeros for the
  * rest of that 32-B sector are written as one full-sector store (the rasteriser writes its channels afterwards): a
  * partial-sector store costs the memory system a read-modify-write.
  * ---------------------------------------------------------------------------------- */
