@@ -3,7 +3,7 @@
 One refiner step is ``n_iterations x (pose_prep, crop, rasterise, ~40 conv launches, head, pose_update)`` --
 about 250 launches per lane whose shapes and buffers do not change between calls of the same signature.
 Capturing the step once and replaying it takes the host out of the loop (the reference has no counterpart: its
-loop is Python + Panda3D worker processes per iteration).  Measured on MI355X (``profiles/r02h_bench_line*_graphs.json``):
+loop is Python + Panda3D worker processes per iteration).  Measured on MI355X (``profiles/r02j_bench_line*_graphs.json``):
 +1.5 % on C2 and C3 -- with two lanes the kernels of a step add up to 1.5x its wall time, the GPU is the bound, not
 the host's launch rate -- so replay is opt-in (``create_model_pose(..., graphs=True)``); it pays where the host is
 slower or the batches smaller than in the benchmark configurations.
