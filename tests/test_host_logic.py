@@ -313,3 +313,18 @@ def test_mip_chain_matches_box_filter():
     pm = PackedMeshes(make_object_dataset(2, seed=1, tex_size=64))
     assert pm.obj[0, 7] == 7 and pm.obj[1, 4] == sum(4 * (64 >> k) ** 2 for k in range(7))
     assert pm.tex.size == 2 * pm.obj[1, 4]
+
+
+def test_graph_cache_structure_helpers():
+    """``graphs.flatten`` / ``unflatten`` round-trip the nested per-lane / per-iteration records (tensors, None, scalars)."""
+    from happypose_amd.graphs import GraphCache, flatten, unflatten
+
+    rec = [[dict(TCO=torch.ones(2, 4, 4), pose=None, render_time=0.5, parts=(torch.zeros(3), torch.arange(2)))], [dict(TCO=torch.eye(4))]]
+    flat = []
+    spec = flatten(rec, flat)
+    assert len(flat) == 4 and all(isinstance(t, torch.Tensor) for t in flat)
+    back = unflatten(spec, [t + 1 for t in flat])
+    assert back[0][0]["pose"] is None and back[0][0]["render_time"] == 0.5
+    assert torch.equal(back[0][0]["TCO"], torch.full((2, 4, 4), 2.0)) and torch.equal(back[0][0]["parts"][1], torch.arange(2) + 1)
+    assert torch.equal(back[1][0]["TCO"], torch.eye(4) + 1)
+    assert GraphCache.MAX_ENTRIES >= 2
