@@ -544,7 +544,7 @@ def main():
                 "note": "same job with hp_net_set_conv_algo(WINOGRAD): every multiply an fp32 FMA on the fp32 matrix path"}
         if args.workload == "C2":
             line["stages"] = stage_rates(store, scene, images, K, TCO0, im_ids, device)
-        if not args.no_cpu_baseline and args.workload == "C2":
+        if not args.no_cpu_baseline and args.workload == "C2" and world == 1:  # the CPU baseline is a 1-GPU-run item
             base, cpu_poses = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds)
             line["cpu_baseline"] = base
             line["speedup_vs_cpu"] = line["value"] / base["value"]
