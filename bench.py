@@ -39,7 +39,7 @@ N_DET, N_HYP, N_ITERS = 8, 16, 5
 WORKLOADS = ("C2", "C3", "C5", "E2E")
 
 
-def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32", n_lanes=1):
+def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32", n_lanes=1, update_scale=0.002, renderer_kw=None):
     """Synthetic world of SURVEY.md 8(d) for a BASELINE.json config:
     C2 CosyPose refiner (8 det x 16 hyp, WideResNet-34 on 6 channels, 1 RGB view);
     C3 MegaPose RGB-D refiner (64 hypotheses, 4 views x (RGB + normals + depth), ResNet-34 on 32 ch);
@@ -49,15 +49,15 @@ def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32",
     from happypose_amd.synthetic import make_object_dataset, make_scene, predictor_weights
 
     ds = make_object_dataset(8, seed=1, tex_size=1024)
-    renderer = BatchRenderer(ds, device=device)
+    renderer = BatchRenderer(ds, device=device, **(renderer_kw or {}))
     if workload == "C2":
         scene = make_scene(n_detections=N_DET, n_hypotheses=N_HYP, n_objects=8, seed=2 + seed)
-        weights = predictor_weights(pose_model_param_shapes(arch, 6), seed=0)
+        weights = predictor_weights(pose_model_param_shapes(arch, 6), seed=0, update_scale=update_scale)
         model = create_pose_model_cosypose(dict(backbone_str=arch), renderer, state_dict=weights,
                                            max_batch=N_DET * N_HYP, precision=precision, n_lanes=n_lanes)
     elif workload == "C3":
         scene = make_scene(n_detections=8, n_hypotheses=8, n_objects=8, seed=2 + seed, with_depth=True)
-        weights = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 32), seed=0)
+        weights = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 32), seed=0, update_scale=update_scale)
         cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views",
                    render_normals=True, render_depth=True, input_depth=True, predict_pose_update=True,
                    depth_augmentation=False, depth_normalization_type="tCR_scale_clamp_center")
@@ -321,7 +321,8 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: this process only spawns the ranks
-        assert torch.cuda.device_count() >= args.gpus, f"--gpus {args.gpus} but {torch.cuda.device_count()} visible"
+        # (no device query here: it would initialise HIP in this parent, which only spawns; a rank without a GPU fails
+        # with its own message)
         sys.exit(spawn_ranks(args.gpus))
 
     from happypose_amd import distributed as D

@@ -40,6 +40,8 @@ _PROTOS = {
                                            c_u8p, C.c_int64, C.c_void_p, C.c_int, c_f32p, C.c_int]),
     "hp_mesh_store_destroy": (None, [C.c_void_p]),
     "hp_mesh_store_points": (C.c_void_p, [C.c_void_p]),
+    "hp_mesh_store_reserve_raster": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hp_mesh_store_scratch_generation": (C.c_int64, [C.c_void_p]),
     "hp_rasterize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
                                C.POINTER(Strides), c_f32p, C.POINTER(Strides), c_u8p, c_f32p, C.c_int,

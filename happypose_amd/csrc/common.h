@@ -56,6 +56,7 @@ struct MeshStore {
   size_t bin_count_bytes = 0;
   float4* xverts = nullptr;  // per-(view, vertex) screen-space vertices of the current chunk (2 float4 each)
   size_t xverts_bytes = 0;
+  int64_t scratch_generation = 0;  // bumped whenever the scratch above is reallocated (captured graphs hold the old pointers)
   int n_obj = 0;
   int n_pad = 0;
   int64_t max_verts = 0;  // max vertices of a single object

@@ -281,6 +281,11 @@ int conv_plan_split(ConvArgs& a, int T, size_t lds_bytes, int k_units, int ktile
   a.sk_counters = nullptr;
   if (S > 1) {
     const size_t need_slab = (size_t)tail * S * BM * 128 * sizeof(float), need_cnt = (size_t)tail * sizeof(int);
+    if (ws.slab_bytes < need_slab || ws.counter_bytes < need_cnt) {  // must not grow under capture: the first (eager) call of a signature sizes it
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (stream) (void)hipStreamIsCapturing(stream, &cap);
+      HP_REQUIRE(cap == hipStreamCaptureStatusNone, "conv tail split: the K-slice workspace of this stream would have to grow during stream capture");
+    }
     if (ws.slab_bytes < need_slab) {
       if (ws.slabs) (void)hipFree(ws.slabs);
       ws.slabs = nullptr; ws.slab_bytes = 0;

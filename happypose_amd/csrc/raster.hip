@@ -669,6 +669,57 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
 
 }  // namespace hp
 
+// Rasteriser scratch of a mesh store for `n` views of `n_bands` bands: per-(view, band) triangle lists, their counters
+// and the per-(view, vertex) screen-space records.  Grows, never shrinks; refuses to grow under stream capture (a
+// captured launch would keep the pointer that is freed here) -- run the call once eagerly, or reserve.
+static int raster_scratch(hp::MeshStore* ms, int n, int n_bands, hipStream_t st, int* chunk_out) {
+  const size_t per_view = (size_t)n_bands * (size_t)ms->max_faces * sizeof(int32_t);
+  const size_t budget = (size_t)512 << 20;
+  int chunk = (int)(budget / (per_view ? per_view : 1));
+  if (chunk < 1) chunk = 1;
+  if (chunk > n) chunk = n;
+  *chunk_out = chunk;
+  const size_t need_list = (size_t)chunk * per_view, need_cnt = (size_t)chunk * n_bands * sizeof(int32_t);
+  const size_t need_xv = (size_t)chunk * (size_t)ms->max_verts * 2 * sizeof(float4);
+  if (ms->bin_list_bytes >= need_list && ms->bin_count_bytes >= need_cnt && ms->xverts_bytes >= need_xv) return HP_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (st) (void)hipStreamIsCapturing(st, &cap);
+  HP_REQUIRE(cap == hipStreamCaptureStatusNone,
+             "hp_rasterize: the rasteriser scratch would have to grow during stream capture (hp_mesh_store_reserve_raster first)");
+  auto grow = [](void** p, size_t* have, size_t need) -> int {
+    if (*have >= need) return HP_OK;
+    if (*p) (void)hipFree(*p);  // hipFree waits for the device: nothing in flight reads it any more
+    *p = nullptr; *have = 0;
+    HP_CHECK_HIP(hipMalloc(p, need));
+    *have = need;
+    return HP_OK;
+  };
+  int rc = grow((void**)&ms->bin_list, &ms->bin_list_bytes, need_list);
+  if (!rc) rc = grow((void**)&ms->bin_count, &ms->bin_count_bytes, need_cnt);
+  if (!rc) rc = grow((void**)&ms->xverts, &ms->xverts_bytes, need_xv);
+  ms->scratch_generation += 1;
+  return rc;
+}
+
+static int raster_bands(int h, int w, int msaa) {
+  const int band_rows = msaa ? hp::kBandKeysMsaa / (hp::kSamplesMsaa * w) : hp::kBandPixels / w;
+  return (h + band_rows - 1) / band_rows;
+}
+
+extern "C" int hp_mesh_store_reserve_raster(hp_mesh_store* store, int n_views, int h, int w, int flags) {
+  using namespace hp;
+  HP_REQUIRE(store != nullptr, "hp_mesh_store_reserve_raster: null mesh store");
+  HP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= kBandPixels, "hp_mesh_store_reserve_raster: bad size");
+  if (n_views == 0) return HP_OK;
+  int chunk = 0;
+  int rc = raster_scratch(store, n_views, raster_bands(h, w, 0), nullptr, &chunk);
+  if (!rc && (flags & HP_RASTER_MSAA4) && kSamplesMsaa * w <= kBandKeysMsaa)
+    rc = raster_scratch(store, n_views, raster_bands(h, w, 1), nullptr, &chunk);
+  return rc;
+}
+
+extern "C" int64_t hp_mesh_store_scratch_generation(const hp_mesh_store* store) { return store ? store->scratch_generation : -1; }
+
 extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
                             const int32_t* d_obj_ids, const float* d_TCO, const float* d_K,
                             const float* d_ambient, int n_lights, const float* d_light_pos,
@@ -708,42 +759,23 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   a.band_rows = a.msaa ? kBandKeysMsaa / (kSamplesMsaa * w) : kBandPixels / w;
   a.n_bands = (h + a.band_rows - 1) / a.band_rows;
   a.depth_max = kZNear / (1.0f - (1.0f - 1e-3f) * (kZFar - kZNear) / kZFar);
-  // Views are processed in chunks so that the per-(view, band) triangle lists stay within a
-  // fixed scratch budget; the scratch (owned by the store) only grows on the first call of
-  // a given size -- callers sharing one store must be stream-ordered.
+  // Views are processed in chunks so that the per-(view, band) triangle lists stay within a fixed scratch budget.  The
+  // scratch is owned by the store and only ever grows (hp_mesh_store_reserve_raster pre-sizes it; predictors do that at
+  // construction for their largest batch); a growth bumps the store's scratch generation, which tells holders of
+  // captured hipGraphs that the pointers their launches carry are gone.  Callers sharing one store must be stream-ordered.
   hp::MeshStore* ms = const_cast<hp_mesh_store*>(store);
   a.max_faces = (int)store->max_faces;
   a.bin_cap = a.max_faces;
-  const size_t per_view = (size_t)a.n_bands * a.bin_cap * sizeof(int32_t);
-  const size_t budget = (size_t)512 << 20;
-  int chunk = (int)(budget / per_view);
-  if (chunk < 1) chunk = 1;
-  if (chunk > n) chunk = n;
-  const size_t need_list = (size_t)chunk * per_view, need_cnt = (size_t)chunk * a.n_bands * sizeof(int32_t);
-  if (ms->bin_list_bytes < need_list) {
-    if (ms->bin_list) (void)hipFree(ms->bin_list);
-    ms->bin_list = nullptr; ms->bin_list_bytes = 0;
-    HP_CHECK_HIP(hipMalloc((void**)&ms->bin_list, need_list));
-    ms->bin_list_bytes = need_list;
-  }
-  if (ms->bin_count_bytes < need_cnt) {
-    if (ms->bin_count) (void)hipFree(ms->bin_count);
-    ms->bin_count = nullptr; ms->bin_count_bytes = 0;
-    HP_CHECK_HIP(hipMalloc((void**)&ms->bin_count, need_cnt));
-    ms->bin_count_bytes = need_cnt;
-  }
   a.max_verts = (int)store->max_verts;
-  const size_t need_xv = (size_t)chunk * a.max_verts * 2 * sizeof(float4);
-  if (ms->xverts_bytes < need_xv) {
-    if (ms->xverts) (void)hipFree(ms->xverts);
-    ms->xverts = nullptr; ms->xverts_bytes = 0;
-    HP_CHECK_HIP(hipMalloc((void**)&ms->xverts, need_xv));
-    ms->xverts_bytes = need_xv;
+  hipStream_t st = (hipStream_t)stream;
+  int chunk = 0;
+  {
+    const int rc = raster_scratch(ms, n, a.n_bands, st, &chunk);
+    if (rc) return rc;
   }
   a.bin_list = ms->bin_list;
   a.bin_count = ms->bin_count;
   a.xverts = ms->xverts;
-  hipStream_t st = (hipStream_t)stream;
   for (int v0 = 0; v0 < n; v0 += chunk) {
     const int nv = n - v0 < chunk ? n - v0 : chunk;
     a.view0 = v0;

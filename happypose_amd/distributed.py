@@ -56,61 +56,104 @@ def shard_range(n: int, rank: Optional[int] = None, world: Optional[int] = None)
     return start, start + q + (1 if rank < r else 0)
 
 
+def gather_rows(rows: torch.Tensor, start: int, n_total: int) -> torch.Tensor:
+    """The ONE collective of the path.  ``rows [N_local, C]`` fp32 = this rank's contiguous shard of a global row table
+    beginning at global row ``start``; every rank returns the whole table ``[n_total, C]`` in global order.  Ragged
+    shards are padded to the largest one; a trailing id column (-1 = padding) travels with the rows, so the result does
+    not depend on how the ranks cut the table.  ``all_gather_into_tensor``: RCCL over xGMI with backend "nccl", gloo in
+    the CPU tests."""
+    world = get_world_size()
+    n_local, c = rows.shape
+    if world == 1:
+        assert n_local == n_total
+        return rows
+    dev = rows.device
+    cap = (n_total + world - 1) // world
+    assert n_local <= cap, "a shard is larger than ceil(n_total / world): not a shard_range() partition"
+    buf = torch.full((cap, c + 1), -1.0, dtype=torch.float32, device=dev)
+    buf[:n_local, :c] = rows.float()
+    buf[:n_local, c] = torch.arange(start, start + n_local, device=dev, dtype=torch.float32)
+    out = torch.empty((world * cap, c + 1), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, buf)
+    ids = out[:, c].long()
+    keep = ids >= 0
+    out, ids = out[keep], ids[keep]
+    assert out.shape[0] == n_total, "shards do not cover the row table"
+    res = torch.empty((n_total, c), dtype=torch.float32, device=dev)
+    res[ids] = out[:, :c]
+    return res
+
+
 def gather_poses(poses: torch.Tensor, scores: Optional[torch.Tensor], start: int, n_total: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """All ranks get all results.  ``poses [N_local,4,4]`` (this rank's contiguous shard
     beginning at global index ``start``), ``scores [N_local]`` or None.  Returns
-    ``(poses [n_total,4,4], scores [n_total])`` in global order."""
-    world = get_world_size()
+    ``(poses [n_total,4,4], scores [n_total])`` in global order: one ``[N_local, 18]`` row per hypothesis
+    (16 pose floats + score + global id) through :func:`gather_rows`."""
     n_local = poses.shape[0]
-    dev = poses.device
     if scores is None:
-        scores = torch.zeros(n_local, device=dev)
-    if world == 1:
+        scores = torch.zeros(n_local, device=poses.device)
+    if get_world_size() == 1:
         assert n_local == n_total
         return poses, scores
-    cap = (n_total + world - 1) // world  # ragged shards are padded to the largest one
-    rows = torch.full((cap, ROW), -1.0, dtype=torch.float32, device=dev)
-    rows[:n_local, :16] = poses.reshape(n_local, 16).float()
-    rows[:n_local, 16] = scores.float()
-    rows[:n_local, 17] = torch.arange(start, start + n_local, device=dev, dtype=torch.float32)
-    out = torch.empty((world * cap, ROW), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(out, rows)
-    ids = out[:, 17].long()
-    keep = ids >= 0
-    out, ids = out[keep], ids[keep]
-    assert out.shape[0] == n_total, "shards do not cover the hypothesis set"
-    res = torch.empty((n_total, ROW), dtype=torch.float32, device=dev)
-    res[ids] = out
+    rows = torch.cat([poses.reshape(n_local, 16).float(), scores.reshape(n_local, 1).float()], dim=1)
+    res = gather_rows(rows, start, n_total)
     return res[:, :16].reshape(n_total, 4, 4), res[:, 16]
 
 
+def sharding_active(flag: Optional[bool] = None) -> bool:
+    """Whether an entry point shards its hypothesis rows over the ranks: ``flag`` if given, else whenever
+    ``torch.distributed`` is initialised with more than one rank.  Sharding is a COLLECTIVE: every rank must make the
+    same call with the same inputs (the frame, detections, meshes and weights are replicated).  Pass
+    ``False`` where ranks work on different scenes (the reference's evaluation sampler)."""
+    return get_world_size() > 1 if flag is None else bool(flag and get_world_size() > 1)
+
+
+def all_ranks_max(value: int, device) -> int:
+    """MAX of a small integer over the ranks (the estimators agree on a guard re-run with it)."""
+    if get_world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 def refine_sharded(model, images: torch.Tensor, K: torch.Tensor, labels, TCO: torch.Tensor, n_iterations: int,
-                   im_ids: Optional[torch.Tensor] = None, scores_fn=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                   im_ids: Optional[torch.Tensor] = None, scores_fn=None, bsz: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """every rank holds the frame(s), meshes and weights; the hypotheses -- sorted by
     (detection, hypothesis id) by the caller -- are split into contiguous shards, each rank runs the
-    refiner loop on its shard (no collective inside the loop) and ONE ``all_gather_into_tensor``
-    hands every rank all refined poses (``[N,4,4]`` in the caller's order) and scores.
+    refiner loop on its shard (no collective inside the loop; chunks of ``bsz``, default the predictor's
+    ``max_batch``) and ONE ``all_gather_into_tensor`` hands every rank all refined poses (``[N,4,4]`` in the caller's
+    order) and scores.  Replaces the reference's rank files + barriers
+    (``TB/utils/tensor_collection.py:166-187``, ``MP/evaluation/prediction_runner.py:65-76``).
 
-    ``model`` is a predictor (``PosePredictor`` / ``CosyPosePosePredictor``: anything whose
+    ``model`` is a predictor (``PosePredictor`` / ``CosyPosePosePredictor`` / ``TwoLanePredictor``: anything whose
     ``forward(images, K, labels, TCO, n_iterations=, im_ids=)`` returns the per-iteration outputs);
-    ``scores_fn(last_output) -> [n_local]`` optionally attaches a score to every hypothesis."""
+    ``scores_fn(last_output) -> [n_chunk]`` optionally attaches a score to every hypothesis."""
     n = len(labels)
     assert TCO.shape == (n, 4, 4)
     s, e = shard_range(n)
     labels = list(labels)
-    ids = None if im_ids is None else im_ids[s:e]
     if im_ids is None:  # reference convention: images / K already gathered per hypothesis -> shard them too
         assert K.shape[0] == n and images.shape[0] == n, "without im_ids, images and K must hold one row per hypothesis"
-        images, K = images[s:e], K[s:e]
-    # with im_ids the frames stay whole on every rank: im_ids[s:e] keeps indexing the global frame list
-    if e > s:
-        out = model.forward(images, K, labels[s:e], TCO[s:e], n_iterations=n_iterations, im_ids=ids)
+    # with im_ids the frames stay whole on every rank: im_ids[a:b] keeps indexing the global frame list
+    if bsz is None:
+        bsz = int(getattr(model, "max_batch", 0) or 0) or max(e - s, 1)
+    poses_l, scores_l = [], []
+    for a in range(s, e, bsz):
+        b = min(e, a + bsz)
+        if im_ids is None:
+            out = model.forward(images[a:b], K[a:b], labels[a:b], TCO[a:b], n_iterations=n_iterations, im_ids=None)
+        else:
+            out = model.forward(images, K, labels[a:b], TCO[a:b], n_iterations=n_iterations, im_ids=im_ids[a:b])
         last = out[f"iteration={n_iterations}"]
-        poses = last.TCO_output
-        scores = None if scores_fn is None else scores_fn(last)
+        poses_l.append(last.TCO_output)
+        if scores_fn is not None:
+            scores_l.append(scores_fn(last))
+    if poses_l:
+        poses = torch.cat(poses_l) if len(poses_l) > 1 else poses_l[0]
+        scores = (torch.cat(scores_l) if len(scores_l) > 1 else scores_l[0]) if scores_l else None
     else:  # more ranks than hypotheses
-        poses = TCO[:0].to(torch.float32)
-        scores = None
+        poses, scores = torch.zeros((0, 4, 4), dtype=torch.float32, device=getattr(model, "device", TCO.device)), None
     return gather_poses(poses, scores, s, n)
 
 

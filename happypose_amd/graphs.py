@@ -73,11 +73,15 @@ class GraphCache:
     def clear(self) -> None:
         self.entries.clear()
 
+    @staticmethod
+    def key_of(consts: Tuple, inputs: Sequence[torch.Tensor]) -> Tuple:
+        return (tuple(consts), tuple((tuple(t.shape), t.dtype) for t in inputs))
+
     def run(self, consts: Tuple, inputs: Sequence[torch.Tensor], fn: Callable[..., Any], keepalive: Callable[[], List[Any]] = None):
         """``fn(*inputs)`` -> nested structure of tensors; ``consts`` = everything else the launches depend on.
         ``keepalive()`` returns objects whose device memory the launches reference besides inputs and outputs
         (reused scratch buffers): the entry holds them so that a later reallocation cannot free them under the graph."""
-        key = (consts, tuple((tuple(t.shape), t.dtype) for t in inputs))
+        key = self.key_of(consts, inputs)
         e = self.entries.pop(key, None)
         cur = torch.cuda.current_stream(self.device)
         if e is None:

@@ -214,13 +214,25 @@ def mip_chain(tex: np.ndarray):
     return levels
 
 
+def hpr_to_matrix(ypr_deg) -> np.ndarray:
+    """Rotation of Panda3D's ``NodePath.setHpr(h, p, r)`` (degrees; Z-up, Y-forward frame): heading about +Z, pitch
+    about +X, roll about +Y, applied roll first, then pitch, then heading -- ``R = Rz(h) @ Rx(p) @ Ry(r)`` on column
+    vectors.  **[unverified]**: Panda3D's documented convention; Panda3D is absent here."""
+    h, p, r = (np.deg2rad(float(a)) for a in ypr_deg)
+    ch, sh, cp, sp, cr, sr = np.cos(h), np.sin(h), np.cos(p), np.sin(p), np.cos(r), np.sin(r)
+    Rz = np.array([[ch, -sh, 0.0], [sh, ch, 0.0], [0.0, 0.0, 1.0]])
+    Rx = np.array([[1.0, 0.0, 0.0], [0.0, cp, -sp], [0.0, sp, cp]])
+    Ry = np.array([[cr, 0.0, sr], [0.0, 1.0, 0.0], [-sr, 0.0, cr]])
+    return Rz @ Rx @ Ry
+
+
 class PackedMeshes:
     """Flat layout consumed by the rasteriser (HIP and oracle).
 
     ``verts [Vtot,3] f32`` (metres), ``normals [Vtot,3] f32``, ``uvs [Vtot,2] f32``,
     ``colors [Vtot,4] u8``, ``faces [Ftot,3] i32`` (ids local to the object),
     ``tex`` RGBA8 pool, ``obj [n_obj,8] i64`` = (vert_off, n_verts, face_off, n_faces,
-    tex_off | -1, tex_w, tex_h, n_mip_levels), ``radius [n_obj] f32`` = bounding radius (m).  A texture is stored as its
+    tex_off | -1, tex_w, tex_h, n_mip_levels), ``radius [n_obj] f32`` = largest vertex norm (m), ``bounds_center`` / ``bounds_radius`` = the bounding sphere light-positioning functions see.  A texture is stored as its
     level 0 followed by its mip chain (:func:`mip_chain`; level ``k`` is ``max(1, w >> k) x max(1, h >> k)``): the
     bilinear level-0 fetch ignores the chain, ``HP_RASTER_TEX_ANISO`` (the reference's ``texture-minfilter mipmap`` +
     ``texture-anisotropic-degree 16``) walks it."""
@@ -229,15 +241,22 @@ class PackedMeshes:
         self.labels = [o.label for o in object_ds.list_objects]
         self.label_to_id = {l: i for i, l in enumerate(self.labels)}
         verts, normals, uvs, colors, faces, tex, rows, radius = [], [], [], [], [], [], [], []
+        centers, bradius = [], []
         voff = foff = toff = 0
         for obj in object_ds.list_objects:
             m = obj.load()
-            v = (np.asarray(m.vertices, dtype=np.float64) * obj.scale).astype(np.float32)
-            if tuple(obj.ypr_offset_deg) != (0.0, 0.0, 0.0):
-                raise NotImplementedError("ypr_offset_deg (Panda3D-only mesh rotation)")
+            v64 = np.asarray(m.vertices, dtype=np.float64) * obj.scale
+            n64 = np.asarray(m.normals, np.float64)
+            if tuple(float(a) for a in obj.ypr_offset_deg) != (0.0, 0.0, 0.0):
+                # the RENDER mesh only is rotated (get_object_node: setScale, setHpr --
+                # TB/renderer/panda3d_scene_renderer.py:206-219); the point table of MeshDataBase is not
+                # (TB/lib3d/rigid_mesh_database.py:109-111)
+                R = hpr_to_matrix(obj.ypr_offset_deg)
+                v64, n64 = v64 @ R.T, n64 @ R.T
+            v = v64.astype(np.float32)
             nv, nf = len(v), len(m.faces)
             verts.append(v)
-            normals.append(np.asarray(m.normals, np.float32))
+            normals.append(n64.astype(np.float32))
             uvs.append(np.zeros((nv, 2), np.float32) if m.uvs is None else np.asarray(m.uvs, np.float32))
             if m.colors is not None:
                 colors.append(np.asarray(m.colors, np.uint8).reshape(nv, 4))
@@ -254,6 +273,11 @@ class PackedMeshes:
             else:
                 rows.append((voff, nv, foff, nf, -1, 0, 0, 0))
             radius.append(float(np.linalg.norm(v, axis=1).max()) if nv else 0.0)
+            # bounding sphere as Panda3D builds it for a Geom (centre of the vertices' bounding box, radius = the farthest
+            # vertex from it): what ``root_node.getBounds()`` answers to a light-positioning function  [unverified]
+            c = (v.min(0).astype(np.float64) + v.max(0).astype(np.float64)) / 2 if nv else np.zeros(3)
+            centers.append(c)
+            bradius.append(float(np.linalg.norm(v.astype(np.float64) - c, axis=1).max()) if nv else 0.0)
             voff += nv
             foff += nf
         self.verts = np.concatenate(verts)
@@ -264,6 +288,8 @@ class PackedMeshes:
         self.tex = np.concatenate(tex) if tex else np.zeros(4, np.uint8)
         self.obj = np.asarray(rows, dtype=np.int64)
         self.radius = np.asarray(radius, dtype=np.float32)
+        self.bounds_center = np.asarray(centers, dtype=np.float64).reshape(-1, 3)
+        self.bounds_radius = np.asarray(bradius, dtype=np.float32)
 
     def ids_of(self, labels) -> np.ndarray:
         return np.asarray([self.label_to_id[l] for l in labels], dtype=np.int32)

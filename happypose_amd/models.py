@@ -206,7 +206,7 @@ def _two_lanes(make, renderer: BatchRenderer, max_batch: int):
     from .pose_predictor import TwoLanePredictor
 
     half = (max_batch + 1) // 2
-    r1 = BatchRenderer(renderer._object_dataset, device=renderer.device)
+    r1 = renderer.clone_for_lane()  # same render state (msaa / aniso / ...), own store
     return TwoLanePredictor([make(renderer, half), make(r1, half)])
 
 

@@ -104,6 +104,18 @@ class MeshStore:
     def ids_of(self, labels: Sequence[str]) -> torch.Tensor:
         return torch.as_tensor([self.label_to_id[l] for l in labels], dtype=torch.int32, device=self.device)
 
+    def reserve_raster(self, n_views: int, resolution: Tuple[int, int] = (240, 320), msaa: bool = False) -> None:
+        """Size the rasteriser scratch for ``n_views`` views per call once (``hp_mesh_store_reserve_raster``): later
+        calls of up to that size never reallocate it, so captured hipGraphs keep valid pointers."""
+        with torch.cuda.device(self.device):
+            check(lib().hp_mesh_store_reserve_raster(self.handle, int(n_views), resolution[0], resolution[1], 32 if msaa else 0),
+                  "hp_mesh_store_reserve_raster")
+
+    def scratch_generation(self) -> int:
+        """Number of times the rasteriser scratch was reallocated (``hp_mesh_store_scratch_generation``): graphs
+        captured under an older generation hold freed pointers."""
+        return int(lib().hp_mesh_store_scratch_generation(self.handle))
+
     def point_ids(self, n_points: int) -> torch.Tensor:
         """ids of ``sample_points(n, deterministic=True)`` (TB/lib3d/mesh_ops.py:74-84)."""
         if n_points not in self._point_ids:
@@ -156,7 +168,8 @@ def rasterize(store: MeshStore, obj_ids: torch.Tensor, TCO: torch.Tensor, K: tor
 def rasterize_into(store: MeshStore, x: torch.Tensor, chan0: int, obj_ids: torch.Tensor,
                    TCV_O: torch.Tensor, KV: torch.Tensor, render_normals: bool, render_depth: bool,
                    depth_norm_z: Optional[torch.Tensor] = None, depth_norm_mode: int = 0,
-                   ambient: Optional[torch.Tensor] = None, msaa: bool = False, aniso: bool = False) -> None:
+                   ambient: Optional[torch.Tensor] = None, msaa: bool = False, aniso: bool = False,
+                   light_pos: Optional[torch.Tensor] = None, light_col: Optional[torch.Tensor] = None) -> None:
     """Render ``V`` views per hypothesis straight into channel slices of the NHWC network
     input ``x [b,h,w,c_pad]``: view ``v`` occupies channels ``chan0 + v*C_r ...`` in the
     reference's order rgb, normals, depth (MP/models/pose_rigid.py:437-453)."""
@@ -175,9 +188,17 @@ def rasterize_into(store: MeshStore, x: torch.Tensor, chan0: int, obj_ids: torch
     nrm_p = C.c_void_p(base + esz * 3) if render_normals else None
     dep_p = C.c_void_p(base + esz * (6 if render_normals else 3)) if render_depth else None
     flags = 8 | (16 if x.dtype == torch.float16 else 0) | (32 if msaa else 0) | (64 if aniso else 0)
+    n_lights = 0
+    if light_pos is not None:  # [b*V, L, 3] object-frame positions + colours of point lights, ambient [b*V, 3]
+        light_pos, light_col = _f32(light_pos, dev), _f32(light_col, dev)
+        n_lights = light_pos.shape[1]
+        assert light_pos.shape == (b * V, n_lights, 3) and light_col.shape == (b * V, n_lights, 3)
+    if ambient is not None:
+        ambient = _f32(ambient, dev)
+        assert ambient.shape == (b * V, 3)
     with torch.cuda.device(dev):
-        check(lib().hp_rasterize(store.handle, b * V, V, ptr(obj_ids), ptr(TCV_O), ptr(KV), ptr(ambient), 0,
-                                 None, None, h, w, flags, rgb_p, nrm_p, C.byref(cs), dep_p, C.byref(cs), None,
+        check(lib().hp_rasterize(store.handle, b * V, V, ptr(obj_ids), ptr(TCV_O), ptr(KV), ptr(ambient), n_lights,
+                                 ptr(light_pos), ptr(light_col), h, w, flags, rgb_p, nrm_p, C.byref(cs), dep_p, C.byref(cs), None,
                                  ptr(depth_norm_z), depth_norm_mode if render_depth else 0, stream_ptr(dev)),
               "hp_rasterize")
 
@@ -320,6 +341,8 @@ class Net:
     """``hp_net``: backbone + heads with BN folded, on one device."""
 
     profiling = False  # set_profiling(True): conv stretches are timed with HIP events (no graph capture then)
+    tail_split = True  # hp_net_set_tail_split state: changes the launch plan, so it is part of a graph signature
+    _exact_only = False  # last seen HP_STATUS_EXACT_ONLY (the guard's switch to the exact-fp32 kernels)
 
     def __init__(self, arch: str, n_inputs: int, state_dict: Dict[str, "np.ndarray | torch.Tensor"],
                  max_batch: int = 128, device="cuda", h: int = 240, w: int = 320, precision: str = "f32"):
@@ -328,6 +351,7 @@ class Net:
         self.device = torch.device(device)
         self.arch, self.n_inputs, self.h, self.w = arch, n_inputs, h, w
         self.precision = precision
+        self.max_batch = max_batch
         self.n_features = N_FEATURES[arch]
         with torch.cuda.device(self.device):
             self._h = lib().hp_net_create(ARCH[arch], n_inputs, h, w)
@@ -420,6 +444,7 @@ class Net:
         """K-slicing of the tail tiles of this network's conv launches (``hp_net_set_tail_split``): off while a
         second lane shares the GPU."""
         check(lib().hp_net_set_tail_split(self.handle, int(on)), "hp_net_set_tail_split")
+        self.tail_split = bool(on)
 
     def status(self, stream=None) -> int:
         """``hp_net_status``: waits for ``stream`` (default: the current one) and returns the guard flags --
@@ -430,8 +455,13 @@ class Net:
         sp = stream_ptr(self.device) if stream is None else C.c_void_p(stream.cuda_stream)
         with torch.cuda.device(self.device):
             check(lib().hp_net_status(self.handle, sp, C.byref(flags)), "hp_net_status")
-        if flags.value:
-            bump_graph_epoch()  # the network switched kernels: captured graphs still hold the old ones
+        exact = bool(flags.value & STATUS_EXACT_ONLY)
+        if (flags.value & STATUS_NONFINITE) or exact != self._exact_only:
+            # the network switched kernels (or just poisoned a forward): captured graphs still hold the old launches.
+            # Only the TRANSITION bumps: the sticky EXACT_ONLY bit alone would otherwise drop every graph cache of the
+            # process after every stage of the estimators
+            bump_graph_epoch()
+        self._exact_only = exact
         return flags.value
 
     def profile_collect(self):

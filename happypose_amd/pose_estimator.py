@@ -15,8 +15,13 @@ Differences that are deliberate:
     python loop of ``pd.DataFrame([row] * M)`` (seconds at M = 576 in the reference);
   * ``bsz_objects`` / ``bsz_images`` only bound the working-set size (chunks are large by
     default because 288 GB of HBM are available), results are independent of them;
-  * with ``torch.distributed`` initialised, ``forward_refiner`` can shard hypotheses over
-    ranks and merge with ONE all-gather (``happypose_amd.distributed``).
+  * with ``torch.distributed`` initialised (more than one rank) the estimators SHARD their hypothesis rows: every
+    rank runs ``forward_refiner`` / ``forward_coarse_model`` / ``forward_scoring_model`` on its contiguous
+    ``distributed.shard_range`` of the rows and ONE all-gather per stage (``distributed.gather_rows``) hands every rank
+    the whole result -- identical on every rank and to a single-process run.  This replaces the reference's rank files +
+    barriers (``TB/utils/tensor_collection.py:166-187``, ``MP/evaluation/prediction_runner.py:65-76``).  It is a
+    collective: all ranks must call with the same inputs; ``estimator.shard_hypotheses = False`` switches it off for
+    scene-parallel use (each rank on its own frames).
 """
 
 from __future__ import annotations
@@ -30,6 +35,7 @@ import numpy as np
 import pandas as pd
 import torch
 
+from . import distributed as D
 from . import ops
 from .tensor_collection import PandasTensorCollection, concatenate, filter_top_pose_estimates
 
@@ -197,15 +203,29 @@ class _EstimatorBase:
     def eval(self):
         return self
 
-    @staticmethod
-    def _guarded(model, stage):
+    # None: shard the hypothesis rows over the ranks whenever torch.distributed runs with more than one
+    # (happypose_amd.distributed.sharding_active); False: never (ranks work on different frames)
+    shard_hypotheses: Optional[bool] = None
+
+    def _shard(self, n_rows: int) -> Tuple[int, int, bool]:
+        """``(start, end, sharded)``: the rows of an ``n_rows`` table this rank computes."""
+        if D.sharding_active(self.shard_hypotheses):
+            s, e = D.shard_range(n_rows)
+            return s, e, True
+        return 0, n_rows, False
+
+    def _guarded(self, model, stage):
         """Run ``stage()`` and ask the model's backbone for its numerical guard at the stage's end (one stream
         synchronisation, where the pipeline synchronises anyway to read scores).  If an activation left the fp16 range
         of the default split-fp16 conv kernels (``HP_STATUS_NONFINITE``) the results are invalid; the backbone has
-        switched to its exact-fp32 kernels, so the stage is simply run again -- the reference's fp32 arithmetic."""
+        switched to its exact-fp32 kernels, so the stage is simply run again -- the reference's fp32 arithmetic.
+        A sharded stage ends in a collective, so the ranks decide TOGETHER (MAX over ranks) whether to repeat it."""
         out = stage()
         status = getattr(model, "numerics_status", None)
-        if status is not None and status() & ops.STATUS_NONFINITE:
+        flag = int(status() & ops.STATUS_NONFINITE) if status is not None else 0
+        if D.sharding_active(self.shard_hypotheses):
+            flag = D.all_ranks_max(flag, self.device)
+        if flag:
             out = stage()
         return out
 
@@ -214,20 +234,30 @@ class _EstimatorBase:
         return self._guarded(model, lambda: self._run_model_chunks_once(
             model, observation, data_TCO_input, n_iterations, bsz, tag, keep_all_outputs, **kw))
 
+    _ITER_COLS = (("poses", 16, (4, 4)), ("poses_input", 16, (4, 4)), ("K_crop", 9, (3, 3)), ("boxes_rend", 4, (4,)),
+                  ("boxes_crop", 4, (4,)))
+
     def _run_model_chunks_once(self, model, observation, data_TCO_input, n_iterations, bsz, tag,
                                keep_all_outputs=False, **kw) -> Tuple[dict, dict]:
-        """Shared body of forward_refiner / CosyPose forward_coarse_model."""
+        """Shared body of forward_refiner / CosyPose forward_coarse_model.  Rows ``[s, e)`` of the hypothesis table
+        are this rank's (all of them without sharding); they run in chunks of ``bsz``; with sharding the per-iteration
+        outputs of all ranks meet in one all-gather of ``[n_local, 49 * n_iterations]`` rows."""
         t_start = time.time()
         B = len(data_TCO_input)
-        preds = defaultdict(list)
+        s, e, sharded = self._shard(B)
+        # bookkeeping columns of the reference (``MP/inference/pose_estimator.py:196-197``), by GLOBAL row so that they
+        # do not depend on the number of ranks
+        df_all = data_TCO_input.infos.copy()
+        df_all[f"{tag}_batch_idx"] = np.arange(B) // bsz
+        df_all[f"{tag}_instance_idx"] = np.arange(B) % bsz
+        cols: Dict[str, List[List[torch.Tensor]]] = {f"iteration={n}": [[] for _ in self._ITER_COLS]
+                                                     for n in range(1, n_iterations + 1)}
         all_outputs = []
         model_time = 0.0
-        for batch_idx, s in enumerate(range(0, B, bsz)):
-            ids = np.arange(s, min(B, s + bsz))
+        for a in range(s, e, bsz):
+            ids = np.arange(a, min(e, a + bsz))
             chunk = data_TCO_input[ids]
             df_ = chunk.infos
-            df_[f"{tag}_batch_idx"] = batch_idx
-            df_[f"{tag}_instance_idx"] = np.arange(len(df_))
             im_ids = torch.as_tensor(df_["batch_im_id"].values, device=self.device)
             t0 = time.time()
             outputs_ = model(images=observation.images, K=observation.K, TCO=chunk.poses,
@@ -237,12 +267,31 @@ class _EstimatorBase:
                 all_outputs.append(outputs_)
             for n in range(1, n_iterations + 1):
                 o = outputs_[f"iteration={n}"]
-                preds[f"iteration={n}"].append(PandasTensorCollection(
-                    df_, poses=o.TCO_output, poses_input=o.TCO_input, K_crop=o.K_crop, K=o.K,
-                    boxes_rend=o.boxes_rend, boxes_crop=o.boxes_crop))
-        preds = {k: concatenate(v) for k, v in preds.items()}
+                for dst, t in zip(cols[f"iteration={n}"], (o.TCO_output, o.TCO_input, o.K_crop, o.boxes_rend, o.boxes_crop)):
+                    dst.append(t)
+        n_local = e - s
+        f = dict(dtype=torch.float32, device=self.device)
+        table = {k: [torch.cat(parts) if parts else torch.zeros((0,) + shape, **f) for parts, (_, _, shape) in zip(v, self._ITER_COLS)]
+                 for k, v in cols.items()}
+        if sharded:
+            packed = torch.cat([t.reshape(n_local, -1).float() for k in table for t in table[k]], dim=1) if n_iterations else \
+                torch.zeros((n_local, 0), **f)
+            full = D.gather_rows(packed.contiguous(), s, B)
+            c0 = 0
+            for k in table:
+                for i, (_, width, shape) in enumerate(self._ITER_COLS):
+                    table[k][i] = full[:, c0:c0 + width].reshape((B,) + shape)
+                    c0 += width
+        im_all = torch.as_tensor(df_all["batch_im_id"].values, device=self.device).long()
+        K_all = observation.K.to(self.device)[im_all]  # PosePredictorOutput.K: the intrinsics of each hypothesis' frame
+        preds = {}
+        for k, ts in table.items():
+            named = {name: t for (name, _, _), t in zip(self._ITER_COLS, ts)}
+            preds[k] = PandasTensorCollection(df_all, poses=named["poses"], poses_input=named["poses_input"],
+                                              K_crop=named["K_crop"], K=K_all, boxes_rend=named["boxes_rend"],
+                                              boxes_crop=named["boxes_crop"])
         extra_data = {"n_iterations": n_iterations, "outputs": all_outputs, "model_time": model_time,
-                      "time": time.time() - t_start}
+                      "time": time.time() - t_start, "shard": (s, e)}
         return preds, extra_data
 
 
@@ -282,11 +331,14 @@ class PoseEstimator(_EstimatorBase):
         t_start = time.time()
         assert self.coarse_model is not None
         df = data_TCO.infos
+        N = len(df)
+        # debug pixels stay on the rank that made them: a call that wants them is not sharded
+        s, e, sharded = (0, N, False) if return_debug_data else self._shard(N)
         logits_l, scores_l, crops_l, renders_l = [], [], [], []
         render_time = model_time = 0.0
         n_batches = 0
-        for s in range(0, len(df), self.bsz_images):
-            ids = np.arange(s, min(len(df), s + self.bsz_images))
+        for a in range(s, e, self.bsz_images):
+            ids = np.arange(a, min(e, a + self.bsz_images))
             chunk = data_TCO[ids]
             im_ids = torch.as_tensor(chunk.infos["batch_im_id"].values, device=self.device)
             out_ = self.coarse_model.forward_coarse(images=observation.images, K=observation.K,
@@ -301,7 +353,14 @@ class PoseEstimator(_EstimatorBase):
                 crops_l.append(out_["images_crop"])
                 renders_l.append(out_["renders"])
             n_batches += 1
-        logits, scores = torch.cat(logits_l), torch.cat(scores_l)
+        f = dict(dtype=torch.float32, device=self.device)
+        logits = torch.cat(logits_l) if logits_l else torch.zeros((0, 1), **f)
+        scores = torch.cat(scores_l) if scores_l else torch.zeros((0, 1), **f)
+        if sharded:  # one all-gather of [n_local, 2] rows
+            tail = logits.shape[1:]
+            full = D.gather_rows(torch.cat([logits.reshape(e - s, -1), scores.reshape(e - s, -1)], dim=1), s, N)
+            w = full.shape[1] // 2
+            logits, scores = full[:, :w].reshape((N,) + tuple(tail)), full[:, w:].reshape((N,) + tuple(tail))
         debug_data = {"images_crop": torch.cat(crops_l), "renders": torch.cat(renders_l)} if return_debug_data else {}
         df["pose_logit"] = logits.cpu().numpy()
         df["pose_score"] = scores.cpu().numpy()
@@ -341,8 +400,11 @@ class PoseEstimator(_EstimatorBase):
         render_time = model_time = 0.0
         n_batches = 0
         labels_all = df_hyp["label"].tolist()
-        for s in range(0, B * M, self.bsz_images):
-            e = min(B * M, s + self.bsz_images)
+        # the (detection x grid rotation) rows are sharded over the ranks; one all-gather of [n_local, 18] rows
+        # (logit, score, the 16 floats of TCO_init) merges them.  Debug pixels are not gathered: such a call runs whole.
+        s0, e0, sharded = (0, B * M, False) if return_debug_data else self._shard(B * M)
+        for s in range(s0, e0, self.bsz_images):
+            e = min(e0, s + self.bsz_images)
             TCO_init_ = ops.tco_init_autodepth(store, bboxes_all, observation.K, im_all[s:e], obj_all[s:e],
                                                R=self._SO3_grid, box_ids=box_all[s:e], rot_ids=rot_all[s:e])
             out_ = coarse_model.forward_coarse(images=observation.images, K=observation.K, labels=labels_all[s:e],
@@ -357,9 +419,15 @@ class PoseEstimator(_EstimatorBase):
                 crops_l.append(out_["images_crop"])
                 renders_l.append(out_["renders"])
             n_batches += 1
-        logits = torch.cat(logits_l).reshape(B, M)
-        scores = torch.cat(scores_l).reshape(B, M)
-        TCO = torch.cat(TCO_l)
+        f = dict(dtype=torch.float32, device=self.device)
+        n_loc = e0 - s0
+        logits = torch.cat(logits_l).reshape(n_loc) if logits_l else torch.zeros(0, **f)
+        scores = torch.cat(scores_l).reshape(n_loc) if scores_l else torch.zeros(0, **f)
+        TCO = torch.cat(TCO_l) if TCO_l else torch.zeros((0, 4, 4), **f)
+        if sharded:
+            full = D.gather_rows(torch.cat([logits[:, None], scores[:, None], TCO.reshape(n_loc, 16)], dim=1), s0, B * M)
+            logits, scores, TCO = full[:, 0].contiguous(), full[:, 1].contiguous(), full[:, 2:].reshape(B * M, 4, 4)
+        logits, scores = logits.reshape(B, M), scores.reshape(B, M)
         debug_data = {}
         if return_debug_data:
             ic, rd = torch.cat(crops_l), torch.cat(renders_l)

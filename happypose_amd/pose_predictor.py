@@ -108,7 +108,14 @@ class _RenderAndCompare:
         # signature run eagerly / capture, and callers that time single launches want the eager path
         self.use_graphs = False
         self._graphs = None
-        self._graph_epoch = -1
+        self._graph_epoch = None
+
+    def _reserve(self, n_views_per_hypothesis: int):
+        """Pre-size the store's rasteriser scratch for this predictor's largest call (``max_batch`` hypotheses x views):
+        it then never reallocates in normal use, which keeps captured graphs valid and ``hipFree`` out of the loop."""
+        mb = getattr(self.backbone, "max_batch", None)
+        if mb:
+            self.store.reserve_raster(int(mb) * n_views_per_hypothesis, self.render_size, msaa=self.renderer.msaa)
 
     def eval(self):
         return self
@@ -146,12 +153,28 @@ class _RenderAndCompare:
             return fn(*inputs)
         from .graphs import GraphCache
 
-        if self._graphs is None or self._graph_epoch != ops.graph_epoch():
-            self._graphs, self._graph_epoch = GraphCache(self.device), ops.graph_epoch()
-        return self._graphs.run(consts, inputs, fn, keepalive=self._graph_keepalive)
+        # what invalidates captured launches: the process-wide launch-plan epoch and this store's scratch generation (a
+        # larger eager call, or another predictor sharing the store, reallocated the rasteriser scratch the graphs point to)
+        epoch = (ops.graph_epoch(), self.store.scratch_generation())
+        if self._graphs is None or self._graph_epoch != epoch:
+            self._graphs, self._graph_epoch = GraphCache(self.device), epoch
+        # everything else the launch plan depends on is part of the signature: tail K-slicing differs between the
+        # single-lane call (on) and a lane of TwoLanePredictor (off) on the same shapes
+        consts = tuple(consts) + (("tail_split", bool(self.backbone.tail_split)), ("msaa", self.renderer.msaa), ("aniso", self.renderer.aniso))
+        out = self._graphs.run(consts, inputs, fn, keepalive=self._graph_keepalive)
+        if self.store.scratch_generation() != epoch[1]:
+            # the eager first call of a signature larger than the reservation grew the scratch: every graph captured
+            # before holds freed pointers -- start over (this call's result is valid: it ran eagerly)
+            self._graphs = None
+        return out
 
     def _profiling(self) -> bool:
         return bool(self.backbone.profiling)
+
+    @property
+    def max_batch(self) -> int:
+        """Largest hypothesis batch one ``forward`` call takes (the backbone's activation arena)."""
+        return int(self.backbone.max_batch)
 
     def _graph_keepalive(self):
         return [self._x]
@@ -164,7 +187,8 @@ class _RenderAndCompare:
         return self.backbone.status()
 
     def _one_pass(self, images, K, im_ids, obj_ids, TCO_in, *, n_img_channels, multiview_type, normalize,
-                  render_normals, render_depth, depth_mode, want_pose, want_logits, remove_TCO_rendering=False):
+                  render_normals, render_depth, depth_mode, want_pose, want_logits, remove_TCO_rendering=False,
+                  scene_lights=False):
         b = TCO_in.shape[0]
         prep = ops.pose_prep(self.store, TCO_in, K, im_ids, obj_ids, tuple(images.shape[-2:]),
                              self.render_size, multiview_type=multiview_type, normalize=normalize,
@@ -175,8 +199,15 @@ class _RenderAndCompare:
                            depth_norm_z=z, depth_norm_mode=depth_mode if n_img_channels == 4 else 0,
                            n_channels=n_img_channels, owns_record=True)  # the rasteriser writes the rest of the record next
         t0 = time.time()
+        lights = {}
+        if scene_lights:  # the reference's make_scene_lights() per view: ambient 0.1 + six point lights around the object
+            amb, pos, col = self.renderer.scene_light_tables()
+            V = prep["TCV_O"].shape[1]
+            ov = obj_ids.long().repeat_interleave(V)
+            lights = dict(ambient=amb[None].expand(b * V, 3).contiguous(), light_pos=pos[ov].contiguous(),
+                          light_col=col[None].expand(b * V, -1, 3).contiguous())
         ops.rasterize_into(self.store, x, n_img_channels, obj_ids, prep["TCV_O"], prep["K_crop"],
-                           render_normals, render_depth, z, depth_mode, msaa=self.renderer.msaa, aniso=self.renderer.aniso)
+                           render_normals, render_depth, z, depth_mode, msaa=self.renderer.msaa, aniso=self.renderer.aniso, **lights)
         render_time = time.time() - t0
         pose, logits, _ = self.backbone.forward(x, want_pose=want_pose, want_logits=want_logits)
         return prep, x, pose, logits, render_time
@@ -227,6 +258,7 @@ class PosePredictor(_RenderAndCompare):
         self.predict_rendered_views_logits = predict_rendered_views_logits
         self.remove_TCO_rendering = remove_TCO_rendering
         self._n_img = 4 if input_depth else 3
+        self._reserve(n_rendered_views)
         self._n_single_render_channels = 3 + (3 if render_normals else 0) + (1 if render_depth else 0)
         n_inputs = self._n_img + self._n_single_render_channels * n_rendered_views
         assert backbone.n_inputs == n_inputs, (
@@ -264,7 +296,7 @@ class PosePredictor(_RenderAndCompare):
                 multiview_type=self.multiview_type, normalize=True, render_normals=self.render_normals,
                 render_depth=self.render_depth, depth_mode=self._depth_mode,
                 want_pose=self.predict_pose_update, want_logits=self.predict_rendered_views_logits,
-                remove_TCO_rendering=self._skip_tco)
+                remove_TCO_rendering=self._skip_tco, scene_lights=not self.render_normals)
             TCO_norm = prep["TCO"]
             if self.predict_pose_update:
                 TCO_output = ops.pose_update(TCO_norm, prep["K_crop_main"].contiguous() if self._skip_tco else prep["K_crop"], pose,
@@ -316,7 +348,8 @@ class PosePredictor(_RenderAndCompare):
         prep, x, _, logits, render_time = self._one_pass(
             images, K, im_ids, obj_ids, TCO_input.to(self.device, torch.float32), n_img_channels=self._n_img,
             multiview_type="TCO", normalize=True, render_normals=self.render_normals,
-            render_depth=self.render_depth, depth_mode=self._depth_mode, want_pose=False, want_logits=True)
+            render_depth=self.render_depth, depth_mode=self._depth_mode, want_pose=False, want_logits=True,
+            scene_lights=not self.render_normals)
         timer.stop()
         out = {"logits": logits, "scores": torch.sigmoid(logits), "time": timer.elapsed(),
                "render_time": render_time, "model_time": timer.elapsed()}
@@ -338,6 +371,7 @@ class CosyPosePosePredictor(_RenderAndCompare):
             raise ValueError(f"pose_dim={pose_dim} not supported")
         self.pose_dim = pose_dim
         assert backbone.n_inputs == 6 and backbone.pose_dim == 9
+        self._reserve(1)
 
     @torch.no_grad()
     def forward(self, images: torch.Tensor, K: torch.Tensor, labels: Sequence[str], TCO: torch.Tensor,
@@ -483,15 +517,19 @@ class TwoLanePredictor:
         self.backbone = _LaneBackbones([l.backbone for l in lanes])
         self.use_graphs = False  # hipGraph replay of forward() (happypose_amd.graphs)
         self._graphs = None
-        self._graph_epoch = -1
+        self._graph_epoch = None
 
     def __getattr__(self, name):
-        if name in ("lanes", "streams", "backbone", "device", "use_graphs", "_graphs", "_graph_epoch"):  # not set yet: no recursion through lanes[0]
+        if name in ("lanes", "streams", "backbone", "device", "use_graphs", "_graphs", "_graph_epoch", "max_batch"):  # not set yet: no recursion through lanes[0]
             raise AttributeError(name)
         return getattr(self.lanes[0], name)
 
     def eval(self):
         return self
+
+    @property
+    def max_batch(self) -> int:
+        return sum(int(l.backbone.max_batch) for l in self.lanes)
 
     def to(self, device):
         self.lanes[0].to(device)

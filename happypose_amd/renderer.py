@@ -36,11 +36,12 @@ class BatchRenderOutput:
 
 @dataclass
 class Panda3dLightData:
-    """``light_type``: "ambient" | "point".  The reference positions point lights with a
-    ``positioning_function(root_node, light_node)`` that needs a Panda3D scene graph;
-    here a point light carries ``direction`` (unit vector in the object frame) and is
-    placed at ``direction * bounds_radius * radius_factor`` exactly like
-    ``make_scene_lights`` does."""
+    """``TB/renderer/types.py:139-150``.  ``light_type``: "ambient" | "point".  A point light is placed by its
+    ``positioning_function(root_node, light_node)`` exactly as the reference's ``setup_lights`` calls it
+    (``TB/renderer/panda3d_scene_renderer.py:294-318``); there is no Panda3D scene graph here, so the two arguments are
+    duck-typed stand-ins (:class:`SceneRootProxy`: ``getBounds().radius`` = bounding-sphere radius of the object;
+    :class:`LightNodeProxy`: records ``setPos``).  ``direction`` / ``radius_factor`` are this repository's shorthand for
+    the same placement (``direction * bounds_radius * radius_factor``) and are used when no function is given."""
 
     light_type: str
     color: RgbaColor = (1.0, 1.0, 1.0, 1.0)
@@ -49,12 +50,83 @@ class Panda3dLightData:
     radius_factor: float = 10.0
 
 
+class _Bounds:
+    """What positioning functions read from ``root_node.getBounds()``: a bounding sphere."""
+
+    def __init__(self, center, radius: float):
+        self.center, self.radius = tuple(float(c) for c in center), float(radius)
+
+    def getRadius(self) -> float:
+        return self.radius
+
+    get_radius = getRadius
+
+    def getCenter(self):
+        return self.center
+
+    get_center = getCenter
+
+
+class SceneRootProxy:
+    """Stand-in for the Panda3D root ``NodePath`` of a one-object scene (``render_scene``: the object sits at the world
+    origin, ``TB/renderer/panda3d_batch_renderer.py:172``)."""
+
+    def __init__(self, center, radius: float):
+        self._bounds = _Bounds(center, radius)
+
+    def getBounds(self) -> _Bounds:
+        return self._bounds
+
+    get_bounds = getBounds
+
+    def getTightBounds(self):
+        c, r = np.asarray(self._bounds.center), self._bounds.radius
+        return tuple(c - r), tuple(c + r)
+
+    get_tight_bounds = getTightBounds
+
+
+class LightNodeProxy:
+    """Stand-in for the light's ``NodePath``: records the position a positioning function sets (world = object frame)."""
+
+    def __init__(self):
+        self.pos = (0.0, 0.0, 0.0)
+
+    def setPos(self, *args) -> None:
+        if len(args) == 1:  # a tuple / Vec3 / LPoint3-like
+            v = args[0]
+            args = tuple(v) if not hasattr(v, "x") else (v.x, v.y, v.z)
+        if len(args) == 4:  # setPos(other_node, x, y, z): relative to the root, which sits at the origin
+            args = args[1:]
+        assert len(args) == 3, "setPos(x, y, z) or setPos((x, y, z))"
+        self.pos = tuple(float(a) for a in args)
+
+    set_pos = setPos
+
+    def getPos(self):
+        return self.pos
+
+    get_pos = getPos
+
+    def __getattr__(self, name):  # anything else a positioning function may try (lookAt, setHpr ...) needs a scene graph
+        raise NotImplementedError(f"light positioning functions may call setPos / getBounds only (got NodePath.{name})")
+
+
+def _axis_light_position(root_node, light_node, pos: np.ndarray) -> None:
+    """``pos_fn`` of the reference's ``make_scene_lights`` (``TB/renderer/panda3d_scene_renderer.py:121-129``)."""
+    radius = root_node.getBounds().radius
+    light_node.setPos(tuple((np.asarray(pos) * radius * 10).tolist()))
+
+
 def make_scene_lights(ambient_light_color: RgbaColor = (0.1, 0.1, 0.1, 1.0),
                       point_lights_color: RgbaColor = (0.4, 0.4, 0.4, 1.0)) -> List[Panda3dLightData]:
-    """1 ambient + 6 point lights on the +/- axes at 10 bounding radii."""
+    """1 ambient + 6 point lights on the +/- axes at 10 bounding radii, each carrying a ``positioning_function`` like
+    the reference's (``TB/renderer/panda3d_scene_renderer.py:105-141``)."""
+    from functools import partial
+
     lights = [Panda3dLightData("ambient", ambient_light_color)]
     for d in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
-        lights.append(Panda3dLightData("point", point_lights_color, direction=d))
+        lights.append(Panda3dLightData("point", point_lights_color, positioning_function=partial(_axis_light_position, pos=np.array(d))))
     return lights
 
 
@@ -79,6 +151,21 @@ class BatchRenderer:
         self.device = self.store.device
         self._is_closed = False
 
+    def scene_light_tables(self):
+        """``make_scene_lights()`` evaluated once per object of the store: ``(ambient [3], pos [n_obj, 6, 3], col [6, 3])``
+        on the device.  The predictors index ``pos`` with the object ids of a batch (MegaPose without the normals
+        channel lights every view with these, ``MP/models/pose_rigid.py:422``)."""
+        if getattr(self, "_scene_lights", None) is None:
+            n_obj = len(self.store.labels)
+            amb, pos, col = self._lights(list(self.store.labels), [make_scene_lights() for _ in range(n_obj)], n_obj)
+            self._scene_lights = (amb[0].contiguous(), pos.contiguous(), col[0].contiguous())
+        return self._scene_lights
+
+    def clone_for_lane(self) -> "BatchRenderer":
+        """A renderer with the SAME render state on a mesh store of its own (the second lane of a
+        ``TwoLanePredictor`` writes its own rasteriser scratch)."""
+        return BatchRenderer(self._object_dataset, device=self.device, msaa=self.msaa, aniso=self.aniso)
+
     def _lights(self, labels, light_datas, n):
         if light_datas is None:
             return None, None, None
@@ -87,17 +174,22 @@ class BatchRenderer:
         n_pts = max(sum(1 for l in ls if l.light_type == "point") for ls in light_datas) if n else 0
         pos = np.zeros((n, n_pts, 3), np.float32) if n_pts else None
         col = np.zeros((n, n_pts, 3), np.float32) if n_pts else None
-        radius = self.store.packed.radius
+        packed = self.store.packed
         for i, ls in enumerate(light_datas):
             k = 0
+            oid = self.store.label_to_id[labels[i]]
             for l in ls:
                 if l.light_type == "ambient":
                     amb[i] += np.asarray(l.color[:3], np.float32)
                 elif l.light_type == "point":
-                    if l.direction is None:
-                        raise NotImplementedError("point lights need `direction` (no Panda3D scene graph here)")
-                    r = radius[self.store.label_to_id[labels[i]]]
-                    pos[i, k] = np.asarray(l.direction, np.float32) * r * l.radius_factor
+                    if l.positioning_function is not None:  # the reference's way (setup_lights): call it on the scene
+                        node = LightNodeProxy()
+                        l.positioning_function(SceneRootProxy(packed.bounds_center[oid], packed.bounds_radius[oid]), node)
+                        pos[i, k] = np.asarray(node.pos, np.float32)
+                    elif l.direction is not None:
+                        pos[i, k] = np.asarray(l.direction, np.float32) * packed.bounds_radius[oid] * l.radius_factor
+                    else:
+                        raise AssertionError("a point light needs a positioning_function")  # setup_lights asserts it (:303)
                     col[i, k] = np.asarray(l.color[:3], np.float32)
                     k += 1
                 else:

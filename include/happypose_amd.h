@@ -62,6 +62,14 @@ hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float* h_normals
 void hp_mesh_store_destroy(hp_mesh_store* store);
 /* device pointer of the [n_obj][n_pad][3] point table (NULL if not uploaded) */
 const float* hp_mesh_store_points(const hp_mesh_store* store);
+/* The rasteriser keeps per-(view, band) triangle lists and per-(view, vertex) records in scratch memory owned by the
+ * store; it grows on demand (never under stream capture: hp_rasterize then fails with HP_ERR_ARG).  Reserve it for the
+ * largest call -- n_views views of h x w, flags: HP_RASTER_MSAA4 if multisampled renders will be asked for -- so that no
+ * later call reallocates it (the reference's worker pool pre-loads its scene the same way,
+ * TB/renderer/panda3d_batch_renderer.py:129-142).  hp_mesh_store_scratch_generation counts the reallocations: a holder
+ * of captured hipGraphs that launch hp_rasterize compares it before every replay. */
+int hp_mesh_store_reserve_raster(hp_mesh_store* store, int n_views, int h, int w, int flags);
+int64_t hp_mesh_store_scratch_generation(const hp_mesh_store* store);
 
 /* ------------------------------------------------------------------------------------
  * Rasteriser.  Replaces Panda3dBatchRenderer.render(labels, TCO, K, light_datas,

@@ -245,6 +245,8 @@ def net_forward(x: torch.Tensor, sd, arch: str, heads=("pose",)) -> Dict[str, to
         f = wide_resnet_forward(x, sd, 34 if arch == "resnet34" else 18, "backbone.")
         f = f.flatten(2).mean(dim=-1)
     out = {}
+    if "features" in heads:  # the pooled backbone features the heads read (feature-level parity tests)
+        out["features"] = f
     if "pose" in heads:
         out["pose"] = F.linear(f, _t(sd, "pose_fc.weight"), _t(sd, "pose_fc.bias"))
     if "renderings_logits" in heads:

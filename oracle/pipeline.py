@@ -71,8 +71,19 @@ class OraclePredictor:
             KV[:, 0] = K_crop
         for v in range(1 if not skip else 0, V):  # compute_crops_multiview: 200 points, boxes only
             _, _, KV[:, v] = self._crop_inputs(images, Kb, TCV_O[:, v], TCV_O[:, v, :3, 3], obj_ids, im_ids, 200)
+        lights = {}
+        if not c["cosypose"] and not c["render_normals"]:
+            # MP/models/pose_rigid.py:415-422: without the normals channel the scene is lit by make_scene_lights()
+            # (TB/renderer/panda3d_scene_renderer.py:105-141): ambient 0.1 + six point lights of colour 0.4 on the +/- axes at
+            # 10 radii of root_node.getBounds() (the object's bounding sphere); CosyPose and render_normals use ambient 1
+            ov = np.repeat(obj_ids, V)
+            dirs = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float64)
+            rad = np.asarray(self.meshes.bounds_radius, np.float64)[ov]
+            lights = dict(ambient=np.full((len(ov), 3), 0.1, np.float32),
+                          light_pos=(dirs[None] * rad[:, None, None] * 10).astype(np.float32),
+                          light_col=np.full((len(ov), 6, 3), 0.4, np.float32))
         r = native.rasterize(self.meshes, np.repeat(obj_ids, V), TCV_O.reshape(-1, 4, 4), KV.reshape(-1, 3, 3),
-                             self.render_size, c["render_normals"], c["render_depth"], msaa=c["msaa"], aniso=c["aniso"])
+                             self.render_size, c["render_normals"], c["render_depth"], msaa=c["msaa"], aniso=c["aniso"], **lights)
         parts = [r["rgbs"]]
         if c["render_normals"]:
             parts.append(r["normals"])

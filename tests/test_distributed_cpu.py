@@ -73,6 +73,118 @@ WORKER = textwrap.dedent("""
 """)
 
 
+ESTIMATOR_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch, pandas as pd
+    sys.path.insert(0, os.environ["HP_ROOT"])
+    from types import SimpleNamespace
+    from happypose_amd import distributed as D, ops
+    from happypose_amd.pose_estimator import CosyPoseEstimator, ObservationTensor, PoseEstimator
+    from happypose_amd.tensor_collection import PandasTensorCollection
+
+    rank, local_rank, world = D.init_distributed("gloo")
+    n_det, n_hyp = int(os.environ["HP_N"]), 3
+    rs = np.random.RandomState(0)
+    LABELS = [f"obj{i}" for i in range(4)]
+
+    class FakeStore:
+        labels = LABELS
+        def ids_of(self, labels):
+            return torch.as_tensor([LABELS.index(l) for l in labels], dtype=torch.int32)
+
+    class FakeModel:
+        # a deterministic stand-in predictor: every output row depends only on its own input row
+        device = torch.device("cpu")
+        mesh_db = None
+        cfg = SimpleNamespace(init_method="v0")
+        store = FakeStore()
+        calls = 0
+        def _obj(self, labels):
+            return torch.as_tensor([float(LABELS.index(l)) for l in labels])
+        def __call__(self, images, K, TCO, n_iterations, labels, im_ids):
+            FakeModel.calls += 1
+            out, T = {}, TCO.clone().float()
+            fr = images[im_ids.long()].mean(dim=(1, 2, 3))
+            for n in range(1, n_iterations + 1):
+                Tn = T * 0.5 + fr[:, None, None] + self._obj(labels)[:, None, None] * 0.1
+                out[f"iteration={n}"] = SimpleNamespace(TCO_output=Tn, TCO_input=T, K_crop=K[im_ids.long()] * (1 + n),
+                                                        boxes_rend=Tn[:, 0, :4] * 2, boxes_crop=Tn[:, 1, :4] * 3)
+                T = Tn
+            return out
+        def forward_coarse(self, images, K, labels, TCO_input, cuda_timer=False, return_debug_data=False, im_ids=None):
+            logit = (TCO_input[:, :3, :3].reshape(len(labels), -1) * torch.arange(9.0)).sum(1, keepdim=True) + self._obj(labels)[:, None]
+            return {"logits": logit, "scores": torch.sigmoid(logit), "render_time": 0.0, "model_time": 0.0, "time": 0.0}
+        def numerics_status(self):
+            return 0
+
+    def fake_init(store, boxes, K, im_ids, obj_ids, R=None, box_ids=None, rot_ids=None, n_points=None):
+        n = len(obj_ids)
+        T = torch.eye(4).repeat(n, 1, 1)
+        T[:, :3, :3] = R[rot_ids.long()]
+        T[:, :2, 3] = boxes[box_ids.long()][:, :2] * 1e-3
+        T[:, 2, 3] = 0.5 + 0.01 * obj_ids.float()
+        return T
+    ops.tco_init_autodepth = fake_init
+
+    images = torch.as_tensor(rs.uniform(size=(2, 3, 6, 8)).astype(np.float32))
+    Kc = torch.as_tensor(rs.uniform(1, 2, size=(2, 3, 3)).astype(np.float32))
+    obs = ObservationTensor(images, Kc)
+
+    def same(a, b):
+        assert list(a.infos.columns) == list(b.infos.columns), (list(a.infos.columns), list(b.infos.columns))
+        pd.testing.assert_frame_equal(a.infos, b.infos)
+        assert sorted(a.tensors) == sorted(b.tensors)
+        for k in a.tensors:
+            assert torch.equal(a.tensors[k], b.tensors[k]), k
+
+    # CosyPose: externally generated hypotheses -> refiner (the C2 / C4 shape)
+    N = n_det * n_hyp
+    hyp = lambda: PandasTensorCollection(pd.DataFrame({"label": [LABELS[i % 4] for i in range(N)], "batch_im_id": np.arange(N) % 2,
+                                                       "instance_id": np.arange(N) // n_hyp}),
+                                         poses=torch.as_tensor(rs.normal(size=(N, 4, 4)).astype(np.float32)))
+    rs = np.random.RandomState(1); h1 = hyp(); rs = np.random.RandomState(1); h2 = hyp()
+    est = CosyPoseEstimator(refiner_model=FakeModel(), coarse_model=FakeModel(), bsz_objects=4)
+    assert est.shard_hypotheses is None and D.sharding_active(None)
+    FakeModel.calls = 0
+    f_sh, e_sh = est.run_inference_pipeline(obs, data_TCO_init=h1, n_coarse_iterations=0, n_refiner_iterations=3)
+    calls_sharded = FakeModel.calls
+    est.shard_hypotheses = False
+    FakeModel.calls = 0
+    f_1, e_1 = est.run_inference_pipeline(obs, data_TCO_init=h2, n_coarse_iterations=0, n_refiner_iterations=3)
+    assert calls_sharded < FakeModel.calls or N <= 4, (calls_sharded, FakeModel.calls)   # each rank ran only its shard
+    same(f_sh, f_1)
+    for k in e_1["refiner_all_hypotheses"]["preds"]:
+        same(e_sh["refiner_all_hypotheses"]["preds"][k], e_1["refiner_all_hypotheses"]["preds"][k])
+    s, e = D.shard_range(N)
+    assert e_sh["refiner"]["data"]["shard"] == (s, e) and e_1["refiner"]["data"]["shard"] == (0, N)
+
+    # MegaPose: detections -> coarse grid (sharded over detection x rotation rows) -> top-K -> refiner -> scoring -> top-1
+    det = lambda: PandasTensorCollection(pd.DataFrame({"label": [LABELS[i % 4] for i in range(n_det)], "batch_im_id": np.arange(n_det) % 2,
+                                                       "instance_id": np.arange(n_det)}),
+                                         bboxes=torch.as_tensor(rs.uniform(10, 200, size=(n_det, 4)).astype(np.float32)))
+    rs = np.random.RandomState(2); d1 = det(); rs = np.random.RandomState(2); d2 = det()
+    mp = PoseEstimator(refiner_model=FakeModel(), coarse_model=FakeModel(), bsz_objects=4, bsz_images=16, SO3_grid_size=72)
+    g_sh, x_sh = mp.run_inference_pipeline(obs, detections=d1, n_refiner_iterations=2, n_pose_hypotheses=2)
+    mp.shard_hypotheses = False
+    g_1, x_1 = mp.run_inference_pipeline(obs, detections=d2, n_refiner_iterations=2, n_pose_hypotheses=2)
+    same(g_sh, g_1)
+    same(x_sh["coarse"]["preds"], x_1["coarse"]["preds"])
+    same(x_sh["coarse_filter"]["preds"], x_1["coarse_filter"]["preds"])
+    same(x_sh["scoring"]["preds"], x_1["scoring"]["preds"])
+    assert torch.equal(x_sh["coarse"]["data"]["logits"], x_1["coarse"]["data"]["logits"])
+    assert torch.equal(x_sh["coarse"]["data"]["TCO"], x_1["coarse"]["data"]["TCO"])
+    # every rank holds the same final table: compare a checksum across ranks
+    chk = torch.tensor([float(g_sh.poses.double().sum()), float(f_sh.poses.double().sum())], dtype=torch.float64)
+    lo, hi = chk.clone(), chk.clone()
+    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    assert torch.equal(lo, hi)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    print(f"rank {rank} ok")
+""")
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -100,6 +212,32 @@ def test_shard_and_all_gather_gloo(tmp_path, world, n_total):
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in out, out[-2000:]
+
+
+@pytest.mark.parametrize("world,n_det", [(2, 5), (3, 4), (2, 1)])
+def test_estimators_shard_behind_the_entry_point_gloo(tmp_path, world, n_det):
+    """``run_inference_pipeline`` with torch.distributed initialised: every rank computes its shard of the hypothesis
+    rows (refiner, coarse grid, scoring) and the merged result equals the unsharded run bit for bit, infos included --
+    the estimator's bookkeeping driven by stand-in predictors (the real ones need the GPU: tests/test_gpu_pipeline.py)."""
+    script = tmp_path / "worker_est.py"
+    script.write_text(ESTIMATOR_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HP_ROOT=str(ROOT), HP_N=str(n_det), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in out, out[-3000:]
 
 
 def test_single_process_is_identity():

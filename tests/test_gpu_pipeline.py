@@ -1,10 +1,15 @@
 """End-to-end parity of the refinement path (predictors + run_inference_pipeline) against
 the CPU oracle loop on the same seeded inputs.  Needs a real MI355X: ``pytest -m gpu``.
 
-Stated tolerance on poses after n iterations: fp32 path,
-translation error <= 1e-4 m and rotation geodesic <= 1e-3 rad.  The residual comes from
-fp32 summation order in the conv stack and from the <= 0.05 % silhouette pixels whose
-coverage may differ between the HIP rasteriser and the C oracle.
+Stated tolerance on poses after n iterations (SURVEY.md section 8d proposed 1e-4 m / 1e-3 rad; tightened in round 3 to
+what the path measures, x5): fp32 path, translation error <= 2e-5 m and rotation geodesic <= 1e-4 rad at every
+iteration, with the synthetic pose head at ``update_scale = 0.002`` (a relative feature error eps reaches the pose as
+~eps x 3e-3 rad).  The residual comes from fp32 summation order in the conv stack and from the <= 0.05 % silhouette
+pixels whose coverage may differ between the HIP rasteriser and the C oracle.  The HIGH-GAIN cases (``update_scale =
+0.05``: every iteration moves a pose by ~0.1 rad, 1000x the tolerance of the low-gain cases) carry ``T_TOL_HI`` /
+``R_TOL_HI``: there the legitimate residual is amplified 25x per iteration and fed back through the renders.  A 1 %
+error injected into one conv layer's weights fails every one of these checks (``tools/parity_sharpness.py`` measures
+both sides; numbers in DESIGN.md section 2).
 """
 
 import numpy as np
@@ -13,7 +18,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-T_TOL, R_TOL = 1e-4, 1e-3
+T_TOL, R_TOL = 2e-5, 1e-4
+T_TOL_HI, R_TOL_HI = 5e-4, 2.5e-3  # update_scale = 0.05 cases
+FEAT_TOL = 2e-4  # backbone features vs the CPU restatement, relative to max|ref| of the sample
 
 
 def _pose_err(A, B):
@@ -74,8 +81,8 @@ def test_cosypose_refiner_vs_oracle(dev, world):
         o = out[f"iteration={n + 1}"]
         dt, dr = _pose_err(o.TCO_output.cpu().numpy(), ref[n]["TCO_output"])
         assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
-        np.testing.assert_allclose(o.boxes_crop.cpu().numpy(), ref[n]["boxes_crop"], rtol=1e-4, atol=5e-2)
-        np.testing.assert_allclose(o.K_crop.cpu().numpy(), ref[n]["K_crop"], rtol=1e-4, atol=5e-2)
+        np.testing.assert_allclose(o.boxes_crop.cpu().numpy(), ref[n]["boxes_crop"], rtol=1e-5, atol=5e-3)
+        np.testing.assert_allclose(o.K_crop.cpu().numpy(), ref[n]["K_crop"], rtol=1e-5, atol=5e-3)
         assert o.TCO_input.shape == (B, 4, 4) and o.K.shape == (B, 3, 3)
     # the update is not a no-op
     assert _pose_err(out["iteration=3"].TCO_output.cpu().numpy(), sc["TCO_hyp"])[1] > 1e-3
@@ -423,7 +430,7 @@ def test_c2_full_size_two_lanes_vs_oracle(dev):
 
 def test_c3_full_size_vs_oracle(dev):
     """C3 as benchmarked: MegaPose RGB-D refiner, 64 hypotheses x 4 views x (rgb + normals + depth), ResNet-34 on 32
-    channels, two lanes; 2 iterations against the oracle (the 7x7 / 32-channel stem, 256 renders per iteration)."""
+    channels, two lanes; all 5 iterations against the oracle (the 7x7 / 32-channel stem, 256 renders per iteration)."""
     from oracle.pipeline import OraclePredictor
 
     bench = _bench()
@@ -433,17 +440,18 @@ def test_c3_full_size_vs_oracle(dev):
     assert B == 64
     images, K = torch.as_tensor(scene["images"], device=dev), torch.as_tensor(scene["K"], device=dev)
     labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
-    out = model.forward(images, K, labels, torch.as_tensor(scene["TCO_hyp"], device=dev), n_iterations=2,
+    out = model.forward(images, K, labels, torch.as_tensor(scene["TCO_hyp"], device=dev), n_iterations=5,
                         im_ids=torch.zeros(B, dtype=torch.int32, device=dev))
     assert model.numerics_status() == 0
     torch.set_num_threads(bench.effective_cpu_count())
     ora = OraclePredictor(weights, store.packed, store.mesh_db.points, arch="vanilla_resnet34", n_views=4,
                           multiview_type="TCO+front_3views", render_normals=True, render_depth=True, input_depth=True,
                           depth_normalization_type="tCR_scale_clamp_center")
-    ref = ora.forward(scene["images"], scene["K"], np.zeros(B, np.int32), scene["hyp_obj_ids"], scene["TCO_hyp"], 2, bsz_objects=8)
-    for n in range(2):
-        dt, dr = _pose_err(out[f"iteration={n + 1}"].TCO_output.cpu().numpy(), ref[n]["TCO_output"])
-        assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
+    ref = ora.forward(scene["images"], scene["K"], np.zeros(B, np.int32), scene["hyp_obj_ids"], scene["TCO_hyp"], 5, bsz_objects=8)
+    errs = []
+    for n in range(5):
+        errs.append(_pose_err(out[f"iteration={n + 1}"].TCO_output.cpu().numpy(), ref[n]["TCO_output"]))
+        assert errs[-1][0] <= T_TOL and errs[-1][1] <= R_TOL, (n, errs)
 
 
 C5_LOGIT_TOL = 2e-2  # fp16 weights / activations (fp32 accumulation) vs the fp32 oracle, on logits of O(1..5)
@@ -618,9 +626,9 @@ def test_refiners_vs_reference_golden_g10(dev, golden_dir):
             o = out[f"iteration={n}"]
             dt, dr = _pose_err(o.TCO_output.cpu().numpy(), g[f"{tag}/it{n}/TCO_output"])
             assert dt <= T_TOL and dr <= R_TOL, (tag, n, dt, dr)
-            np.testing.assert_allclose(o.boxes_crop.cpu().numpy(), g[f"{tag}/it{n}/boxes_crop"], rtol=1e-4, atol=5e-2)
-            np.testing.assert_allclose(o.K_crop.cpu().numpy(), g[f"{tag}/it{n}/K_crop"], rtol=1e-4, atol=5e-2)
-            np.testing.assert_allclose(o.boxes_rend.cpu().numpy(), g[f"{tag}/it{n}/boxes_rend"], rtol=1e-4, atol=5e-2)
+            np.testing.assert_allclose(o.boxes_crop.cpu().numpy(), g[f"{tag}/it{n}/boxes_crop"], rtol=1e-5, atol=5e-3)
+            np.testing.assert_allclose(o.K_crop.cpu().numpy(), g[f"{tag}/it{n}/K_crop"], rtol=1e-5, atol=5e-3)
+            np.testing.assert_allclose(o.boxes_rend.cpu().numpy(), g[f"{tag}/it{n}/boxes_rend"], rtol=1e-5, atol=5e-3)
 
     sel = g["cosy/sel"]
     lab = [labels_all[i] for i in sc["hyp_obj_ids"][sel]]
@@ -638,7 +646,7 @@ def test_refiners_vs_reference_golden_g10(dev, golden_dir):
                            max_batch=4)
     out4 = m4.forward(images, K, lab4, torch.as_tensor(sc["TCO_hyp"][sel4]), n_iterations=2, im_ids=torch.zeros(3, dtype=torch.int32))
     check("mp_rgbd4", out4, 2)
-    np.testing.assert_allclose(out4["iteration=1"].KV_crop.cpu().numpy(), g["mp_rgbd4/it1/KV_crop"], rtol=1e-4, atol=5e-2)
+    np.testing.assert_allclose(out4["iteration=1"].KV_crop.cpu().numpy(), g["mp_rgbd4/it1/KV_crop"], rtol=1e-5, atol=5e-3)
     np.testing.assert_allclose(out4["iteration=1"].TCV_O_input.cpu().numpy(), g["mp_rgbd4/it1/TCV_O_input"], rtol=0, atol=2e-5)
 
 
@@ -832,7 +840,7 @@ def test_refiners_on_other_frame_sizes_vs_oracle(dev, world, H, W, flavour):
         o = out[f"iteration={n + 1}"]
         dt, dr = _pose_err(o.TCO_output.cpu().numpy(), ref[n]["TCO_output"])
         assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
-        np.testing.assert_allclose(o.boxes_crop.cpu().numpy(), ref[n]["boxes_crop"], rtol=1e-4, atol=5e-2)
+        np.testing.assert_allclose(o.boxes_crop.cpu().numpy(), ref[n]["boxes_crop"], rtol=1e-5, atol=5e-3)
 
 
 def test_megapose_refiner_remove_tco_rendering_vs_oracle(dev, world):
@@ -861,7 +869,7 @@ def test_megapose_refiner_remove_tco_rendering_vs_oracle(dev, world):
         dt, dr = _pose_err(o.TCO_output.cpu().numpy(), ref[n]["TCO_output"])
         assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
         assert o.KV_crop.shape == (len(sel), 3, 3, 3) and o.TCV_O_input.shape == (len(sel), 3, 4, 4)
-        np.testing.assert_allclose(o.K_crop.cpu().numpy(), ref[n]["K_crop"], rtol=1e-4, atol=5e-2)
+        np.testing.assert_allclose(o.K_crop.cpu().numpy(), ref[n]["K_crop"], rtol=1e-5, atol=5e-3)
     # the first rendered view is the re-aimed camera, not the TCO view
     assert not torch.allclose(out["iteration=1"].TCV_O_input[:, 0], out["iteration=1"].TCO_input, atol=1e-4)
 
@@ -904,3 +912,349 @@ def test_refiner_with_reference_render_state_vs_oracle(dev, world):
     dep_idx = [v * 7 + 6 for v in range(4)]
     assert (r_on[:, rgb_idx] != r_off[:, rgb_idx]).float().mean() > 0.01
     assert torch.equal(r_on[:, dep_idx], r_off[:, dep_idx])  # depth stays centre-sampled
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Sharp parity: high-gain heads at the benchmarked sizes, features at batch 128 on two lanes,
+# and the proof that the checks would see a 1 % error in one layer.
+# ---------------------------------------------------------------------------------------------------------------
+def _oracle_for(workload, weights, store):
+    from oracle.pipeline import OraclePredictor
+
+    if workload == "C2":
+        return OraclePredictor(weights, store.packed, store.mesh_db.points, arch="resnet34", cosypose=True), 3
+    return OraclePredictor(weights, store.packed, store.mesh_db.points, arch="vanilla_resnet34", n_views=4,
+                           multiview_type="TCO+front_3views", render_normals=True, render_depth=True, input_depth=True,
+                           depth_normalization_type="tCR_scale_clamp_center"), 4
+
+
+@pytest.mark.parametrize("workload", ["C2", "C3"])
+def test_full_size_high_gain_head_vs_oracle(dev, workload):
+    """The benchmarked worlds with the pose head at ``update_scale = 0.05``: every iteration rotates a hypothesis by
+    ~0.1 rad and moves it by centimetres -- >= 100x T_TOL_HI / R_TOL_HI -- so a relative error of 1 % anywhere in the
+    features shows up in the pose.  5 iterations, two lanes, against the CPU oracle in the reference's chunks of 8."""
+    bench = _bench()
+    ds, renderer, scene, weights, model = bench.build_world(dev, "resnet34", seed=0, workload=workload, n_lanes=2, update_scale=0.05)
+    store = renderer.store
+    B = len(scene["TCO_hyp"])
+    images, K = torch.as_tensor(scene["images"], device=dev), torch.as_tensor(scene["K"], device=dev)
+    labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
+    out = model.forward(images, K, labels, torch.as_tensor(scene["TCO_hyp"], device=dev), n_iterations=5,
+                        im_ids=torch.zeros(B, dtype=torch.int32, device=dev))
+    assert model.numerics_status() == 0
+    torch.set_num_threads(bench.effective_cpu_count())
+    ora, n_ch = _oracle_for(workload, weights, store)
+    ref = ora.forward(scene["images"][:, :n_ch], scene["K"], np.zeros(B, np.int32), scene["hyp_obj_ids"], scene["TCO_hyp"], 5, bsz_objects=8)
+    errs, prev = [], scene["TCO_hyp"]
+    for n in range(5):
+        got = out[f"iteration={n + 1}"].TCO_output.cpu().numpy()
+        errs.append(_pose_err(got, ref[n]["TCO_output"]))
+        assert errs[-1][0] <= T_TOL_HI and errs[-1][1] <= R_TOL_HI, (n, errs)
+        # the update of THIS iteration is >= 20x the tolerance for the typical hypothesis (median over the batch)
+        A, Bm = np.asarray(got, np.float64), np.asarray(prev, np.float64)
+        chord = np.linalg.norm(A[:, :3, :3] - Bm[:, :3, :3], axis=(1, 2))
+        assert np.median(2 * np.arcsin(np.clip(chord / (2 * np.sqrt(2)), 0, 1))) > 20 * R_TOL_HI, n
+        prev = got
+
+
+def _lane_features(model, x):
+    """Backbone features of a batch through BOTH lanes of a TwoLanePredictor exactly as ``forward`` runs them: the two
+    halves on the two streams, concurrently, tail K-slicing off (the planner paths of half-CU slicing)."""
+    h = x.shape[0] // 2
+    cur = torch.cuda.current_stream(x.device)
+    feats = []
+    model.backbone.set_tail_split(False)
+    try:
+        for lane, stream, sl in zip(model.lanes, model.streams, (slice(0, h), slice(h, x.shape[0]))):
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                feats.append(lane.backbone.forward(x[sl].contiguous(), want_pose=False, want_features=True)[2])
+    finally:
+        model.backbone.set_tail_split(True)
+    for stream in model.streams:
+        cur.wait_stream(stream)
+    return torch.cat(feats)
+
+
+@pytest.mark.parametrize("workload", ["C2", "C3"])
+def test_backbone_features_at_benchmark_batch_two_lanes(dev, workload):
+    """Feature-level parity at the BENCHMARKED batch (C2: 128 x 6 ch WideResNet-34; C3: 64 x 32 ch ResNet-34), two lanes
+    running concurrently: the 512 pooled features of every sample against ``oracle/backbones.py`` on the very same
+    network input, FEAT_TOL x max|ref| PER SAMPLE.  No renders, no pose head in between: this is the check a wrong tile,
+    a dropped K slice or a 1 % weight error cannot pass (the second half of the test injects exactly that)."""
+    from oracle import backbones as ob
+
+    bench = _bench()
+    ds, renderer, scene, weights, model = bench.build_world(dev, "resnet34", seed=0, workload=workload, n_lanes=2)
+    store = renderer.store
+    B = len(scene["TCO_hyp"])
+    images, K = torch.as_tensor(scene["images"], device=dev), torch.as_tensor(scene["K"], device=dev)
+    labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
+    # the network input of iteration 1, assembled by the product's crop + rasteriser (one lane, eager)
+    lane = model.lanes[0]
+    im_ids, obj_ids = lane._ids(images, K, labels, torch.zeros(B, dtype=torch.int32, device=dev))
+    xs = []
+    for s0 in range(0, B, B // 2):  # a lane's network holds half the batch
+        sl = slice(s0, s0 + B // 2)
+        kw = dict(n_img_channels=3, multiview_type="TCO", normalize=False, render_normals=False, render_depth=False, depth_mode=0,
+                  want_pose=True, want_logits=False) if workload == "C2" else \
+            dict(n_img_channels=lane._n_img, multiview_type=lane.multiview_type, normalize=True, render_normals=lane.render_normals,
+                 render_depth=lane.render_depth, depth_mode=lane._depth_mode, want_pose=True, want_logits=False)
+        _, x, _, _, _ = lane._one_pass(images, K, im_ids[sl], obj_ids[sl], torch.as_tensor(scene["TCO_hyp"][sl], device=dev), **kw)
+        xs.append(x.clone())
+    x = torch.cat(xs)
+    n_in = lane.backbone.n_inputs
+    feats = _lane_features(model, x).cpu().numpy()
+    assert model.numerics_status() == 0
+    torch.set_num_threads(bench.effective_cpu_count())
+    arch = "resnet34" if workload == "C2" else "vanilla_resnet34"
+    x_nchw = x[..., :n_in].permute(0, 3, 1, 2).contiguous().cpu()
+    with torch.no_grad():
+        ref = torch.cat([ob.net_forward(x_nchw[i:i + 16], {k: torch.as_tensor(np.asarray(v)) for k, v in weights.items()}, arch,
+                                        heads=("features",))["features"] for i in range(0, B, 16)]).numpy()
+    assert feats.shape == ref.shape == (B, 512)
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    err = np.abs(feats - ref) / scale
+    assert err.max() <= FEAT_TOL, (err.max(), int(err.max(axis=1).argmax()))
+    # an injected 1 % error in ONE layer's weights is far outside that bound
+    from happypose_amd import ops
+
+    w_bad = dict(weights)
+    w_bad["backbone.layer2.1.conv1.weight"] = (np.asarray(weights["backbone.layer2.1.conv1.weight"]) * 1.01).astype(np.float32)
+    bad = ops.Net(arch, n_in, w_bad, max_batch=16, device=dev)
+    f_bad = bad.forward(x[:16].contiguous(), want_pose=False, want_features=True)[2].cpu().numpy()
+    err_bad = (np.abs(f_bad - ref[:16]) / scale[:16]).max()
+    assert err_bad > 10 * FEAT_TOL, err_bad
+
+
+def test_c4_refine_sharded_1024_hypotheses(dev):
+    """C4 on the HIP path: ``distributed.refine_sharded`` with the real two-lane CosyPose predictor at world = 1 on a
+    1024-hypothesis batch (64 detections x 16 hypotheses on one frame: 8 chunks of 128, the per-GPU share of the
+    8-GPU configuration).  Poses must equal eight direct ``forward`` calls bit for bit and agree with the CPU oracle
+    on a 128-hypothesis subset (16 rows of every chunk)."""
+    from happypose_amd import distributed as D
+    from happypose_amd.synthetic import make_scene
+    from oracle.pipeline import OraclePredictor
+
+    bench = _bench()
+    ds, renderer, _, weights, model = bench.build_world(dev, "resnet34", seed=0, workload="C2", n_lanes=2)
+    store = renderer.store
+    scene = make_scene(n_detections=64, n_hypotheses=16, n_objects=8, seed=11)
+    B = len(scene["TCO_hyp"])
+    assert B == 1024 and model.max_batch == 128
+    images, K = torch.as_tensor(scene["images"], device=dev), torch.as_tensor(scene["K"], device=dev)
+    labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
+    TCO = torch.as_tensor(scene["TCO_hyp"], device=dev)
+    im_ids = torch.zeros(B, dtype=torch.int32, device=dev)
+    poses, scores = D.refine_sharded(model, images, K, labels, TCO, 5, im_ids=im_ids)
+    assert poses.shape == (B, 4, 4) and scores.shape == (B,) and torch.isfinite(poses).all()
+    assert model.numerics_status() == 0
+    direct = torch.cat([model.forward(images, K, labels[s:s + 128], TCO[s:s + 128], n_iterations=5, im_ids=im_ids[s:s + 128])[
+        "iteration=5"].TCO_output for s in range(0, B, 128)])
+    assert torch.equal(poses, direct)
+    sub = np.concatenate([np.arange(s, s + 16) for s in range(0, B, 128)])
+    torch.set_num_threads(bench.effective_cpu_count())
+    ora = OraclePredictor(weights, store.packed, store.mesh_db.points, arch="resnet34", cosypose=True)
+    ref = ora.forward(scene["images"][:, :3], scene["K"], np.zeros(len(sub), np.int32), scene["hyp_obj_ids"][sub], scene["TCO_hyp"][sub], 5,
+                      bsz_objects=8)[-1]["TCO_output"]
+    dt, dr = _pose_err(poses[torch.as_tensor(sub, device=dev)].cpu().numpy(), ref)
+    assert dt <= T_TOL and dr <= R_TOL, (dt, dr)
+    # the estimator entry point on the same batch (world = 1: no sharding, chunks of bsz_objects = 128)
+    import pandas as pd
+
+    from happypose_amd.pose_estimator import CosyPoseEstimator, ObservationTensor
+    from happypose_amd.tensor_collection import PandasTensorCollection
+
+    hyp = PandasTensorCollection(pd.DataFrame({"label": labels, "batch_im_id": 0, "instance_id": scene["hyp_det_ids"]}), poses=TCO)
+    est = CosyPoseEstimator(refiner_model=model, coarse_model=model, bsz_objects=128)
+    final, extra = est.run_inference_pipeline(ObservationTensor(images, K), data_TCO_init=hyp, n_coarse_iterations=0, n_refiner_iterations=5)
+    assert torch.equal(final.poses, direct) and extra["refiner"]["data"]["shard"] == (0, B)
+    assert final.infos.refiner_batch_idx.tolist() == (np.arange(B) // 128).tolist()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# hipGraph replay under the conditions ADVICE r2 named
+# ---------------------------------------------------------------------------------------------------------------
+def test_graph_replay_survives_scratch_growth(dev, world):
+    """A captured graph holds the store's rasteriser-scratch pointers.  A later, larger user of the SAME store (a
+    predictor with a bigger batch) reallocates that scratch: the older graphs must not be replayed through the freed
+    memory (hp_mesh_store_scratch_generation drops them); results stay equal to the eager path."""
+    from happypose_amd.models import create_pose_model_cosypose
+    from happypose_amd.renderer import BatchRenderer
+    from happypose_amd.synthetic import make_scene
+
+    renderer = BatchRenderer(world["ds"], device=dev)  # a store of its own: its scratch starts empty
+    store = renderer.store
+    w = _weights("resnet18", 6, seed=3)
+    sc = make_scene(n_detections=8, n_hypotheses=12, n_objects=len(store.labels), seed=5)
+    labels = [store.labels[j] for j in sc["hyp_obj_ids"]]
+    images, K = torch.as_tensor(sc["images"], device=dev), torch.as_tensor(sc["K"], device=dev)
+    T = torch.as_tensor(sc["TCO_hyp"], device=dev)
+    ids = torch.zeros(len(labels), dtype=torch.int32)
+    small = create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=w, max_batch=8, graphs=True)
+    eager = create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=w, max_batch=8)
+    g0 = store.scratch_generation()
+    run = lambda m, n: m.forward(images, K, labels[:n], T[:n], n_iterations=2, im_ids=ids[:n])["iteration=2"].TCO_output  # noqa: E731
+    ref8 = run(eager, 8)
+    for _ in range(3):  # eager, capture, replay
+        assert torch.equal(run(small, 8), ref8)
+    assert small._graphs.replays >= 2 and store.scratch_generation() == g0
+    big = create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=w, max_batch=96)  # reserves 96 views
+    assert store.scratch_generation() > g0
+    ref96 = run(big, 96)
+    # poison what the allocator may hand out next, then replay the old signature
+    junk = [torch.full((1 << 22,), float("nan"), device=dev) for _ in range(8)]
+    got = run(small, 8)
+    del junk
+    assert torch.equal(got, ref8)
+    assert torch.equal(run(big, 96), ref96)
+    for _ in range(3):
+        assert torch.equal(run(small, 8), ref8)
+
+
+def test_graph_signature_includes_tail_split(dev, world):
+    """TwoLanePredictor with graphs: a 40-hypothesis frame runs lane 0 on 20 rows with tail K-slicing OFF, a
+    20-hypothesis frame runs the same lane on 20 rows with tail K-slicing ON -- same shapes, different launch plans:
+    two graph signatures, each equal to its eager twin, in any interleaving."""
+    from happypose_amd.models import create_pose_model_cosypose
+    from happypose_amd.synthetic import make_scene
+
+    renderer = world["renderer"]
+    store = renderer.store
+    w = _weights("resnet18", 6, seed=3)
+    sc = make_scene(n_detections=5, n_hypotheses=8, n_objects=len(store.labels), seed=6)
+    labels = [store.labels[j] for j in sc["hyp_obj_ids"]]
+    images, K = torch.as_tensor(sc["images"], device=dev), torch.as_tensor(sc["K"], device=dev)
+    T = torch.as_tensor(sc["TCO_hyp"], device=dev)
+    ids = torch.zeros(len(labels), dtype=torch.int32)
+    make = lambda g: create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=w, max_batch=48, n_lanes=2, graphs=g)  # noqa: E731
+    eager, graphed = make(False), make(True)
+    run = lambda m, n: m.forward(images, K, labels[:n], T[:n], n_iterations=2, im_ids=ids[:n])["iteration=2"].TCO_output.clone()  # noqa: E731
+    ref40, ref20 = run(eager, 40), run(eager, 20)
+    for n in (40, 20, 40, 20, 20, 40, 40, 20):
+        assert torch.equal(run(graphed, n), ref40 if n == 40 else ref20), n
+    keys = [k for k in graphed.lanes[0]._graphs.entries]
+    assert len(keys) == 2 and {dict(k[0][1:])["tail_split"] for k in keys} == {True, False}
+
+
+def test_two_lanes_keep_the_render_state(dev, world):
+    """``n_lanes=2`` must render BOTH halves of the batch with the renderer's state (msaa / aniso): lane 1's renderer is
+    a clone of lane 0's.  One lane vs two lanes on a multisampled, mip-filtered renderer: same poses."""
+    from happypose_amd.models import create_pose_model_cosypose
+    from happypose_amd.renderer import BatchRenderer
+    from happypose_amd.synthetic import make_scene
+
+    renderer = BatchRenderer(world["ds"], device=dev, msaa=True, aniso=True)
+    store = renderer.store
+    w = _weights("resnet18", 6, seed=3, scale=0.05)
+    sc = make_scene(n_detections=6, n_hypotheses=8, n_objects=len(store.labels), seed=9)
+    labels = [store.labels[j] for j in sc["hyp_obj_ids"]]
+    args = (torch.as_tensor(sc["images"], device=dev), torch.as_tensor(sc["K"], device=dev), labels, torch.as_tensor(sc["TCO_hyp"], device=dev))
+    ids = torch.zeros(len(labels), dtype=torch.int32)
+    outs = []
+    for lanes in (1, 2):
+        m = create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=w, max_batch=48, n_lanes=lanes)
+        if lanes == 2:
+            assert m.lanes[1].renderer.msaa and m.lanes[1].renderer.aniso
+        outs.append(m.forward(*args, n_iterations=2, im_ids=ids)["iteration=2"].TCO_output)
+    dt, dr = _pose_err(outs[0].cpu().numpy(), outs[1].cpu().numpy())
+    assert dt <= T_TOL and dr <= R_TOL, (dt, dr)
+    plain = create_pose_model_cosypose(dict(backbone_str="resnet18"), world["renderer"], state_dict=w, max_batch=48, n_lanes=2)
+    off = plain.forward(*args, n_iterations=2, im_ids=ids)["iteration=2"].TCO_output
+    assert _pose_err(off.cpu().numpy(), outs[1].cpu().numpy())[1] > R_TOL  # the state does reach both lanes' renders
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Lights (VERDICT r2 missing #4): positioning functions through the renderer plug, and the lit MegaPose loop
+# ---------------------------------------------------------------------------------------------------------------
+def test_renderer_honours_positioning_functions(dev, world):
+    """Light lists as REFERENCE code builds them -- a re-statement of ``make_scene_lights``'s signature and body
+    (TB/renderer/panda3d_scene_renderer.py:105-141: ``partial(pos_fn, pos=...)`` reading ``root_node.getBounds().radius``
+    and calling ``light_node.setPos(tuple)``) -- pass through ``BatchRenderer.render`` and light the scene like the oracle
+    with the positions written out by hand."""
+    from functools import partial
+
+    from happypose_amd.renderer import Panda3dLightData, make_scene_lights
+    from oracle import native
+
+    def reference_style_lights(ambient_light_color=(0.1, 0.1, 0.1, 1.0), point_lights_color=(0.4, 0.4, 0.4, 1.0)):
+        pos = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
+
+        def pos_fn(root_node, light_node, pos):
+            radius = root_node.getBounds().radius
+            xyz_ = pos * radius * 10
+            light_node.setPos(tuple(xyz_.tolist()))
+
+        out = [Panda3dLightData(light_type="ambient", color=ambient_light_color)]
+        for pos_n in pos:
+            out.append(Panda3dLightData(light_type="point", color=point_lights_color, positioning_function=partial(pos_fn, pos=pos_n)))
+        return out
+
+    sc, store, renderer = world["scene"], world["store"], world["renderer"]
+    sel = np.array([0, 5, 10, 3])
+    obj = sc["hyp_obj_ids"][sel]
+    T = sc["TCO_hyp"][sel]
+    K = np.tile(np.array([[700.0, 0, 160], [0, 700.0, 120], [0, 0, 1]], np.float32), (len(sel), 1, 1))
+    labels = _labels(world, obj)
+    dirs = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    lp = dirs[None] * (10 * store.packed.bounds_radius[obj])[:, None, None]
+    ref = native.rasterize(store.packed, obj, T, K, (240, 320), ambient=np.full((len(sel), 3), 0.1, np.float32), light_pos=lp.astype(np.float32),
+                           light_col=np.full((len(sel), 6, 3), 0.4, np.float32))
+    for lights in ([reference_style_lights() for _ in sel], [make_scene_lights() for _ in sel]):
+        out = renderer.render(labels, torch.as_tensor(T, device=dev), torch.as_tensor(K, device=dev), light_datas=lights, resolution=(240, 320))
+        got = out.rgbs.cpu().numpy()
+        cov = ref["rgbs"].sum(1) > 0
+        assert ((got.sum(1) > 0) != cov).mean() < 5e-4
+        ok = np.broadcast_to(((got.sum(1) > 0) == cov)[:, None], got.shape)
+        assert np.abs(got - ref["rgbs"])[ok].max() <= 1.01 / 255
+    with pytest.raises(AssertionError):  # setup_lights asserts a point light has its function (:303)
+        renderer.render(labels, torch.as_tensor(T, device=dev), torch.as_tensor(K, device=dev),
+                        light_datas=[[Panda3dLightData("point")] for _ in sel], resolution=(240, 320))
+
+
+def test_lit_megapose_refiner_vs_reference_golden_g10(dev, golden_dir):
+    """``render_normals=False``: the predictor lights every view with ``make_scene_lights()`` like
+    MP/models/pose_rigid.py:422.  Against the reference's own ``PosePredictor.forward`` run with ITS lights (golden G10,
+    ``mp_lit``; high-gain head) and against the high-gain CosyPose / RGB-D cases of the same golden."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import gen_golden_loop as ggl
+
+    from happypose_amd.models import create_model_pose, create_pose_model_cosypose
+    from happypose_amd.renderer import BatchRenderer
+
+    g = np.load(golden_dir / "g10_loop.npz")
+    ds, packed, mesh_db, sc = ggl.world()
+    renderer = BatchRenderer(ds, device=dev)
+    labels_all = list(renderer.store.labels)
+    images, K = torch.as_tensor(sc["images"], device=dev), torch.as_tensor(sc["K"], device=dev)
+    sel, sel4 = g["cosy/sel"], g["mp_rgbd4/sel"]
+    lab = [labels_all[i] for i in sc["hyp_obj_ids"][sel]]
+    ids = torch.zeros(len(sel), dtype=torch.int32)
+
+    def check(tag, out, n_it, t_tol, r_tol):
+        for n in range(1, n_it + 1):
+            dt, dr = _pose_err(out[f"iteration={n}"].TCO_output.cpu().numpy(), g[f"{tag}/it{n}/TCO_output"])
+            assert dt <= t_tol and dr <= r_tol, (tag, n, dt, dr)
+
+    lit = create_model_pose(dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=False,
+                                 depth_augmentation=False), renderer, state_dict=ggl.case_weights("mp_lit"), max_batch=8)
+    lit.keep_pixels = True
+    out = lit.forward(images[:, :3].contiguous(), K, lab, torch.as_tensor(sc["TCO_hyp"][sel]), n_iterations=2, im_ids=ids)
+    check("mp_lit", out, 2, T_TOL_HI, R_TOL_HI)
+    rend = out["iteration=1"].renders.cpu().numpy()
+    np.testing.assert_allclose(rend.astype(np.float64).mean(axis=(0, 2, 3)), g["mp_lit/it1/renders_mean"], atol=1e-4)
+    dx = np.abs(rend[:, :, ::7, ::11] - g["mp_lit/it1/renders_sample"])
+    assert (dx > 1.01 / 255).mean() < 2e-3
+    cosy = create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=ggl.case_weights("cosy_hi"), max_batch=8)
+    check("cosy_hi", cosy.forward(images[:, :3].contiguous(), K, lab, torch.as_tensor(sc["TCO_hyp"][sel]), n_iterations=3, im_ids=ids), 3,
+          T_TOL_HI, R_TOL_HI)
+    lab4 = [labels_all[i] for i in sc["hyp_obj_ids"][sel4]]
+    m4 = create_model_pose(dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+                                render_depth=True, input_depth=True, depth_augmentation=False,
+                                depth_normalization_type="tCR_scale_clamp_center"), renderer, state_dict=ggl.case_weights("mp_rgbd4_hi"),
+                           max_batch=4)
+    check("mp_rgbd4_hi", m4.forward(images, K, lab4, torch.as_tensor(sc["TCO_hyp"][sel4]), n_iterations=3,
+                                    im_ids=torch.zeros(3, dtype=torch.int32)), 3, T_TOL_HI, R_TOL_HI)

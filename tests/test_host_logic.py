@@ -183,12 +183,59 @@ def test_model_config_defaults_and_key_renames():
 
 
 def test_lights_and_render_argument_checks():
-    from happypose_amd.renderer import Panda3dLightData, make_scene_lights
+    from happypose_amd.renderer import LightNodeProxy, Panda3dLightData, SceneRootProxy, make_scene_lights
 
     lights = make_scene_lights()
     assert len(lights) == 7 and lights[0].light_type == "ambient" and lights[0].color[:3] == (0.1, 0.1, 0.1)
-    assert sorted(l.direction for l in lights[1:]) == sorted([(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)])
     assert Panda3dLightData("ambient").color == (1.0, 1.0, 1.0, 1.0)
+    # every point light carries a positioning_function(root_node, light_node) like the reference's
+    # (TB/renderer/panda3d_scene_renderer.py:121-141); called on the NodePath stand-ins it lands on +/- axis x radius x 10
+    got = []
+    for l in lights[1:]:
+        assert l.light_type == "point" and l.color[:3] == (0.4, 0.4, 0.4) and callable(l.positioning_function)
+        node = LightNodeProxy()
+        l.positioning_function(SceneRootProxy((0.0, 0.0, 0.0), 0.2), node)
+        got.append(tuple(round(v, 6) for v in node.pos))
+    assert sorted(got) == sorted([(2.0, 0, 0), (-2.0, 0, 0), (0, 2.0, 0), (0, -2.0, 0), (0, 0, 2.0), (0, 0, -2.0)])
+    # the stand-ins accept the spellings Panda3D offers, and refuse what needs a scene graph
+    node = LightNodeProxy()
+    node.set_pos(1, 2, 3)
+    assert node.getPos() == (1.0, 2.0, 3.0)
+    node.setPos((4.0, 5.0, 6.0))
+    assert node.get_pos() == (4.0, 5.0, 6.0)
+    root = SceneRootProxy((0.1, 0.0, 0.0), 0.5)
+    assert root.get_bounds().get_radius() == 0.5 and root.getBounds().getCenter() == (0.1, 0.0, 0.0)
+    with pytest.raises(NotImplementedError):
+        node.lookAt(0, 0, 0)
+
+
+def test_ypr_offset_rotates_the_render_mesh_only():
+    """``RigidObject.ypr_offset_deg`` (TB/datasets/object_dataset.py:42, applied by get_object_node's setHpr,
+    TB/renderer/panda3d_scene_renderer.py:210-217): the RENDER mesh is rotated (heading about Z, pitch about X, roll about
+    Y), the MeshDataBase point table is not (TB/lib3d/rigid_mesh_database.py:109-111).  Checked against scipy's intrinsic
+    Z-X-Y Euler composition, an independent statement of the same convention."""
+    from scipy.spatial.transform import Rotation
+
+    from happypose_amd.mesh_store import MeshDataBase, PackedMeshes, RigidObject, RigidObjectDataset, hpr_to_matrix
+    from happypose_amd.synthetic import make_mesh
+
+    m = make_mesh(2, n_lat=12, n_lon=16, tex_size=16)
+    for ypr in ((0.0, -90.0, 0.0), (30.0, 20.0, -10.0)):
+        plain = PackedMeshes(RigidObjectDataset([RigidObject("a", m)]))
+        ds = RigidObjectDataset([RigidObject("a", m, ypr_offset_deg=ypr)])
+        rot = PackedMeshes(ds)
+        R = Rotation.from_euler("ZXY", ypr, degrees=True).as_matrix()
+        np.testing.assert_allclose(hpr_to_matrix(ypr), R, atol=1e-12)
+        np.testing.assert_allclose(rot.verts, plain.verts @ R.T.astype(np.float32), atol=2e-6)
+        np.testing.assert_allclose(rot.normals, plain.normals @ R.T.astype(np.float32), atol=2e-6)
+        assert np.array_equal(rot.faces, plain.faces) and np.array_equal(rot.uvs, plain.uvs)
+        np.testing.assert_allclose(rot.bounds_radius, plain.bounds_radius, rtol=0.2)  # a rotated box: the same order
+        pts = MeshDataBase.from_object_ds(ds).batched().points
+        np.testing.assert_array_equal(pts, MeshDataBase.from_object_ds(RigidObjectDataset([RigidObject("a", m)])).batched().points)
+    # axis checks of the convention: pitch turns +Y towards +Z, heading turns +X towards +Y (ShapeNet's (0, -90, 0) maps +Z to +Y)
+    np.testing.assert_allclose(hpr_to_matrix((0, -90, 0)) @ np.array([0, 0, 1.0]), [0, 1, 0], atol=1e-12)
+    np.testing.assert_allclose(hpr_to_matrix((0, 90, 0)) @ np.array([0, 1.0, 0]), [0, 0, 1], atol=1e-12)
+    np.testing.assert_allclose(hpr_to_matrix((90, 0, 0)) @ np.array([1.0, 0, 0]), [0, 1, 0], atol=1e-12)
 
 
 def test_synthetic_scene_is_seeded_and_in_view():

@@ -253,6 +253,70 @@ def test_g10_megapose_loops(golden_dir, loop_world):
     assert (dx[:, depth_ch] > 2e-3).mean() < 1e-2
 
 
+def test_g10_high_gain_loops(golden_dir, loop_world):
+    """Round 3: the same loops with the pose head at update_scale = 0.05 (a pose moves ~0.14 rad and 4-8 cm per iteration,
+    three iterations): the reference's own run vs OraclePredictor.  Errors feed back through the renders 25x stronger than
+    in the low-gain cases, so the bound is HI_ATOL on the 4x4 entries -- still 1000x below the update."""
+    from oracle.pipeline import OraclePredictor
+
+    g, w = load(golden_dir, "g10_loop.npz"), loop_world
+    sc, sel, sel4 = w["scene"], g["cosy/sel"], g["mp_rgbd4/sel"]
+    ora = OraclePredictor(w["weights"]("cosy_hi"), w["packed"], w["points"], arch="resnet18", cosypose=True)
+    ref = ora.forward(sc["images"][:, :3], sc["K"], np.zeros(len(sel), np.int32), sc["hyp_obj_ids"][sel], sc["TCO_hyp"][sel], 3)
+    ora4 = OraclePredictor(w["weights"]("mp_rgbd4_hi"), w["packed"], w["points"], arch="vanilla_resnet34", n_views=4,
+                           multiview_type="TCO+front_3views", render_normals=True, render_depth=True, input_depth=True,
+                           depth_normalization_type="tCR_scale_clamp_center")
+    ref4 = ora4.forward(sc["images"], sc["K"], np.zeros(3, np.int32), sc["hyp_obj_ids"][sel4], sc["TCO_hyp"][sel4], 3)
+    HI_ATOL = 2e-4
+    for tag, r in (("cosy_hi", ref), ("mp_rgbd4_hi", ref4)):
+        for n in range(1, 4):
+            got, want = r[n - 1]["TCO_output"], g[f"{tag}/it{n}/TCO_output"]
+            np.testing.assert_allclose(got, want, rtol=0, atol=HI_ATOL, err_msg=f"{tag} it{n}")
+            np.testing.assert_allclose(r[n - 1]["boxes_crop"], g[f"{tag}/it{n}/boxes_crop"], rtol=1e-5, atol=0.1)
+            upd = np.abs(g[f"{tag}/it{n}/TCO_output"][:, :3, :3] - g[f"{tag}/it{n}/TCO_input"][:, :3, :3]).max()
+            assert upd > 100 * HI_ATOL, (tag, n, upd)
+
+
+def test_g10_scene_lights_and_lit_refiner(golden_dir, loop_world):
+    """render_normals=False (MP/models/pose_rigid.py:415-422): the reference lights the scene with ITS
+    ``make_scene_lights()``; the golden was made by calling the reference's own positioning functions
+    (TB/renderer/panda3d_scene_renderer.py:121-129) on the product's NodePath stand-ins.  Pins (1) the product's
+    ``make_scene_lights`` (types, colours, placements) against the reference's and (2) the oracle's lit loop."""
+    from functools import partial
+
+    from happypose_amd.renderer import LightNodeProxy, SceneRootProxy, make_scene_lights
+    from oracle.pipeline import OraclePredictor
+
+    g, w = load(golden_dir, "g10_loop.npz"), loop_world
+    lights = make_scene_lights()
+    assert [l.light_type for l in lights] == [str(t) for t in g["lights/types"]]
+    np.testing.assert_allclose(np.array([l.color for l in lights], np.float32), g["lights/colors"], rtol=0, atol=0)
+    pos = []
+    for l in lights[1:]:
+        assert isinstance(l.positioning_function, partial)  # same calling convention: f(root_node, light_node)
+        node = LightNodeProxy()
+        l.positioning_function(SceneRootProxy((0.0, 0.0, 0.0), 0.25), node)
+        pos.append(node.pos)
+    np.testing.assert_allclose(np.array(pos, np.float32), g["lights/pos_r025"], rtol=0, atol=0)
+    sc, sel = w["scene"], g["cosy/sel"]
+    ora = OraclePredictor(w["weights"]("mp_lit"), w["packed"], w["points"], arch="vanilla_resnet34", n_views=1, multiview_type="TCO",
+                          render_normals=False)
+    ref = ora.forward(sc["images"][:, :3], sc["K"], np.zeros(len(sel), np.int32), sc["hyp_obj_ids"][sel], sc["TCO_hyp"][sel], 2)
+    for n in (1, 2):
+        np.testing.assert_allclose(ref[n - 1]["TCO_output"], g[f"mp_lit/it{n}/TCO_output"], rtol=0, atol=2e-4)
+    it = ora._iteration(sc["images"][:, :3], np.repeat(sc["K"], len(sel), 0), np.zeros(len(sel), np.int32), sc["hyp_obj_ids"][sel],
+                        sc["TCO_hyp"][sel], heads=("pose",))
+    rend = it["x"][:, 3:6]
+    np.testing.assert_allclose(rend.astype(np.float64).mean(axis=(0, 2, 3)), g["mp_lit/it1/renders_mean"], atol=5e-5)
+    dx = np.abs(rend[:, :, ::7, ::11] - g["mp_lit/it1/renders_sample"])
+    assert (dx > 1e-5).mean() < 1e-2 and np.median(dx) == 0
+    # lit, not ambient-1: far darker than the albedo render
+    amb = OraclePredictor(w["weights"]("mp_lit"), w["packed"], w["points"], arch="vanilla_resnet34", n_views=1, multiview_type="TCO",
+                          render_normals=False, cosypose=True)._iteration(sc["images"][:, :3], np.repeat(sc["K"], len(sel), 0), np.zeros(len(sel), np.int32),
+                                                                          sc["hyp_obj_ids"][sel], sc["TCO_hyp"][sel], heads=("pose",))["x"][:, 3:6]
+    assert rend.mean() < 0.8 * amb.mean()
+
+
 def test_g10_coarse_logits(golden_dir, loop_world):
     """forward_coarse (MP/models/pose_rigid.py:708-788) run by the reference vs OraclePredictor.forward_coarse."""
     from oracle.pipeline import OraclePredictor

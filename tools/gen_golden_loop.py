@@ -57,6 +57,12 @@ CASES = {
     "mp_rgbd4": dict(arch="vanilla_resnet34", n_in=32, seed=2, scale=0.002),
     "mp_rgb4": dict(arch="vanilla_resnet34", n_in=27, seed=5, scale=0.002),
     "coarse": dict(arch="vanilla_resnet34", n_in=9, seed=3, scale=1.0),
+    # round 3: HIGH-GAIN heads (every iteration moves a pose by ~0.1 rad: a 1 % feature error becomes visible in the pose)
+    "cosy_hi": dict(arch="resnet18", n_in=6, seed=1, scale=0.05),
+    "mp_rgbd4_hi": dict(arch="vanilla_resnet34", n_in=32, seed=2, scale=0.05),
+    # render_normals=False: the reference lights the scene with ITS make_scene_lights() (ambient 0.1 + six point lights
+    # placed by positioning functions, MP/models/pose_rigid.py:422)
+    "mp_lit": dict(arch="vanilla_resnet34", n_in=6, seed=6, scale=0.05),
 }
 
 
@@ -127,11 +133,30 @@ def main():
 
         def render(self, labels, TCO, K, light_datas, resolution, render_depth=False, render_binary_mask=False,
                    render_normals=False):
-            for lights in light_datas:  # the configurations used here light with ambient (1,1,1) only
-                assert len(lights) == 1 and lights[0].light_type == "ambient" and tuple(lights[0].color)[:3] == (1.0, 1.0, 1.0)
             obj = np.array([packed.label_to_id[l] for l in labels], np.int32)
+            # lights as setup_lights applies them (TB/renderer/panda3d_scene_renderer.py:294-318): ambient colours add up,
+            # a point light is placed by calling ITS positioning_function(root_node, light_node) -- the reference's own
+            # function objects (make_scene_lights' pos_fn) run here on duck-typed stand-ins for the two NodePaths
+            from happypose_amd.renderer import LightNodeProxy, SceneRootProxy
+
+            n = len(labels)
+            amb = np.zeros((n, 3), np.float32)
+            n_pts = max(sum(1 for l in ls if l.light_type == "point") for ls in light_datas)
+            lp = np.zeros((n, n_pts, 3), np.float32) if n_pts else None
+            lc = np.zeros((n, n_pts, 3), np.float32) if n_pts else None
+            for i, ls in enumerate(light_datas):
+                k = 0
+                for l in ls:
+                    if l.light_type == "ambient":
+                        amb[i] += np.asarray(l.color[:3], np.float32)
+                    else:
+                        assert l.light_type == "point" and l.positioning_function is not None
+                        node = LightNodeProxy()
+                        l.positioning_function(SceneRootProxy(packed.bounds_center[obj[i]], packed.bounds_radius[obj[i]]), node)
+                        lp[i, k], lc[i, k] = node.pos, l.color[:3]
+                        k += 1
             r = native.rasterize(packed, obj, TCO.detach().cpu().numpy(), K.detach().cpu().numpy(), tuple(resolution),
-                                 render_normals, render_depth, render_binary_mask)
+                                 render_normals, render_depth, render_binary_mask, ambient=amb, light_pos=lp, light_col=lc)
             return rtypes.BatchRenderOutput(
                 rgbs=T(r["rgbs"]), normals=None if r["normals"] is None else T(r["normals"]),
                 depths=None if r["depths"] is None else T(r["depths"]),
@@ -204,6 +229,34 @@ def main():
         g["mp_rgbd4/it1/x_chan_absmean"] = x.double().abs().mean(dim=(0, 2, 3)).numpy()
         g["mp_rgbd4/it1/x_sample"] = x[:, :, ::7, ::11].numpy()
         g["mp_rgbd4/sel"] = sel4
+
+        # ---- round 3: the same two refiners with HIGH-GAIN heads, 3 iterations (a pose moves ~0.1 rad per iteration)
+        cosy_hi = load(cp_pose.PosePredictor(backbone=wrn.WideResNet18(n_inputs=6), renderer=renderer, mesh_db=ref_mesh_db),
+                       case_weights("cosy_hi"))
+        outs = cosy_hi(images[:, :3].expand(nb, -1, -1, -1), K.expand(nb, -1, -1), lab, T(scene["TCO_hyp"][sel]), n_iterations=3)
+        rec_iters("cosy_hi", outs, 3)
+        m4h = mp_model("mp_rgbd4_hi", multiview_type="TCO+front_3views", n_rendered_views=4, render_normals=True, render_depth=True,
+                       input_depth=True, depth_normalization_type="tCR_scale_clamp_center")
+        outs = m4h(images.expand(3, -1, -1, -1), K.expand(3, -1, -1), lab4, T(scene["TCO_hyp"][sel4]), n_iterations=3)
+        rec_iters("mp_rgbd4_hi", outs, 3)
+
+        # ---- round 3: render_normals=False -> the reference's own make_scene_lights() and its positioning functions
+        ml = mp_model("mp_lit", multiview_type="TCO", n_rendered_views=1, render_normals=False)
+        outs = ml(images[:, :3].expand(nb, -1, -1, -1), K.expand(nb, -1, -1), lab, T(scene["TCO_hyp"][sel]), n_iterations=2)
+        rec_iters("mp_lit", outs, 2)
+        g["mp_lit/it1/renders_sample"] = outs["iteration=1"].renders[:, :, ::7, ::11].numpy()
+        g["mp_lit/it1/renders_mean"] = outs["iteration=1"].renders.double().mean(dim=(0, 2, 3)).numpy()
+        psr = gg.imp("happypose.toolbox.renderer.panda3d_scene_renderer")
+        from happypose_amd.renderer import LightNodeProxy, SceneRootProxy
+        lights = psr.make_scene_lights()
+        g["lights/types"] = np.array([l.light_type for l in lights])
+        g["lights/colors"] = np.array([l.color for l in lights], np.float32)
+        pos = []
+        for l in lights[1:]:
+            node = LightNodeProxy()
+            l.positioning_function(SceneRootProxy((0.0, 0.0, 0.0), 0.25), node)
+            pos.append(node.pos)
+        g["lights/pos_r025"] = np.array(pos, np.float32)
 
         # ---- coarse model: forward_coarse logits (MP/models/pose_rigid.py:708-788)
         selc = np.array([0, 4, 8, 9, 2, 7])
