@@ -126,14 +126,19 @@ def bench_e2e(args, device, rank, world):
 
     for _ in range(args.warmup):
         step()
+    from happypose_amd import ops as _ops
+
     for m in (coarse, refiner):
         m.backbone.set_profiling(True)
     fence()
+    _ops.profile_mark_reference(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         final, extra = step()
     fence()
     elapsed = time.perf_counter() - t0
+    # the time during which ANY conv kernel of either backbone ran (lanes and backbones overlap: their sum is not a share)
+    conv_union_ms = union_ms([iv for m in (coarse, refiner) for iv in m.backbone.profile_intervals()])
     prof = [m.backbone.profile_collect() for m in (coarse, refiner)]
     for m in (coarse, refiner):
         m.backbone.set_profiling(False)
@@ -166,10 +171,82 @@ def bench_e2e(args, device, rank, world):
                    "detections_per_gpu": N_DET, "parallelism": f"frame-replica x{world}"},
         "roofline": {"bound": "mfma", "kernel": f"all conv launches of the {names[dom]} backbone (the one with more conv time)", "per_backbone": per_net,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                     "launches": int(sum(p[1] for p in prof)), "conv_time_share": conv_ms * 1e-3 / elapsed},
+                     "launches": int(sum(p[1] for p in prof)), "conv_time_share": conv_union_ms * 1e-3 / elapsed,
+                     "conv_time_sum_over_wall": conv_ms * 1e-3 / elapsed},
         "stage_seconds_last_frame": extra["timing_str"],
     }
     print(json.dumps(line), flush=True)
+
+
+def union_ms(intervals) -> float:
+    """Length of the union of ``[(t0, t1), ...]``: the time during which ANY of the timed stretches ran (the lanes /
+    backbones overlap, so their sum can exceed the wall time)."""
+    union, end = 0.0, -1.0
+    for a0, a1 in sorted(intervals):
+        if a1 > end:
+            union += a1 - max(a0, end)
+            end = a1
+    return union
+
+
+def recorded_traffic(kind="conv"):
+    """HBM bytes per launch from the PMC passes of THIS command committed under profiles/ (counters cannot be read
+    inside the run; collected with rocprofv3 ``--pmc FETCH_SIZE`` / ``WRITE_SIZE`` in separate passes, tools/pmc_traffic.py):
+    the newest ``profiles/*_{kind}_hbm_traffic.json``.  Returns ``(bytes_per_launch | None, source file | None)``."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{kind}_hbm_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as fh:
+            d = json.load(fh)
+        return float(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
+def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2):
+    """A short run of another BASELINE.json config in the same process (C3: MegaPose RGB-D refiner, fp32; C5: coarse
+    scoring in fp16): ``{value, unit, ms_per_step, frac, algorithmic_tflops, steps}`` -- the driver-visible twin of
+    ``bench.py --workload C3|C5``."""
+    from happypose_amd import ops as _ops
+
+    ds, renderer, scene, weights, model = build_world(device, "resnet34", seed=0, workload=workload, precision=precision, n_lanes=n_lanes)
+    store = renderer.store
+    B = len(scene["TCO_hyp"])
+    images, K = torch.as_tensor(scene["images"], device=device), torch.as_tensor(scene["K"], device=device)
+    TCO0 = torch.as_tensor(scene["TCO_hyp"], device=device)
+    labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
+    im_ids = torch.zeros(B, dtype=torch.int32, device=device)
+
+    def step():
+        if workload == "C5":
+            ck = 576 * n_lanes
+            return torch.cat([model.forward_coarse(images, K, labels[i:i + ck], TCO0[i:i + ck], im_ids=im_ids[i:i + ck])["logits"]
+                              for i in range(0, B, ck)])
+        return model.forward(images, K, labels, TCO0, n_iterations=N_ITERS, im_ids=im_ids)[f"iteration={N_ITERS}"].TCO_output
+
+    for _ in range(warmup):
+        step()
+    model.backbone.set_profiling(True)
+    torch.cuda.synchronize(device)
+    _ops.profile_mark_reference(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    conv_ms = union_ms(model.backbone.profile_intervals())
+    _, n_launch, conv_flops, mfma_flops = model.backbone.profile_collect()
+    model.backbone.set_profiling(False)
+    assert torch.isfinite(out).all() and model.numerics_status() == 0
+    sec = conv_ms * 1e-3
+    executed_f16 = (16.0 if precision == "f32" else 1.0) * mfma_flops / sec / 1e12 if sec > 0 else 0.0
+    return {"value": B * steps / elapsed, "unit": "refined poses/s" if workload != "C5" else "views/s", "dtype": precision,
+            "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "frac": executed_f16 / PEAK_F16_MFMA_TFLOPS,
+            "algorithmic_tflops": conv_flops / sec / 1e12 if sec > 0 else 0.0, "conv_time_share": sec / elapsed,
+            "hypotheses_per_step": B, "lanes": n_lanes}
 
 
 def effective_cpu_count() -> int:
@@ -243,13 +320,13 @@ def stage_rates(store, scene, images, K, TCO0, im_ids, device, reps=20):
     from happypose_amd import ops
 
     B = TCO0.shape[0]
-    obj = torch.as_tensor(scene["hyp_obj_ids"], device=device)
+    obj = torch.as_tensor(scene["hyp_obj_ids"][:B], device=device)
     prep = ops.pose_prep(store, TCO0, K, im_ids, obj, (480, 640))
     Kc = prep["K_crop"][:, 0].contiguous()
     x = torch.zeros((B, 240, 320, 8), device=device)
     depth = ops.rasterize(store, obj, TCO0, Kc, (240, 320), render_depth=True)[2]
     covered = float((depth > 0).sum().item())
-    rows = store.packed.obj[np.asarray(scene["hyp_obj_ids"])]  # (voff, nv, foff, nf, ...)
+    rows = store.packed.obj[np.asarray(scene["hyp_obj_ids"][:B])]  # (voff, nv, foff, nf, ...)
     nv, nf = rows[:, 1].astype(np.float64), rows[:, 3].astype(np.float64)
     raster_bytes = float((nv * 32 + nf * 12).sum()) + B * 76800 * 3 * 4 + covered * 4
     crop_bytes = float(B * 76800 * 3 * 4)
@@ -316,6 +393,7 @@ def main():
                     help="replay the refiner step as a captured hipGraph (happypose_amd.graphs).  Measured: within 2 %% of the "
                          "eager path on C2 and C3 -- the steps are bound by the GPU, not by the host's launch rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-workloads", action="store_true", help="skip the 3-step C3 / C5 runs appended to the C2 line")
     ap.add_argument("--no-cpu-1thread", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -346,11 +424,19 @@ def main():
                                                       precision=precision, n_lanes=n_lanes)
     store = renderer.store
     B = len(scene["TCO_hyp"])
+    sharded = world > 1 and args.workload == "C2"
+    if sharded:
+        # C4: ONE hypothesis batch of world x 128 rows on one frame (8 x world detections x 16 hypotheses), the same on
+        # every rank; distributed.refine_sharded cuts it into contiguous shards of 128 and merges the refined poses
+        # with one all-gather -- weak scaling: 128 rows per GPU whatever the number of GPUs
+        from happypose_amd.synthetic import make_scene
+        scene = make_scene(n_detections=N_DET * world, n_hypotheses=N_HYP, n_objects=8, seed=2)
+        assert len(scene["TCO_hyp"]) == world * B
     images = torch.as_tensor(scene["images"], device=device)  # inputs resident in HBM
     K = torch.as_tensor(scene["K"], device=device)
     TCO0 = torch.as_tensor(scene["TCO_hyp"], device=device)
     labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
-    im_ids = torch.zeros(B, dtype=torch.int32, device=device)
+    im_ids = torch.zeros(len(labels), dtype=torch.int32, device=device)
 
     def step():
         if args.workload == "C5":  # coarse scoring, one object (576 grid poses) per chunk and lane as in 8(e)
@@ -358,6 +444,8 @@ def main():
             scores = [model.forward_coarse(images, K, labels[i:i + ck], TCO0[i:i + ck], im_ids=im_ids[i:i + ck])["logits"]
                       for i in range(0, B, ck)]
             poses, logits = TCO0, torch.cat(scores).reshape(-1)
+        elif sharded:
+            return D.refine_sharded(model, images, K, labels, TCO0, N_ITERS, im_ids=im_ids)[0]
         else:
             out = model.forward(images, K, labels, TCO0, n_iterations=N_ITERS, im_ids=im_ids)
             poses, logits = out[f"iteration={N_ITERS}"].TCO_output, None
@@ -404,13 +492,7 @@ def main():
         """(union ms, sum ms, launches, algorithmic FLOPs, matrix-pipe FLOPs in fp32-MFMA-time equivalents) of the conv
         launches timed since profiling was switched on.  Union = the time during which ANY conv kernel was running: with
         two lanes the timed stretches of the two networks overlap (the summed kernel time exceeds the wall time)."""
-        ivs = sorted(model.backbone.profile_intervals())
-        union, end = 0.0, -1.0
-        for a0, a1 in ivs:
-            if a1 > end:
-                union += a1 - max(a0, end)
-                end = a1
-        return (union,) + tuple(model.backbone.profile_collect())
+        return (union_ms(model.backbone.profile_intervals()),) + tuple(model.backbone.profile_collect())
 
     conv_ms, conv_sum_ms, n_launch, conv_flops, mfma_flops = conv_profile()
     model.backbone.set_profiling(False)
@@ -466,6 +548,7 @@ def main():
         # FLOP occupies the pipe 1/16 as long as an fp32 one.  fp16-rate units = x16.
         # fp16-rate units = x16 (the fp16 plan's count is in fp16 FLOPs already).
         executed_f16 = (16.0 if precision == "f32" else 1.0) * mfma_flops / sec / 1e12 if sec > 0 else 0.0
+        traffic, traffic_src = recorded_traffic("conv") if (args.workload == "C2" and args.arch == "resnet34" and precision == "f32") else (None, None)
         desc = {
             "C2": f"C2: CosyPose refiner, one 640x480 frame per GPU, {N_DET} detections x {N_HYP} hypotheses = {B} "
                   f"hypotheses/GPU, {N_ITERS} iterations, {args.arch}{' (WideResNet)' if 'resnet' in args.arch else ''} on 6x240x320",
@@ -484,7 +567,7 @@ def main():
             "config": {"workload": desc + (", two half-batch lanes on two streams" if n_lanes == 2 else "") +
                        (", the 5-iteration step replayed as one captured hipGraph" if graphs else ""),
                        "hypotheses_per_gpu": B, "iterations": N_ITERS if args.workload != "C5" else 1,
-                       "parallelism": f"hypothesis-shard x{world}"},
+                       "parallelism": f"hypothesis-shard x{world}" + (f" (one {world * B}-hypothesis batch, distributed.refine_sharded)" if sharded else "")},
             # The roofline of the instruction that is issued: v_mfma_f32_32x32x16_f16 (dense fp16 MFMA peak 2516.6 TFLOP/s).
             # achieved = fp16 MFMA FLOPs the matrix cores EXECUTE per second of conv time (for the fp32 path: three fp16
             # MFMAs per fp32 product, padded tiles included) -> frac = busy fraction of the matrix pipe, always <= 1.
@@ -496,7 +579,7 @@ def main():
                                     "conv_igemm_f16 / conv3x3_patch_f16: v_mfma_f32_32x32x16_f16 on fp16 operands, fp32 accumulate")
                                    + "; all conv launches of a forward",
                          "achieved": executed_f16, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": executed_f16 / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                         "frac": executed_f16 / PEAK_F16_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_tflops": algorithmic,
                          "algorithmic_ceiling_tflops": PEAK_F16_MFMA_TFLOPS / (3.0 if precision == "f32" else 1.0),
                          "launches": n_launch, "avg_launch_us": 1e3 * conv_sum_ms / max(n_launch, 1),
@@ -504,7 +587,8 @@ def main():
                          "note": ("achieved = executed fp16-MFMA FLOPs / conv-busy time; conv-busy = the union over both lanes of the "
                                   "timed conv stretches (HIP events on the launch streams; the two lanes run concurrently, so a "
                                   "launch shares the machine with the other lane's and avg_launch_us is its duration as it ran); "
-                                  "traffic: not measurable inside the run -- PMC passes of this command are under profiles/"),
+                                  "traffic: HBM bytes per conv launch from the rocprofv3 PMC passes of this command committed under "
+                                  "profiles/ (traffic_source; FETCH_SIZE x 2 + WRITE_SIZE) -- counters cannot be read inside the run"),
                          "conv_time_share": conv_ms * 1e-3 / (elapsed if instrumented_ms is None else instrumented_ms * 1e-3 * args.steps)},
         }
         if instrumented_ms is not None:
@@ -544,7 +628,14 @@ def main():
                              "note": "executed fp32 MFMA FLOPs (Winograd layers execute 2.25x fewer than the direct convolution)"},
                 "note": "same job with hp_net_set_conv_algo(WINOGRAD): every multiply an fp32 FMA on the fp32 matrix path"}
         if args.workload == "C2":
-            line["stages"] = stage_rates(store, scene, images, K, TCO0, im_ids, device)
+            line["stages"] = stage_rates(store, scene, images[:1], K[:1], TCO0[:B], im_ids[:B], device)
+        if args.workload == "C2" and world == 1 and not args.no_extra_workloads:
+            # the other single-GPU configurations of BASELINE.json, 3 steps each, so that the driver's record carries them
+            for key, wl, prec in (("c3", "C3", "f32"), ("c5", "C5", "f16")):
+                try:
+                    line[key] = quick_workload(device, wl, prec, n_lanes)
+                except Exception as e:  # never lose the headline line to an extra
+                    line[key] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and args.workload == "C2" and world == 1:  # the CPU baseline is a 1-GPU-run item
             base, cpu_poses = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds)
             line["cpu_baseline"] = base
