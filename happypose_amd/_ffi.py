@@ -27,6 +27,12 @@ class Strides(C.Structure):
                 ("s_row", C.c_int64), ("s_col", C.c_int64)]
 
 
+class InputLayout(C.Structure):
+    """``hp_input_layout``: where view ``v`` of an item writes its render / crop channels inside a pixel record."""
+
+    _fields_ = [("view_c0", C.c_int * 8), ("crop_c0", C.c_int * 8), ("crop_src0", C.c_int * 8), ("crop_n", C.c_int * 8)]
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -46,6 +52,9 @@ _PROTOS = {
                                c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
                                C.POINTER(Strides), c_f32p, C.POINTER(Strides), c_u8p, c_f32p, C.c_int,
                                C.c_void_p]),
+    "hp_render_inputs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int,
+                                   C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p, C.c_int, c_f32p, C.c_int,
+                                   C.c_void_p, C.c_int, C.POINTER(InputLayout), C.c_void_p]),
     "hp_pose_prep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_i32p,
                                c_i32p, c_i32p, C.c_int, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,

@@ -22,12 +22,21 @@
 //     kernel's roofline is HBM bandwidth ("rasteriser").
 //   * workgroups are renumbered so that each XCD gets a contiguous range of views:
 //     consecutive hypotheses share an object, hence the mesh stays in that XCD's L2.
+//
+// Round 3: ONE WRITER PER PIXEL RECORD.  The kernel can also produce the observed crop (roi_align of the frame, crop_math.h)
+// for its pixels and stores the crop channels and the render channels of a view as one run of the network-input record
+// (hp_render_inputs): the separate crop launch and the 12-B-of-24/32-B partial-sector stores of two kernels (a
+// read-modify-write in the memory system: rocprofv3 counted 3x the algorithmic bytes, profiles/r03a_raster_hbm_traffic.json)
+// are gone.  Inside a workgroup the work is re-organised in four passes: coverage (triangle-parallel, LDS z-buffer) ->
+// compaction of the covered pixels -> shading of the compacted list (every lane has a fragment; the 8-bit colour codes go
+// back into the z-buffer slots) -> pixel-parallel output pass (crop taps + record assembly, coalesced stores).
 #include "common.h"
+#include "crop_math.h"
 
-// Band size: a band is one workgroup.  Only the bands the object covers carry work (5 of 8 bands of
-// 30 rows on the benchmark scenes), so the launch is as long as the busiest CU's sequence of busy
-// bands; 15-row bands with 512 threads (4 workgroups per CU, the same 8 waves per SIMD) halve that
-// granularity.
+// Band size: a band is one workgroup.  Only the bands the object covers carry work, so the launch is as long as the busiest
+// CU's sequence of busy bands.  LDS per workgroup: 8 B (z key / colour codes) + 2 B (codes) + 2 B (covered-pixel list) per
+// pixel + the crop folds: 15 rows of 320 pixels = 68 KB -> two 512-thread workgroups per CU, which is also what the
+// kernel's ~110 VGPRs allow (16 waves per CU).
 #ifndef HP_RASTER_BAND_PIXELS
 #define HP_RASTER_BAND_PIXELS 4800
 #endif
@@ -52,6 +61,7 @@ constexpr int kSamplesMsaa = 5;
 #ifndef HP_RASTER_BAND_KEYS_MSAA
 #define HP_RASTER_BAND_KEYS_MSAA 6400
 #endif
+constexpr int kMaxViews = 8;  // views per item a record layout can describe
 constexpr int kBandKeysMsaa = HP_RASTER_BAND_KEYS_MSAA;
 __device__ __forceinline__ float sample_x(int ns, int sm) {
   const float sx[5] = {0.375f, 0.875f, 0.125f, 0.625f, 0.5f};
@@ -65,7 +75,7 @@ constexpr int kBigQueue = 512;
 constexpr int kBigArea = 128;  // bbox pixels above which a triangle is walked cooperatively
 constexpr int kThreads = HP_RASTER_THREADS;  // band kernel
 constexpr int kBinThreads = 1024;  // binning kernel
-constexpr int kMaxBands = 128;
+constexpr int kMaxBands = 256;
 
 struct RasterArgs {
   const float4* verts4;   // xyz + pad
@@ -98,6 +108,18 @@ struct RasterArgs {
   // screen-space vertices of the chunk's views, written by raster_xform_kernel:
   // [view][vertex] {X, Y, Z, X/Z}, {Y/Z, -, -, -}
   float4* xverts;
+  // ---- record mode (rec != nullptr): the network input [item][row][col][rec_col elements], fp32 or fp16.  View v of an
+  // item writes its render channels (rgb, normals, depth as requested) at element v_c0[v] of the pixel record and, when
+  // v_crop_n[v] > 0, the observed crop's source channels [v_crop_src0[v], + v_crop_n[v]) at element v_crop_c0[v]
+  void* rec;
+  int rec_half, rec_own_all;           // fp16 records; V == 1 and the view owns the whole 16-half record (zero pads written too)
+  int64_t rec_item, rec_row, rec_col;  // element strides
+  int v_c0[kMaxViews], v_crop_c0[kMaxViews], v_crop_src0[kMaxViews], v_crop_n[kMaxViews];
+  int want_nrm, want_depth;            // record mode: which render channels exist
+  // fused crop: the frame(s), one box per item, roi_align sampling ratio, depth rule / normalisation of source channel 3
+  const float* images; int Bi, Ct, IH, IW, sr, crop_nc, crop_depth_mode;
+  const float* boxes; const int32_t* im_ids;
+  unsigned w_magic;                    // p / w = (p * w_magic) >> 32 for p < 2^16
 };
 
 __device__ __forceinline__ void edge_fn(const float* P0, int i0, const float* P1, int i1, float* e) {
@@ -466,11 +488,57 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
   o_n[2] = quant8(normal_code(-nc[2]), q8);
 }
 
+// ---- the band kernel ------------------------------------------------------------------------------------------------
+// LDS of a workgroup (dynamic): zb[npix_max * NS] u64 | ex[npix_max] u16 | plist[npix_max] u16 | folds_y[rows] | folds_x[w]
+// zb: during coverage the 64-bit keys {depth bits : triangle id}; after shading the centre slot of a pixel holds
+// {depth bits (0xFFFFFFFF = no depth) : r | g << 8 | b << 16 | nx << 24} and ex holds ny | nz << 8 (8-bit colour codes).
+struct BandLds {
+  unsigned long long* zb; unsigned short* ex; unsigned short* plist; Fold* fy; Fold* fx;
+};
+__device__ __forceinline__ BandLds carve_lds(unsigned char* base, int npix_max, int ns, int rows) {
+  BandLds l;
+  l.zb = reinterpret_cast<unsigned long long*>(base);
+  base += (size_t)npix_max * ns * 8;
+  l.ex = reinterpret_cast<unsigned short*>(base);
+  base += (size_t)npix_max * 2;
+  l.plist = reinterpret_cast<unsigned short*>(base);
+  base += (size_t)((npix_max * 2 + 15) & ~15);
+  l.fy = reinterpret_cast<Fold*>(base);
+  l.fx = l.fy + rows;
+  return l;
+}
+static size_t band_lds_bytes(int npix_max, int ns, int rows, int w, bool crop) {
+  return (size_t)npix_max * ns * 8 + (size_t)npix_max * 2 + (size_t)((npix_max * 2 + 15) & ~15) + (crop ? (size_t)(rows + w) * sizeof(Fold) : 0) + 16;
+}
+
+__device__ __forceinline__ unsigned code8(float c) {  // quant8(c) = code8(c) / 255
+  c = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+  return (unsigned)floorf(fmaf(c, 255.0f, 0.5f));
+}
+
+// stores n consecutive floats (n <= 8) at dst, 4-B aligned: the widest pieces first
+__device__ __forceinline__ void store_run(float* dst, const float* v, int n) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float f3 __attribute__((ext_vector_type(3)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  switch (n) {
+    case 1: dst[0] = v[0]; break;
+    case 2: *reinterpret_cast<f2*>(dst) = f2{v[0], v[1]}; break;
+    case 3: *reinterpret_cast<f3*>(dst) = f3{v[0], v[1], v[2]}; break;
+    case 4: *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]}; break;
+    case 5: *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]}; dst[4] = v[4]; break;
+    case 6: *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<f2*>(dst + 4) = f2{v[4], v[5]}; break;
+    case 7: *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<f3*>(dst + 4) = f3{v[4], v[5], v[6]}; break;
+    case 8: *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<f4*>(dst + 4) = f4{v[4], v[5], v[6], v[7]}; break;
+    default: break;
+  }
+}
+
 template <int NS>
-__global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
-  __shared__ unsigned long long zb[NS == 1 ? kBandPixels : kBandKeysMsaa];
+__global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a, int npix_max) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int big_q[kBigQueue];
-  __shared__ int big_n;
+  __shared__ int big_n, n_cov, span_max[2];
 
   // XCD-aware renumbering: dispatch order b -> XCD b % 8; give each XCD a contiguous range.
   const int total = a.n * a.n_bands;  // a.n = views of this chunk
@@ -483,6 +551,8 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   const int row1 = min(a.h, row0 + a.band_rows) - 1;
   const int npix = (row1 - row0 + 1) * a.w;
   const int tid = threadIdx.x;
+  const BandLds L = carve_lds(smem, npix_max, NS, a.band_rows);
+  unsigned long long* const zb = L.zb;
 
   float T[12], Kv[9];
 #pragma unroll
@@ -497,7 +567,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) finite &= isfinite(Kv[k]);
 
-  const int item = view / a.views_per_item;
+  const int item = view / a.views_per_item, vi = view % a.views_per_item;
   const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
   const int64_t voff = ob[0], foff = ob[2], toff = ob[4];
   const int nf = finite ? (int)ob[3] : 0;
@@ -505,19 +575,42 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   const float4* xv = a.xverts + 2 * (int64_t)(lin / a.n_bands) * a.max_verts;
   const int32_t* fbase = a.faces + 3 * foff;
 
+  // ---- fused crop: folded roi_align weights of the band's rows and of every column (crop_math.h) ----
+  const int ncrop = (a.rec && a.images && vi < kMaxViews) ? a.v_crop_n[vi] : 0;
+  float cx1 = 0.f, cy1 = 0.f, bin_h = 1.f, bin_w = 1.f;
+  if (ncrop > 0) {
+    const float* box = a.boxes + 4 * (int64_t)item;
+    cx1 = box[0]; cy1 = box[1];
+    float roi_w = box[2] - cx1, roi_h = box[3] - cy1;
+    roi_w = roi_w < 1.0f ? 1.0f : roi_w;  // aligned=False
+    roi_h = roi_h < 1.0f ? 1.0f : roi_h;
+    bin_h = roi_h / (float)a.h; bin_w = roi_w / (float)a.w;
+    if (tid < 2) span_max[tid] = 0;
+    __syncthreads();
+    const int nrows = row1 - row0 + 1;
+    for (int t = tid; t < nrows + a.w; t += kThreads) {
+      const bool is_x = t >= nrows;
+      const int k = is_x ? t - nrows : t;
+      Axis ax;
+      Fold f;
+      if (is_x) make_axis(cx1, k, bin_w, a.sr, a.IW, ax);
+      else make_axis(cy1, row0 + k, bin_h, a.sr, a.IH, ax);
+      fold_axis(ax, a.sr, f.first, f.span, f.w);
+      if (is_x) L.fx[k] = f; else L.fy[k] = f;
+      atomicMax(&span_max[is_x ? 1 : 0], f.span);
+    }
+  }
+
   // ---- coverage + depth: only the triangles binned to this band ----
   const int cnt = nf > 0 ? min(a.bin_count[lin], a.bin_cap) : 0;
   const int32_t* list = a.bin_list + (int64_t)lin * a.bin_cap;
-  // a band no triangle touches (40 % of the bands of the benchmark scenes) skips the z-buffer altogether: the resolve
-  // loop below sees every pixel empty and only streams the background out
+  // a band no triangle touches skips the z-buffer passes altogether: the output pass streams the background (and the crop)
   const bool band_empty = cnt == 0;
   if (!band_empty) {
     for (int p = tid; p < npix * NS; p += kThreads) zb[p] = kKeyEmpty;
-    if (tid == 0) big_n = 0;
-    __syncthreads();
+    if (tid == 0) { big_n = 0; n_cov = 0; }
   }
-  // the list entry and the corner indices of the NEXT triangle are fetched while this one is set up:
-  // the loop is a chain of dependent gathers (list -> faces -> vertices), not arithmetic
+  __syncthreads();
 #ifdef HP_RABL_NO_COVER
   const int cnt_loop = 0;
 #else
@@ -548,8 +641,35 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
       int q = atomicAdd(&big_n, 1);
       if (q < kBigQueue) { big_q[q] = f; continue; }
     }
-    for (int i = s.y0; i <= s.y1; ++i)
-      for (int j = s.x0; j <= s.x1; ++j) shade_pixel<NS>(s, i, j, (uint32_t)f, zb, row0, a.w);
+    if (NS == 1) {
+      for (int i = s.y0; i <= s.y1; ++i)
+        for (int j = s.x0; j <= s.x1; ++j) shade_pixel<NS>(s, i, j, (uint32_t)f, zb, row0, a.w);
+    } else {
+      // multisampling: the bounding box is grown by the sample spread, so most of its pixels have no sample inside the
+      // triangle.  A pixel is skipped when the edge functions at its CENTRE, widened by the largest sample offset (and by
+      // a bound on the rounding of the fp32 evaluation), leave no sample on the inner side of some edge for either
+      // orientation -- the five exact sample tests then all fail anyway.
+      float m[3], sl[3];
+      const float* const ee[3] = {s.e0, s.e1, s.e2};
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const float ax = fabsf(ee[e][0]), ay = fabsf(ee[e][1]);
+        m[e] = fmaxf(fmaf(0.125f, ax, 0.375f * ay), fmaf(0.375f, ax, 0.125f * ay));
+        sl[e] = 4e-6f * fmaf(ax, (float)(s.x1 + 1), fmaf(ay, (float)(s.y1 + 1), fabsf(ee[e][2])));
+        m[e] = m[e] * 1.001f + sl[e];
+      }
+      for (int i = s.y0; i <= s.y1; ++i)
+        for (int j = s.x0; j <= s.x1; ++j) {
+          const float pu = (float)j + 0.5f, pv = (float)i + 0.5f;
+          const float l0 = fmaf(s.e0[0], pu, fmaf(s.e0[1], pv, s.e0[2]));
+          const float l1 = fmaf(s.e1[0], pu, fmaf(s.e1[1], pv, s.e1[2]));
+          const float l2 = fmaf(s.e2[0], pu, fmaf(s.e2[1], pv, s.e2[2]));
+          const bool no_pos = (l0 + m[0] < 0.0f) | (l1 + m[1] < 0.0f) | (l2 + m[2] < 0.0f);
+          const bool no_neg = (l0 - m[0] > 0.0f) | (l1 - m[1] > 0.0f) | (l2 - m[2] > 0.0f);
+          if (no_pos & no_neg) continue;
+          shade_pixel<NS>(s, i, j, (uint32_t)f, zb, row0, a.w);
+        }
+    }
   }
   if (!band_empty) __syncthreads();
   const int nbig = band_empty ? 0 : min(big_n, kBigQueue);
@@ -565,73 +685,264 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
   }
   if (!band_empty) __syncthreads();
 
-  // ---- resolve ----
+  // ---- shading of the compacted covered pixels (8-bit colour codes back into the z-buffer slots) ----
   const int q8 = a.flags & HP_RASTER_QUANT8;
   float amb[3] = {1.0f, 1.0f, 1.0f};
   if (a.ambient) { amb[0] = a.ambient[3 * view]; amb[1] = a.ambient[3 * view + 1]; amb[2] = a.ambient[3 * view + 2]; }
-  const int64_t cbase = (int64_t)item * a.cs.s_item + (int64_t)(view % a.views_per_item) * a.cs.s_view;
-  const int64_t dbase = (int64_t)item * a.ds.s_item + (int64_t)(view % a.views_per_item) * a.ds.s_view;
-  const float zn = a.depth_norm_z ? a.depth_norm_z[item] : 1.0f;
-
   const ShadeCtx cx{T, Kv, amb, xv, fbase, voff, toff, tw, th, view, q8, (int)ob[7] > 0 ? (int)ob[7] : 1,
                     (a.flags & HP_RASTER_TEX_ANISO) != 0};
-  for (int p = tid; p < npix; p += kThreads) {
-    const int i = row0 + p / a.w, j = p % a.w;
-    const unsigned long long key = band_empty ? kKeyEmpty : zb[p * NS + (NS - 1)];  // the pixel centre
-    float o_rgb[3] = {0.f, 0.f, 0.f}, o_n[3] = {0.f, 0.f, 0.f}, o_d = 0.0f;
-    if (key != kKeyEmpty) {
-      const float Z = __uint_as_float((uint32_t)(key >> 32));
-      o_d = Z > a.depth_max ? 0.0f : Z;
+  const bool want_colour = a.rec ? true : (a.rgb != nullptr || a.nrm != nullptr);
+  const bool coded = q8 != 0 && !band_empty;  // colours travel as 8-bit codes through LDS; otherwise the output pass shades
+  if (coded) {
+    const int lane = tid & 63;
+    for (int p0 = 0; p0 < npix; p0 += kThreads) {
+      const int p = p0 + tid;
+      bool cov = false;
+      if (p < npix) {
+        if (NS == 1) cov = zb[p] != kKeyEmpty;
+        else {
+#pragma unroll
+          for (int sm = 0; sm < 4; ++sm) cov |= zb[p * NS + sm] != kKeyEmpty;
+        }
+        cov = cov && want_colour;
+        if (!cov) {  // no fragment: colour codes 0, the depth bits stay
+          zb[p * NS + (NS - 1)] &= 0xFFFFFFFF00000000ull;
+          L.ex[p] = 0;
+        }
+      }
+      const unsigned long long m = __ballot(cov);
+      int base = 0;
+      if (lane == 0 && m != 0) base = atomicAdd(&n_cov, __popcll(m));
+      base = __shfl(base, 0);
+      if (cov) L.plist[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
     }
-    if (NS == 1) {
+    __syncthreads();
+    const int ncov = n_cov;
 #ifdef HP_RABL_NO_SHADE
-      if (key != kKeyEmpty && a.w < 0)
+    const int ncov_loop = a.w < 0 ? ncov : 0;
 #else
-      if (key != kKeyEmpty)
+    const int ncov_loop = ncov;
 #endif
-        shade_centre(a, cx, (int)(key & 0xFFFFFFFFull), i, j, o_rgb, o_n);
-    } else if (!band_empty) {
-      // mean over the four samples of the colour their triangle has at the pixel centre; one invocation per pixel and triangle
-      int cf[4];
-      float crgb[4][3], cn[4][3];
-      int ncached = 0;
-      float a_rgb[3] = {0.f, 0.f, 0.f}, a_n[3] = {0.f, 0.f, 0.f};
+    for (int q = tid; q < ncov_loop; q += kThreads) {
+      const int p = L.plist[q];
+      const int pr = (int)(((unsigned long long)p * a.w_magic) >> 32);
+      const int i = row0 + pr, j = p - pr * a.w;
+      unsigned cr[3], cn[3];
+      if (NS == 1) {
+        float o_rgb[3], o_n[3];
+        shade_centre(a, cx, (int)(zb[p] & 0xFFFFFFFFull), i, j, o_rgb, o_n);
 #pragma unroll
-      for (int sm = 0; sm < 4; ++sm) {
-        const unsigned long long ks = zb[p * NS + sm];
-        if (ks == kKeyEmpty) continue;  // the clear colour
-        const int f = (int)(ks & 0xFFFFFFFFull);
-        int k = ncached;
+        for (int c = 0; c < 3; ++c) { cr[c] = code8(o_rgb[c]); cn[c] = code8(o_n[c]); }
+      } else {
+        // one fragment-shader invocation per pixel and triangle; the pixel's colour is the mean of the four samples' 8-bit
+        // colours (uncovered samples: the clear colour 0), rounded half up -- integer arithmetic, no rounding ties
+        int cf[4];
+        unsigned srgb[4][3], sn[4][3];
+        int ncached = 0;
+        unsigned a_rgb[3] = {0, 0, 0}, a_n[3] = {0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (q < ncached && cf[q] == f) k = q;
-        if (k == ncached) {
-          float r3[3], n3[3];
-          shade_centre(a, cx, f, i, j, r3, n3);
+        for (int sm = 0; sm < 4; ++sm) {
+          const unsigned long long ks = zb[p * NS + sm];
+          if (ks == kKeyEmpty) continue;
+          const int f = (int)(ks & 0xFFFFFFFFull);
+          int k = ncached;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q == ncached) {
-              cf[q] = f;
+          for (int t = 0; t < 4; ++t)
+            if (t < ncached && cf[t] == f) k = t;
+          if (k == ncached) {
+            float r3[3], n3[3];
+            shade_centre(a, cx, f, i, j, r3, n3);
 #pragma unroll
-              for (int c = 0; c < 3; ++c) { crgb[q][c] = r3[c]; cn[q][c] = n3[c]; }
+            for (int t = 0; t < 4; ++t)
+              if (t == ncached) {
+                cf[t] = f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { srgb[t][c] = code8(r3[c]); sn[t][c] = code8(n3[c]); }
+              }
+            ++ncached;
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (t == k) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { a_rgb[c] += srgb[t][c]; a_n[c] += sn[t][c]; }
             }
-          ++ncached;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (q == k) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { a_rgb[c] += crgb[q][c]; a_n[c] += cn[q][c]; }
-          }
+        for (int c = 0; c < 3; ++c) { cr[c] = (a_rgb[c] + 2u) >> 2; cn[c] = (a_n[c] + 2u) >> 2; }
       }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { o_rgb[c] = quant8(a_rgb[c] * 0.25f, q8); o_n[c] = quant8(a_n[c] * 0.25f, q8); }
+      const unsigned long long hi = zb[p * NS + (NS - 1)] & 0xFFFFFFFF00000000ull;
+      zb[p * NS + (NS - 1)] = hi | (unsigned long long)(cr[0] | (cr[1] << 8) | (cr[2] << 16) | (cn[0] << 24));
+      L.ex[p] = (unsigned short)(cn[1] | (cn[2] << 8));
     }
+  }
+  __syncthreads();
+
+  // ---- output pass: pixel-parallel; crop taps + the view's run(s) of the pixel record, or the strided planes ----
+  const float zn = a.depth_norm_z ? a.depth_norm_z[item] : 1.0f;
+  const int64_t cbase = (int64_t)item * a.cs.s_item + (int64_t)vi * a.cs.s_view;
+  const int64_t dbase = (int64_t)item * a.ds.s_item + (int64_t)vi * a.ds.s_view;
+  const bool half_out = (a.flags & HP_RASTER_OUT_F16) != 0;  // fp16 network input written directly
+  // crop source
+  const float* img = nullptr;
+  bool bad_id = false;
+  int nr_max = 0, nc_max = 0, csrc0 = 0;
+  bool separable = true;
+  if (ncrop > 0) {
+    const int im_id = a.im_ids[item];
+    bad_id = (unsigned)im_id >= (unsigned)a.Bi;  // reads frame 0, writes zeros (the reference's indexing would raise)
+    img = a.images + (int64_t)(bad_id ? 0 : im_id) * a.Ct * a.IH * a.IW;
+    nr_max = span_max[0]; nc_max = span_max[1];
+    separable = nr_max <= kSpan && nc_max <= kSpan;
+    csrc0 = a.v_crop_src0[vi];
+  }
+  const int HW = a.IH * a.IW;
+  const float count = (float)(a.sr * a.sr);
+  for (int p = tid; p < npix; p += kThreads) {
+    const int pr = (int)(((unsigned long long)p * a.w_magic) >> 32);
+    const int i = row0 + pr, j = p - pr * a.w;
+    float o_rgb[3] = {0.f, 0.f, 0.f}, o_n[3] = {0.f, 0.f, 0.f}, o_d = 0.0f;
+    if (!band_empty) {
+      const unsigned long long slot = zb[p * NS + (NS - 1)];
+      const uint32_t zbits = (uint32_t)(slot >> 32);
+      if (zbits != 0xFFFFFFFFu) {
+        const float Z = __uint_as_float(zbits);
+        o_d = Z > a.depth_max ? 0.0f : Z;
+      }
+      if (coded) {
+        const uint32_t lo = (uint32_t)slot;
+        const uint32_t ex = L.ex[p];
+        o_rgb[0] = (float)(lo & 255u) / 255.0f; o_rgb[1] = (float)((lo >> 8) & 255u) / 255.0f; o_rgb[2] = (float)((lo >> 16) & 255u) / 255.0f;
+        o_n[0] = (float)(lo >> 24) / 255.0f; o_n[1] = (float)(ex & 255u) / 255.0f; o_n[2] = (float)(ex >> 8) / 255.0f;
+      } else if (want_colour) {  // unquantised colours (diagnostics): shaded here, in pixel order
+        if (NS == 1) {
+          if (slot != kKeyEmpty) shade_centre(a, cx, (int)(slot & 0xFFFFFFFFull), i, j, o_rgb, o_n);
+        } else {
+          float a_rgb[3] = {0.f, 0.f, 0.f}, a_n[3] = {0.f, 0.f, 0.f};
+          for (int sm = 0; sm < 4; ++sm) {
+            const unsigned long long ks = zb[p * NS + sm];
+            if (ks == kKeyEmpty) continue;
+            float r3[3], n3[3];
+            shade_centre(a, cx, (int)(ks & 0xFFFFFFFFull), i, j, r3, n3);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a_rgb[c] += r3[c]; a_n[c] += n3[c]; }
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { o_rgb[c] = a_rgb[c] * 0.25f; o_n[c] = a_n[c] * 0.25f; }
+        }
+      }
+    }
+    float d_out = o_d;
+    if (a.depth_norm_mode == 1) d_out = o_d / zn;
+    else if (a.depth_norm_mode == 2) d_out = fminf(fmaxf(o_d / zn, 0.0f), 2.0f) - 1.0f;
+    else if (a.depth_norm_mode == 3) d_out = fminf(fmaxf(o_d - zn, -2.0f), 2.0f);
+
+    if (a.rec) {
+      // ---- crop channels of this pixel (roi_align of the frame; same taps in the same order as crop_tile_kernel) ----
+      float cropv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ncrop > 0) {
+        const Fold fy = L.fy[pr], fx = L.fx[j];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float vacc = 0.0f;
+        if (separable) {
+          const int off0 = fy.first * a.IW + fx.first;
+#pragma unroll
+          for (int r = 0; r < kSpan; ++r) {
+            if (r >= nr_max) break;
+            if (r < fy.span) {
+              const int off = off0 + r * a.IW;
+              float racc[4] = {0.f, 0.f, 0.f, 0.f};
+              float rv = 0.0f;
+#pragma unroll
+              for (int c2 = 0; c2 < kSpan; ++c2) {
+                if (c2 >= nc_max) break;
+                if (c2 < fx.span) {
+                  const float wj = fx.w[c2];
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    if (c < ncrop) {
+                      const int sc = csrc0 + c;
+                      const float v = img[sc * HW + off + c2];
+                      racc[c] += wj * v;
+                      if (sc == 3) rv += wj * (v > 0.0f ? 1.0f : 0.0f);
+                    }
+                  }
+                }
+              }
+              const float wi = fy.w[r];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[c] += wi * racc[c];
+              vacc += wi * rv;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < ncrop) {
+              const int sc = csrc0 + c;
+              float sacc = 0.0f, svv = 0.0f;
+              slow_pixel(img + (int64_t)sc * HW, a.IH, a.IW, cy1, cx1, i, j, bin_h, bin_w, a.sr, sc == 3, sacc, svv);
+              acc[c] = sacc;
+              if (sc == 3) vacc = svv;
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c < ncrop) {
+            float val = acc[c] / count;
+            if (csrc0 + c == 3) {
+              if (vacc / count < 0.99f) val = 0.0f;  // TB/lib3d/cropping.py:184-195
+              if (a.crop_depth_mode == 1) val = val / zn;
+              else if (a.crop_depth_mode == 2) val = fminf(fmaxf(val / zn, 0.0f), 2.0f) - 1.0f;
+              else if (a.crop_depth_mode == 3) val = fminf(fmaxf(val - zn, -2.0f), 2.0f);
+            }
+            cropv[c] = bad_id ? 0.0f : val;
+          }
+        }
+      }
+      // ---- the record ----
+      float rend[7];
+      int nrend = 3;
+      rend[0] = o_rgb[0]; rend[1] = o_rgb[1]; rend[2] = o_rgb[2];
+      if (a.want_nrm) { rend[3] = o_n[0]; rend[4] = o_n[1]; rend[5] = o_n[2]; nrend = 6; }
+      if (a.want_depth) {
+        if (nrend == 6) rend[6] = d_out; else rend[3] = d_out;
+        ++nrend;
+      }
+      const int64_t pix = (int64_t)item * a.rec_item + (int64_t)i * a.rec_row + (int64_t)j * a.rec_col;
+      const int c0 = a.v_c0[vi], cc0 = a.v_crop_c0[vi];
+      if (a.rec_half) {
+        _Float16* const o = reinterpret_cast<_Float16*>(a.rec) + pix;
+        if (a.rec_own_all) {  // one view owns the whole 16-half record: two 16-B stores, pads included
+          typedef _Float16 halfx8v __attribute__((ext_vector_type(8)));
+          _Float16 hv[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {  // compile-time k: no indexed register array (a stack would break hipGraph replay)
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v = (c < ncrop && cc0 + c == k) ? cropv[c] : v;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) v = (c < nrend && c0 + c == k) ? rend[c] : v;
+            hv[k] = (_Float16)v;
+          }
+          *reinterpret_cast<halfx8v*>(o) = halfx8v{hv[0], hv[1], hv[2], hv[3], hv[4], hv[5], hv[6], hv[7]};
+          *reinterpret_cast<halfx8v*>(o + 8) = halfx8v{hv[8], hv[9], hv[10], hv[11], hv[12], hv[13], hv[14], hv[15]};
+        } else {
+          for (int c = 0; c < ncrop; ++c) o[cc0 + c] = (_Float16)cropv[c];
+          for (int c = 0; c < nrend; ++c) o[c0 + c] = (_Float16)rend[c];
+        }
+      } else {
+        float* const o = reinterpret_cast<float*>(a.rec) + pix;
+        if (ncrop > 0) store_run(o + cc0, cropv, ncrop);
+        store_run(o + c0, rend, nrend);
+      }
+      continue;
+    }
+
+    // ---- strided planes (hp_rasterize: NCHW tensors or any strides) ----
     const int64_t co = cbase + (int64_t)i * a.cs.s_row + (int64_t)j * a.cs.s_col;
-    // channel-interleaved destinations (NHWC slices of the network input): one 12-B store per pixel
-    // instead of three 4-B ones (the slice is 4-B aligned only, so no wider)
     typedef float float3v __attribute__((ext_vector_type(3)));
-    const bool half_out = (a.flags & HP_RASTER_OUT_F16) != 0;  // fp16 network input written directly
     if (a.rgb) {
       if (half_out) {
         _Float16* const o = reinterpret_cast<_Float16*>(a.rgb);
@@ -656,13 +967,9 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a) {
     }
     if (a.mask) a.mask[((int64_t)view * a.h + i) * a.w + j] = o_d > 0.0f ? 1 : 0;
     if (a.depth) {
-      float d = o_d;
-      if (a.depth_norm_mode == 1) d = d / zn;
-      else if (a.depth_norm_mode == 2) d = fminf(fmaxf(d / zn, 0.0f), 2.0f) - 1.0f;
-      else if (a.depth_norm_mode == 3) d = fminf(fmaxf(d - zn, -2.0f), 2.0f);
       const int64_t dof = dbase + (int64_t)i * a.ds.s_row + (int64_t)j * a.ds.s_col;
-      if (half_out) reinterpret_cast<_Float16*>(a.depth)[dof] = (_Float16)d;
-      else a.depth[dof] = d;
+      if (half_out) reinterpret_cast<_Float16*>(a.depth)[dof] = (_Float16)d_out;
+      else a.depth[dof] = d_out;
     }
   }
 }
@@ -720,6 +1027,61 @@ extern "C" int hp_mesh_store_reserve_raster(hp_mesh_store* store, int n_views, i
 
 extern "C" int64_t hp_mesh_store_scratch_generation(const hp_mesh_store* store) { return store ? store->scratch_generation : -1; }
 
+namespace hp {
+// Common launch path of hp_rasterize (strided planes) and hp_render_inputs (network-input records + fused crop).
+static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool crop, hipStream_t st) {
+  const int h = a.h, w = a.w;
+  a.msaa = (a.flags & HP_RASTER_MSAA4) && (a.rec || a.rgb || a.nrm) ? 1 : 0;  // depth-only renders have nothing to multisample
+  const int ns = a.msaa ? kSamplesMsaa : 1;
+  static const int rows_env = std::getenv("HP_RASTER_ROWS") ? std::atoi(std::getenv("HP_RASTER_ROWS")) : 0;
+  const int budget = a.msaa ? kBandKeysMsaa / kSamplesMsaa : kBandPixels;  // pixels of a band
+  HP_REQUIRE(w <= budget, "hp_rasterize: image too wide for one band");
+  a.band_rows = rows_env > 0 && !a.msaa && rows_env * w <= 2 * kBandPixels ? rows_env : budget / w;
+  if (a.band_rows > h) a.band_rows = h;
+  a.n_bands = (h + a.band_rows - 1) / a.band_rows;
+  HP_REQUIRE(a.n_bands <= kMaxBands, "hp_rasterize: unsupported resolution (too many bands)");
+  const int npix_max = a.band_rows * w;
+  HP_REQUIRE(npix_max < 65536, "hp_rasterize: band too large");
+  a.w_magic = (unsigned)(0x100000000ull / (unsigned)w + 1);
+  a.depth_max = kZNear / (1.0f - (1.0f - 1e-3f) * (kZFar - kZNear) / kZFar);
+  // Views are processed in chunks so that the per-(view, band) triangle lists stay within a fixed scratch budget.  The
+  // scratch is owned by the store and only ever grows (hp_mesh_store_reserve_raster pre-sizes it; predictors do that at
+  // construction for their largest batch); a growth bumps the store's scratch generation, which tells holders of
+  // captured hipGraphs that the pointers their launches carry are gone.  Callers sharing one store must be stream-ordered.
+  hp::MeshStore* ms = const_cast<hp_mesh_store*>(store);
+  a.max_faces = (int)store->max_faces;
+  a.bin_cap = a.max_faces;
+  a.max_verts = (int)store->max_verts;
+  int chunk = 0;
+  {
+    const int rc = raster_scratch(ms, n, a.n_bands, st, &chunk);
+    if (rc) return rc;
+  }
+  a.bin_list = ms->bin_list;
+  a.bin_count = ms->bin_count;
+  a.xverts = ms->xverts;
+  const size_t lds = band_lds_bytes(npix_max, ns, a.band_rows, w, crop);
+  HP_REQUIRE(lds <= 150 * 1024, "hp_rasterize: band does not fit the LDS");
+  static size_t opted[2] = {0, 0};
+  if (opted[a.msaa] < lds) {
+    if (a.msaa) HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&raster_kernel<kSamplesMsaa>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&raster_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    opted[a.msaa] = lds;
+  }
+  for (int v0 = 0; v0 < n; v0 += chunk) {
+    const int nv = n - v0 < chunk ? n - v0 : chunk;
+    a.view0 = v0;
+    a.n = nv;
+    hipLaunchKernelGGL(raster_xform_kernel, dim3((a.max_verts + 255) / 256, nv), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(raster_bin_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
+    const int total = nv * a.n_bands;
+    if (a.msaa) hipLaunchKernelGGL(raster_kernel<kSamplesMsaa>, dim3(8 * ((total + 7) / 8)), dim3(kThreads), lds, st, a, npix_max);
+    else hipLaunchKernelGGL(raster_kernel<1>, dim3(8 * ((total + 7) / 8)), dim3(kThreads), lds, st, a, npix_max);
+  }
+  return check_launch("raster_kernel");
+}
+}  // namespace hp
+
 extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
                             const int32_t* d_obj_ids, const float* d_TCO, const float* d_K,
                             const float* d_ambient, int n_lights, const float* d_light_pos,
@@ -731,14 +1093,12 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   HP_REQUIRE(store != nullptr, "hp_rasterize: null mesh store");
   HP_REQUIRE(n >= 0 && views_per_item >= 1 && n % views_per_item == 0,
              "hp_rasterize: n must be a multiple of views_per_item");
-  HP_REQUIRE(h > 0 && w > 0 && w <= kBandPixels && (h + kBandPixels / w - 1) / (kBandPixels / w) <= kMaxBands,
-             "hp_rasterize: unsupported resolution");
+  HP_REQUIRE(h > 0 && w > 0, "hp_rasterize: unsupported resolution");
   HP_REQUIRE(!d_mask || d_depth, "Binary mask can only be rendered if depth is rendered");
   if (n == 0) return HP_OK;
   HP_REQUIRE(d_TCO && d_K && d_obj_ids, "hp_rasterize: null pose/intrinsics/object ids");
   HP_REQUIRE(!(d_rgb || d_nrm) || color_strides, "hp_rasterize: colour strides missing");
   HP_REQUIRE(!d_depth || depth_strides, "hp_rasterize: depth strides missing");
-  HP_REQUIRE(!d_mask || d_depth, "Binary mask can only be rendered if depth is rendered");
   HP_REQUIRE(n_lights == 0 || (d_light_pos && d_light_col), "hp_rasterize: lights missing");
   HP_REQUIRE(depth_norm_mode >= 0 && depth_norm_mode <= 3, "hp_rasterize: bad depth_norm_mode");
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_rasterize: depth_norm_z missing");
@@ -752,39 +1112,64 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   if (depth_strides) a.ds = *depth_strides;
   a.n = n; a.views_per_item = views_per_item; a.n_lights = n_lights; a.h = h; a.w = w;
   a.flags = flags; a.depth_norm_mode = depth_norm_mode;
-  a.msaa = (flags & HP_RASTER_MSAA4) && (d_rgb || d_nrm) ? 1 : 0;  // depth-only renders have nothing to multisample
-  if (a.msaa)
-    HP_REQUIRE(kSamplesMsaa * w <= kBandKeysMsaa && (h + kBandKeysMsaa / (kSamplesMsaa * w) - 1) / (kBandKeysMsaa / (kSamplesMsaa * w)) <= kMaxBands,
-               "hp_rasterize: resolution too large for HP_RASTER_MSAA4");
-  a.band_rows = a.msaa ? kBandKeysMsaa / (kSamplesMsaa * w) : kBandPixels / w;
-  a.n_bands = (h + a.band_rows - 1) / a.band_rows;
-  a.depth_max = kZNear / (1.0f - (1.0f - 1e-3f) * (kZFar - kZNear) / kZFar);
-  // Views are processed in chunks so that the per-(view, band) triangle lists stay within a fixed scratch budget.  The
-  // scratch is owned by the store and only ever grows (hp_mesh_store_reserve_raster pre-sizes it; predictors do that at
-  // construction for their largest batch); a growth bumps the store's scratch generation, which tells holders of
-  // captured hipGraphs that the pointers their launches carry are gone.  Callers sharing one store must be stream-ordered.
-  hp::MeshStore* ms = const_cast<hp_mesh_store*>(store);
-  a.max_faces = (int)store->max_faces;
-  a.bin_cap = a.max_faces;
-  a.max_verts = (int)store->max_verts;
-  hipStream_t st = (hipStream_t)stream;
-  int chunk = 0;
-  {
-    const int rc = raster_scratch(ms, n, a.n_bands, st, &chunk);
-    if (rc) return rc;
+  return launch_raster(store, a, n, false, (hipStream_t)stream);
+}
+
+extern "C" int hp_render_inputs(const hp_mesh_store* store, int n_items, int views_per_item, const int32_t* d_obj_ids,
+                                const float* d_TCV_O, const float* d_KV, const float* d_ambient, int n_lights,
+                                const float* d_light_pos, const float* d_light_col, int h, int w, int flags,
+                                const float* d_images, int Bi, int Ct, int H, int W, const float* d_boxes,
+                                const int32_t* d_im_ids, int sampling_ratio, const float* d_depth_norm_z, int depth_norm_mode,
+                                void* d_x, int record_elems, const hp_input_layout* layout, void* stream) {
+  using namespace hp;
+  HP_REQUIRE(store != nullptr, "hp_render_inputs: null mesh store");
+  HP_REQUIRE(n_items >= 0 && views_per_item >= 1 && views_per_item <= kMaxViews, "hp_render_inputs: 1..8 views per item");
+  HP_REQUIRE(h > 0 && w > 0 && record_elems > 0 && layout && d_x, "hp_render_inputs: bad sizes / null pointer");
+  if (n_items == 0) return HP_OK;
+  HP_REQUIRE(d_TCV_O && d_KV && d_obj_ids, "hp_render_inputs: null pose/intrinsics/object ids");
+  HP_REQUIRE(n_lights == 0 || (d_light_pos && d_light_col), "hp_render_inputs: lights missing");
+  HP_REQUIRE(depth_norm_mode >= 0 && depth_norm_mode <= 3, "hp_render_inputs: bad depth_norm_mode");
+  HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_render_inputs: depth_norm_z missing");
+  const int want_nrm = (flags & HP_RENDER_NORMALS) != 0, want_depth = (flags & HP_RENDER_DEPTH) != 0;
+  const int n_rc = 3 + 3 * want_nrm + want_depth;
+  bool crop = false;
+  for (int v = 0; v < views_per_item; ++v) {
+    HP_REQUIRE(layout->view_c0[v] >= 0 && layout->view_c0[v] + n_rc <= record_elems, "hp_render_inputs: a view's render channels leave the record");
+    const int nc = layout->crop_n[v];
+    HP_REQUIRE(nc >= 0 && nc <= 4, "hp_render_inputs: 0..4 crop channels per view");
+    if (nc > 0) {
+      crop = true;
+      HP_REQUIRE(layout->crop_src0[v] >= 0 && layout->crop_src0[v] + nc <= Ct && layout->crop_c0[v] >= 0 &&
+                 layout->crop_c0[v] + nc <= record_elems, "hp_render_inputs: crop channels leave the frame / the record");
+    }
   }
-  a.bin_list = ms->bin_list;
-  a.bin_count = ms->bin_count;
-  a.xverts = ms->xverts;
-  for (int v0 = 0; v0 < n; v0 += chunk) {
-    const int nv = n - v0 < chunk ? n - v0 : chunk;
-    a.view0 = v0;
-    a.n = nv;
-    hipLaunchKernelGGL(raster_xform_kernel, dim3((a.max_verts + 255) / 256, nv), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(raster_bin_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
-    const int total = nv * a.n_bands;
-    if (a.msaa) hipLaunchKernelGGL(raster_kernel<kSamplesMsaa>, dim3(8 * ((total + 7) / 8)), dim3(kThreads), 0, st, a);
-    else hipLaunchKernelGGL(raster_kernel<1>, dim3(8 * ((total + 7) / 8)), dim3(kThreads), 0, st, a);
+  if (crop) {
+    HP_REQUIRE(d_images && d_boxes && d_im_ids, "hp_render_inputs: crop source missing");
+    HP_REQUIRE((Ct == 3 || Ct == 4) && H > 0 && W > 0 && Bi > 0, "hp_render_inputs: frames must be [Bi][3|4][H][W]");
+    HP_REQUIRE(sampling_ratio >= 1 && sampling_ratio <= kMaxSR, "hp_render_inputs: sampling_ratio must be 1..4");
   }
-  return check_launch("raster_kernel");
+  RasterArgs a{};
+  a.verts4 = store->verts4; a.normals4 = store->normals4; a.uvs = store->uvs; a.colors = store->colors;
+  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj;
+  a.obj_ids = d_obj_ids; a.TCO = d_TCV_O; a.K = d_KV; a.ambient = d_ambient;
+  a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
+  a.n = n_items * views_per_item; a.views_per_item = views_per_item; a.n_lights = n_lights; a.h = h; a.w = w;
+  a.flags = flags & ~(HP_RENDER_NORMALS | HP_RENDER_DEPTH);
+  a.depth_norm_mode = want_depth ? depth_norm_mode : 0;
+  a.rec = d_x;
+  a.rec_half = (flags & HP_RASTER_OUT_F16) != 0;
+  a.rec_col = record_elems; a.rec_row = (int64_t)record_elems * w; a.rec_item = (int64_t)record_elems * w * h;
+  a.rec_own_all = a.rec_half && views_per_item == 1 && record_elems == 16 && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0;
+  a.want_nrm = want_nrm; a.want_depth = want_depth;
+  for (int v = 0; v < kMaxViews; ++v) {
+    const bool on = v < views_per_item;
+    a.v_c0[v] = on ? layout->view_c0[v] : 0;
+    a.v_crop_c0[v] = on ? layout->crop_c0[v] : 0;
+    a.v_crop_src0[v] = on ? layout->crop_src0[v] : 0;
+    a.v_crop_n[v] = on ? layout->crop_n[v] : 0;
+  }
+  a.images = crop ? d_images : nullptr; a.Bi = Bi; a.Ct = Ct; a.IH = H; a.IW = W; a.sr = sampling_ratio;
+  a.crop_depth_mode = depth_norm_mode;
+  a.boxes = d_boxes; a.im_ids = d_im_ids;
+  return launch_raster(store, a, a.n, crop, (hipStream_t)stream);
 }

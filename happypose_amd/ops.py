@@ -165,29 +165,49 @@ def rasterize(store: MeshStore, obj_ids: torch.Tensor, TCO: torch.Tensor, K: tor
     return rgb, nrm, dep, (msk.bool() if msk is not None else None)
 
 
-def rasterize_into(store: MeshStore, x: torch.Tensor, chan0: int, obj_ids: torch.Tensor,
-                   TCV_O: torch.Tensor, KV: torch.Tensor, render_normals: bool, render_depth: bool,
-                   depth_norm_z: Optional[torch.Tensor] = None, depth_norm_mode: int = 0,
-                   ambient: Optional[torch.Tensor] = None, msaa: bool = False, aniso: bool = False,
-                   light_pos: Optional[torch.Tensor] = None, light_col: Optional[torch.Tensor] = None) -> None:
-    """Render ``V`` views per hypothesis straight into channel slices of the NHWC network
-    input ``x [b,h,w,c_pad]``: view ``v`` occupies channels ``chan0 + v*C_r ...`` in the
-    reference's order rgb, normals, depth (MP/models/pose_rigid.py:437-453)."""
+def render_inputs(store: MeshStore, x: torch.Tensor, obj_ids: torch.Tensor, TCV_O: torch.Tensor, KV: torch.Tensor,
+                  render_normals: bool, render_depth: bool, *, images: Optional[torch.Tensor] = None,
+                  boxes: Optional[torch.Tensor] = None, im_ids: Optional[torch.Tensor] = None, n_img_channels: int = 0,
+                  depth_norm_z: Optional[torch.Tensor] = None, depth_norm_mode: int = 0, chan0: Optional[int] = None,
+                  layout=None, ambient: Optional[torch.Tensor] = None, light_pos: Optional[torch.Tensor] = None,
+                  light_col: Optional[torch.Tensor] = None, msaa: bool = False, aniso: bool = False,
+                  sampling_ratio: int = 4) -> None:
+    """``hp_render_inputs``: the network input ``x [b,h,w,c_rec]`` (fp32 or fp16) of one iteration in ONE pass -- ``V``
+    rendered views per hypothesis (channels rgb, normals, depth in the reference's order,
+    ``MP/models/pose_rigid.py:437-453``) and, when ``images`` is given, the observed crop (``crop_images`` =
+    torchvision ``roi_align`` of frame ``im_ids[i]`` over ``boxes[i]``, ``TB/lib3d/cropping.py:155-197``, with the RGB-D
+    validity rule and the depth normalisation of ``normalize_images``).  Default layout = the reference's
+    ``cat((images_crop, renders))``: crop channels ``[0, n_img_channels)`` (written by view 0's workgroups), view ``v`` at
+    ``chan0 + v * C_r`` (``chan0`` defaults to ``n_img_channels``).  ``layout`` = ``(view_c0, crop_c0, crop_src0,
+    crop_n)`` lists per view overrides it (permuted inputs).  Every pixel record is written once."""
     dev = store.device
     b, h, w, cp = x.shape
     V = TCV_O.shape[1]
-    assert TCV_O.shape == (b, V, 4, 4) and KV.shape == (b, V, 3, 3)
+    assert TCV_O.shape == (b, V, 4, 4) and KV.shape == (b, V, 3, 3) and 1 <= V <= 8
     c_r = 3 + (3 if render_normals else 0) + (1 if render_depth else 0)
-    assert chan0 + V * c_r <= cp
-    TCV_O, KV, obj_ids = _f32(TCV_O, dev), _f32(KV, dev), _i32(obj_ids, dev)
-    cs = Strides(h * w * cp, c_r, 1, w * cp, cp)
     assert x.dtype in (torch.float32, torch.float16) and x.is_contiguous()
-    esz = x.element_size()  # fp16: the input of an fp16 network plan, written directly (HP_RASTER_OUT_F16)
-    base = x.data_ptr() + esz * chan0
-    rgb_p = C.c_void_p(base)
-    nrm_p = C.c_void_p(base + esz * 3) if render_normals else None
-    dep_p = C.c_void_p(base + esz * (6 if render_normals else 3)) if render_depth else None
-    flags = 8 | (16 if x.dtype == torch.float16 else 0) | (32 if msaa else 0) | (64 if aniso else 0)
+    TCV_O, KV, obj_ids = _f32(TCV_O, dev), _f32(KV, dev), _i32(obj_ids, dev)
+    crop = images is not None
+    lay = _ffi.InputLayout()
+    if layout is None:
+        c0 = (n_img_channels if crop else 0) if chan0 is None else chan0
+        assert c0 + V * c_r <= cp
+        for v in range(V):
+            lay.view_c0[v] = c0 + v * c_r
+        if crop:
+            lay.crop_n[0], lay.crop_c0[0], lay.crop_src0[0] = n_img_channels, 0, 0
+    else:
+        for name, vals in zip(("view_c0", "crop_c0", "crop_src0", "crop_n"), layout):
+            assert len(vals) == V
+            for v, val in enumerate(vals):
+                getattr(lay, name)[v] = int(val)
+    Bi = Ct = H = W = 0
+    if crop:
+        assert images.dtype == torch.float32 and images.is_contiguous() and images.dim() == 4
+        Bi, Ct, H, W = images.shape
+        _check_ids(im_ids, Bi, "render_inputs: im_ids -> images")
+        boxes, im_ids = _f32(boxes, dev), _i32(im_ids, dev)
+        assert boxes.shape == (b, 4) and im_ids.shape == (b,)
     n_lights = 0
     if light_pos is not None:  # [b*V, L, 3] object-frame positions + colours of point lights, ambient [b*V, 3]
         light_pos, light_col = _f32(light_pos, dev), _f32(light_col, dev)
@@ -196,11 +216,28 @@ def rasterize_into(store: MeshStore, x: torch.Tensor, chan0: int, obj_ids: torch
     if ambient is not None:
         ambient = _f32(ambient, dev)
         assert ambient.shape == (b * V, 3)
+    flags = 8 | (16 if x.dtype == torch.float16 else 0) | (32 if msaa else 0) | (64 if aniso else 0) | \
+        (0x1000 if render_normals else 0) | (0x2000 if render_depth else 0)
+    mode = depth_norm_mode if (render_depth or (crop and n_img_channels == 4)) else 0
     with torch.cuda.device(dev):
-        check(lib().hp_rasterize(store.handle, b * V, V, ptr(obj_ids), ptr(TCV_O), ptr(KV), ptr(ambient), n_lights,
-                                 ptr(light_pos), ptr(light_col), h, w, flags, rgb_p, nrm_p, C.byref(cs), dep_p, C.byref(cs), None,
-                                 ptr(depth_norm_z), depth_norm_mode if render_depth else 0, stream_ptr(dev)),
-              "hp_rasterize")
+        check(lib().hp_render_inputs(store.handle, b, V, ptr(obj_ids), ptr(TCV_O), ptr(KV), ptr(ambient), n_lights, ptr(light_pos),
+                                     ptr(light_col), h, w, flags, ptr(images) if crop else None, Bi, Ct, H, W,
+                                     ptr(boxes) if crop else None, ptr(im_ids) if crop else None, sampling_ratio,
+                                     ptr(depth_norm_z) if mode else None, mode, C.c_void_p(x.data_ptr()), cp, C.byref(lay),
+                                     stream_ptr(dev)), "hp_render_inputs")
+
+
+def rasterize_into(store: MeshStore, x: torch.Tensor, chan0: int, obj_ids: torch.Tensor,
+                   TCV_O: torch.Tensor, KV: torch.Tensor, render_normals: bool, render_depth: bool,
+                   depth_norm_z: Optional[torch.Tensor] = None, depth_norm_mode: int = 0,
+                   ambient: Optional[torch.Tensor] = None, msaa: bool = False, aniso: bool = False,
+                   light_pos: Optional[torch.Tensor] = None, light_col: Optional[torch.Tensor] = None) -> None:
+    """Render ``V`` views per hypothesis straight into channel slices of the NHWC network
+    input ``x [b,h,w,c_pad]``: view ``v`` occupies channels ``chan0 + v*C_r ...`` in the
+    reference's order rgb, normals, depth (MP/models/pose_rigid.py:437-453).  (:func:`render_inputs` without the crop.)"""
+    render_inputs(store, x, obj_ids, TCV_O, KV, render_normals, render_depth, depth_norm_z=depth_norm_z,
+                  depth_norm_mode=depth_norm_mode, chan0=chan0, ambient=ambient, light_pos=light_pos, light_col=light_col,
+                  msaa=msaa, aniso=aniso)
 
 
 def pose_prep(store: MeshStore, TCO: torch.Tensor, K: torch.Tensor, im_ids: torch.Tensor,

@@ -195,9 +195,6 @@ class _RenderAndCompare:
                              remove_TCO_rendering=remove_TCO_rendering)
         x = self._input_buffer(b)
         z = prep["tCR"][:, 2].contiguous() if depth_mode else None
-        ops.crop_roi_align(images, prep["boxes_crop"], im_ids, self.render_size, out=x,
-                           depth_norm_z=z, depth_norm_mode=depth_mode if n_img_channels == 4 else 0,
-                           n_channels=n_img_channels, owns_record=True)  # the rasteriser writes the rest of the record next
         t0 = time.time()
         lights = {}
         if scene_lights:  # the reference's make_scene_lights() per view: ambient 0.1 + six point lights around the object
@@ -206,8 +203,10 @@ class _RenderAndCompare:
             ov = obj_ids.long().repeat_interleave(V)
             lights = dict(ambient=amb[None].expand(b * V, 3).contiguous(), light_pos=pos[ov].contiguous(),
                           light_col=col[None].expand(b * V, -1, 3).contiguous())
-        ops.rasterize_into(self.store, x, n_img_channels, obj_ids, prep["TCV_O"], prep["K_crop"],
-                           render_normals, render_depth, z, depth_mode, msaa=self.renderer.msaa, aniso=self.renderer.aniso, **lights)
+        # crop of the observation + the rendered views: one launch, every pixel record of x written once
+        ops.render_inputs(self.store, x, obj_ids, prep["TCV_O"], prep["K_crop"], render_normals, render_depth,
+                          images=images, boxes=prep["boxes_crop"], im_ids=im_ids, n_img_channels=n_img_channels,
+                          depth_norm_z=z, depth_norm_mode=depth_mode, msaa=self.renderer.msaa, aniso=self.renderer.aniso, **lights)
         render_time = time.time() - t0
         pose, logits, _ = self.backbone.forward(x, want_pose=want_pose, want_logits=want_logits)
         return prep, x, pose, logits, render_time

@@ -124,6 +124,46 @@ int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
                  const float* d_depth_norm_z, int depth_norm_mode, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Network input of one refiner / scoring iteration in ONE pass: render the views of every hypothesis AND crop the
+ * observation, each pixel record of the NHWC input written once.  Replaces, per iteration,
+ *   crop_inputs -> crop_images (torchvision roi_align)       MP/models/pose_rigid.py:199-277, TB/lib3d/cropping.py:155-197
+ *   render_images_multiview -> Panda3dBatchRenderer.render    MP/models/pose_rigid.py:376-453
+ *   normalize_images + torch.cat((images_crop, renders))      MP/models/pose_rigid.py:455-544,624-629
+ * (CosyPose: CP/models/pose.py:58-93,129-157).  Same arithmetic as hp_crop_roi_align followed by hp_rasterize into channel
+ * slices; what changes is the memory traffic: no kernel touches a 32-B sector another kernel (or another workgroup) also
+ * writes -- rocprofv3 counted 3x the algorithmic bytes for the two-launch form (profiles/r03a_raster_hbm_traffic.json).
+ *
+ * d_x: [n_items][h][w][record_elems] fp32, or fp16 with HP_RASTER_OUT_F16.  View v of an item writes
+ *   its render channels -- rgb, then normals (HP_RENDER_NORMALS), then depth (HP_RENDER_DEPTH, normalised per
+ *   depth_norm_mode as in hp_rasterize) -- at elements [view_c0[v], ...) of every pixel record, and
+ *   crop_n[v] channels of the observed crop, source channels [crop_src0[v], crop_src0[v] + crop_n[v]) of the frame
+ *   d_images[d_im_ids[item]] resampled from d_boxes[item] with torchvision's roi_align (sampling_ratio^2 samples,
+ *   aligned = False; source channel 3 = depth: validity rule of TB/lib3d/cropping.py:184-195 and the same
+ *   normalisation), at elements [crop_c0[v], ...).
+ * The reference's channel order is {crop_n = {C_img, 0, ...}, crop_c0 = {0}, view_c0[v] = C_img + v * C_r}; any other
+ * assignment (e.g. view v = one 32-B sector holding its 7 channels + crop channel v) needs the network's first layer
+ * permuted accordingly.  Elements of a record nobody is assigned keep their value (the pads of a zeroed input stay 0).
+ * ---------------------------------------------------------------------------------- */
+#define HP_RENDER_NORMALS 0x1000
+#define HP_RENDER_DEPTH 0x2000
+
+typedef struct {
+  int view_c0[8];   /* first record element of view v's render channels */
+  int crop_c0[8];   /* first record element of the crop channels view v produces */
+  int crop_src0[8]; /* first source channel of those */
+  int crop_n[8];    /* how many (0 = this view produces no crop channel) */
+} hp_input_layout;
+
+int hp_render_inputs(const hp_mesh_store* store, int n_items, int views_per_item, const int32_t* d_obj_ids /* [n_items] */,
+                     const float* d_TCV_O /* [n_items][V][16] */, const float* d_KV /* [n_items][V][9] */,
+                     const float* d_ambient /* [n_items * V][3] or NULL */, int n_lights,
+                     const float* d_light_pos /* [n_items * V][n_lights][3] */, const float* d_light_col, int h, int w,
+                     int flags /* HP_RASTER_* | HP_RENDER_* */, const float* d_images /* [Bi][Ct][H][W] */, int Bi, int Ct,
+                     int H, int W, const float* d_boxes /* [n_items][4] xyxy */, const int32_t* d_im_ids /* [n_items] */,
+                     int sampling_ratio, const float* d_depth_norm_z /* [n_items] */, int depth_norm_mode, void* d_x,
+                     int record_elems, const hp_input_layout* layout, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Iteration prologue ("pose prep"), one launch for all hypotheses and views:
  *   [normalize_T]  TB/lib3d/transform_ops.py:107-120   (MP/models/pose_rigid.py:571)
  *   tCR            MP/models/pose_rigid.py:574-576     (tOR = 0 -> tCR = tCO)

@@ -427,6 +427,7 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
           } else {
             int64_t cf[4]; float crgb[4][3], cn[4][3]; int ncached = 0;
             float a_rgb[3] = {0, 0, 0}, a_n[3] = {0, 0, 0};
+            unsigned k_rgb[3] = {0, 0, 0}, k_n[3] = {0, 0, 0}; /* sums of the samples' 8-bit colour codes */
             for (int sm = 0; sm < 4; ++sm) {
               if (keys[sm] == KEY_EMPTY) continue; /* the clear colour: 0 */
               const int64_t f = (int64_t)(keys[sm] & 0xFFFFFFFFull);
@@ -438,9 +439,18 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
                              j, q8, crgb[k], cn[k]);
                 ++ncached;
               }
-              for (int c = 0; c < 3; ++c) { a_rgb[c] += crgb[k][c]; a_n[c] += cn[k][c]; }
+              for (int c = 0; c < 3; ++c) {
+                a_rgb[c] += crgb[k][c]; a_n[c] += cn[k][c];
+                k_rgb[c] += (unsigned)floorf(fmaf(crgb[k][c], 255.0f, 0.5f)); k_n[c] += (unsigned)floorf(fmaf(cn[k][c], 255.0f, 0.5f));
+              }
             }
-            for (int c = 0; c < 3; ++c) { o_rgb[c] = quant8(a_rgb[c] * 0.25f, q8); o_n[c] = quant8(a_n[c] * 0.25f, q8); }
+            /* the resolve of an 8-bit multisampled colour buffer: the mean of the four samples' 8-bit values, rounded half
+             * up -- integer arithmetic (a float mean puts every sum that is 2 mod 4 exactly on a rounding tie).  Without
+             * the 8-bit quantisation (diagnostics) the plain float mean. */
+            for (int c = 0; c < 3; ++c) {
+              if (q8) { o_rgb[c] = (float)((k_rgb[c] + 2u) >> 2) / 255.0f; o_n[c] = (float)((k_n[c] + 2u) >> 2) / 255.0f; }
+              else { o_rgb[c] = a_rgb[c] * 0.25f; o_n[c] = a_n[c] * 0.25f; }
+            }
           }
           const int64_t base = (int64_t)view * sv + (int64_t)i * sr + (int64_t)j * sp;
           if (rgb) for (int c = 0; c < 3; ++c) rgb[base + c * sc] = o_rgb[c];

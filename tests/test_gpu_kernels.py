@@ -726,3 +726,72 @@ def test_torch_ops_match_ctypes_path(dev, scene_store):
         o.net_forward(10 ** 9, xin)  # not a live ticket
     with pytest.raises(NotImplementedError):
         o.pose_update(prep[0].cpu(), prep[5][:, 0].cpu().contiguous(), pose9.cpu(), prep[1].cpu())  # no CPU kernels
+
+
+@pytest.mark.parametrize("case", ["cosypose6", "megapose32", "coarse_f16", "permuted32", "msaa_aniso6"])
+def test_render_inputs_vs_oracle(dev, scene_store, case):
+    """``hp_render_inputs``: crop + V rendered views into the pixel records of the network input in one launch, against the
+    oracle's roi_align (C) and rasteriser (C) run separately: the reference's channel order for CosyPose (dense 6-float
+    records) and MegaPose RGB-D (32 floats, 4 views x 7 channels, depth normalised), the 16-half records of an fp16
+    plan, a permuted layout (view v = one 32-B sector: its 7 channels + crop channel v), and the reference's render state."""
+    from happypose_amd import ops
+    from oracle import native
+
+    rs = np.random.RandomState(3)
+    b = 5
+    H, W = 480, 640
+    rgbd = case in ("megapose32", "permuted32")
+    Ct = 4 if rgbd else 3
+    frames = rs.uniform(0, 1, size=(2, Ct, H, W)).astype(np.float32)
+    if rgbd:
+        frames[:, 3] = rs.uniform(0.3, 0.9, size=(2, H, W)).astype(np.float32)
+        frames[:, 3, 100:140, 200:260] = 0.0  # holes: the validity rule
+    im_ids = np.array([0, 1, 1, 0, 1], np.int32)
+    boxes = np.array([[100, 80, 400, 305], [50.5, 20.25, 600.0, 432.5], [300, 200, 340, 230], [-40, -30, 280, 210], [0, 0, 640, 480]], np.float32)
+    V = 4 if rgbd else 1
+    T = _poses(b * V, 17).reshape(b, V, 4, 4)
+    K = np.tile(np.array([[700.0, 0, 160], [0, 700.0, 120], [0, 0, 1]], np.float32), (b, V, 1, 1))
+    obj = np.array([0, 1, 2, 1, 0], np.int32)
+    z = rs.uniform(0.4, 0.8, size=b).astype(np.float32)
+    nrm, dep = case in ("megapose32", "permuted32", "coarse_f16"), rgbd
+    c_r = 3 + 3 * nrm + dep
+    msaa = aniso = case == "msaa_aniso6"
+    mode = 2 if rgbd else 0
+    kw = dict(images=torch.as_tensor(frames, device=dev), boxes=torch.as_tensor(boxes, device=dev), im_ids=torch.as_tensor(im_ids),
+              n_img_channels=Ct, depth_norm_z=torch.as_tensor(z, device=dev) if mode else None, depth_norm_mode=mode, msaa=msaa, aniso=aniso)
+    if case == "coarse_f16":
+        x = torch.zeros((b, 240, 320, 16), dtype=torch.float16, device=dev)
+    elif case == "permuted32":
+        x = torch.full((b, 240, 320, 32), 0.0, device=dev)
+        kw["layout"] = ([8 * v for v in range(4)], [8 * v + 7 for v in range(4)], [0, 1, 2, 3], [1, 1, 1, 1])
+    else:
+        x = torch.zeros((b, 240, 320, 6 if not rgbd else 32), device=dev)
+    ops.render_inputs(scene_store, x, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), nrm, dep, **kw)
+    got = x.float().cpu().numpy()
+    crop = native.crop_images(frames, boxes, im_ids, (240, 320))
+    if rgbd:
+        crop[:, 3] = np.clip(crop[:, 3] / z[:, None, None], 0, 2) - 1
+    r = native.rasterize(scene_store.packed, np.repeat(obj, V), T.reshape(-1, 4, 4), K.reshape(-1, 3, 3), (240, 320), nrm, dep, msaa=msaa, aniso=aniso)
+    parts = [r["rgbs"]] + ([r["normals"]] if nrm else []) + ([np.clip(r["depths"] / np.repeat(z, V)[:, None, None, None], 0, 2) - 1] if dep else [])
+    rend = np.concatenate(parts, 1).reshape(b, V, c_r, 240, 320)
+    if case == "permuted32":
+        want = np.zeros((b, 32, 240, 320), np.float32)
+        for v in range(4):
+            want[:, 8 * v:8 * v + 7] = rend[:, v]
+            want[:, 8 * v + 7] = crop[:, v]
+    else:
+        want = np.concatenate([crop, rend.reshape(b, V * c_r, 240, 320)], 1)
+    n_ch = want.shape[1]
+    got = got.transpose(0, 3, 1, 2)
+    assert np.all(got[:, n_ch:] == 0)  # pads untouched
+    tol = 2e-3 if case == "coarse_f16" else 0.0
+    crop_ch = [8 * v + 7 for v in range(4)] if case == "permuted32" else list(range(Ct))
+    colour_ch = crop_ch[:3]
+    np.testing.assert_allclose(got[:, colour_ch], want[:, colour_ch], rtol=1e-5 + tol, atol=2e-6 + tol)
+    if rgbd:  # the depth channel: the validity rule (mask >= 0.99) may flip on a few hole-border pixels
+        dd = np.abs(got[:, crop_ch[3]] - want[:, crop_ch[3]])
+        assert (dd > 1e-5).mean() < 1e-3 and np.median(dd) < 1e-6
+    rend_ch = [c for c in range(n_ch) if c not in crop_ch]
+    d = np.abs(got[:, rend_ch] - want[:, rend_ch])
+    assert (d > 1.01 / 255 + tol).mean() < (3e-3 if msaa else 1e-3), (d > 1.01 / 255 + tol).mean()  # silhouette pixels only
+    assert np.median(d) <= tol

@@ -40,6 +40,10 @@ for wl in ("C2", "C3"):
     def raster():
         ops.rasterize_into(store, x, n_img, obj, prep["TCV_O"], prep["K_crop"], not c2, not c2, z, mode, **flags)
 
+    def fused():  # what the predictors launch: crop + views, every pixel record written once
+        ops.render_inputs(store, x, obj, prep["TCV_O"], prep["K_crop"], not c2, not c2, images=images, boxes=prep["boxes_crop"], im_ids=im_ids,
+                          n_img_channels=n_img, depth_norm_z=z, depth_norm_mode=mode, **flags)
+
     depth = ops.rasterize(store, obj.repeat_interleave(V), prep["TCV_O"].reshape(-1, 4, 4), prep["K_crop"].reshape(-1, 3, 3), (240, 320),
                           render_depth=True)[2]
     covered = float((depth > 0).sum().item())
@@ -47,7 +51,7 @@ for wl in ("C2", "C3"):
     raster_bytes = float((rows[:, 1] * 32 + rows[:, 3] * 12).sum()) + B * V * 76800 * c_r * 4 + covered * 4
     crop_bytes = float(B * 76800 * n_img * 4)
     res = {}
-    for name, fn, nbytes in (("crop", crop, crop_bytes), ("raster", raster, raster_bytes)):
+    for name, fn, nbytes in (("crop", crop, crop_bytes), ("raster", raster, raster_bytes), ("render_inputs", fused, raster_bytes + crop_bytes)):
         for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
