@@ -35,10 +35,10 @@
 
 // Band size: a band is one workgroup.  Only the bands the object covers carry work, so the launch is as long as the busiest
 // CU's sequence of busy bands.  LDS per workgroup: 8 B (z key / colour codes) + 2 B (codes) + 2 B (covered-pixel list) per
-// pixel + the crop folds: 15 rows of 320 pixels = 68 KB -> two 512-thread workgroups per CU, which is also what the
-// kernel's ~110 VGPRs allow (16 waves per CU).
+// pixel + the crop folds: 10 rows of 320 pixels = 49 KB -> three 512-thread workgroups per CU, which is also what the
+// fp32 kernel's 80 VGPRs allow (24 waves per CU).
 #ifndef HP_RASTER_BAND_PIXELS
-#define HP_RASTER_BAND_PIXELS 4800
+#define HP_RASTER_BAND_PIXELS 3200
 #endif
 #ifndef HP_RASTER_THREADS
 #define HP_RASTER_THREADS 512
@@ -112,7 +112,7 @@ struct RasterArgs {
   // item writes its render channels (rgb, normals, depth as requested) at element v_c0[v] of the pixel record and, when
   // v_crop_n[v] > 0, the observed crop's source channels [v_crop_src0[v], + v_crop_n[v]) at element v_crop_c0[v]
   void* rec;
-  int rec_half, rec_own_all;           // fp16 records; V == 1 and the view owns the whole 16-half record (zero pads written too)
+  int rec_half, rec_own_all;           // fp16 records; V == 1, reference order: the view owns the whole 16-half record (pads written too)
   int64_t rec_item, rec_row, rec_col;  // element strides
   int v_c0[kMaxViews], v_crop_c0[kMaxViews], v_crop_src0[kMaxViews], v_crop_n[kMaxViews];
   int want_nrm, want_depth;            // record mode: which render channels exist
@@ -221,6 +221,106 @@ __device__ __forceinline__ void tex_fetch_aniso(const uint8_t* tex, int tw, int 
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[c] += c0[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rgb[c] = acc[c] / (float)N;
+}
+
+// ---- the same filter, organised for the machine: the mip levels' offsets / sizes come from a per-workgroup table (LDS),
+// power-of-two sizes wrap with a mask instead of an integer modulo (identical results for every integer), and the probes
+// are processed in PAIRS so that the 16 texel loads of two trilinear probes are in flight together (the rolled loop of
+// tex_fetch_aniso pays one L2 round trip per probe).  Same operations on the same values in the same order.
+struct MipTable { int off[16], w[16], h[16]; };
+
+struct BiTap { const uint8_t* p00; const uint8_t* p01; const uint8_t* p10; const uint8_t* p11; float fx, fy; };
+
+__device__ __forceinline__ BiTap bi_setup(const uint8_t* tex, int tw, int th, float u, float v) {
+  float x = fmaf(u, (float)tw, -0.5f);
+  float y = fmaf(1.0f - v, (float)th, -0.5f);
+  float xf = floorf(x), yf = floorf(y);
+  BiTap t;
+  t.fx = x - xf; t.fy = y - yf;
+  int x0, y0;
+  if ((tw & (tw - 1)) == 0) x0 = (int)xf & (tw - 1);
+  else { x0 = (int)xf % tw; if (x0 < 0) x0 += tw; }
+  if ((th & (th - 1)) == 0) y0 = (int)yf & (th - 1);
+  else { y0 = (int)yf % th; if (y0 < 0) y0 += th; }
+  const int x1 = x0 + 1 == tw ? 0 : x0 + 1;
+  const int y1 = y0 + 1 == th ? 0 : y0 + 1;
+  t.p00 = tex + 4 * (y0 * tw + x0); t.p01 = tex + 4 * (y0 * tw + x1);
+  t.p10 = tex + 4 * (y1 * tw + x0); t.p11 = tex + 4 * (y1 * tw + x1);
+  return t;
+}
+
+struct BiTexels { uchar4 a, b, c, d; };
+__device__ __forceinline__ BiTexels bi_load(const BiTap& t) {
+  BiTexels r;
+  r.a = *reinterpret_cast<const uchar4*>(t.p00); r.b = *reinterpret_cast<const uchar4*>(t.p01);
+  r.c = *reinterpret_cast<const uchar4*>(t.p10); r.d = *reinterpret_cast<const uchar4*>(t.p11);
+  return r;
+}
+__device__ __forceinline__ void bi_finish(const BiTap& t, const BiTexels& q, float* rgb) {
+  const float c00[3] = {(float)q.a.x, (float)q.a.y, (float)q.a.z};
+  const float c01[3] = {(float)q.b.x, (float)q.b.y, (float)q.b.z};
+  const float c10[3] = {(float)q.c.x, (float)q.c.y, (float)q.c.z};
+  const float c11[3] = {(float)q.d.x, (float)q.d.y, (float)q.d.z};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float a = fmaf(t.fx, c01[c] - c00[c], c00[c]);
+    float b = fmaf(t.fx, c11[c] - c10[c], c10[c]);
+    rgb[c] = fmaf(t.fy, b - a, a) / 255.0f;
+  }
+}
+
+__device__ __forceinline__ void tex_fetch_aniso_fast(const uint8_t* tex, const MipTable& mt, int tw, int th, int nlev, float u, float v,
+                                                     float ux, float vx, float uy, float vy, float* rgb) {
+  const float px = sqrtf(fmaf(ux * (float)tw, ux * (float)tw, vx * (float)th * (vx * (float)th)));
+  const float py = sqrtf(fmaf(uy * (float)tw, uy * (float)tw, vy * (float)th * (vy * (float)th)));
+  const bool along_x = px >= py;
+  const float pmax = along_x ? px : py, pmin = along_x ? py : px;
+  float nf = pmin > 0.0f ? ceilf(pmax / pmin) : 16.0f;
+  if (!(nf >= 1.0f)) nf = 1.0f;
+  if (nf > 16.0f) nf = 16.0f;
+  const int N = (int)nf;
+  float lod = pmax > 0.0f ? log2f(pmax / nf) : 0.0f;
+  if (!(lod > 0.0f)) lod = 0.0f;
+  if (lod > (float)(nlev - 1)) lod = (float)(nlev - 1);
+  const int l0 = (int)lod;
+  const float fl = lod - (float)l0;
+  const float du = along_x ? ux : uy, dv = along_x ? vx : vy;
+  const bool two = fl > 0.0f && l0 + 1 < nlev;
+  const int l1 = two ? l0 + 1 : l0;
+  const uint8_t* const t0 = tex + mt.off[l0];
+  const uint8_t* const t1 = tex + mt.off[l1];
+  const int w0 = mt.w[l0], h0 = mt.h[l0], w1 = mt.w[l1], h1 = mt.h[l1];
+  float acc[3] = {0.0f, 0.0f, 0.0f};
+  for (int i = 1; i <= N; i += 2) {
+    const bool second = i + 1 <= N;
+    const float ta = (float)i / (float)(N + 1) - 0.5f;
+    const float tb = (float)(second ? i + 1 : i) / (float)(N + 1) - 0.5f;
+    const float sua = fmaf(ta, du, u), sva = fmaf(ta, dv, v), sub = fmaf(tb, du, u), svb = fmaf(tb, dv, v);
+    const BiTap a0 = bi_setup(t0, w0, h0, sua, sva), a1 = bi_setup(t1, w1, h1, sua, sva);
+    const BiTap b0 = bi_setup(t0, w0, h0, sub, svb), b1 = bi_setup(t1, w1, h1, sub, svb);
+    const BiTexels qa0 = bi_load(a0), qa1 = bi_load(a1), qb0 = bi_load(b0), qb1 = bi_load(b1);
+    float ca[3], cb[3], c1[3];
+    bi_finish(a0, qa0, ca);
+    if (two) {
+      bi_finish(a1, qa1, c1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ca[c] = fmaf(fl, c1[c] - ca[c], ca[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += ca[c];
+    if (second) {
+      bi_finish(b0, qb0, cb);
+      if (two) {
+        bi_finish(b1, qb1, c1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cb[c] = fmaf(fl, c1[c] - cb[c], cb[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += cb[c];
+    }
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) rgb[c] = acc[c] / (float)N;
@@ -406,7 +506,9 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
 struct ShadeCtx {
   const float* T; const float* Kv; const float* amb; const float4* xv; const int32_t* fbase;
   int64_t voff, toff; int tw, th, view, q8, nlev, aniso;
+  const MipTable* mips;  // per-workgroup table of the object's mip levels (LDS)
 };
+template <bool ANISO>
 __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx& cx, int f, int i, int j, float* o_rgb, float* o_n) {
   const float* T = cx.T; const float* Kv = cx.Kv; const float* amb = cx.amb; const float4* xv = cx.xv;
   const int32_t* fbase = cx.fbase;
@@ -434,7 +536,7 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
     const float2 t2 = *reinterpret_cast<const float2*>(a.uvs + 2 * g2);
     float tu = fmaf(b0, t0.x, fmaf(b1, t1.x, b2 * t2.x));
     float tv = fmaf(b0, t0.y, fmaf(b1, t1.y, b2 * t2.y));
-    if (cx.aniso && cx.nlev > 1) {
+    if (ANISO && cx.nlev > 1) {
       // screen-space derivatives of the perspective-correct barycentrics: b_i = l_i / sum, l_i affine in (x, y)
       const float sx = e0[0] + e1[0] + e2[0], sy = e0[1] + e1[1] + e2[1];
       const float bx[3] = {(e0[0] - b0 * sx) / sum, (e1[0] - b1 * sx) / sum, (e2[0] - b2 * sx) / sum};
@@ -443,7 +545,7 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
       const float vx = fmaf(bx[0], t0.y, fmaf(bx[1], t1.y, bx[2] * t2.y));
       const float uy = fmaf(by[0], t0.x, fmaf(by[1], t1.x, by[2] * t2.x));
       const float vy = fmaf(by[0], t0.y, fmaf(by[1], t1.y, by[2] * t2.y));
-      tex_fetch_aniso(a.tex + toff, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
+      tex_fetch_aniso_fast(a.tex + toff, *cx.mips, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
     } else {
       tex_fetch(a.tex + toff, tw, th, tu, tv, alb);
     }
@@ -534,11 +636,53 @@ __device__ __forceinline__ void store_run(float* dst, const float* v, int n) {
   }
 }
 
-template <int NS>
-__global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a, int npix_max) {
+// The separable roi_align taps of one output pixel for NC consecutive source channels starting at `sc0` (crop_math.h: the
+// same taps in the same order as crop_tile_kernel).  Branch-free inside: the loops run to the band's largest spans (uniform
+// bounds), taps past a pixel's own span carry weight 0 and read a clamped -- in-image -- address, so the loads of a row are
+// issued together instead of one basic block (and one L2 round trip) per tap.
+template <int NC>
+__device__ __forceinline__ void crop_taps(const float* __restrict__ img, int HW, int IW, int IH, int sc0, const Fold& fy, const Fold& fx,
+                                          int nr_max, int nc_max, float (&acc)[4], float& vacc) {
+#pragma unroll
+  for (int r = 0; r < kSpan; ++r) {
+    if (r >= nr_max) break;
+    const int rr = min(fy.first + r, IH - 1);
+    float racc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) racc[c] = 0.f;
+    float rv = 0.0f;
+#pragma unroll
+    for (int c2 = 0; c2 < kSpan; ++c2) {
+      if (c2 >= nc_max) break;
+      const int off = rr * IW + min(fx.first + c2, IW - 1);
+      const float wj = fx.w[c2];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+#ifdef HP_RABL_CROP_NOLOAD
+        const float v = wj + (float)off;
+#else
+        const float v = img[(sc0 + c) * HW + off];
+#endif
+        racc[c] += wj * v;
+        if (sc0 + c == 3) rv += wj * (v > 0.0f ? 1.0f : 0.0f);
+      }
+    }
+    const float wi = fy.w[r];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] += wi * racc[c];
+    vacc += wi * rv;
+  }
+}
+
+// HALF: fp16 destinations (the input of an fp16 network plan) -- its own instantiation so that the fp32 path's register
+// budget (80 VGPRs: three 512-thread workgroups per CU) does not carry the 16-half record assembly
+template <int NS, bool HALF, bool ANISO>
+__global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) void raster_kernel(RasterArgs a, int npix_max) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int big_q[kBigQueue];
   __shared__ int big_n, n_cov, span_max[2];
+  __shared__ MipTable mips;
+  __shared__ uint32_t cov_q[NS == 1 ? 1 : kThreads / 64][NS == 1 ? 1 : 128];  // multisampling: (lane, pixel) pairs awaiting their sample tests
 
   // XCD-aware renumbering: dispatch order b -> XCD b % 8; give each XCD a contiguous range.
   const int total = a.n * a.n_bands;  // a.n = views of this chunk
@@ -601,6 +745,13 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a, int npix
     }
   }
 
+  if (tid == 0) {  // level k of the texture: max(1, tw >> k) x max(1, th >> k), stored behind the levels before it
+    int off = 0, lw = tw, lh = th;
+    for (int k = 0; k < 16; ++k) {
+      mips.off[k] = off; mips.w[k] = lw; mips.h[k] = lh;
+      off += 4 * lw * lh; lw = lw > 1 ? lw >> 1 : 1; lh = lh > 1 ? lh >> 1 : 1;
+    }
+  }
   // ---- coverage + depth: only the triangles binned to this band ----
   const int cnt = nf > 0 ? min(a.bin_count[lin], a.bin_cap) : 0;
   const int32_t* list = a.bin_list + (int64_t)lin * a.bin_cap;
@@ -625,50 +776,98 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a, int npix
   int32_t tri0[3] = {fbase[3 * f0], fbase[3 * f0 + 1], fbase[3 * f0 + 2]};
   int32_t tri1[3] = {fbase[3 * f1], fbase[3 * f1 + 1], fbase[3 * f1 + 2]};
   TriVerts tv0 = load_tri_verts(xv, tri0);
-  for (int k = tid; k < cnt_loop; k += kThreads) {
-    const int f = f0;
-    const int32_t tri[3] = {tri0[0], tri0[1], tri0[2]};
-    const TriVerts tv = tv0;
-    f0 = f1; tri0[0] = tri1[0]; tri0[1] = tri1[1]; tri0[2] = tri1[2];
-    tv0 = load_tri_verts(xv, tri0);
-    f1 = f2;
-    tri1[0] = fbase[3 * f1]; tri1[1] = fbase[3 * f1 + 1]; tri1[2] = fbase[3 * f1 + 2];
-    f2 = k + 3 * kThreads < cnt_loop ? list[k + 3 * kThreads] : 0;
-    TriSetup s;
-    if (!setup_triangle(a, tv, tri, row0, row1, s)) continue;
-    const int area = (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
-    if (area > kBigArea) {
-      int q = atomicAdd(&big_n, 1);
-      if (q < kBigQueue) { big_q[q] = f; continue; }
-    }
-    if (NS == 1) {
-      for (int i = s.y0; i <= s.y1; ++i)
-        for (int j = s.x0; j <= s.x1; ++j) shade_pixel<NS>(s, i, j, (uint32_t)f, zb, row0, a.w);
-    } else {
-      // multisampling: the bounding box is grown by the sample spread, so most of its pixels have no sample inside the
-      // triangle.  A pixel is skipped when the edge functions at its CENTRE, widened by the largest sample offset (and by
-      // a bound on the rounding of the fp32 evaluation), leave no sample on the inner side of some edge for either
-      // orientation -- the five exact sample tests then all fail anyway.
-      float m[3], sl[3];
-      const float* const ee[3] = {s.e0, s.e1, s.e2};
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        const float ax = fabsf(ee[e][0]), ay = fabsf(ee[e][1]);
-        m[e] = fmaxf(fmaf(0.125f, ax, 0.375f * ay), fmaf(0.375f, ax, 0.125f * ay));
-        sl[e] = 4e-6f * fmaf(ax, (float)(s.x1 + 1), fmaf(ay, (float)(s.y1 + 1), fabsf(ee[e][2])));
-        m[e] = m[e] * 1.001f + sl[e];
+  if (NS == 1) {
+    for (int k = tid; k < cnt_loop; k += kThreads) {
+      const int f = f0;
+      const int32_t tri[3] = {tri0[0], tri0[1], tri0[2]};
+      const TriVerts tv = tv0;
+      f0 = f1; tri0[0] = tri1[0]; tri0[1] = tri1[1]; tri0[2] = tri1[2];
+      tv0 = load_tri_verts(xv, tri0);
+      f1 = f2;
+      tri1[0] = fbase[3 * f1]; tri1[1] = fbase[3 * f1 + 1]; tri1[2] = fbase[3 * f1 + 2];
+      f2 = k + 3 * kThreads < cnt_loop ? list[k + 3 * kThreads] : 0;
+      TriSetup s;
+      if (!setup_triangle(a, tv, tri, row0, row1, s)) continue;
+      const int area = (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
+      if (area > kBigArea) {
+        int q = atomicAdd(&big_n, 1);
+        if (q < kBigQueue) { big_q[q] = f; continue; }
       }
       for (int i = s.y0; i <= s.y1; ++i)
-        for (int j = s.x0; j <= s.x1; ++j) {
-          const float pu = (float)j + 0.5f, pv = (float)i + 0.5f;
+        for (int j = s.x0; j <= s.x1; ++j) shade_pixel<NS>(s, i, j, (uint32_t)f, zb, row0, a.w);
+    }
+  } else {
+    // Multisampling.  The bounding box is grown by the sample spread, so most of its pixels have no sample inside the
+    // triangle, and the five exact sample tests of the pixels that do are ~100 instructions.  Two measures keep the lanes
+    // of a wave busy: (1) a pixel is dropped when the edge functions at its CENTRE, widened by the largest sample offset
+    // (and by a bound on the rounding of the fp32 evaluation), leave no sample on the inner side of some edge for either
+    // orientation -- the five exact tests would all fail anyway; (2) the surviving (triangle, pixel) pairs of the whole
+    // wave go through a per-wave queue in LDS and are popped 64 at a time, each lane fetching the owner lane's edge
+    // functions with ds_bpermute: the expensive part runs on dense lanes whatever the sizes of the 64 bounding boxes are.
+    volatile uint32_t* const q = cov_q[tid >> 6];
+    const int lane = tid & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    int qh = 0, qt = 0;  // wave-uniform
+    for (int kb = 0; kb < cnt_loop; kb += kThreads) {
+      const int k = kb + tid;
+      const int f = f0;
+      const int32_t tri[3] = {tri0[0], tri0[1], tri0[2]};
+      const TriVerts tv = tv0;
+      f0 = f1; tri0[0] = tri1[0]; tri0[1] = tri1[1]; tri0[2] = tri1[2];
+      tv0 = load_tri_verts(xv, tri0);
+      f1 = f2;
+      tri1[0] = fbase[3 * f1]; tri1[1] = fbase[3 * f1 + 1]; tri1[2] = fbase[3 * f1 + 2];
+      f2 = k + 3 * kThreads < cnt_loop ? list[k + 3 * kThreads] : 0;
+      TriSetup s{};
+      bool valid = k < cnt_loop && setup_triangle(a, tv, tri, row0, row1, s);
+      if (valid && (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1) > kBigArea) {
+        int bq = atomicAdd(&big_n, 1);
+        if (bq < kBigQueue) { big_q[bq] = f; valid = false; }
+      }
+      float m[3] = {0.f, 0.f, 0.f};
+      if (valid) {
+        const float* const ee[3] = {s.e0, s.e1, s.e2};
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const float ax = fabsf(ee[e][0]), ay = fabsf(ee[e][1]);
+          const float sl = 4e-6f * fmaf(ax, (float)(s.x1 + 1), fmaf(ay, (float)(s.y1 + 1), fabsf(ee[e][2])));
+          m[e] = fmaxf(fmaf(0.125f, ax, 0.375f * ay), fmaf(0.375f, ax, 0.125f * ay)) * 1.001f + sl;
+        }
+      }
+      int ci = s.y0, cj = s.x0;
+      bool more = valid;
+      while (__any(more)) {
+        bool surv = false;
+        const int pi = ci, pj = cj;
+        if (more) {
+          const float pu = (float)cj + 0.5f, pv = (float)ci + 0.5f;
           const float l0 = fmaf(s.e0[0], pu, fmaf(s.e0[1], pv, s.e0[2]));
           const float l1 = fmaf(s.e1[0], pu, fmaf(s.e1[1], pv, s.e1[2]));
           const float l2 = fmaf(s.e2[0], pu, fmaf(s.e2[1], pv, s.e2[2]));
           const bool no_pos = (l0 + m[0] < 0.0f) | (l1 + m[1] < 0.0f) | (l2 + m[2] < 0.0f);
           const bool no_neg = (l0 - m[0] > 0.0f) | (l1 - m[1] > 0.0f) | (l2 - m[2] > 0.0f);
-          if (no_pos & no_neg) continue;
-          shade_pixel<NS>(s, i, j, (uint32_t)f, zb, row0, a.w);
+          surv = !(no_pos & no_neg);
+          if (++cj > s.x1) { cj = s.x0; ++ci; }
+          more = ci <= s.y1;
         }
+        const unsigned long long sm = __ballot(surv);
+        if (surv) q[(qt + __popcll(sm & lt_mask)) & 127] = ((uint32_t)lane << 16) | (uint32_t)((pi - row0) * a.w + pj);  // npix_max < 65536
+        qt += __popcll(sm);
+        while (qt - qh >= 64 || (qt > qh && !__any(more))) {  // a full wave of pairs, or the rest once every box is walked
+          const int n = min(64, qt - qh);
+          const uint32_t e = q[(qh + lane) & 127];
+          const int owner = (int)(e >> 16) & 63;
+          const int ep = (int)(e & 0xFFFFu);
+          const int er = (int)(((unsigned long long)ep * a.w_magic) >> 32);
+          TriSetup t;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { t.e0[c] = __shfl(s.e0[c], owner); t.e1[c] = __shfl(s.e1[c], owner); t.e2[c] = __shfl(s.e2[c], owner); }
+          t.z0 = __shfl(s.z0, owner); t.z1 = __shfl(s.z1, owner); t.z2 = __shfl(s.z2, owner);
+          const int tf = __shfl(f, owner);
+          if (lane < n) shade_pixel<NS>(t, row0 + er, ep - er * a.w, (uint32_t)tf, zb, row0, a.w);
+          qh += n;
+        }
+      }
     }
   }
   if (!band_empty) __syncthreads();
@@ -686,13 +885,13 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a, int npix
   if (!band_empty) __syncthreads();
 
   // ---- shading of the compacted covered pixels (8-bit colour codes back into the z-buffer slots) ----
-  const int q8 = a.flags & HP_RASTER_QUANT8;
+  const int q8 = 1;  // colours are 8-bit quantised like the reference's uint8 read-back (HP_RASTER_QUANT8 is implied)
   float amb[3] = {1.0f, 1.0f, 1.0f};
   if (a.ambient) { amb[0] = a.ambient[3 * view]; amb[1] = a.ambient[3 * view + 1]; amb[2] = a.ambient[3 * view + 2]; }
   const ShadeCtx cx{T, Kv, amb, xv, fbase, voff, toff, tw, th, view, q8, (int)ob[7] > 0 ? (int)ob[7] : 1,
-                    (a.flags & HP_RASTER_TEX_ANISO) != 0};
+                    (a.flags & HP_RASTER_TEX_ANISO) != 0, &mips};
   const bool want_colour = a.rec ? true : (a.rgb != nullptr || a.nrm != nullptr);
-  const bool coded = q8 != 0 && !band_empty;  // colours travel as 8-bit codes through LDS; otherwise the output pass shades
+  const bool coded = !band_empty;  // colours travel as 8-bit codes through LDS
   if (coded) {
     const int lane = tid & 63;
     for (int p0 = 0; p0 < npix; p0 += kThreads) {
@@ -730,43 +929,32 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a, int npix
       unsigned cr[3], cn[3];
       if (NS == 1) {
         float o_rgb[3], o_n[3];
-        shade_centre(a, cx, (int)(zb[p] & 0xFFFFFFFFull), i, j, o_rgb, o_n);
+        shade_centre<ANISO>(a, cx, (int)(zb[p] & 0xFFFFFFFFull), i, j, o_rgb, o_n);
 #pragma unroll
         for (int c = 0; c < 3; ++c) { cr[c] = code8(o_rgb[c]); cn[c] = code8(o_n[c]); }
       } else {
         // one fragment-shader invocation per pixel and triangle; the pixel's colour is the mean of the four samples' 8-bit
         // colours (uncovered samples: the clear colour 0), rounded half up -- integer arithmetic, no rounding ties
-        int cf[4];
-        unsigned srgb[4][3], sn[4][3];
-        int ncached = 0;
         unsigned a_rgb[3] = {0, 0, 0}, a_n[3] = {0, 0, 0};
-#pragma unroll
-        for (int sm = 0; sm < 4; ++sm) {
+#pragma unroll 1
+        for (int sm = 0; sm < 4; ++sm) {  // rolled: ONE copy of the shader; the other samples' keys are re-read from LDS
           const unsigned long long ks = zb[p * NS + sm];
-          if (ks == kKeyEmpty) continue;
-          const int f = (int)(ks & 0xFFFFFFFFull);
-          int k = ncached;
+          if (ks == kKeyEmpty) continue;  // the clear colour 0
+          const uint32_t f = (uint32_t)ks;
+          bool dup = false;
+          unsigned mult = 1;  // samples of this pixel the triangle owns
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (t < ncached && cf[t] == f) k = t;
-          if (k == ncached) {
-            float r3[3], n3[3];
-            shade_centre(a, cx, f, i, j, r3, n3);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              if (t == ncached) {
-                cf[t] = f;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { srgb[t][c] = code8(r3[c]); sn[t][c] = code8(n3[c]); }
-              }
-            ++ncached;
+          for (int t = 0; t < 4; ++t) {
+            const unsigned long long kt = zb[p * NS + t];
+            const bool same = t != sm && kt != kKeyEmpty && (uint32_t)kt == f;
+            dup |= same && t < sm;
+            mult += (same && t > sm) ? 1u : 0u;
           }
+          if (dup) continue;  // shaded with the first of its samples
+          float r3[3], n3[3];
+          shade_centre<ANISO>(a, cx, (int)f, i, j, r3, n3);
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (t == k) {
-#pragma unroll
-              for (int c = 0; c < 3; ++c) { a_rgb[c] += srgb[t][c]; a_n[c] += sn[t][c]; }
-            }
+          for (int c = 0; c < 3; ++c) { a_rgb[c] += mult * code8(r3[c]); a_n[c] += mult * code8(n3[c]); }
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) { cr[c] = (a_rgb[c] + 2u) >> 2; cn[c] = (a_n[c] + 2u) >> 2; }
@@ -782,7 +970,7 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a, int npix
   const float zn = a.depth_norm_z ? a.depth_norm_z[item] : 1.0f;
   const int64_t cbase = (int64_t)item * a.cs.s_item + (int64_t)vi * a.cs.s_view;
   const int64_t dbase = (int64_t)item * a.ds.s_item + (int64_t)vi * a.ds.s_view;
-  const bool half_out = (a.flags & HP_RASTER_OUT_F16) != 0;  // fp16 network input written directly
+  const bool half_out = HALF;  // fp16 network input written directly
   // crop source
   const float* img = nullptr;
   bool bad_id = false;
@@ -801,91 +989,22 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a, int npix
   for (int p = tid; p < npix; p += kThreads) {
     const int pr = (int)(((unsigned long long)p * a.w_magic) >> 32);
     const int i = row0 + pr, j = p - pr * a.w;
-    float o_rgb[3] = {0.f, 0.f, 0.f}, o_n[3] = {0.f, 0.f, 0.f}, o_d = 0.0f;
-    if (!band_empty) {
-      const unsigned long long slot = zb[p * NS + (NS - 1)];
-      const uint32_t zbits = (uint32_t)(slot >> 32);
-      if (zbits != 0xFFFFFFFFu) {
-        const float Z = __uint_as_float(zbits);
-        o_d = Z > a.depth_max ? 0.0f : Z;
-      }
-      if (coded) {
-        const uint32_t lo = (uint32_t)slot;
-        const uint32_t ex = L.ex[p];
-        o_rgb[0] = (float)(lo & 255u) / 255.0f; o_rgb[1] = (float)((lo >> 8) & 255u) / 255.0f; o_rgb[2] = (float)((lo >> 16) & 255u) / 255.0f;
-        o_n[0] = (float)(lo >> 24) / 255.0f; o_n[1] = (float)(ex & 255u) / 255.0f; o_n[2] = (float)(ex >> 8) / 255.0f;
-      } else if (want_colour) {  // unquantised colours (diagnostics): shaded here, in pixel order
-        if (NS == 1) {
-          if (slot != kKeyEmpty) shade_centre(a, cx, (int)(slot & 0xFFFFFFFFull), i, j, o_rgb, o_n);
-        } else {
-          float a_rgb[3] = {0.f, 0.f, 0.f}, a_n[3] = {0.f, 0.f, 0.f};
-          for (int sm = 0; sm < 4; ++sm) {
-            const unsigned long long ks = zb[p * NS + sm];
-            if (ks == kKeyEmpty) continue;
-            float r3[3], n3[3];
-            shade_centre(a, cx, (int)(ks & 0xFFFFFFFFull), i, j, r3, n3);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { a_rgb[c] += r3[c]; a_n[c] += n3[c]; }
-          }
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { o_rgb[c] = a_rgb[c] * 0.25f; o_n[c] = a_n[c] * 0.25f; }
-        }
-      }
-    }
-    float d_out = o_d;
-    if (a.depth_norm_mode == 1) d_out = o_d / zn;
-    else if (a.depth_norm_mode == 2) d_out = fminf(fmaxf(o_d / zn, 0.0f), 2.0f) - 1.0f;
-    else if (a.depth_norm_mode == 3) d_out = fminf(fmaxf(o_d - zn, -2.0f), 2.0f);
-
+    float cropv[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.rec) {
       // ---- crop channels of this pixel (roi_align of the frame; same taps in the same order as crop_tile_kernel) ----
-      float cropv[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef HP_RABL_NO_CROP
+      if (ncrop > 0 && a.w < 0) {
+#else
       if (ncrop > 0) {
+#endif
         const Fold fy = L.fy[pr], fx = L.fx[j];
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         float vacc = 0.0f;
         if (separable) {
-          const int off0 = fy.first * a.IW + fx.first;
-#pragma unroll
-          for (int r = 0; r < kSpan; ++r) {
-            if (r >= nr_max) break;
-            if (r < fy.span) {
-              const int off = off0 + r * a.IW;
-              float racc[4] = {0.f, 0.f, 0.f, 0.f};
-              float rv = 0.0f;
-#pragma unroll
-              for (int c2 = 0; c2 < kSpan; ++c2) {
-                if (c2 >= nc_max) break;
-                if (c2 < fx.span) {
-                  const float wj = fx.w[c2];
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) {
-                    if (c < ncrop) {
-                      const int sc = csrc0 + c;
-                      const float v = img[sc * HW + off + c2];
-                      racc[c] += wj * v;
-                      if (sc == 3) rv += wj * (v > 0.0f ? 1.0f : 0.0f);
-                    }
-                  }
-                }
-              }
-              const float wi = fy.w[r];
-#pragma unroll
-              for (int c = 0; c < 4; ++c) acc[c] += wi * racc[c];
-              vacc += wi * rv;
-            }
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c < ncrop) {
-              const int sc = csrc0 + c;
-              float sacc = 0.0f, svv = 0.0f;
-              slow_pixel(img + (int64_t)sc * HW, a.IH, a.IW, cy1, cx1, i, j, bin_h, bin_w, a.sr, sc == 3, sacc, svv);
-              acc[c] = sacc;
-              if (sc == 3) vacc = svv;
-            }
-          }
+          if (ncrop == 3) crop_taps<3>(img, HW, a.IW, a.IH, csrc0, fy, fx, nr_max, nc_max, acc, vacc);
+          else if (ncrop == 4) crop_taps<4>(img, HW, a.IW, a.IH, csrc0, fy, fx, nr_max, nc_max, acc, vacc);
+          else if (ncrop == 1) crop_taps<1>(img, HW, a.IW, a.IH, csrc0, fy, fx, nr_max, nc_max, acc, vacc);
+          else crop_taps<2>(img, HW, a.IW, a.IH, csrc0, fy, fx, nr_max, nc_max, acc, vacc);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -901,6 +1020,28 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a, int npix
           }
         }
       }
+    }
+    float o_rgb[3] = {0.f, 0.f, 0.f}, o_n[3] = {0.f, 0.f, 0.f}, o_d = 0.0f;
+    if (!band_empty) {
+      const unsigned long long slot = zb[p * NS + (NS - 1)];
+      const uint32_t zbits = (uint32_t)(slot >> 32);
+      if (zbits != 0xFFFFFFFFu) {
+        const float Z = __uint_as_float(zbits);
+        o_d = Z > a.depth_max ? 0.0f : Z;
+      }
+      if (coded) {
+        const uint32_t lo = (uint32_t)slot;
+        const uint32_t ex = L.ex[p];
+        o_rgb[0] = (float)(lo & 255u) / 255.0f; o_rgb[1] = (float)((lo >> 8) & 255u) / 255.0f; o_rgb[2] = (float)((lo >> 16) & 255u) / 255.0f;
+        o_n[0] = (float)(lo >> 24) / 255.0f; o_n[1] = (float)(ex & 255u) / 255.0f; o_n[2] = (float)(ex >> 8) / 255.0f;
+      }
+    }
+    float d_out = o_d;
+    if (a.depth_norm_mode == 1) d_out = o_d / zn;
+    else if (a.depth_norm_mode == 2) d_out = fminf(fmaxf(o_d / zn, 0.0f), 2.0f) - 1.0f;
+    else if (a.depth_norm_mode == 3) d_out = fminf(fmaxf(o_d - zn, -2.0f), 2.0f);
+
+    if (a.rec) {
       // ---- the record ----
       float rend[7];
       int nrend = 3;
@@ -912,30 +1053,59 @@ __global__ __launch_bounds__(kThreads) void raster_kernel(RasterArgs a, int npix
       }
       const int64_t pix = (int64_t)item * a.rec_item + (int64_t)i * a.rec_row + (int64_t)j * a.rec_col;
       const int c0 = a.v_c0[vi], cc0 = a.v_crop_c0[vi];
-      if (a.rec_half) {
+#ifdef HP_RABL_NO_STORE
+      if (a.w > 0 && cropv[0] + rend[0] != -123.0f) continue;
+#endif
+      if (HALF) {
         _Float16* const o = reinterpret_cast<_Float16*>(a.rec) + pix;
         if (a.rec_own_all) {  // one view owns the whole 16-half record: two 16-B stores, pads included
           typedef _Float16 halfx8v __attribute__((ext_vector_type(8)));
+          // the reference's order: crop channels [0, ncrop), render channels behind them, zeros to the end of the record
           _Float16 hv[16];
 #pragma unroll
           for (int k = 0; k < 16; ++k) {  // compile-time k: no indexed register array (a stack would break hipGraph replay)
-            float v = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v = (c < ncrop && cc0 + c == k) ? cropv[c] : v;
-#pragma unroll
-            for (int c = 0; c < 7; ++c) v = (c < nrend && c0 + c == k) ? rend[c] : v;
-            hv[k] = (_Float16)v;
+            const float r3 = (k >= 3 && k - 3 < 7 && k - 3 < nrend) ? rend[k - 3 < 7 ? (k >= 3 ? k - 3 : 0) : 0] : 0.f;
+            const float r4 = (k >= 4 && k - 4 < 7 && k - 4 < nrend) ? rend[k - 4 < 7 ? (k >= 4 ? k - 4 : 0) : 0] : 0.f;
+            const float cv = k < 4 ? cropv[k < 4 ? k : 0] : 0.f;
+            hv[k] = (_Float16)(k < ncrop ? cv : (ncrop == 3 ? r3 : r4));
           }
           *reinterpret_cast<halfx8v*>(o) = halfx8v{hv[0], hv[1], hv[2], hv[3], hv[4], hv[5], hv[6], hv[7]};
           *reinterpret_cast<halfx8v*>(o + 8) = halfx8v{hv[8], hv[9], hv[10], hv[11], hv[12], hv[13], hv[14], hv[15]};
         } else {
-          for (int c = 0; c < ncrop; ++c) o[cc0 + c] = (_Float16)cropv[c];
-          for (int c = 0; c < nrend; ++c) o[c0 + c] = (_Float16)rend[c];
+          if (separable) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < ncrop) o[cc0 + c] = (_Float16)cropv[c];
+          }
+#pragma unroll
+          for (int c = 0; c < 7; ++c)
+            if (c < nrend) o[c0 + c] = (_Float16)rend[c];
         }
       } else {
         float* const o = reinterpret_cast<float*>(a.rec) + pix;
-        if (ncrop > 0) store_run(o + cc0, cropv, ncrop);
+        if (ncrop > 0 && separable) store_run(o + cc0, cropv, ncrop);
         store_run(o + c0, rend, nrend);
+      }
+      if (ncrop > 0 && !separable) {
+        // strongly down-sampling crop (a bin spans more than kSpan source pixels: boxes wider than ~850 px): the literal
+        // sampling_ratio^2-sample evaluation, one channel at a time in a rolled loop (rare; keeps it out of the
+        // register budget of the common path), stored after the record so that it lands on top of the zeros above
+#pragma unroll 1
+        for (int c = 0; c < ncrop; ++c) {
+          const int sc = csrc0 + c;
+          float sacc = 0.0f, svv = 0.0f;
+          slow_pixel(img + (int64_t)sc * HW, a.IH, a.IW, cy1, cx1, i, j, bin_h, bin_w, a.sr, sc == 3, sacc, svv);
+          float val = sacc / count;
+          if (sc == 3) {
+            if (svv / count < 0.99f) val = 0.0f;  // TB/lib3d/cropping.py:184-195
+            if (a.crop_depth_mode == 1) val = val / zn;
+            else if (a.crop_depth_mode == 2) val = fminf(fmaxf(val / zn, 0.0f), 2.0f) - 1.0f;
+            else if (a.crop_depth_mode == 3) val = fminf(fmaxf(val - zn, -2.0f), 2.0f);
+          }
+          if (bad_id) val = 0.0f;
+          if (HALF) reinterpret_cast<_Float16*>(a.rec)[pix + cc0 + c] = (_Float16)val;
+          else reinterpret_cast<float*>(a.rec)[pix + cc0 + c] = val;
+        }
       }
       continue;
     }
@@ -1062,11 +1232,17 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
   a.xverts = ms->xverts;
   const size_t lds = band_lds_bytes(npix_max, ns, a.band_rows, w, crop);
   HP_REQUIRE(lds <= 150 * 1024, "hp_rasterize: band does not fit the LDS");
-  static size_t opted[2] = {0, 0};
-  if (opted[a.msaa] < lds) {
-    if (a.msaa) HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&raster_kernel<kSamplesMsaa>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&raster_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    opted[a.msaa] = lds;
+  const bool half = (a.flags & HP_RASTER_OUT_F16) != 0, aniso = (a.flags & HP_RASTER_TEX_ANISO) != 0;
+  typedef void (*BandKernel)(RasterArgs, int);
+  static const BandKernel kernels[8] = {
+      raster_kernel<1, false, false>, raster_kernel<1, false, true>, raster_kernel<1, true, false>, raster_kernel<1, true, true>,
+      raster_kernel<kSamplesMsaa, false, false>, raster_kernel<kSamplesMsaa, false, true>, raster_kernel<kSamplesMsaa, true, false>,
+      raster_kernel<kSamplesMsaa, true, true>};
+  const int ki = 4 * a.msaa + 2 * (half ? 1 : 0) + (aniso ? 1 : 0);
+  static size_t opted[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (opted[ki] < lds) {
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[ki]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    opted[ki] = lds;
   }
   for (int v0 = 0; v0 < n; v0 += chunk) {
     const int nv = n - v0 < chunk ? n - v0 : chunk;
@@ -1075,8 +1251,7 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
     hipLaunchKernelGGL(raster_xform_kernel, dim3((a.max_verts + 255) / 256, nv), dim3(256), 0, st, a);
     hipLaunchKernelGGL(raster_bin_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
     const int total = nv * a.n_bands;
-    if (a.msaa) hipLaunchKernelGGL(raster_kernel<kSamplesMsaa>, dim3(8 * ((total + 7) / 8)), dim3(kThreads), lds, st, a, npix_max);
-    else hipLaunchKernelGGL(raster_kernel<1>, dim3(8 * ((total + 7) / 8)), dim3(kThreads), lds, st, a, npix_max);
+    hipLaunchKernelGGL(kernels[ki], dim3(8 * ((total + 7) / 8)), dim3(kThreads), lds, st, a, npix_max);
   }
   return check_launch("raster_kernel");
 }
@@ -1159,7 +1334,9 @@ extern "C" int hp_render_inputs(const hp_mesh_store* store, int n_items, int vie
   a.rec = d_x;
   a.rec_half = (flags & HP_RASTER_OUT_F16) != 0;
   a.rec_col = record_elems; a.rec_row = (int64_t)record_elems * w; a.rec_item = (int64_t)record_elems * w * h;
-  a.rec_own_all = a.rec_half && views_per_item == 1 && record_elems == 16 && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0;
+  a.rec_own_all = a.rec_half && views_per_item == 1 && record_elems == 16 && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 &&
+                  layout->crop_c0[0] == 0 && layout->crop_src0[0] == 0 && (layout->crop_n[0] == 3 || layout->crop_n[0] == 4) &&
+                  layout->view_c0[0] == layout->crop_n[0];
   a.want_nrm = want_nrm; a.want_depth = want_depth;
   for (int v = 0; v < kMaxViews; ++v) {
     const bool on = v < views_per_item;

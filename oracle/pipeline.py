@@ -43,7 +43,7 @@ class OraclePredictor:
         self.points = np.asarray(points_table, np.float32)  # [n_obj, n_pad, 3]
         self.cfg = dict(arch="resnet34", n_views=1, multiview_type="TCO", render_normals=False,
                         render_depth=False, input_depth=False, depth_normalization_type=None,
-                        cosypose=False, remove_TCO_rendering=False, msaa=False, aniso=False)
+                        cosypose=False, remove_TCO_rendering=False, msaa=True, aniso=True)  # the reference's render state (panda3d_scene_renderer.py:68-71)
         self.cfg.update(cfg)
         self.render_size = (240, 320)
 

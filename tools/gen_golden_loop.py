@@ -156,7 +156,8 @@ def main():
                         lp[i, k], lc[i, k] = node.pos, l.color[:3]
                         k += 1
             r = native.rasterize(packed, obj, TCO.detach().cpu().numpy(), K.detach().cpu().numpy(), tuple(resolution),
-                                 render_normals, render_depth, render_binary_mask, ambient=amb, light_pos=lp, light_col=lc)
+                                 render_normals, render_depth, render_binary_mask, ambient=amb, light_pos=lp, light_col=lc,
+                                 msaa=True, aniso=True)  # the reference's render state (TB/renderer/panda3d_scene_renderer.py:68-71)
             return rtypes.BatchRenderOutput(
                 rgbs=T(r["rgbs"]), normals=None if r["normals"] is None else T(r["normals"]),
                 depths=None if r["depths"] is None else T(r["depths"]),
