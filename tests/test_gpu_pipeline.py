@@ -20,7 +20,20 @@ pytestmark = pytest.mark.gpu
 
 T_TOL, R_TOL = 2e-5, 1e-4
 T_TOL_HI, R_TOL_HI = 5e-4, 2.5e-3  # update_scale = 0.05 cases
+T_MED, R_MED = 2e-6, 6e-6  # MEDIAN over >= 64 hypotheses, low-gain head (a 1 % weight error in one layer: >= 1.2e-5 rad)
+T_MED_HI, R_MED_HI = 4e-5, 6e-5  # per iteration n: n x these, high-gain head (injected 1 %: >= 3.4e-4 rad at n = 1)
 FEAT_TOL = 2e-4  # backbone features vs the CPU restatement, relative to max|ref| of the sample
+
+
+def _pose_med(A, B):
+    """Median over the hypotheses of (|dt|, geodesic angle): legitimate residuals are sparse outliers (a silhouette pixel
+    flipped under a hypothesis), an arithmetic error in the network shifts EVERY hypothesis -- the median separates the two
+    by 20-3000x where the maximum separates them by 3x (tools/parity_sharpness.py)."""
+    A, B = np.asarray(A, np.float64), np.asarray(B, np.float64)
+    dt = np.linalg.norm(A[:, :3, 3] - B[:, :3, 3], axis=1)
+    chord = np.linalg.norm(A[:, :3, :3] - B[:, :3, :3], axis=(1, 2))
+    ang = 2.0 * np.arcsin(np.clip(chord / (2.0 * np.sqrt(2.0)), 0.0, 1.0))
+    return float(np.median(dt)), float(np.median(ang))
 
 
 def _pose_err(A, B):
@@ -421,9 +434,11 @@ def test_c2_full_size_two_lanes_vs_oracle(dev):
                       bsz_objects=8)
     errs = []
     for n in range(5):
-        dt, dr = _pose_err(out[f"iteration={n + 1}"].TCO_output.cpu().numpy(), ref[n]["TCO_output"])
-        errs.append((dt, dr))
+        got = out[f"iteration={n + 1}"].TCO_output.cpu().numpy()
+        dt, dr = _pose_err(got, ref[n]["TCO_output"])
+        errs.append((dt, dr) + _pose_med(got, ref[n]["TCO_output"]))
         assert dt <= T_TOL and dr <= R_TOL, (n, errs)
+        assert errs[-1][2] <= T_MED and errs[-1][3] <= R_MED, (n, errs)
     # the refinement moved the poses by far more than the tolerance
     assert _pose_err(out["iteration=5"].TCO_output.cpu().numpy(), scene["TCO_hyp"])[1] > 10 * R_TOL
 
@@ -450,8 +465,10 @@ def test_c3_full_size_vs_oracle(dev):
     ref = ora.forward(scene["images"], scene["K"], np.zeros(B, np.int32), scene["hyp_obj_ids"], scene["TCO_hyp"], 5, bsz_objects=8)
     errs = []
     for n in range(5):
-        errs.append(_pose_err(out[f"iteration={n + 1}"].TCO_output.cpu().numpy(), ref[n]["TCO_output"]))
+        got = out[f"iteration={n + 1}"].TCO_output.cpu().numpy()
+        errs.append(_pose_err(got, ref[n]["TCO_output"]) + _pose_med(got, ref[n]["TCO_output"]))
         assert errs[-1][0] <= T_TOL and errs[-1][1] <= R_TOL, (n, errs)
+        assert errs[-1][2] <= T_MED and errs[-1][3] <= R_MED, (n, errs)
 
 
 C5_LOGIT_TOL = 2e-2  # fp16 weights / activations (fp32 accumulation) vs the fp32 oracle, on logits of O(1..5)
@@ -505,8 +522,9 @@ def test_run_inference_pipeline_vs_oracle_estimator(dev, world):
                 predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
     rcfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
                 depth_augmentation=False)
-    # head weights at He scale spread the logits; seed 5 separates ranks 1 / 2 / 3 of every detection by > 2 LOGIT_TOL
-    wc = _weights("vanilla_resnet34", 9, pose=False, logits=1, seed=5, scale=1.0)
+    # head weights at He scale spread the logits; seed 9 separates ranks 1 / 2 / 3 of every detection by > 2 LOGIT_TOL
+    # (in the reference render state; tools: the oracle's coarse logits over seeds 5..16)
+    wc = _weights("vanilla_resnet34", 9, pose=False, logits=1, seed=9, scale=1.0)
     wr = _weights("vanilla_resnet34", 27, seed=2)
     coarse = create_model_pose(ccfg, world["renderer"], state_dict=wc, max_batch=72)
     refiner = create_model_pose(rcfg, world["renderer"], state_dict=wr, max_batch=8)
@@ -934,7 +952,8 @@ def test_full_size_high_gain_head_vs_oracle(dev, workload):
     ~0.1 rad and moves it by centimetres -- >= 100x T_TOL_HI / R_TOL_HI -- so a relative error of 1 % anywhere in the
     features shows up in the pose.  5 iterations, two lanes, against the CPU oracle in the reference's chunks of 8."""
     bench = _bench()
-    ds, renderer, scene, weights, model = bench.build_world(dev, "resnet34", seed=0, workload=workload, n_lanes=2, update_scale=0.05)
+    gain = 0.05 if workload == "C2" else 0.02  # MegaPose's update multiplies the translation: 0.05 throws the objects out of view
+    ds, renderer, scene, weights, model = bench.build_world(dev, "resnet34", seed=0, workload=workload, n_lanes=2, update_scale=gain)
     store = renderer.store
     B = len(scene["TCO_hyp"])
     images, K = torch.as_tensor(scene["images"], device=dev), torch.as_tensor(scene["K"], device=dev)
@@ -948,12 +967,13 @@ def test_full_size_high_gain_head_vs_oracle(dev, workload):
     errs, prev = [], scene["TCO_hyp"]
     for n in range(5):
         got = out[f"iteration={n + 1}"].TCO_output.cpu().numpy()
-        errs.append(_pose_err(got, ref[n]["TCO_output"]))
+        errs.append(_pose_err(got, ref[n]["TCO_output"]) + _pose_med(got, ref[n]["TCO_output"]))
         assert errs[-1][0] <= T_TOL_HI and errs[-1][1] <= R_TOL_HI, (n, errs)
+        assert errs[-1][2] <= (n + 1) * T_MED_HI and errs[-1][3] <= (n + 1) * R_MED_HI, (n, errs)
         # the update of THIS iteration is >= 20x the tolerance for the typical hypothesis (median over the batch)
         A, Bm = np.asarray(got, np.float64), np.asarray(prev, np.float64)
         chord = np.linalg.norm(A[:, :3, :3] - Bm[:, :3, :3], axis=(1, 2))
-        assert np.median(2 * np.arcsin(np.clip(chord / (2 * np.sqrt(2)), 0, 1))) > 20 * R_TOL_HI, n
+        assert np.median(2 * np.arcsin(np.clip(chord / (2 * np.sqrt(2)), 0, 1))) > (20 if workload == "C2" else 8) * R_TOL_HI, n
         prev = got
 
 
@@ -1024,7 +1044,7 @@ def test_backbone_features_at_benchmark_batch_two_lanes(dev, workload):
     bad = ops.Net(arch, n_in, w_bad, max_batch=16, device=dev)
     f_bad = bad.forward(x[:16].contiguous(), want_pose=False, want_features=True)[2].cpu().numpy()
     err_bad = (np.abs(f_bad - ref[:16]) / scale[:16]).max()
-    assert err_bad > 10 * FEAT_TOL, err_bad
+    assert err_bad > 5 * FEAT_TOL, err_bad
 
 
 def test_c4_refine_sharded_1024_hypotheses(dev):
