@@ -50,7 +50,37 @@ struct ConvArgs {
   int no_tail_split;       // 1: leave the tiles of a partially filled last round whole (a second lane fills the CUs)
   unsigned* status;        // host-visible word or null: the epilogue stores 1 when it produced a non-finite value
                            // (split-fp16 launches: an activation beyond the fp16 range turned into inf / NaN)
+  // Dynamic range of the split-fp16 scheme (x = x_hi + x_lo in fp16: |x| must stay below 65504, and x_lo falls into the
+  // fp16 subnormals -- an ABSOLUTE floor of 2^-25 -- once |x| < ~0.1).  Every launch that goes through the shared epilogue
+  // leaves max|y| of what it stored in *amax_out (bits of a non-negative float, atomicMax; the network zeroes its words at
+  // the start of a forward); a split-fp16 consumer of that tensor reads the producer's word, bounds its staged input by
+  // amax_a * max|x| + amax_b (the BN + ReLU prologue: max|scale|, max|shift|; 1, 0 without one) and multiplies what it
+  // splits by the power of two that puts that bound at 2^13 -- exact, undone with the weights' scale in the epilogue.
+  // amax_in == nullptr: no scaling (the first layer, producers that do not track their range).
+  const unsigned* amax_in;
+  float amax_a, amax_b;
+  unsigned* amax_out;
 };
+
+constexpr int kAmaxSlots = 8, kAmaxStride = 64;  // words per op: 8 slots, 64 words (256 B) apart
+#ifdef __HIPCC__
+// the activation scale of a split-fp16 launch (see ConvArgs::amax_in): sx = 2^s with bound * 2^s in [2^12, 2^13), and 1 / sx
+__device__ __forceinline__ void conv_act_scale(const ConvArgs& a, float& sx, float& inv_sx) {
+  sx = 1.f; inv_sx = 1.f;
+  if (a.amax_in) {
+    unsigned m = 0u;  // the producer spreads its atomics over kAmaxSlots words 256 B apart (one L2 channel each)
+#pragma unroll
+    for (int k = 0; k < kAmaxSlots; ++k) m = max(m, a.amax_in[k * kAmaxStride]);
+    const float bound = fmaf(a.amax_a, __uint_as_float(m), a.amax_b);
+    if (bound > 1e-30f && bound < 1e30f) {
+      const int e = (int)((__float_as_uint(bound) >> 23) & 255u) - 126;  // bound = m 2^e, m in [0.5, 1)
+      const int sh = 13 - e;
+      sx = __uint_as_float((unsigned)(127 + sh) << 23);
+      inv_sx = __uint_as_float((unsigned)(127 - sh) << 23);
+    }
+  }
+}
+#endif
 
 // fp16 path (conv_f16.hip): activations / weights / prologue vectors are halves, bias is fp32
 struct ConvArgsH {
@@ -156,6 +186,7 @@ inline bool conv_use_igemm_split(int kh, int Kpad) {
   return kh >= min_kh;
 }
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
+int launch_zero_words(unsigned* p, int n, hipStream_t stream);  // a kernel, not a memset: memset nodes misbehave under hipGraph replay
 // nearest resize to (Ho, Wo) (stride_mode 0) or stride-2 subsampling (stride_mode 1), NHWC, C % 4 == 0
 int launch_resize_nearest(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, int stride_mode, hipStream_t stream);
 // (x - mean) / std per channel, NCHW [n,3,h,w] -> NHWC [n,h,w,4]

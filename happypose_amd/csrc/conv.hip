@@ -400,6 +400,16 @@ int conv_algo() {
   }
   return g_conv_algo;
 }
+__global__ void zero_words_kernel(unsigned* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+int launch_zero_words(unsigned* p, int n, hipStream_t stream) {
+  if (n <= 0) return HP_OK;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n);
+  return check_launch("zero_words_kernel");
+}
+
 }  // namespace hp
 
 extern "C" int hp_conv_select_algo(int algo) {

@@ -62,6 +62,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* lds, epi
   epi_floatx4 bias = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) bias = *reinterpret_cast<const epi_floatx4*>(a.bias + n);  // padded to whole tiles by the planner
   float chk = 0.f;  // running sum of everything this thread stores, before the activation: inf / NaN are sticky in it
+  float amax = 0.f; // largest magnitude this thread stores (ConvArgs::amax_out)
 #pragma unroll
   for (int k = 0; k < ITERS; ++k) {
     const int row = tid / C4 + k * (THREADS / C4);
@@ -78,10 +79,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* lds, epi
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + __expf(-v[q]));
       }
+#ifndef HP_EABL_NO_AMAX_VALU
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#endif
       *reinterpret_cast<epi_floatx4*>(a.y + m * a.Cout + n) = v;
     }
   }
   conv_report_nonfinite(a, chk);
+#ifndef HP_EABL_NO_AMAX_REDUCE
+  if (a.amax_out) {
+    // max is order-independent: deterministic.  The word only grows, so a wave first LOOKS (a plain device-scope load)
+    // and sends its atomic only when it would raise the value: after the first few tiles nearly every wave skips it --
+    // thousands of same-address atomics per launch serialise in one L2 channel (+5 us per launch, measured)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0 && amax > 0.f) {
+      const unsigned mine = __float_as_uint(amax);
+      unsigned* const slot = a.amax_out + (blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride;  // spread over L2 channels
+      if (mine > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mine);
+    }
+  }
+#endif
 }
 
 }  // namespace hp

@@ -131,6 +131,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
     }
   }
   const _Float16* const wsplit = reinterpret_cast<const _Float16*>(a.w);
+  float act_sx, act_inv;  // ConvArgs::amax_in: power-of-two scale of the staged activations and its inverse
+  conv_act_scale(a, act_sx, act_inv);
   const _Float16* wrow[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) wrow[i] = wsplit + (int64_t)(n0 + r0 + 32 * i) * a.Kpad * 2 + 8 * kc;
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
       floatx4 v = st.ra[i];
       if (PRE == 1) v = __builtin_elementwise_max(v * st.ps + st.pb, floatx4{0.f, 0.f, 0.f, 0.f});
       if (PRE == 2) v = v * st.g[PRE == 2 ? i : 0];
+      v = v * act_sx;  // ConvArgs::amax_in: exact power of two (1 when the input's range is not tracked)
       if (!((st.ok >> i) & 1u)) v = floatx4{0.f, 0.f, 0.f, 0.f};
       const halfx4 hi = __builtin_convertvector(v, halfx4);
       const halfx4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), halfx4);
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
   const float* const unscale = reinterpret_cast<const float*>(wsplit + (size_t)rows_pad * a.Kpad * 2);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const float s = unscale[n0 + wn + nt * 32 + (lane & 31)];
+    const float s = unscale[n0 + wn + nt * 32 + (lane & 31)] * act_inv;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -137,6 +137,8 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   _Float16* const patch = reinterpret_cast<_Float16*>(lds_raw);  // [2][P][LDH]
   _Float16* const Bs = patch + 2 * P * LDH;                        // [2][BN][LDH]
   _Float16* const zrow = Bs + 2 * BN * LDH;                        // [LDH] zeros: what a masked tap reads
+  float act_sx = 1.f, act_inv = 1.f;  // ConvArgs::amax_in: power-of-two scale of the staged activations (split mode)
+  if constexpr (MODE == MODE_SPLIT) conv_act_scale(a, act_sx, act_inv);
   // pre-activation BN + ReLU vectors in LDS (fetched from global memory inside the L segment of a chunk's last tap they
   // stalled the whole phase for an HBM / L2 round trip: 1918 instead of 1690 cycles per tap on the PRE layers)
   float* const pre_lds = reinterpret_cast<float*>(zrow + LDH);      // split: [Cin] scale, [Cin] shift (fp32); f16: halves
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   if (tid < LDH / 2) reinterpret_cast<unsigned*>(zrow)[tid] = 0u;
   if (PRE) {
     if constexpr (MODE == MODE_SPLIT) {
-      for (int i = tid; i < Cin; i += kPPThreads) { pre_lds[i] = a.pre_scale[i]; pre_lds[Cin + i] = a.pre_shift[i]; }
+      for (int i = tid; i < Cin; i += kPPThreads) { pre_lds[i] = a.pre_scale[i] * act_sx; pre_lds[Cin + i] = a.pre_shift[i] * act_sx; }  // sx relu(x s + b) = relu(x s sx + b sx)
     } else {
       _Float16* const ph = reinterpret_cast<_Float16*>(pre_lds);
       for (int i = tid; i < Cin; i += kPPThreads) {
@@ -262,6 +264,8 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
             if (PRE) {
               v = __builtin_elementwise_max(v * ps[h] + pb[h], pp_floatx4{0.f, 0.f, 0.f, 0.f});
               if (!real) v = pp_floatx4{0.f, 0.f, 0.f, 0.f};
+            } else {
+              v = v * act_sx;
             }
             hi[h] = __builtin_convertvector(v, pp_halfx4);
             lo[h] = __builtin_convertvector(v - __builtin_convertvector(hi[h], pp_floatx4), pp_halfx4);
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     const float* const unscale = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(a.w) + (size_t)a.Cout * 18 * Cin);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const float s = unscale[n0 + wn + nt * 32 + (lane & 31)];
+      const float s = unscale[n0 + wn + nt * 32 + (lane & 31)] * act_inv;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -116,6 +116,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
   _Float16* const patch = reinterpret_cast<_Float16*>(lds_raw);  // [P][LDH]
   _Float16* const Bs = patch + P * LDH;                            // [2][BN][LDH]
   _Float16* const zrow = Bs + 2 * BN * LDH;                        // [LDH] zeros: what a masked tap reads
+  float act_sx, act_inv;  // ConvArgs::amax_in: power-of-two scale of the staged activations and its inverse
+  conv_act_scale(a, act_sx, act_inv);
 
   // work item = a whole tile, or a (tile, K slice) of the last, partially filled round (conv_splitk.h): one
   // workgroup per CU makes a partial round as long as a full one, so its tiles are cut along K into slices
@@ -197,9 +199,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
     floatx4 ps[2], pb[2];
     if (PRE) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        ps[h] = *reinterpret_cast<const floatx4*>(a.pre_scale + cc * CK + 8 * pk + 4 * h);
-        pb[h] = *reinterpret_cast<const floatx4*>(a.pre_shift + cc * CK + 8 * pk + 4 * h);
+      for (int h = 0; h < 2; ++h) {  // the activation scale rides on the prologue: sx relu(x s + b) = relu(x (s sx) + b sx), exactly
+        ps[h] = *reinterpret_cast<const floatx4*>(a.pre_scale + cc * CK + 8 * pk + 4 * h) * act_sx;
+        pb[h] = *reinterpret_cast<const floatx4*>(a.pre_shift + cc * CK + 8 * pk + 4 * h) * act_sx;
       }
     }
 #pragma unroll
@@ -213,6 +215,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
           if (PRE) {
             v = __builtin_elementwise_max(v * ps[h] + pb[h], floatx4{0.f, 0.f, 0.f, 0.f});
             if (!real) v = floatx4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            v = v * act_sx;
           }
           hi[h] = __builtin_convertvector(v, halfx4);
           lo[h] = __builtin_convertvector(v - __builtin_convertvector(hi[h], floatx4), halfx4);
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) __attribute__((amdgpu_waves
   const float* const unscale = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(a.w) + (size_t)a.Cout * 18 * Cin);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const float s = unscale[n0 + wn + nt * 32 + (lane & 31)];
+    const float s = unscale[n0 + wn + nt * 32 + (lane & 31)] * act_inv;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -541,6 +545,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   _Float16* const patch = reinterpret_cast<_Float16*>(lds_raw);  // [P][LDH]
   _Float16* const Bs = patch + P * LDH;                            // [2][BN][LDH]
   _Float16* const zrow = Bs + 2 * BN * LDH;
+  float act_sx, act_inv;  // ConvArgs::amax_in (see conv3x3_split_f32)
+  conv_act_scale(a, act_sx, act_inv);
 
   const int nblk = a.tiles_m * a.tiles_n;
   const int per_xcd = (nblk + 7) / 8;
@@ -638,8 +644,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (PRE) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        ps[h] = *reinterpret_cast<const floatx4*>(a.pre_scale + c * CK + 8 * pk + 4 * h);
-        pb[h] = *reinterpret_cast<const floatx4*>(a.pre_shift + c * CK + 8 * pk + 4 * h);
+        ps[h] = *reinterpret_cast<const floatx4*>(a.pre_scale + c * CK + 8 * pk + 4 * h) * act_sx;
+        pb[h] = *reinterpret_cast<const floatx4*>(a.pre_shift + c * CK + 8 * pk + 4 * h) * act_sx;
       }
     }
 #pragma unroll
@@ -653,6 +659,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
           if (PRE) {
             v = __builtin_elementwise_max(v * ps[h] + pb[h], floatx4{0.f, 0.f, 0.f, 0.f});
             if (!real) v = floatx4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            v = v * act_sx;
           }
           hi[h] = __builtin_convertvector(v, halfx4);
           lo[h] = __builtin_convertvector(v - __builtin_convertvector(hi[h], floatx4), halfx4);
@@ -740,7 +748,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const float* const unscale = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(a.w) + (size_t)a.Cout * 18 * C);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const float s = unscale[n0 + wn + nt * 32 + (lane & 31)];
+    const float s = unscale[n0 + wn + nt * 32 + (lane & 31)] * act_inv;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -53,6 +53,7 @@ struct ConvLayer {
   DevBuf w, w_wino, w_split, w_isplit, bias, lut, pre_scale, pre_shift;  // w_isplit: hi/lo halves for conv_igemm_split.hip  // w_wino: Winograd-transformed weights (3x3 s1 layers)
                                                                // w_split: fp16 hi/lo halves (conv_split.hip)
   int cout_pad = 0;        // weight rows / bias padded to whole 64-wide tiles
+  float pre_smax = 1.f, pre_bmax = 0.f;  // bound of the BN + ReLU prologue: |x_act| <= pre_smax max|x| + pre_bmax (ConvArgs::amax_a / amax_b)
   int se = 0;              // the input is gated by the squeeze-excitation vector of this block (1x1 projections)
   int run_mode = 0;        // stem with K ordered (kh, [kw x cin run]) over an UNPADDED 6-channel input, see pack_conv
   // fp16 plan: cin rounded to 8, K to 64; packed halves, LUT per 8-half chunk, prologue in halves
@@ -111,10 +112,13 @@ struct Net {
   // per-network switches (no process-wide state on the launch path)
   int algo = -1;               // HP_CONV_ALGO_*; -1 = follow the process-wide default (hp_conv_select_algo / environment)
   bool tail_split = true;      // K-slicing of tail tiles (off while a second lane shares the GPU)
+  bool act_scale = true;       // dynamic power-of-two activation scale of the split-fp16 kernels (hp_net_set_act_scale)
   // non-finite guard of the split-fp16 kernels: a host-visible word the epilogues set (hipHostMalloc, coherent)
   unsigned* h_status = nullptr;  // host address
   unsigned* d_status = nullptr;  // the same word as the device sees it
   bool exact_only = false;       // sticky after the guard fired: exact-fp32 kernels only
+  // dynamic range of the split-fp16 kernels (ConvArgs::amax_in / amax_out): one word per op, zeroed at the start of a forward
+  DevBuf amax;
   ~Net() { if (h_status) (void)hipHostFree(h_status); }
 };
 
@@ -480,6 +484,8 @@ int pack_conv(Net& n, ConvLayer& L) {
     std::vector<float> ps, pb;
     if ((rc = bn_affine(n, L.bn_before, L.cin_real, ps, pb))) return rc;
     ps.resize(L.cin, 0.f); pb.resize(L.cin, 0.f);
+    L.pre_smax = 0.f; L.pre_bmax = 0.f;
+    for (int c = 0; c < L.cin; ++c) { L.pre_smax = std::fmax(L.pre_smax, std::fabs(ps[c])); L.pre_bmax = std::fmax(L.pre_bmax, std::fabs(pb[c])); }
     if ((rc = L.pre_scale.upload(ps.data(), ps.size() * 4))) return rc;
     if ((rc = L.pre_shift.upload(pb.data(), pb.size() * 4))) return rc;
   }
@@ -716,6 +722,7 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
     *net->h_status = 0u;
     HP_CHECK_HIP(hipHostGetDevicePointer((void**)&net->d_status, net->h_status, 0));
   }
+  { int rc_a = net->amax.alloc((net->ops.size() + 1) * (size_t)kAmaxSlots * kAmaxStride * sizeof(unsigned)); if (rc_a) return rc_a; }
   net->max_batch = max_batch;
   net->params.clear();  // host copies are no longer needed
   net->finalized = true;
@@ -757,6 +764,10 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
   // the guard of an EARLIER forward fired (read without synchronising): from now on exact-fp32 kernels only
   if (net->h_status && *(volatile unsigned*)net->h_status) net->exact_only = true;
   const int net_algo = net->exact_only ? HP_CONV_ALGO_WINOGRAD : (net->algo >= 0 ? net->algo : conv_algo());
+  static const bool no_act_scale = std::getenv("HP_CONV_NO_ACT_SCALE") != nullptr;  // A/B: the round-2 arithmetic (no activation scale)
+  unsigned* const amax_words = (f16 || no_act_scale || !net->act_scale) ? nullptr : (unsigned*)net->amax.p;
+  if (amax_words && (rc = launch_zero_words(amax_words, ((int)net->ops.size() + 1) * kAmaxSlots * kAmaxStride, stream))) return rc;
+  std::vector<int> buf_amax(net->bufs.size(), -1);  // arena slot -> op whose launch tracked max|y| of what it holds (-1: unknown)
   int op_index = 0;
   bool pool_fused = false;  // the stem wrote the pooled map itself: skip the max-pool op that follows it
   bool front_fused = false; // the expansion conv ran the depthwise conv after it too (mbconv_front.hip): skip that op
@@ -818,6 +829,15 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       a.H = L.H; a.W = L.W; a.Cin = L.cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.cout;
       a.stride = L.stride; a.pad = L.pad; a.Kpad = L.Kpad; a.ktiles = L.Kpad / 32; a.relu = L.relu;
       a.algo = net_algo; a.no_tail_split = net->tail_split ? 0 : 1;
+      if (amax_words) {
+        static const bool producers_only = std::getenv("HP_ACT_SCALE_PRODUCERS_ONLY") != nullptr;  // A/B
+        if (L.in_buf >= 0 && buf_amax[L.in_buf] >= 0 && !L.se && !producers_only) {
+          a.amax_in = amax_words + (size_t)buf_amax[L.in_buf] * kAmaxSlots * kAmaxStride;
+          a.amax_a = L.pre_scale.p ? L.pre_smax : 1.f; a.amax_b = L.pre_scale.p ? L.pre_bmax : 0.f;
+        }
+        a.amax_out = amax_words + oi * (size_t)kAmaxSlots * kAmaxStride;
+      }
+      bool tracks_amax = amax_words != nullptr;  // cleared below for the launches that do not go through the shared epilogue
       if (L.se) { a.pre_scale = (const float*)net->se_gate.p; a.pre_shift = nullptr; }  // gate [batch][Cin]
       const int variant = L.cout_pad % 128 == 0 ? 0 : 1;  // 128x128 tiles, or 128x64
       if (sync_ops)
@@ -847,7 +867,8 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         f.n = batch; f.H = L.H; f.W = L.W; f.Cin = L.cin; f.Cexp = L.cout; f.Ho = fdw->Ho; f.Wo = fdw->Wo; f.k = fdw->k;
         f.stride = fdw->stride; f.pad_t = f.pad_l = fdw->pad; f.Kpad = L.Kpad; f.rows_pad = L.cout_pad;
         rc = launch_mbconv_front(f, stream);
-        front_fused = true;
+        front_fused = true; tracks_amax = false;
+        buf_amax[fdw->out_buf] = -1;
         dw_partials = mbconv_front_tiles(fdw->Ho, fdw->Wo, fdw->stride);
         const int th = fdw->stride == 1 ? 8 : 4, tw = fdw->stride == 1 ? 16 : 8;
         const int rows = (((th - 1) * fdw->stride + fdw->k) * ((tw - 1) * fdw->stride + fdw->k) + 31) / 32 * 32;
@@ -860,7 +881,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         a.y = (float*)net->bufs[next7->out_buf].p;
         a.status = net->d_status;
         rc = launch_conv_stem7_pool(a, 0, stream);
-        pool_fused = true;
+        pool_fused = true; tracks_amax = false;
         const int sc = L.cin % 8 == 0 ? 8 : 4, ks = (7 * sc + 15) / 16;
         mfma_flops = 3.0 / 16.0 * 2.0 * (double)a.M * (256.0 / 192.0) * L.cout * (L.cin / sc) * 7.0 * ks * 16.0;
       } else if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_split.p && conv_split_launchable(a)) {
@@ -874,6 +895,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       } else if (wino_ok && L.w_wino.p && conv_wino_launchable(a)) {
         a.w = (const float*)L.w_wino.p;
         rc = launch_conv_wino(a, stream);
+        tracks_amax = false;
         mfma_flops = 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout;
       } else {
         mfma_flops = 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout_pad * L.Kpad;
@@ -894,7 +916,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
               rc = launch_conv_igemm_split_pool(a, stream);
               mfma_flops *= 1.24;  // conv pixels under the tile borders are computed twice (7 x 17 per 6 x 16)
             }
-            pool_fused = true;
+            pool_fused = true; tracks_amax = false;
           } else {
             rc = launch_conv_igemm_split(a, variant, stream);
           }
@@ -904,6 +926,8 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         else rc = launch_conv(a, variant, stream);
       }
       if (rc) return rc;
+      if (L.out_buf >= 0) buf_amax[L.out_buf] = tracks_amax ? (int)oi : -1;
+      if (pool_fused && next7 && next7->out_buf >= 0) buf_amax[next7->out_buf] = -1;  // the fused stems write the pooled map untracked
       prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, mfma_flops);
       if ((rc = prof_end(false))) return rc;
     } else if (op.kind == OP_DW && front_fused) {
@@ -912,6 +936,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
     } else if (op.kind == OP_DW) {
       if ((rc = prof_end(true))) return rc;
       const DwLayer& D = *net->dws[op.conv];
+      buf_amax[D.out_buf] = -1;  // the depthwise kernels do not track their range
       DwArgs d{};
       d.x = (const float*)net->bufs[D.in_buf].p; d.w = (const float*)D.w.p; d.bias = (const float*)D.bias.p;
       d.y = (float*)net->bufs[D.out_buf].p;
@@ -935,6 +960,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         return rc;
       dw_partials = 0;
     } else if (op.kind == OP_RESIZE) {
+      buf_amax[op.out_buf] = -1;
       if ((rc = prof_end(true))) return rc;
       if ((rc = launch_resize_nearest((const float*)net->bufs[op.in_buf].p, (float*)net->bufs[op.out_buf].p, batch, op.H, op.W,
                                       op.C, op.Ho, op.Wo, op.conv, stream)))
@@ -952,6 +978,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       if ((rc = prof_end(true))) return rc;
     } else if (op.kind == OP_MAXPOOL) {
       if ((rc = prof_end(true))) return rc;
+      buf_amax[op.out_buf] = buf_amax[op.in_buf];  // a max over windows cannot exceed the input's largest magnitude
       if ((rc = launch_maxpool((const float*)net->bufs[op.in_buf].p, (float*)net->bufs[op.out_buf].p, batch,
                                op.H, op.W, op.C, op.Ho, op.Wo, stream)))
         return rc;
@@ -1130,6 +1157,12 @@ extern "C" int hp_net_set_conv_algo(hp_net* net, int algo) {
   HP_REQUIRE(net, "hp_net_set_conv_algo: null net");
   HP_REQUIRE(algo >= -1 && algo <= HP_CONV_ALGO_SPLIT, "hp_net_set_conv_algo: unknown algorithm");
   net->algo = algo;
+  return HP_OK;
+}
+
+extern "C" int hp_net_set_act_scale(hp_net* net, int enabled) {
+  HP_REQUIRE(net, "hp_net_set_act_scale: null net");
+  net->act_scale = enabled != 0;
   return HP_OK;
 }
 

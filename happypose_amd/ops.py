@@ -483,6 +483,11 @@ class Net:
         check(lib().hp_net_set_tail_split(self.handle, int(on)), "hp_net_set_tail_split")
         self.tail_split = bool(on)
 
+    def set_act_scale(self, on: bool):
+        """Dynamic power-of-two activation scale of the split-fp16 kernels (``hp_net_set_act_scale``; default on)."""
+        check(lib().hp_net_set_act_scale(self.handle, int(on)), "hp_net_set_act_scale")
+        bump_graph_epoch()  # launch arguments change
+
     def status(self, stream=None) -> int:
         """``hp_net_status``: waits for ``stream`` (default: the current one) and returns the guard flags --
         bit 0 (:data:`STATUS_NONFINITE`): a forward since the last call produced inf / NaN in a split-fp16

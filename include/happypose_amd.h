@@ -369,6 +369,13 @@ int hp_net_set_conv_algo(hp_net* net, int algo);
  * independent launches share the GPU (the two half-batch lanes of a predictor on two streams) the other stream fills
  * those CUs and the slicing only costs its reduction: 0 switches it off for this network, 1 back on (the default). */
 int hp_net_set_tail_split(hp_net* net, int enabled);
+/* Dynamic activation scale of the split-fp16 kernels (default on).  x = x_hi + x_lo in fp16 has an ABSOLUTE floor of 2^-25:
+ * activations below ~0.1 lose relative bits (x_lo falls into the fp16 subnormals).  With the scale on, every launch tracks
+ * max|y| of what it stores (one atomicMax per wave into a per-layer word) and a split-fp16 consumer multiplies what it
+ * splits by the power of two that puts its input's bound at 2^13 -- exact, undone in the epilogue together with the
+ * weights' scale; a layer whose activations sit at 1e-4 then keeps the 22 significant bits of the scheme, and the fp16
+ * range cannot be left by a finite input.  0 restores the unscaled arithmetic (A/B, tests). */
+int hp_net_set_act_scale(hp_net* net, int enabled);
 /* Numerical guard of the default (split-fp16) kernels.  They carry fp32 activations through the fp16 matrix path as
  * hi/lo halves, which needs |activation| < 65504; beyond that a half becomes inf and the layer's output inf / NaN where
  * the reference's fp32 arithmetic stays finite.  Every split-fp16 launch reports a non-finite output to a host-visible

@@ -795,3 +795,44 @@ def test_render_inputs_vs_oracle(dev, scene_store, case):
     d = np.abs(got[:, rend_ch] - want[:, rend_ch])
     assert (d > 1.01 / 255 + tol).mean() < (3e-3 if msaa else 1e-3), (d > 1.01 / 255 + tol).mean()  # silhouette pixels only
     assert np.median(d) <= tol
+
+
+def test_split_fp16_small_activations_keep_their_bits(dev):
+    """The low side of the split-fp16 scheme.  x = x_hi + x_lo in fp16 has an absolute floor of 2^-25, so
+    a layer whose activations sit at ~1e-4 loses relative bits unless they are scaled into fp16's normal range first.
+    A WideResNet-18 with "trained-network" statistics -- the BN in front of six 3x3 convs shrinks their input to
+    ~1e-4 .. 1e-3 (gamma, beta x 1e-4), the conv weights undo it (x 1e4) -- against the same network in float64: with the
+    dynamic activation scale (default) every feature agrees to 2e-5 x max|ref| like any other network here; with
+    ``hp_net_set_act_scale(net, 0)`` the very same kernels are ~100x worse."""
+    from happypose_amd import ops
+    from happypose_amd.synthetic import predictor_weights
+    from oracle import backbones as ob
+
+    w = predictor_weights(ob.predictor_param_shapes("resnet18", 6), seed=4)
+    for blk in ("layer1.1", "layer2.0", "layer2.1", "layer3.1", "layer4.0", "layer4.1"):
+        w[f"backbone.{blk}.bn2.weight"] = (w[f"backbone.{blk}.bn2.weight"] * 1e-4).astype(np.float32)
+        w[f"backbone.{blk}.bn2.bias"] = (w[f"backbone.{blk}.bn2.bias"] * 1e-4).astype(np.float32)
+        w[f"backbone.{blk}.conv2.weight"] = (w[f"backbone.{blk}.conv2.weight"] * 1e4).astype(np.float32)
+    x = np.random.RandomState(2).uniform(0, 1, size=(4, 6, 240, 320)).astype(np.float32)
+    with torch.no_grad():
+        ref = ob.net_forward(torch.as_tensor(x).double(), {k: torch.as_tensor(np.asarray(v)).double() if np.asarray(v).dtype.kind == "f" else
+                                                           torch.as_tensor(np.asarray(v)) for k, v in w.items()}, "resnet18", heads=("features",))["features"].numpy()
+    net = ops.Net("resnet18", 6, w, max_batch=4, device=dev)
+    xin = net.new_input(4)
+    xin[..., :6] = torch.as_tensor(x, device=dev).permute(0, 2, 3, 1)
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    errs = {}
+    for on in (True, False):
+        net.set_act_scale(on)
+        f = net.forward(xin, want_pose=False, want_features=True)[2].cpu().numpy()
+        assert net.status() == 0
+        errs[on] = float((np.abs(f - ref) / scale).max())
+    assert errs[True] <= 2e-5, errs
+    assert errs[False] > 10 * errs[True], errs  # the floor the scale removes is real
+    # and on an ordinary network the scale changes nothing beyond round-off
+    w0 = predictor_weights(ob.predictor_param_shapes("resnet18", 6), seed=4)
+    n0 = ops.Net("resnet18", 6, w0, max_batch=4, device=dev)
+    fa = n0.forward(xin, want_pose=False, want_features=True)[2]
+    n0.set_act_scale(False)
+    fb = n0.forward(xin, want_pose=False, want_features=True)[2]
+    assert float((fa - fb).abs().max() / fa.abs().max()) < 5e-6
