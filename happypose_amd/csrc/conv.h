@@ -143,6 +143,11 @@ bool conv_wino_launchable(const ConvArgs& a);  // per launch: batch-dependent li
 size_t conv_wino_weight_floats(int cout, int cin);
 int conv_wino_transform_weights(const float* d_w, float* d_U, int cout, int cin, int Kpad, hipStream_t stream);
 int launch_conv_wino(const ConvArgs& a, hipStream_t stream);
+// Winograd F(2x2,3x3) on the fp16 matrix path with the hi/lo split of conv_split.hip (conv_wino.hip, SPLIT instantiation)
+bool conv_wino_split_launchable(const ConvArgs& a);
+size_t conv_wino_split_weight_bytes(int cout, int cin);
+int conv_wino_split_transform_weights(const float* d_w, void* d_U, int cout, int cin, int Kpad, hipStream_t stream);
+int launch_conv_wino_split(const ConvArgs& a, hipStream_t stream);
 // 3x3 / pad 1, stride 1 (Cin % 32 == 0, Cout % 64 == 0) or stride 2 (Cin % 64 == 0, Cout % 128 == 0): fp32 operands split into fp16 halves, three fp16
 // MFMAs per product (conv_split.hip); a.w must point at weights split by conv_split_transform_weights
 bool conv_split_applicable(const ConvArgs& a, int kh, int kw);
@@ -177,7 +182,16 @@ int launch_conv_igemm_split_pool(const ConvArgs& a, hipStream_t stream);
 // plan-time choice between the split-fp16 kernel and the exact-fp32 ones for a 3x3 stride-1 layer
 inline bool conv_use_split(int algo, int H, int W, int cin, int cout) {
   (void)H; (void)W; (void)cin; (void)cout;  // measured faster than Winograd on every WideResNet / ResNet-34 layer shape
-  return algo == HP_CONV_ALGO_SPLIT || algo == HP_CONV_ALGO_AUTO;
+  return algo == HP_CONV_ALGO_SPLIT || algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINO_SPLIT;
+}
+// which 3x3 stride-1 layers run Winograd on the split operands instead of the direct split kernels: all eligible ones with
+// HP_CONV_ALGO_WINO_SPLIT; otherwise HP_WINO_SPLIT = a bit mask over the map widths {80, 40, 20, 10} -> bits {1, 2, 4, 8}
+// (WideResNet / ResNet-34 at 240 x 320), default 0: measured slower on every layer shape
+inline bool conv_use_wino_split(int algo, int W) {
+  if (algo == HP_CONV_ALGO_WINO_SPLIT) return true;
+  static const int mask = std::getenv("HP_WINO_SPLIT") ? std::atoi(std::getenv("HP_WINO_SPLIT")) : 0;
+  const int bit = W >= 80 ? 1 : W >= 40 ? 2 : W >= 20 ? 4 : 8;
+  return (mask & bit) != 0;
 }
 // which generic-kernel layers move to conv_igemm_split.hip (HP_ISPLIT_MIN_KH: smallest filter size, default 1)
 inline bool conv_use_igemm_split(int kh, int Kpad) {

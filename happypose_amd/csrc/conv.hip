@@ -413,7 +413,7 @@ int launch_zero_words(unsigned* p, int n, hipStream_t stream) {
 }  // namespace hp
 
 extern "C" int hp_conv_select_algo(int algo) {
-  HP_REQUIRE(algo >= HP_CONV_ALGO_AUTO && algo <= HP_CONV_ALGO_SPLIT, "hp_conv_select_algo: unknown algorithm");
+  HP_REQUIRE(algo >= HP_CONV_ALGO_AUTO && algo <= HP_CONV_ALGO_WINO_SPLIT, "hp_conv_select_algo: unknown algorithm");
   hp::g_conv_algo = algo;
   return HP_OK;
 }

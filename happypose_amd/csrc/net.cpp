@@ -50,6 +50,7 @@ struct ConvLayer {
   int cout_real = 0;       // rows of the parameter tensor when cout was rounded up to 4 (zero rows; 0 = cout)
   int H, W, Ho, Wo, Kpad;
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
+  DevBuf w_wsplit;         // Winograd-transformed weights as fp16 hi/lo halves (conv_wino.hip, SPLIT)
   DevBuf w, w_wino, w_split, w_isplit, bias, lut, pre_scale, pre_shift;  // w_isplit: hi/lo halves for conv_igemm_split.hip  // w_wino: Winograd-transformed weights (3x3 s1 layers)
                                                                // w_split: fp16 hi/lo halves (conv_split.hip)
   int cout_pad = 0;        // weight rows / bias padded to whole 64-wide tiles
@@ -449,6 +450,12 @@ int pack_conv(Net& n, ConvLayer& L) {
       if ((rc = L.w_wino.alloc(conv_wino_weight_floats(L.cout, L.cin) * 4))) return rc;
       if ((rc = conv_wino_transform_weights((const float*)L.w.p, (float*)L.w_wino.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
+      static const bool no_wsplit = std::getenv("HP_CONV_NO_WINO_SPLIT") != nullptr;
+      if (!no_wsplit && L.cin >= 64 && L.cin % 32 == 0 && L.cout_pad == L.cout && L.relu != HP_ACT_SWISH && !L.se) {
+        if ((rc = L.w_wsplit.alloc(conv_wino_split_weight_bytes(L.cout, L.cin)))) return rc;
+        if ((rc = conv_wino_split_transform_weights((const float*)L.w.p, L.w_wsplit.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
+        HP_CHECK_HIP(hipStreamSynchronize(nullptr));
+      }
     }
     if (conv_split_applicable(probe, L.kh, L.kw) && L.cout_pad == L.cout && L.relu != HP_ACT_SWISH && !L.se) {
       if ((rc = L.w_split.alloc(conv_split_weight_bytes(L.cout, L.cin)))) return rc;
@@ -884,6 +891,13 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         pool_fused = true; tracks_amax = false;
         const int sc = L.cin % 8 == 0 ? 8 : 4, ks = (7 * sc + 15) / 16;
         mfma_flops = 3.0 / 16.0 * 2.0 * (double)a.M * (256.0 / 192.0) * L.cout * (L.cin / sc) * 7.0 * ks * 16.0;
+      } else if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_wsplit.p && conv_use_wino_split(algo, L.W) &&
+                 conv_wino_split_launchable(a)) {
+        // Winograd F(2x2,3x3) on the split operands: 2.25x fewer products, each three fp16 MFMAs (16x16x16)
+        a.w = (const float*)L.w_wsplit.p;
+        a.status = net->d_status;
+        rc = launch_conv_wino_split(a, stream);
+        mfma_flops = 3.0 * 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout / 16.0;
       } else if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_split.p && conv_split_launchable(a)) {
         a.w = (const float*)L.w_split.p;
         a.status = net->d_status;
@@ -1155,7 +1169,7 @@ extern "C" int hp_net_profile_intervals(hp_net* net, double* t0_ms, double* t1_m
 
 extern "C" int hp_net_set_conv_algo(hp_net* net, int algo) {
   HP_REQUIRE(net, "hp_net_set_conv_algo: null net");
-  HP_REQUIRE(algo >= -1 && algo <= HP_CONV_ALGO_SPLIT, "hp_net_set_conv_algo: unknown algorithm");
+  HP_REQUIRE(algo >= -1 && algo <= HP_CONV_ALGO_WINO_SPLIT, "hp_net_set_conv_algo: unknown algorithm");
   net->algo = algo;
   return HP_OK;
 }

@@ -587,7 +587,7 @@ def probe_mfma_rate(device, random_data: bool = True):
     return tf.value, mhz.value
 
 
-CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2, "winograd-1wave": 3, "winograd": 4, "split": 5}
+CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2, "winograd-1wave": 3, "winograd": 4, "split": 5, "winograd-split": 6}
 
 
 def select_conv_algo(name: str = "auto") -> None:

@@ -361,6 +361,9 @@ int hp_net_set_profiling(hp_net* net, int enabled);
 #define HP_CONV_ALGO_WINOGRAD_1WAVE 3 /* WINOGRAD, but the one-wave-per-SIMD schedule of the Winograd kernel */
 #define HP_CONV_ALGO_WINOGRAD 4 /* exact-fp32 kernels only: Winograd, else patch-staged, else generic */
 #define HP_CONV_ALGO_SPLIT 5 /* split-fp16 kernels (3 fp16 MFMAs per fp32 product) wherever they apply */
+#define HP_CONV_ALGO_WINO_SPLIT 6 /* SPLIT, with the 3x3 stride-1 layers (Cin >= 64) as Winograd F(2x2,3x3) on the split operands:
+                                     2.25x fewer products; measured SLOWER than the direct split kernels on MI355X (LDS-read bound,
+                                     DESIGN.md 4.1), kept selectable */
 int hp_conv_select_algo(int algo);
 /* The same choice for ONE network (what the predictors use: no process-wide state on the launch path, networks on
  * different host threads / streams do not interfere); algo = -1 returns the network to the process-wide default. */
