@@ -354,10 +354,14 @@ def stage_rates(store, scene, images, K, TCO0, im_ids, device, reps=20):
 
     t_ref, t_fast = timeit(fused(True, True)), timeit(fused(False, False))
     t_r = timeit(lambda: ops.rasterize_into(store, x, 3, obj, TCO0[:, None], Kc[:, None], False, False))
+    t_rr = timeit(lambda: ops.rasterize_into(store, x, 3, obj, TCO0[:, None], Kc[:, None], False, False, msaa=True, aniso=True))
     t_c = timeit(lambda: ops.crop_roi_align(images, prep["boxes_crop"], im_ids, out=x, n_channels=3))
     return {
-        "render_inputs": entry(t_ref, raster_bytes + crop_bytes, views=B, crops=B, coverage=covered / (B * 76800),
-                               render_state="reference: 4x MSAA + mipmap / anisotropic-16 (product default)"),
+        "rasterize_reference_state": entry(t_rr, raster_bytes, views=B, coverage=covered / (B * 76800),
+                                           render_state="reference: 4x MSAA + mipmap / anisotropic-16 (product default); what the "
+                                                        "predictors launch after the stand-alone crop"),
+        "render_inputs": entry(t_ref, raster_bytes + crop_bytes, views=B, crops=B,
+                               render_state="reference state, crop fused into the render launch (opt-in: fuse_crop)"),
         "render_inputs_single_sample": entry(t_fast, raster_bytes + crop_bytes, views=B, crops=B,
                                              render_state="single sample, bilinear level 0 (BatchRenderer(msaa=False, aniso=False))"),
         "rasterize": entry(t_r, raster_bytes, views=B, render_state="single sample, bilinear; stand-alone launch into its channel slice"),

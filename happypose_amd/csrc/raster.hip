@@ -507,6 +507,7 @@ struct ShadeCtx {
   const float* T; const float* Kv; const float* amb; const float4* xv; const int32_t* fbase;
   int64_t voff, toff; int tw, th, view, q8, nlev, aniso;
   const MipTable* mips;  // per-workgroup table of the object's mip levels (LDS)
+  bool need_normal;      // the view renders normals or has point lights: otherwise the normal is never looked at
 };
 template <bool ANISO>
 __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx& cx, int f, int i, int j, float* o_rgb, float* o_n) {
@@ -555,16 +556,18 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
       alb[c] = fmaf(b0, (float)a.colors[4 * g0 + c],
                     fmaf(b1, (float)a.colors[4 * g1 + c], b2 * (float)a.colors[4 * g2 + c])) / 255.0f;
   }
-  float no[3], nc[3];
-  const float4 n0 = a.normals4[g0], n1 = a.normals4[g1], n2 = a.normals4[g2];
-  no[0] = fmaf(b0, n0.x, fmaf(b1, n1.x, b2 * n2.x));
-  no[1] = fmaf(b0, n0.y, fmaf(b1, n1.y, b2 * n2.y));
-  no[2] = fmaf(b0, n0.z, fmaf(b1, n1.z, b2 * n2.z));
-  nc[0] = fmaf(T[0], no[0], fmaf(T[1], no[1], T[2] * no[2]));
-  nc[1] = fmaf(T[4], no[0], fmaf(T[5], no[1], T[6] * no[2]));
-  nc[2] = fmaf(T[8], no[0], fmaf(T[9], no[1], T[10] * no[2]));
-  float nn = sqrtf(fmaf(nc[0], nc[0], fmaf(nc[1], nc[1], nc[2] * nc[2])));
-  if (nn > 0.0f) { nc[0] /= nn; nc[1] /= nn; nc[2] /= nn; }
+  float no[3], nc[3] = {0.f, 0.f, 0.f};
+  if (cx.need_normal) {
+    const float4 n0 = a.normals4[g0], n1 = a.normals4[g1], n2 = a.normals4[g2];
+    no[0] = fmaf(b0, n0.x, fmaf(b1, n1.x, b2 * n2.x));
+    no[1] = fmaf(b0, n0.y, fmaf(b1, n1.y, b2 * n2.y));
+    no[2] = fmaf(b0, n0.z, fmaf(b1, n1.z, b2 * n2.z));
+    nc[0] = fmaf(T[0], no[0], fmaf(T[1], no[1], T[2] * no[2]));
+    nc[1] = fmaf(T[4], no[0], fmaf(T[5], no[1], T[6] * no[2]));
+    nc[2] = fmaf(T[8], no[0], fmaf(T[9], no[1], T[10] * no[2]));
+    float nn = sqrtf(fmaf(nc[0], nc[0], fmaf(nc[1], nc[1], nc[2] * nc[2])));
+    if (nn > 0.0f) { nc[0] /= nn; nc[1] /= nn; nc[2] /= nn; }
+  }
   float lit[3] = {amb[0], amb[1], amb[2]};
   if (a.n_lights > 0) {
     float py = (pv - Kv[5]) * Z / Kv[4];
@@ -585,9 +588,13 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) o_rgb[c] = quant8(alb[c] * lit[c], q8);
-  o_n[0] = quant8(normal_code(nc[0]), q8);
-  o_n[1] = quant8(normal_code(-nc[1]), q8);
-  o_n[2] = quant8(normal_code(-nc[2]), q8);
+  if (cx.need_normal) {
+    o_n[0] = quant8(normal_code(nc[0]), q8);
+    o_n[1] = quant8(normal_code(-nc[1]), q8);
+    o_n[2] = quant8(normal_code(-nc[2]), q8);
+  } else {
+    o_n[0] = o_n[1] = o_n[2] = 0.f;
+  }
 }
 
 // ---- the band kernel ------------------------------------------------------------------------------------------------
@@ -889,7 +896,7 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
   float amb[3] = {1.0f, 1.0f, 1.0f};
   if (a.ambient) { amb[0] = a.ambient[3 * view]; amb[1] = a.ambient[3 * view + 1]; amb[2] = a.ambient[3 * view + 2]; }
   const ShadeCtx cx{T, Kv, amb, xv, fbase, voff, toff, tw, th, view, q8, (int)ob[7] > 0 ? (int)ob[7] : 1,
-                    (a.flags & HP_RASTER_TEX_ANISO) != 0, &mips};
+                    (a.flags & HP_RASTER_TEX_ANISO) != 0, &mips, (a.rec ? a.want_nrm != 0 : a.nrm != nullptr) || a.n_lights > 0};
   const bool want_colour = a.rec ? true : (a.rgb != nullptr || a.nrm != nullptr);
   const bool coded = !band_empty;  // colours travel as 8-bit codes through LDS
   if (coded) {

@@ -22,6 +22,7 @@ The reference's per-iteration host work (pickling to renderer processes, numpy
 
 from __future__ import annotations
 
+import os
 import time
 from collections import defaultdict
 from dataclasses import dataclass, field
@@ -103,6 +104,8 @@ class _RenderAndCompare:
         self.device = self.store.device
         self.keep_pixels = False
         self.debug = False
+        # True: the observed crop is produced by the render launch itself (hp_render_inputs with the crop arguments)
+        self.fuse_crop = os.environ.get("HP_FUSE_CROP", "") == "1"
         self._x: Optional[torch.Tensor] = None
         # hipGraph replay of forward() (happypose_amd.graphs): off unless asked for -- the first two calls of a
         # signature run eagerly / capture, and callers that time single launches want the eager path
@@ -203,10 +206,23 @@ class _RenderAndCompare:
             ov = obj_ids.long().repeat_interleave(V)
             lights = dict(ambient=amb[None].expand(b * V, 3).contiguous(), light_pos=pos[ov].contiguous(),
                           light_col=col[None].expand(b * V, -1, 3).contiguous())
-        # crop of the observation + the rendered views: one launch, every pixel record of x written once
-        ops.render_inputs(self.store, x, obj_ids, prep["TCV_O"], prep["K_crop"], render_normals, render_depth,
-                          images=images, boxes=prep["boxes_crop"], im_ids=im_ids, n_img_channels=n_img_channels,
-                          depth_norm_z=z, depth_norm_mode=depth_mode, msaa=self.renderer.msaa, aniso=self.renderer.aniso, **lights)
+        V = prep["TCV_O"].shape[1]
+        fuse = bool(self.fuse_crop)
+        if fuse:
+            # crop of the observation + the rendered views in ONE launch, every pixel record of x written once (opt-in:
+            # ``fuse_crop = True`` / HP_FUSE_CROP=1).  Built to remove the partial-sector traffic of two writers; measured
+            # in the pipeline it is a wash for MegaPose (2261 vs 2270 poses/s) and slower for one-view models (C2 4563
+            # vs 4753, C5 37.9 k vs 38.9 k views/s): every workgroup then carries the crop's taps on top of a VALU-bound
+            # shading pass, so the stand-alone crop launch in front stays the default
+            ops.render_inputs(self.store, x, obj_ids, prep["TCV_O"], prep["K_crop"], render_normals, render_depth,
+                              images=images, boxes=prep["boxes_crop"], im_ids=im_ids, n_img_channels=n_img_channels,
+                              depth_norm_z=z, depth_norm_mode=depth_mode, msaa=self.renderer.msaa, aniso=self.renderer.aniso, **lights)
+        else:
+            ops.crop_roi_align(images, prep["boxes_crop"], im_ids, self.render_size, out=x, depth_norm_z=z,
+                               depth_norm_mode=depth_mode if n_img_channels == 4 else 0, n_channels=n_img_channels, owns_record=True)
+            ops.render_inputs(self.store, x, obj_ids, prep["TCV_O"], prep["K_crop"], render_normals, render_depth,
+                              chan0=n_img_channels, depth_norm_z=z, depth_norm_mode=depth_mode, msaa=self.renderer.msaa,
+                              aniso=self.renderer.aniso, **lights)
         render_time = time.time() - t0
         pose, logits, _ = self.backbone.forward(x, want_pose=want_pose, want_logits=want_logits)
         return prep, x, pose, logits, render_time
