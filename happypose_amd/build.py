@@ -18,7 +18,7 @@ CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libhappypose_amd.so"
 OBJ_DIR = PKG / "build_obj"
-SOURCES = ["api.cpp", "net.cpp", "raster.hip", "geometry.hip", "crop.hip", "conv.hip", "conv_patch.hip", "conv_wino.hip", "conv_split.hip", "conv_pp.hip", "conv_igemm_split.hip", "conv_stem_split.hip", "conv_stem7.hip", "conv_f16.hip", "pool_head.hip", "icp.hip", "mbconv.hip", "mbconv_front.hip", "probe.hip", "detect.hip"]
+SOURCES = ["api.cpp", "net.cpp", "raster.hip", "geometry.hip", "crop.hip", "conv.hip", "conv_patch.hip", "conv_wino.hip", "conv_wino2.hip", "conv_split.hip", "conv_pp.hip", "conv_igemm_split.hip", "conv_stem_split.hip", "conv_stem7.hip", "conv_f16.hip", "pool_head.hip", "icp.hip", "mbconv.hip", "mbconv_front.hip", "probe.hip", "detect.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
          "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 

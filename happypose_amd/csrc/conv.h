@@ -148,6 +148,11 @@ bool conv_wino_split_launchable(const ConvArgs& a);
 size_t conv_wino_split_weight_bytes(int cout, int cin);
 int conv_wino_split_transform_weights(const float* d_w, void* d_U, int cout, int cin, int Kpad, hipStream_t stream);
 int launch_conv_wino_split(const ConvArgs& a, hipStream_t stream);
+// the same arithmetic tiled for the fp16 matrix path: 64 tiles x 64 couts per item, v_mfma_f32_32x32x16_f16 (conv_wino2.hip)
+bool conv_wino2_launchable(const ConvArgs& a);
+size_t conv_wino2_weight_bytes(int cout, int cin);
+int conv_wino2_transform_weights(const float* d_w, void* d_U, int cout, int cin, int Kpad, hipStream_t stream);
+int launch_conv_wino2(const ConvArgs& a, hipStream_t stream);
 // 3x3 / pad 1, stride 1 (Cin % 32 == 0, Cout % 64 == 0) or stride 2 (Cin % 64 == 0, Cout % 128 == 0): fp32 operands split into fp16 halves, three fp16
 // MFMAs per product (conv_split.hip); a.w must point at weights split by conv_split_transform_weights
 bool conv_split_applicable(const ConvArgs& a, int kh, int kw);
@@ -190,6 +195,14 @@ inline bool conv_use_split(int algo, int H, int W, int cin, int cout) {
 inline bool conv_use_wino_split(int algo, int W) {
   if (algo == HP_CONV_ALGO_WINO_SPLIT) return true;
   static const int mask = std::getenv("HP_WINO_SPLIT") ? std::atoi(std::getenv("HP_WINO_SPLIT")) : 0;
+  const int bit = W >= 80 ? 1 : W >= 40 ? 2 : W >= 20 ? 4 : 8;
+  return (mask & bit) != 0;
+}
+// conv_wino2.hip on a layer: always with HP_CONV_ALGO_WINO_SPLIT, else per HP_WINO2 = bit mask over the map widths
+// {80, 40, 20, 10} -> bits {1, 2, 4, 8}
+inline bool conv_use_wino2(int algo, int W) {
+  if (algo == HP_CONV_ALGO_WINO_SPLIT) return true;
+  static const int mask = std::getenv("HP_WINO2") ? std::atoi(std::getenv("HP_WINO2")) : 0;
   const int bit = W >= 80 ? 1 : W >= 40 ? 2 : W >= 20 ? 4 : 8;
   return (mask & bit) != 0;
 }

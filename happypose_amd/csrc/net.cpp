@@ -51,6 +51,7 @@ struct ConvLayer {
   int H, W, Ho, Wo, Kpad;
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
   DevBuf w_wsplit;         // Winograd-transformed weights as fp16 hi/lo halves (conv_wino.hip, SPLIT)
+  DevBuf w_w2;             // the same for conv_wino2.hip (64 x 64 items)
   DevBuf w, w_wino, w_split, w_isplit, bias, lut, pre_scale, pre_shift;  // w_isplit: hi/lo halves for conv_igemm_split.hip  // w_wino: Winograd-transformed weights (3x3 s1 layers)
                                                                // w_split: fp16 hi/lo halves (conv_split.hip)
   int cout_pad = 0;        // weight rows / bias padded to whole 64-wide tiles
@@ -455,6 +456,11 @@ int pack_conv(Net& n, ConvLayer& L) {
         if ((rc = L.w_wsplit.alloc(conv_wino_split_weight_bytes(L.cout, L.cin)))) return rc;
         if ((rc = conv_wino_split_transform_weights((const float*)L.w.p, L.w_wsplit.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
         HP_CHECK_HIP(hipStreamSynchronize(nullptr));
+        if (L.cout % 64 == 0) {
+          if ((rc = L.w_w2.alloc(conv_wino2_weight_bytes(L.cout, L.cin)))) return rc;
+          if ((rc = conv_wino2_transform_weights((const float*)L.w.p, L.w_w2.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
+          HP_CHECK_HIP(hipStreamSynchronize(nullptr));
+        }
       }
     }
     if (conv_split_applicable(probe, L.kh, L.kw) && L.cout_pad == L.cout && L.relu != HP_ACT_SWISH && !L.se) {
@@ -891,6 +897,12 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         pool_fused = true; tracks_amax = false;
         const int sc = L.cin % 8 == 0 ? 8 : 4, ks = (7 * sc + 15) / 16;
         mfma_flops = 3.0 / 16.0 * 2.0 * (double)a.M * (256.0 / 192.0) * L.cout * (L.cin / sc) * 7.0 * ks * 16.0;
+      } else if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_w2.p && conv_use_wino2(algo, L.W) && conv_wino2_launchable(a)) {
+        // Winograd F(2x2,3x3) on the split operands, 64 tiles x 64 couts per workgroup on 32x32x16 MFMAs
+        a.w = (const float*)L.w_w2.p;
+        a.status = net->d_status;
+        rc = launch_conv_wino2(a, stream);
+        mfma_flops = 3.0 * 2.0 * 16.0 * (double)((((int64_t)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2)) + 63) / 64 * 64) * L.cin * L.cout / 16.0;
       } else if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_wsplit.p && conv_use_wino_split(algo, L.W) &&
                  conv_wino_split_launchable(a)) {
         // Winograd F(2x2,3x3) on the split operands: 2.25x fewer products, each three fp16 MFMAs (16x16x16)
