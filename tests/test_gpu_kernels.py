@@ -119,13 +119,18 @@ def test_rasterizer_msaa4_vs_oracle(dev, scene_store):
     assert torch.equal(x[..., 3:6].permute(0, 3, 1, 2), gpu[0])
 
 
-@pytest.mark.parametrize("msaa", [False, True])
-def test_rasterizer_texture_filter_vs_oracle(dev, scene_store, msaa):
+@pytest.mark.parametrize("msaa,tex_size", [(False, 256), (True, 256), (True, 208)])
+def test_rasterizer_texture_filter_vs_oracle(dev, scene_store, msaa, tex_size):
     """HP_RASTER_TEX_ANISO (the reference's texture state: mip-mapped trilinear + anisotropic 16) against the oracle's
-    definition, alone and together with multisampling; geometry outputs do not depend on it."""
+    definition, alone and together with multisampling; geometry outputs do not depend on it.  Power-of-two textures take
+    the mask / shift / probe-table path of the kernel, a 208 x 208 texture the generic one (integer modulo wraps)."""
     from happypose_amd import ops
     from oracle import native
 
+    if tex_size != 256:
+        from happypose_amd.synthetic import make_object_dataset
+
+        scene_store = ops.MeshStore(make_object_dataset(3, seed=1, tex_size=tex_size), dev)
     n = 9
     T = _poses(n, 7, zlo=0.3, zhi=1.6)  # near and far: magnified and strongly minified textures
     K = np.tile(np.array([[900.0, 0, 160], [0, 900.0, 120], [0, 0, 1]], np.float32), (n, 1, 1))
