@@ -413,10 +413,18 @@ __device__ __forceinline__ void shade_pixel(const TriSetup& s, int i, int j, uin
     bool in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (sum < 0.0f);
     if (!(in_pos | in_neg)) continue;
     // depth = the vertex depths interpolated with the perspective-correct barycentrics (oracle.c explains why not det / sum)
+#ifdef HP_RABL_NO_SAMPLE_DIV
+    float Z = fmaf(l0, s.z0, fmaf(l1, s.z1, l2 * s.z2)) * sum;
+#else
     float Z = fmaf(l0, s.z0, fmaf(l1, s.z1, l2 * s.z2)) / sum;
+#endif
     if (!(Z >= kZNear) || !(Z <= kZFar)) continue;
     unsigned long long key = ((unsigned long long)__float_as_uint(Z) << 32) | f;
+#ifndef HP_RABL_NO_SAMPLE_ATOMIC
     atomicMin(&zb[((i - row0) * w + j) * NS + sm], key);
+#else
+    if (key == 12345ull) zb[0] = key;
+#endif
   }
 }
 
@@ -696,6 +704,9 @@ __device__ __forceinline__ void crop_taps(const float* __restrict__ img, int HW,
 
 // HALF: fp16 destinations (the input of an fp16 network plan) -- its own instantiation so that the fp32 path's register
 // budget (80 VGPRs: three 512-thread workgroups per CU) does not carry the 16-half record assembly
+#ifdef HP_RABL_COUNT
+__device__ unsigned long long hp_dbg_cnt[8];  // [0] walk iterations (wave level), [1] sum of bbox areas, [2] triangles, [3] survivors, [4] waves
+#endif
 template <int NS, bool HALF, bool ANISO>
 __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) void raster_kernel(RasterArgs a, int npix_max) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -860,8 +871,20 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
           m[e] = fmaxf(fmaf(0.125f, ax, 0.375f * ay), fmaf(0.375f, ax, 0.125f * ay)) * 1.001f + sl;
         }
       }
+#ifdef HP_RABL_COUNT
+      {
+        const int ar = valid ? (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1) : 0;
+        atomicAdd(&hp_dbg_cnt[1], (unsigned long long)ar);
+        if (valid) atomicAdd(&hp_dbg_cnt[2], 1ull);
+        if (lane == 0) atomicAdd(&hp_dbg_cnt[4], 1ull);
+      }
+#endif
       int ci = s.y0, cj = s.x0;
+#ifdef HP_RABL_NO_WALK
+      bool more = valid && s.z0 == 12345.f;
+#else
       bool more = valid;
+#endif
       while (__any(more)) {
         bool surv = false;
         const int pi = ci, pj = cj;
@@ -877,6 +900,9 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
           more = ci <= s.y1;
         }
         const unsigned long long sm = __ballot(surv);
+#ifdef HP_RABL_COUNT
+        if (lane == 0) { atomicAdd(&hp_dbg_cnt[0], 1ull); atomicAdd(&hp_dbg_cnt[3], (unsigned long long)__popcll(sm)); }
+#endif
         if (surv) q[(qt + __popcll(sm & lt_mask)) & 127] = ((uint32_t)lane << 16) | (uint32_t)((pi - row0) * a.w + pj);  // npix_max < 65536
         qt += __popcll(sm);
         while (qt - qh >= 64 || (qt > qh && !__any(more))) {  // a full wave of pairs, or the rest once every box is walked
@@ -890,7 +916,11 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
           for (int c = 0; c < 3; ++c) { t.e0[c] = __shfl(s.e0[c], owner); t.e1[c] = __shfl(s.e1[c], owner); t.e2[c] = __shfl(s.e2[c], owner); }
           t.z0 = __shfl(s.z0, owner); t.z1 = __shfl(s.z1, owner); t.z2 = __shfl(s.z2, owner);
           const int tf = __shfl(f, owner);
+#ifndef HP_RABL_NO_POP
           if (lane < n) shade_pixel<NS>(t, row0 + er, ep - er * a.w, (uint32_t)tf, zb, row0, a.w);
+#else
+          if (lane < n && t.e0[0] == 12345.f && tf == 77) zb[0] = 0;
+#endif
           qh += n;
         }
       }
@@ -1376,3 +1406,11 @@ extern "C" int hp_render_inputs(const hp_mesh_store* store, int n_items, int vie
   a.boxes = d_boxes; a.im_ids = d_im_ids;
   return launch_raster(store, a, a.n, crop, (hipStream_t)stream);
 }
+
+#ifdef HP_RABL_COUNT
+extern "C" int hp_debug_raster_counters(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hp::hp_dbg_cnt), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hp::hp_dbg_cnt), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
