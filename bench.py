@@ -423,10 +423,15 @@ def main():
 
     from happypose_amd import distributed as D
 
-    rank, local_rank, world = D.init_distributed("nccl" if args.gpus > 1 else None)
+    # HP_BENCH_DIST_BACKEND=gloo + HP_BENCH_ONE_DEVICE=1: every rank on cuda:0 with gloo collectives -- how the N > 1 path
+    # (sharded batch, refine_sharded with the real predictor, the all-gather, max-over-ranks timing) is exercised on a
+    # one-GPU box (tests/test_gpu_pipeline.py); RCCL refuses two ranks on one device.  Not a measurement.
+    backend = os.environ.get("HP_BENCH_DIST_BACKEND", "nccl")
+    one_device = os.environ.get("HP_BENCH_ONE_DEVICE") == "1"
+    rank, local_rank, world = D.init_distributed(backend if args.gpus > 1 else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required (no CPU fallback)"
-    device = torch.device(f"cuda:{local_rank}")
+    device = torch.device("cuda:0" if one_device else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
     if args.workload == "E2E":

@@ -1279,3 +1279,28 @@ def test_lit_megapose_refiner_vs_reference_golden_g10(dev, golden_dir):
                            max_batch=4)
     check("mp_rgbd4_hi", m4.forward(images, K, lab4, torch.as_tensor(sc["TCO_hyp"][sel4]), n_iterations=3,
                                     im_ids=torch.zeros(3, dtype=torch.int32)), 3, T_TOL_HI, R_TOL_HI)
+
+
+def test_bench_two_ranks_on_one_device(dev):
+    """``bench.py --gpus 2`` as the driver launches it (two processes, RANK / WORLD_SIZE wiring, the 2 x 128-hypothesis batch
+    of C4 cut by ``distributed.refine_sharded`` with the REAL two-lane predictor in both processes, the all-gather of the
+    refined poses, max-over-ranks timing, one JSON line from rank 0) -- on the one GPU of this box: both ranks on cuda:0,
+    gloo instead of RCCL (which refuses two ranks on one device).  Everything but the transport of the collective."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HP_BENCH_DIST_BACKEND="gloo", HP_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-exact-fp32", "--no-extra-workloads"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    assert d["config"]["hypotheses_per_gpu"] == 128 and "all_gather_us" in d
+    assert d["value"] > 0 and abs(d["value"] - 2 * 128 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]  # whole-job rate
