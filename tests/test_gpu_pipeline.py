@@ -1304,3 +1304,33 @@ def test_bench_two_ranks_on_one_device(dev):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
     assert d["config"]["hypotheses_per_gpu"] == 128 and "all_gather_us" in d
     assert d["value"] > 0 and abs(d["value"] - 2 * 128 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]  # whole-job rate
+
+
+def test_estimators_shard_with_real_predictors_two_ranks(dev):
+    """8(e) behind the entry point with the HIP predictors: two processes (both on cuda:0, gloo) run MegaPose's and
+    CosyPose's ``run_inference_pipeline`` sharded and unsharded (tests/gpu_shard_worker.py): same ids / labels / order,
+    poses within the parity tolerance of the unsharded run, and bit-identical results on both ranks."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "gpu_shard_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in out, out[-3000:]
