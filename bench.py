@@ -400,7 +400,7 @@ def main():
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS),
                     help="BASELINE.json config (default C2 = the one the headline metric is quoted on)")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the secondary run on the exact-fp32 kernels")
-    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2, 3, 4],
                     help="refiner workloads (C2, C3): 2 = two half-batch chains on two streams (TwoLanePredictor)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16"],
                     help="conv arithmetic (default: f32, the reference's; f16 for C5 as BASELINE.json names it)")
@@ -590,7 +590,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
             "config": {"workload": desc + (", renders in the reference's state (4x MSAA, mipmap + anisotropic-16)" if args.render_state == "reference"
                                            else ", single-sample bilinear renders") +
-                       (", two half-batch lanes on two streams" if n_lanes == 2 else "") +
+                       (f", {n_lanes} lanes (shares of the batch as independent chains on their own streams)" if n_lanes >= 2 else "") +
                        (", the 5-iteration step replayed as one captured hipGraph" if graphs else ""),
                        "hypotheses_per_gpu": B, "iterations": N_ITERS if args.workload != "C5" else 1,
                        "parallelism": f"hypothesis-shard x{world}" + (f" (one {world * B}-hypothesis batch, distributed.refine_sharded)" if sharded else "")},

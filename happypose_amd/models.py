@@ -201,13 +201,13 @@ def _efficientnet_b3_param_shapes(n_inputs: int, pose_dim: int, n_views_logits: 
     return s
 
 
-def _two_lanes(make, renderer: BatchRenderer, max_batch: int):
-    """Two predictors for :class:`TwoLanePredictor`: lane 1 gets its own mesh store (rasteriser scratch)."""
+def _two_lanes(make, renderer: BatchRenderer, max_batch: int, n_lanes: int = 2):
+    """``n_lanes`` predictors for :class:`TwoLanePredictor`: every lane after the first gets its own mesh store
+    (rasteriser scratch) through ``renderer.clone_for_lane()`` -- same render state (msaa / aniso / ...)."""
     from .pose_predictor import TwoLanePredictor
 
-    half = (max_batch + 1) // 2
-    r1 = renderer.clone_for_lane()  # same render state (msaa / aniso / ...), own store
-    return TwoLanePredictor([make(renderer, half), make(r1, half)])
+    share = (max_batch + n_lanes - 1) // n_lanes
+    return TwoLanePredictor([make(renderer if i == 0 else renderer.clone_for_lane(), share) for i in range(n_lanes)])
 
 
 def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Optional[Dict] = None,
@@ -217,8 +217,8 @@ def create_model_pose(cfg, renderer: BatchRenderer, mesh_db=None, state_dict: Op
     ``forward`` runs two half-batch chains on two streams (:class:`TwoLanePredictor`).  ``graphs=True``: ``forward`` is
     captured once per call signature and replayed as a hipGraph (``happypose_amd.graphs``; pays off when the launches
     are shorter than the host's launch rate: refiner batches of <= 64)."""
-    if n_lanes == 2:
-        model = _two_lanes(lambda r, mb: create_model_pose(cfg, r, mesh_db, state_dict, mb, precision), renderer, max_batch)
+    if n_lanes >= 2:
+        model = _two_lanes(lambda r, mb: create_model_pose(cfg, r, mesh_db, state_dict, mb, precision), renderer, max_batch, n_lanes)
         model.use_graphs = graphs
         return model
     assert n_lanes == 1
@@ -246,7 +246,7 @@ def create_pose_model_cosypose(cfg, renderer: BatchRenderer, mesh_db=None, state
                                graphs: bool = False) -> CosyPosePosePredictor:
     """``CP/training/pose_models_cfg.py:30-53`` (6 input channels; ``n_pose_dims`` = 9).  ``n_lanes`` as in
     :func:`create_model_pose`."""
-    if n_lanes == 2:
+    if n_lanes >= 2:
         model = _two_lanes(lambda r, mb: create_pose_model_cosypose(cfg, r, mesh_db, state_dict, mb, precision), renderer,
                            max_batch)
         model.use_graphs = graphs

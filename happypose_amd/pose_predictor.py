@@ -525,7 +525,7 @@ class TwoLanePredictor:
     MIN_BATCH = 32
 
     def __init__(self, lanes):
-        assert len(lanes) == 2
+        assert len(lanes) >= 2
         self.lanes = list(lanes)
         self.device = lanes[0].device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in lanes]
@@ -550,6 +550,14 @@ class TwoLanePredictor:
         self.lanes[0].to(device)
         return self
 
+    def _cuts(self, bsz: int):
+        """Contiguous shares of a batch, one per lane (the first lanes take the remainder; two lanes: bsz // 2 + the rest
+        as before would put the odd row on lane 1 -- kept: lane 0 gets floor, the last lane the remainder)."""
+        n = len(self.lanes)
+        q = bsz // n
+        edges = [i * q for i in range(n)] + [bsz]
+        return [slice(edges[i], edges[i + 1]) for i in range(n)]
+
     def numerics_status(self) -> int:
         """Guard flags over both lanes' backbones (see ``_RenderAndCompare.numerics_status``)."""
         torch.cuda.current_stream(self.device).synchronize()  # forward() already joined the lane streams into it
@@ -564,7 +572,7 @@ class TwoLanePredictor:
             return self.lanes[0].forward(images, K, labels, TCO, n_iterations=n_iterations, im_ids=im_ids, **kw)
         assert not kw.get("random_ambient_light", False), "random_ambient_light is a training-time augmentation"
         labels = list(labels)
-        h = bsz // 2
+        cuts = self._cuts(bsz)
         lane0 = self.lanes[0]
         assert TCO.shape == (bsz, 4, 4) and K.dim() == 3 and K.shape[1:] == (3, 3) and images.dim() == 4
         per_hyp = im_ids is None  # the reference's calling convention: images / K already gathered per hypothesis
@@ -578,7 +586,7 @@ class TwoLanePredictor:
         # add its reduction (C2: 24.5 ms with, 22.5 ms without)
         self.backbone.set_tail_split(False)  # per network: other predictors are not affected
         try:
-            for lane, stream, sl in zip(self.lanes, self.streams, (slice(0, h), slice(h, bsz))):
+            for lane, stream, sl in zip(self.lanes, self.streams, cuts):
                 lane.use_graphs = self.use_graphs
                 stream.wait_stream(cur)
                 with torch.cuda.stream(stream):
@@ -604,12 +612,12 @@ class TwoLanePredictor:
         if bsz < 2 * self.MIN_BATCH or cuda_timer or return_debug_data:
             return self.lanes[0].forward_coarse(images, K, labels, TCO_input, cuda_timer, return_debug_data, im_ids)
         labels = list(labels)
-        h = bsz // 2
+        cuts = self._cuts(bsz)
         cur = torch.cuda.current_stream(self.device)
         parts = []
         self.backbone.set_tail_split(False)
         try:
-            for lane, stream, sl in zip(self.lanes, self.streams, (slice(0, h), slice(h, bsz))):
+            for lane, stream, sl in zip(self.lanes, self.streams, cuts):
                 per_hyp = im_ids is None
                 stream.wait_stream(cur)
                 with torch.cuda.stream(stream):
