@@ -239,6 +239,12 @@ __device__ __forceinline__ void tex_fetch_aniso(const uint8_t* tex, int tw, int 
 // ---- the same filter, organised for the machine (power-of-two textures; others take tex_fetch_aniso above): the mip
 // levels' offsets / sizes come from a per-workgroup table (LDS) and the probes are processed in PAIRS so that the 16 texel
 // loads of two trilinear probes are in flight together (the rolled loop pays one L2 round trip per probe).
+#ifdef HP_RABL_COUNT
+// tools/raster_walk_count.py: [0] low half: walk iterations (wave level), high half: probe-pair iterations (wave level), [1] sum of bbox
+// areas, [2] triangles, [3] survivors, [4] wave batches, [5] shading invocations with the anisotropic filter, [6] their probes,
+// [7] those blending two levels
+__device__ unsigned long long hp_dbg_cnt[8];
+#endif
 struct MipTable {
   int off[16], w[16], h[16];
   int sh[16];        // log2(w) + 2 when the texture's sizes are powers of two (row pitch in bytes as a shift)
@@ -305,9 +311,15 @@ __device__ __forceinline__ void tex_fetch_aniso_p2(const uint8_t* tex, const Mip
   const int off0 = mt.off[l0], w0 = mt.w[l0], h0 = mt.h[l0], s0 = mt.sh[l0];
   const int off1 = mt.off[l1], w1 = mt.w[l1], h1 = mt.h[l1], s1 = mt.sh[l1];
   const float* const tt = mt.tt[N - 1];
+#ifdef HP_RABL_COUNT
+  atomicAdd(&hp_dbg_cnt[5], 1ull); atomicAdd(&hp_dbg_cnt[6], (unsigned long long)N); if (two) atomicAdd(&hp_dbg_cnt[7], 1ull);
+#endif
   float acc[3] = {0.0f, 0.0f, 0.0f};
   for (int i = 1; i <= N; i += 2) {
     const bool second = i + 1 <= N;
+#ifdef HP_RABL_COUNT
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&hp_dbg_cnt[0], 1ull << 32);
+#endif
     const float ta = tt[i - 1];
     const float tb = tt[second ? i : i - 1];
     const float sua = fmaf(ta, du, u), sva = fmaf(ta, dv, v), sub = fmaf(tb, du, u), svb = fmaf(tb, dv, v);
@@ -704,9 +716,6 @@ __device__ __forceinline__ void crop_taps(const float* __restrict__ img, int HW,
 
 // HALF: fp16 destinations (the input of an fp16 network plan) -- its own instantiation so that the fp32 path's register
 // budget (80 VGPRs: three 512-thread workgroups per CU) does not carry the 16-half record assembly
-#ifdef HP_RABL_COUNT
-__device__ unsigned long long hp_dbg_cnt[8];  // [0] walk iterations (wave level), [1] sum of bbox areas, [2] triangles, [3] survivors, [4] waves
-#endif
 template <int NS, bool HALF, bool ANISO>
 __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) void raster_kernel(RasterArgs a, int npix_max) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

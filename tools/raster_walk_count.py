@@ -32,6 +32,9 @@ for wl in ("C2", "C3"):
                        0 if c2 else 2, msaa=True, aniso=True)
     torch.cuda.synchronize()
     lib.hp_debug_raster_counters(buf, 1)
-    it, area, tri, surv, waves = [int(buf[i]) for i in range(5)]
+    it, area, tri, surv, waves, inv, probes, two = [int(buf[i]) for i in range(8)]
+    pair_it, it = it >> 32, it & 0xFFFFFFFF
     print(wl, dict(walk_iterations=it, sum_area=area, triangles=tri, survivors=surv, waves=waves, mean_area=area / max(tri, 1),
-                   iterations_per_wave=it / max(waves, 1), lane_utilisation=area / max(64 * it, 1), survivor_fraction=surv / max(area, 1)))
+                   iterations_per_wave=it / max(waves, 1), lane_utilisation=area / max(64 * it, 1), survivor_fraction=surv / max(area, 1), shading_invocations=inv, probes_per_invocation=probes / max(inv, 1),
+                   two_level_fraction=two / max(inv, 1), probe_pair_iterations=pair_it,
+                   probe_lane_utilisation=probes / max(128 * pair_it, 1)))
