@@ -206,13 +206,14 @@ def recorded_traffic(kind="conv"):
         return None, None
 
 
-def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2):
+def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2, renderer_kw=None):
     """A short run of another BASELINE.json config in the same process (C3: MegaPose RGB-D refiner, fp32; C5: coarse
-    scoring in fp16): ``{value, unit, ms_per_step, frac, algorithmic_tflops, steps}`` -- the driver-visible twin of
-    ``bench.py --workload C3|C5``."""
+    scoring in fp16; C2 again in another render state): ``{value, unit, ms_per_step, frac, algorithmic_tflops, steps}`` --
+    the driver-visible twin of ``bench.py --workload C3|C5`` / ``--render-state single-sample``."""
     from happypose_amd import ops as _ops
 
-    ds, renderer, scene, weights, model = build_world(device, "resnet34", seed=0, workload=workload, precision=precision, n_lanes=n_lanes)
+    ds, renderer, scene, weights, model = build_world(device, "resnet34", seed=0, workload=workload, precision=precision, n_lanes=n_lanes,
+                                                      renderer_kw=renderer_kw)
     store = renderer.store
     B = len(scene["TCO_hyp"])
     images, K = torch.as_tensor(scene["images"], device=device), torch.as_tensor(scene["K"], device=device)
@@ -657,9 +658,13 @@ def main():
             line["stages"] = stage_rates(store, scene, images[:1], K[:1], TCO0[:B], im_ids[:B], device)
         if args.workload == "C2" and world == 1 and not args.no_extra_workloads:
             # the other single-GPU configurations of BASELINE.json, 3 steps each, so that the driver's record carries them
-            for key, wl, prec in (("c3", "C3", "f32"), ("c5", "C5", "f16")):
+            extras = [("c3", "C3", "f32", None), ("c5", "C5", "f16", None)]
+            if args.render_state == "reference" and args.arch == "resnet34" and precision == "f32":
+                # the job rounds 1-2 measured (one sample per pixel, bilinear level-0 texturing), for continuity
+                extras.append(("c2_single_sample_renders", "C2", "f32", dict(msaa=False, aniso=False)))
+            for key, wl, prec, rk in extras:
                 try:
-                    line[key] = quick_workload(device, wl, prec, n_lanes)
+                    line[key] = quick_workload(device, wl, prec, n_lanes, steps=5 if wl == "C2" else 3, renderer_kw=rk)
                 except Exception as e:  # never lose the headline line to an extra
                     line[key] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and args.workload == "C2" and world == 1:  # the CPU baseline is a 1-GPU-run item
