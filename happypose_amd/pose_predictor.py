@@ -528,11 +528,25 @@ class TwoLanePredictor:
         assert len(lanes) >= 2
         self.lanes = list(lanes)
         self.device = lanes[0].device
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in lanes]
+        self.streams = self._lane_streams(self.device, len(lanes))
         self.backbone = _LaneBackbones([l.backbone for l in lanes])
         self.use_graphs = False  # hipGraph replay of forward() (happypose_amd.graphs)
         self._graphs = None
         self._graph_epoch = None
+
+    _STREAMS: dict = {}  # device -> the lane streams every instance on that device uses
+
+    @classmethod
+    def _lane_streams(cls, device, n: int):
+        """One set of lane streams per device for the whole process.  HIP maps streams onto a few hardware queues in creation
+        order; a predictor whose two fresh streams happened to share a queue ran its lanes one after the other (measured:
+        every other predictor built in a process stepped in 32.3 instead of 23.5 ms).  The first streams a process makes sit
+        on different queues, and predictors are called one at a time, so they all use those."""
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        pool = cls._STREAMS.setdefault(key, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=device))
+        return pool[:n]
 
     def __getattr__(self, name):
         if name in ("lanes", "streams", "backbone", "device", "use_graphs", "_graphs", "_graph_epoch", "max_batch"):  # not set yet: no recursion through lanes[0]
