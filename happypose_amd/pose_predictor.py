@@ -540,13 +540,46 @@ class TwoLanePredictor:
     def _lane_streams(cls, device, n: int):
         """One set of lane streams per device for the whole process.  HIP maps streams onto a few hardware queues in creation
         order; a predictor whose two fresh streams happened to share a queue ran its lanes one after the other (measured:
-        every other predictor built in a process stepped in 32.3 instead of 23.5 ms).  The first streams a process makes sit
-        on different queues, and predictors are called one at a time, so they all use those."""
+        every other predictor built in a process stepped in 32.3 instead of 23.5 ms).  So the streams are made once, each
+        new one checked to run CONCURRENTLY with the ones already chosen (two one-thread spin kernels: together they take
+        the time of one, or of two), and every predictor of the process uses them -- predictors are called one at a time."""
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
         pool = cls._STREAMS.setdefault(key, [])
+        tries = 0
         while len(pool) < n:
-            pool.append(torch.cuda.Stream(device=device))
+            cand = torch.cuda.Stream(device=device)
+            tries += 1
+            if tries > 12 or all(cls._concurrent(device, cand, s) for s in pool):
+                pool.append(cand)
         return pool[:n]
+
+    @staticmethod
+    def _concurrent(device, a, b, cycles: int = 400_000) -> bool:
+        """Do kernels on streams ``a`` and ``b`` overlap?  (True when it cannot be measured.)"""
+        import time
+
+        sleep = getattr(torch.cuda, "_sleep", None)
+        if sleep is None or torch.cuda.is_current_stream_capturing():
+            return True
+
+        def spin(streams):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for st in streams:
+                with torch.cuda.stream(st):
+                    sleep(cycles)
+            for st in streams:
+                st.synchronize()
+            return time.perf_counter() - t0
+
+        try:
+            with torch.cuda.device(device):
+                spin((a, b))  # first launches: lazy initialisation
+                one = min(spin((a,)) for _ in range(3))
+                two = min(spin((a, b)) for _ in range(3))
+        except RuntimeError:
+            return True
+        return two < 1.6 * one
 
     def __getattr__(self, name):
         if name in ("lanes", "streams", "backbone", "device", "use_graphs", "_graphs", "_graph_epoch", "max_batch"):  # not set yet: no recursion through lanes[0]

@@ -1334,3 +1334,20 @@ def test_estimators_shard_with_real_predictors_two_ranks(dev):
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in out, out[-3000:]
+
+
+def test_lane_streams_are_shared_and_concurrent(dev, world):
+    """Every TwoLanePredictor of a process runs its lanes on the same, probed pair of streams: fresh streams can share a
+    hardware queue (HIP maps them in creation order), which serialised the lanes of every other predictor (+37 % step time)."""
+    from happypose_amd.models import create_pose_model_cosypose
+    from happypose_amd.pose_predictor import TwoLanePredictor
+
+    junk = [torch.cuda.Stream(dev) for _ in range(3)]  # shift the creation order
+    w = _weights("resnet34", 6)
+    m1 = create_pose_model_cosypose(dict(backbone_str="resnet34"), world["renderer"], state_dict=w, max_batch=64, n_lanes=2)
+    m2 = create_pose_model_cosypose(dict(backbone_str="resnet34"), world["renderer"], state_dict=w, max_batch=64, n_lanes=2)
+    assert isinstance(m1, TwoLanePredictor) and len(m1.streams) == 2
+    assert all(a is b for a, b in zip(m1.streams, m2.streams))
+    assert m1.streams[0].cuda_stream != m1.streams[1].cuda_stream
+    assert TwoLanePredictor._concurrent(dev, *m1.streams)
+    del junk
