@@ -636,7 +636,10 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
 // {depth bits (0xFFFFFFFF = no depth) : r | g << 8 | b << 16 | nx << 24} and ex holds ny | nz << 8 (8-bit colour codes).
 struct BandLds {
   unsigned long long* zb; unsigned short* ex; unsigned short* plist; Fold* fy; Fold* fx;
+  uint32_t* nsum;  // multisampling: per pixel, the three 10-bit sums of the normal codes of its samples
 };
+// list entries per pixel: the covered pixels (single sample) or the shading invocations {pixel | sample << 14} (multisampling: <= 4)
+__host__ __device__ constexpr int band_list_per_pixel(int ns) { return ns == 1 ? 1 : 4; }
 __device__ __forceinline__ BandLds carve_lds(unsigned char* base, int npix_max, int ns, int rows) {
   BandLds l;
   l.zb = reinterpret_cast<unsigned long long*>(base);
@@ -644,13 +647,16 @@ __device__ __forceinline__ BandLds carve_lds(unsigned char* base, int npix_max, 
   l.ex = reinterpret_cast<unsigned short*>(base);
   base += (size_t)npix_max * 2;
   l.plist = reinterpret_cast<unsigned short*>(base);
-  base += (size_t)((npix_max * 2 + 15) & ~15);
+  base += (size_t)((npix_max * band_list_per_pixel(ns) * 2 + 15) & ~15);
+  l.nsum = reinterpret_cast<uint32_t*>(base);
+  if (ns > 1) base += (size_t)npix_max * 4;
   l.fy = reinterpret_cast<Fold*>(base);
   l.fx = l.fy + rows;
   return l;
 }
 static size_t band_lds_bytes(int npix_max, int ns, int rows, int w, bool crop) {
-  return (size_t)npix_max * ns * 8 + (size_t)npix_max * 2 + (size_t)((npix_max * 2 + 15) & ~15) + (crop ? (size_t)(rows + w) * sizeof(Fold) : 0) + 16;
+  return (size_t)npix_max * ns * 8 + (size_t)npix_max * 2 + (size_t)((npix_max * band_list_per_pixel(ns) * 2 + 15) & ~15) +
+         (ns > 1 ? (size_t)npix_max * 4 : 0) + (crop ? (size_t)(rows + w) * sizeof(Fold) : 0) + 16;
 }
 
 __device__ __forceinline__ unsigned code8(float c) {  // quant8(c) = code8(c) / 255
@@ -957,20 +963,15 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
                     (a.flags & HP_RASTER_TEX_ANISO) != 0, &mips, (a.rec ? a.want_nrm != 0 : a.nrm != nullptr) || a.n_lights > 0};
   const bool want_colour = a.rec ? true : (a.rgb != nullptr || a.nrm != nullptr);
   const bool coded = !band_empty;  // colours travel as 8-bit codes through LDS
-  if (coded) {
+  if (coded && NS == 1) {
     const int lane = tid & 63;
     for (int p0 = 0; p0 < npix; p0 += kThreads) {
       const int p = p0 + tid;
       bool cov = false;
       if (p < npix) {
-        if (NS == 1) cov = zb[p] != kKeyEmpty;
-        else {
-#pragma unroll
-          for (int sm = 0; sm < 4; ++sm) cov |= zb[p * NS + sm] != kKeyEmpty;
-        }
-        cov = cov && want_colour;
+        cov = zb[p] != kKeyEmpty && want_colour;
         if (!cov) {  // no fragment: colour codes 0, the depth bits stay
-          zb[p * NS + (NS - 1)] &= 0xFFFFFFFF00000000ull;
+          zb[p] &= 0xFFFFFFFF00000000ull;
           L.ex[p] = 0;
         }
       }
@@ -992,40 +993,93 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
       const int pr = (int)(((unsigned long long)p * a.w_magic) >> 32);
       const int i = row0 + pr, j = p - pr * a.w;
       unsigned cr[3], cn[3];
-      if (NS == 1) {
-        float o_rgb[3], o_n[3];
-        shade_centre<ANISO>(a, cx, (int)(zb[p] & 0xFFFFFFFFull), i, j, o_rgb, o_n);
+      float o_rgb[3], o_n[3];
+      shade_centre<ANISO>(a, cx, (int)(zb[p] & 0xFFFFFFFFull), i, j, o_rgb, o_n);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { cr[c] = code8(o_rgb[c]); cn[c] = code8(o_n[c]); }
-      } else {
-        // one fragment-shader invocation per pixel and triangle; the pixel's colour is the mean of the four samples' 8-bit
-        // colours (uncovered samples: the clear colour 0), rounded half up -- integer arithmetic, no rounding ties
-        unsigned a_rgb[3] = {0, 0, 0}, a_n[3] = {0, 0, 0};
-#pragma unroll 1
-        for (int sm = 0; sm < 4; ++sm) {  // rolled: ONE copy of the shader; the other samples' keys are re-read from LDS
-          const unsigned long long ks = zb[p * NS + sm];
-          if (ks == kKeyEmpty) continue;  // the clear colour 0
-          const uint32_t f = (uint32_t)ks;
-          bool dup = false;
-          unsigned mult = 1;  // samples of this pixel the triangle owns
+      for (int c = 0; c < 3; ++c) { cr[c] = code8(o_rgb[c]); cn[c] = code8(o_n[c]); }
+      const unsigned long long hi = zb[p] & 0xFFFFFFFF00000000ull;
+      zb[p] = hi | (unsigned long long)(cr[0] | (cr[1] << 8) | (cr[2] << 16) | (cn[0] << 24));
+      L.ex[p] = (unsigned short)(cn[1] | (cn[2] << 8));
+    }
+  } else if (coded) {
+    // Multisampling: one fragment-shader invocation per pixel and triangle (the first of the triangle's samples stands
+    // for it, weighted by the number of samples the triangle owns); the pixel's colour is the mean of the four samples'
+    // 8-bit colours (uncovered samples: the clear colour 0), rounded half up -- integer arithmetic, no rounding ties.
+    // The INVOCATIONS are compacted, not the pixels: a lane looping over its pixel's four samples ran the shader four
+    // times per wave with half of the lanes idle (1.97 invocations per covered pixel); the shading is bound by its
+    // latency chains, so the number of passes is what counts.  Sums: 3 x 10 bits in the low word of the pixel's centre key
+    // (its triangle id is not needed any more) and in nsum, by LDS atomics -- integer, order-independent.
+    const int lane = tid & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t* const zlo = reinterpret_cast<uint32_t*>(zb);  // little endian: word 2 k = low half of key k
+    for (int p0 = 0; p0 < npix; p0 += kThreads) {
+      const int p = p0 + tid;
+      unsigned inv = 0;  // bit sm: sample sm starts an invocation
+      if (p < npix) {
+        uint32_t kf[4];
+        bool kc[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const unsigned long long kt = zb[p * NS + t];
-            const bool same = t != sm && kt != kKeyEmpty && (uint32_t)kt == f;
-            dup |= same && t < sm;
-            mult += (same && t > sm) ? 1u : 0u;
+        for (int t = 0; t < 4; ++t) { const unsigned long long kt = zb[p * NS + t]; kc[t] = kt != kKeyEmpty; kf[t] = (uint32_t)kt; }
+        const bool cov = (kc[0] | kc[1] | kc[2] | kc[3]) && want_colour;
+        zb[p * NS + (NS - 1)] &= 0xFFFFFFFF00000000ull;  // colour sums / codes 0, the depth bits stay
+        L.nsum[p] = 0;
+        L.ex[p] = 0;
+        if (cov) {
+#pragma unroll
+          for (int sm = 0; sm < 4; ++sm) {
+            bool first = kc[sm];
+#pragma unroll
+            for (int t = 0; t < sm; ++t) first &= !(kc[t] && kf[t] == kf[sm]);
+            inv |= first ? (1u << sm) : 0u;
           }
-          if (dup) continue;  // shaded with the first of its samples
-          float r3[3], n3[3];
-          shade_centre<ANISO>(a, cx, (int)f, i, j, r3, n3);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { a_rgb[c] += mult * code8(r3[c]); a_n[c] += mult * code8(n3[c]); }
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { cr[c] = (a_rgb[c] + 2u) >> 2; cn[c] = (a_n[c] + 2u) >> 2; }
       }
-      const unsigned long long hi = zb[p * NS + (NS - 1)] & 0xFFFFFFFF00000000ull;
-      zb[p * NS + (NS - 1)] = hi | (unsigned long long)(cr[0] | (cr[1] << 8) | (cr[2] << 16) | (cn[0] << 24));
+      const int cnt = __popc(inv);
+      int pre = 0, tot = 0;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const unsigned long long m = __ballot((cnt >> b) & 1);
+        pre += __popcll(m & lt_mask) << b;
+        tot += __popcll(m) << b;
+      }
+      int base = 0;
+      if (lane == 0 && tot != 0) base = atomicAdd(&n_cov, tot);
+      base = __shfl(base, 0) + pre;
+#pragma unroll
+      for (int sm = 0; sm < 4; ++sm)
+        if (inv & (1u << sm)) L.plist[base++] = (unsigned short)(p | (sm << 14));
+    }
+    __syncthreads();
+    const int ninv = n_cov;
+#ifdef HP_RABL_NO_SHADE
+    const int ninv_loop = a.w < 0 ? ninv : 0;
+#else
+    const int ninv_loop = ninv;
+#endif
+    for (int q = tid; q < ninv_loop; q += kThreads) {
+      const unsigned e = L.plist[q];
+      const int p = (int)(e & 0x3FFFu), sm = (int)(e >> 14);
+      const int pr = (int)(((unsigned long long)p * a.w_magic) >> 32);
+      const int i = row0 + pr, j = p - pr * a.w;
+      const uint32_t f = zlo[2 * (p * NS + sm)];
+      unsigned mult = 1;  // samples of this pixel the triangle owns
+      for (int t = sm + 1; t < 4; ++t) {
+        const unsigned long long kt = zb[p * NS + t];
+        mult += (kt != kKeyEmpty && (uint32_t)kt == f) ? 1u : 0u;
+      }
+      float r3[3], n3[3];
+      shade_centre<ANISO>(a, cx, (int)f, i, j, r3, n3);
+      atomicAdd(&zlo[2 * (p * NS + (NS - 1))], mult * (code8(r3[0]) | (code8(r3[1]) << 10) | (code8(r3[2]) << 20)));
+      if (cx.need_normal) atomicAdd(&L.nsum[p], mult * (code8(n3[0]) | (code8(n3[1]) << 10) | (code8(n3[2]) << 20)));
+    }
+    __syncthreads();
+    for (int p = tid; p < npix; p += kThreads) {
+      const uint32_t sr = zlo[2 * (p * NS + (NS - 1))], sn = L.nsum[p];
+      if ((sr | sn) == 0) continue;  // nothing shaded: the codes are 0 already
+      unsigned cr[3], cn[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { cr[c] = (((sr >> (10 * c)) & 1023u) + 2u) >> 2; cn[c] = (((sn >> (10 * c)) & 1023u) + 2u) >> 2; }
+      zlo[2 * (p * NS + (NS - 1))] = cr[0] | (cr[1] << 8) | (cr[2] << 16) | (cn[0] << 24);
       L.ex[p] = (unsigned short)(cn[1] | (cn[2] << 8));
     }
   }
@@ -1277,6 +1331,7 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
   HP_REQUIRE(a.n_bands <= kMaxBands, "hp_rasterize: unsupported resolution (too many bands)");
   const int npix_max = a.band_rows * w;
   HP_REQUIRE(npix_max < 65536, "hp_rasterize: band too large");
+  HP_REQUIRE(!a.msaa || npix_max < 16384, "hp_rasterize: multisampled band too large");  // invocation entries: pixel | sample << 14
   a.w_magic = (unsigned)(0x100000000ull / (unsigned)w + 1);
   a.depth_max = kZNear / (1.0f - (1.0f - 1e-3f) * (kZFar - kZNear) / kZFar);
   // Views are processed in chunks so that the per-(view, band) triangle lists stay within a fixed scratch budget.  The
