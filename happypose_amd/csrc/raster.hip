@@ -414,6 +414,9 @@ __device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const TriVer
 template <int NS>
 __device__ __forceinline__ void shade_pixel(const TriSetup& s, int i, int j, uint32_t f,
                                             unsigned long long* zb, int row0, int w) {
+#ifdef HP_RABL_COUNT
+  int n_in = 0;
+#endif
 #pragma unroll
   for (int sm = 0; sm < NS; ++sm) {
     const float pv = (float)i + sample_y(NS, sm), pu = (float)j + sample_x(NS, sm);
@@ -424,6 +427,9 @@ __device__ __forceinline__ void shade_pixel(const TriSetup& s, int i, int j, uin
     bool in_pos = (l0 >= 0.0f) & (l1 >= 0.0f) & (l2 >= 0.0f) & (sum > 0.0f);
     bool in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (sum < 0.0f);
     if (!(in_pos | in_neg)) continue;
+#ifdef HP_RABL_COUNT
+    ++n_in;
+#endif
     // depth = the vertex depths interpolated with the perspective-correct barycentrics (oracle.c explains why not det / sum)
 #ifdef HP_RABL_NO_SAMPLE_DIV
     float Z = fmaf(l0, s.z0, fmaf(l1, s.z1, l2 * s.z2)) * sum;
@@ -438,6 +444,9 @@ __device__ __forceinline__ void shade_pixel(const TriSetup& s, int i, int j, uin
     if (key == 12345ull) zb[0] = key;
 #endif
   }
+#ifdef HP_RABL_COUNT
+  if (NS > 1) { atomicAdd(&hp_dbg_cnt[7], (unsigned long long)(n_in > 0) << 32); atomicAdd(&hp_dbg_cnt[6], (unsigned long long)n_in << 32); }
+#endif
 }
 
 struct ViewXform { float T[12], Kv[9]; bool finite; };

@@ -34,7 +34,10 @@ for wl in ("C2", "C3"):
     lib.hp_debug_raster_counters(buf, 1)
     it, area, tri, surv, waves, inv, probes, two = [int(buf[i]) for i in range(8)]
     pair_it, it = it >> 32, it & 0xFFFFFFFF
+    pairs_hit, two = two >> 32, two & 0xFFFFFFFF
+    samples_hit, probes = probes >> 32, probes & 0xFFFFFFFF
     print(wl, dict(walk_iterations=it, sum_area=area, triangles=tri, survivors=surv, waves=waves, mean_area=area / max(tri, 1),
                    iterations_per_wave=it / max(waves, 1), lane_utilisation=area / max(64 * it, 1), survivor_fraction=surv / max(area, 1), shading_invocations=inv, probes_per_invocation=probes / max(inv, 1),
                    two_level_fraction=two / max(inv, 1), probe_pair_iterations=pair_it,
-                   probe_lane_utilisation=probes / max(128 * pair_it, 1)))
+                   probe_lane_utilisation=probes / max(128 * pair_it, 1),
+                   tested_pairs_with_a_covered_sample=pairs_hit, covered_samples=samples_hit))
