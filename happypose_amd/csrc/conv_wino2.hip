@@ -147,7 +147,9 @@ __global__ __launch_bounds__(kThr) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   };
   // weight tile: LDS-direct loads (no registers): a chunk's tile is four 16-KB steps (position column p of every position
   // row); the eight waves move a step with two 1-KB instructions each.  The compiler does not see these loads: every
-  // barrier that publishes them is preceded by an explicit s_waitcnt vmcnt(0).
+  // barrier that publishes them is preceded by an explicit s_waitcnt vmcnt(0).  M0 (the LDS base of the transfer) is
+  // written inside the asm statement and cannot be named as a clobber (hipcc: reserved register); nothing else in this
+  // kernel uses it -- LDS instructions do not read M0 on gfx9+, and the ISA of every instantiation was checked for it.
   const unsigned ul_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ul;
   auto dma_half = [&](int c, int half) {
 #ifdef HP_W2ABL_NO_DMA
