@@ -132,8 +132,9 @@ def rasterize(store: MeshStore, obj_ids: torch.Tensor, TCO: torch.Tensor, K: tor
               resolution: Tuple[int, int], render_normals=False, render_depth=False,
               render_binary_mask=False, ambient: Optional[torch.Tensor] = None,
               light_pos: Optional[torch.Tensor] = None, light_col: Optional[torch.Tensor] = None,
-              quant8: bool = True, msaa: bool = False, aniso: bool = False):
-    """NCHW outputs shaped like ``BatchRenderOutput`` (TB/renderer/types.py:45-56).  ``msaa``: 4x multisampled colour /
+              quant8: bool = True, msaa: bool = False, aniso: bool = False, render_rgb: bool = True):
+    """NCHW outputs shaped like ``BatchRenderOutput`` (TB/renderer/types.py:45-56; ``render_rgb=False``: no colour buffer,
+    ``rgbs`` is None -- the depth-only launches of a C caller).  ``msaa``: 4x multisampled colour /
     normal buffers (``HP_RASTER_MSAA4``), ``aniso``: mip-mapped trilinear + anisotropic-16 texture filtering
     (``HP_RASTER_TEX_ANISO``) -- the reference renderer's framebuffer / texture state."""
     dev = store.device
@@ -146,7 +147,7 @@ def rasterize(store: MeshStore, obj_ids: torch.Tensor, TCO: torch.Tensor, K: tor
     TCO = _f32(TCO, dev)
     K = _f32(K, dev)
     obj_ids = _i32(obj_ids, dev)
-    rgb = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+    rgb = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev) if render_rgb else None
     nrm = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev) if render_normals else None
     dep = torch.empty((n, 1, h, w), dtype=torch.float32, device=dev) if render_depth else None
     msk = torch.empty((n, 1, h, w), dtype=torch.uint8, device=dev) if render_binary_mask else None

@@ -117,6 +117,11 @@ def test_rasterizer_msaa4_vs_oracle(dev, scene_store):
     Tv, Kv = torch.as_tensor(T, device=dev)[:, None].contiguous(), torch.as_tensor(K, device=dev)[:, None].contiguous()
     ops.rasterize_into(scene_store, x, 3, torch.as_tensor(obj), Tv, Kv, False, False, msaa=True)
     assert torch.equal(x[..., 3:6].permute(0, 3, 1, 2), gpu[0])
+    # depth / mask only (no colour buffer: nothing is shaded) and normals without colours
+    dm = ops.rasterize(*args, render_depth=True, render_binary_mask=True, msaa=True, render_rgb=False)
+    assert dm[0] is None and torch.equal(dm[2], gpu[2]) and torch.equal(dm[3], gpu[3])
+    nm = ops.rasterize(*args, render_normals=True, msaa=True, render_rgb=False)
+    assert torch.equal(nm[1], gpu[1])
 
 
 @pytest.mark.parametrize("msaa,tex_size", [(False, 256), (True, 256), (True, 208)])
