@@ -865,7 +865,10 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
     // orientation -- the five exact tests would all fail anyway; (2) the surviving (triangle, pixel) pairs of the whole
     // wave go through a per-wave queue in LDS and are popped 64 at a time, each lane fetching the owner lane's edge
     // functions with ds_bpermute: the expensive part runs on dense lanes whatever the sizes of the 64 bounding boxes are.
-    volatile uint32_t* const q = cov_q[tid >> 6];
+    // plain LDS accesses (a `volatile` pointer made them FLAT stores with system scope + s_waitcnt vmcnt(0) per walk step,
+    // which also drained the triangle prefetch).  One wave writes and reads its own queue: the LDS executes a wave's
+    // accesses in order, and the wave barriers below keep the compiler from moving them across one another.
+    uint32_t* const q = cov_q[tid >> 6];
     const int lane = tid & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     int qh = 0, qt = 0;  // wave-uniform
@@ -929,9 +932,11 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
 #endif
         if (surv) q[(qt + __popcll(sm & lt_mask)) & 127] = ((uint32_t)lane << 16) | (uint32_t)((pi - row0) * a.w + pj);  // npix_max < 65536
         qt += __popcll(sm);
+        __builtin_amdgcn_wave_barrier();
         while (qt - qh >= 64 || (qt > qh && !__any(more))) {  // a full wave of pairs, or the rest once every box is walked
           const int n = min(64, qt - qh);
           const uint32_t e = q[(qh + lane) & 127];
+          __builtin_amdgcn_wave_barrier();
           const int owner = (int)(e >> 16) & 63;
           const int ep = (int)(e & 0xFFFFu);
           const int er = (int)(((unsigned long long)ep * a.w_magic) >> 32);
