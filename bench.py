@@ -665,6 +665,8 @@ def main():
                              "algorithmic_tflops": exact[6] / e_sec / 1e12 if e_sec > 0 else 0.0,
                              "note": "executed fp32 MFMA FLOPs (Winograd layers execute 2.25x fewer than the direct convolution)"},
                 "note": "same job with hp_net_set_conv_algo(WINOGRAD): every multiply an fp32 FMA on the fp32 matrix path"}
+        # launches of kernels that use scratch (spilled tile variants; they would also keep hipGraph replay off): 0 expected
+        line["scratch_launches"] = int(_ops.scratch_launches())
         if args.workload == "C2":
             line["stages"] = stage_rates(store, scene, images[:1], K[:1], TCO0[:B], im_ids[:B], device)
         if args.workload == "C2" and world == 1 and not args.no_extra_workloads:

@@ -95,6 +95,7 @@ _PROTOS = {
                                                 C.POINTER(C.c_float), C.POINTER(C.c_float), c_f32p, C.c_void_p]),
     "hp_net_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_conv_occupancy": (C.c_int, [C.c_int]),
+    "hp_scratch_launches": (C.c_longlong, []),
     "hp_probe_mfma_rate": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
     "hp_net_set_tail_split": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_net_set_act_scale": (C.c_int, [C.c_void_p, C.c_int]),

@@ -212,6 +212,10 @@ inline bool conv_use_igemm_split(int kh, int Kpad) {
   (void)Kpad;
   return kh >= min_kh;
 }
+// hipGraph safety (hp_scratch_launches): does kernel `fn` use scratch?  (asked once per instantiation, where it opts in to its
+// LDS size); every launch of such a kernel is counted
+bool note_kernel(const void* fn);
+void count_scratch_launch();
 int launch_maxpool(const float* x, float* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
 int launch_zero_words(unsigned* p, int n, hipStream_t stream);  // a kernel, not a memset: memset nodes misbehave under hipGraph replay
 // nearest resize to (Ho, Wo) (stride_mode 0) or stride-2 subsampling (stride_mode 1), NHWC, C % 4 == 0

@@ -41,6 +41,7 @@
 // roofline and the measured fraction.
 // Numerics: exact fp32 FMA chains (the f32 MFMA is bitwise an fmaf chain), K-order differs
 // from the reference's oneDNN/cuDNN kernels, so results agree to fp32 round-off, not bitwise.
+#include <atomic>
 #include <cstdlib>
 
 #include "conv.h"
@@ -411,6 +412,17 @@ int launch_zero_words(unsigned* p, int n, hipStream_t stream) {
 }
 
 }  // namespace hp
+
+namespace hp {
+static std::atomic<long long> g_scratch_launches{0};
+bool note_kernel(const void* fn) {
+  hipFuncAttributes at{};
+  return hipFuncGetAttributes(&at, fn) == hipSuccess && at.localSizeBytes > 0;
+}
+void count_scratch_launch() { g_scratch_launches.fetch_add(1); }
+}  // namespace hp
+
+extern "C" long long hp_scratch_launches(void) { return hp::g_scratch_launches.load(); }
 
 extern "C" int hp_conv_select_algo(int algo) {
   HP_REQUIRE(algo >= HP_CONV_ALGO_AUTO && algo <= HP_CONV_ALGO_WINO_SPLIT, "hp_conv_select_algo: unknown algorithm");

@@ -472,12 +472,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 template <int BN, bool PRE, int NPC>
 int launch_patch_variant(ConvArgsH args, hipStream_t stream) {
-  static bool opted = false;
+  static bool opted = false, spills = false;
   if (!opted) {
     HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_f16<BN, PRE, NPC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_patch_f16<BN, PRE, NPC>));
     opted = true;
   }
+  if (spills) count_scratch_launch();
   const int P = BM + 2 * args.W + 2;
   size_t lds = ((size_t)P * LDH + 2 * (size_t)BN * LDH) * 2;
   const size_t epi = (size_t)BM * (BN + 4) * 4;
@@ -514,12 +516,14 @@ int launch_patch(const ConvArgsH& a, int npc, hipStream_t stream) {
 
 template <int BN, bool PRE>
 int launch_variant(ConvArgsH args, hipStream_t stream) {
-  static bool opted = false;
+  static bool opted = false, spills = false;
   if (!opted) {
     HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16<BN, PRE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_f16<BN>()));
+    spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_f16<BN, PRE>));
     opted = true;
   }
+  if (spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = args.Cout / BN;
   if (args.M >= (1ll << 31)) return fail(HP_ERR_ARG, "conv: more than 2^31 output pixels");

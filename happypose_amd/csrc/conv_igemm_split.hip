@@ -305,12 +305,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3
 
 template <int BN, int PRE, int NBUF>
 int launch_igs_pool(ConvArgs args, hipStream_t stream) {
-  static bool opted = false;
+  static bool opted = false, spills = false;
   if (!opted) {
     HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)igs_lds_bytes<BN, NBUF>()));
+    spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, true>));
     opted = true;
   }
+  if (spills) count_scratch_launch();
   const int Hp = (args.Ho - 1) / 2 + 1, Wp = (args.Wo - 1) / 2 + 1;
   const int tiles_y = (Hp + kPoolRows - 1) / kPoolRows, tiles_x = (Wp + kPoolCols - 1) / kPoolCols;
   const int n_img = (int)(args.M / ((int64_t)args.Ho * args.Wo));
@@ -331,12 +333,14 @@ int launch_igs_pool(ConvArgs args, hipStream_t stream) {
 
 template <int BN, int PRE, int NBUF>
 int launch_igs(ConvArgs args, hipStream_t stream) {
-  static bool opted = false;
+  static bool opted = false, spills = false;
   if (!opted) {
     HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)igs_lds_bytes<BN, NBUF>()));
+    spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false>));
     opted = true;
   }
+  if (spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = (args.Cout + BN - 1) / BN;
   if (args.M >= (1ll << 31)) return fail(HP_ERR_ARG, "conv: more than 2^31 output pixels");

@@ -432,12 +432,14 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
 template <int MODE, bool PRE, int NPC>
 int launch_pp_variant(ConvArgs args, hipStream_t stream) {
   using T = PP<MODE>;
-  static bool opted = false;
+  static bool opted = false, spills = false;
   if (!opted) {
     HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));  // + the static ticket word
+    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC>));
     opted = true;
   }
+  if (spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = args.Cout / BN;
   args.fd_howo = make_fastdiv((unsigned)(args.H * args.W));

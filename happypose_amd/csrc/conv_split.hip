@@ -772,12 +772,14 @@ struct SplitTileS2 {
 template <int WAVES_M, int WAVES_N, bool PRE, int NPC>
 int launch_split_s2_variant(ConvArgs args, hipStream_t stream) {
   using T = SplitTileS2<WAVES_M, WAVES_N>;
-  static bool opted = false;
+  static bool opted = false, spills = false;
   if (!opted) {
     HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_split_f32<WAVES_M, WAVES_N, PRE, NPC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3s2_split_f32<WAVES_M, WAVES_N, PRE, NPC>));
     opted = true;
   }
+  if (spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + T::BM - 1) / T::BM);
   args.tiles_n = args.Cout / T::BN;
   args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
@@ -861,12 +863,14 @@ int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_
 template <int WAVES_M, int WAVES_N, bool PRE, int NPC>
 int launch_split_variant(ConvArgs args, hipStream_t stream) {
   using T = SplitTile<WAVES_M, WAVES_N>;
-  static bool opted = false;
+  static bool opted = false, spills = false;
   if (!opted) {
     HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_f32<WAVES_M, WAVES_N, PRE, NPC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));  // + the static ticket word
+    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_split_f32<WAVES_M, WAVES_N, PRE, NPC>));
     opted = true;
   }
+  if (spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + T::BM - 1) / T::BM);
   args.tiles_n = args.Cout / T::BN;
   args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));

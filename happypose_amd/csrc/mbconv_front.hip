@@ -246,14 +246,16 @@ __global__ __launch_bounds__(256, 2) void mbconv_front_kernel(FrontArgs a) {
 template <int K, int S, int KP>
 int launch_front_t(const FrontArgs& a, hipStream_t stream) {
   using T = FrontTile<K, S>;
-  static bool opted = false;
+  static bool opted = false, spills = false;
   constexpr size_t lds = front_lds_bytes<K, S, KP>();
   static_assert(lds <= 160 * 1024, "LDS of a CU");
   if (!opted) {
     HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_front_kernel<K, S, KP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    spills = note_kernel(reinterpret_cast<const void*>(&mbconv_front_kernel<K, S, KP>));
     opted = true;
   }
+  if (spills) count_scratch_launch();
   const dim3 grid((unsigned)((a.Wo + T::TW - 1) / T::TW), (unsigned)((a.Ho + T::TH - 1) / T::TH), (unsigned)a.n);
   hipLaunchKernelGGL((mbconv_front_kernel<K, S, KP>), grid, dim3(256), lds, stream, a);
   return check_launch("mbconv_front_kernel");

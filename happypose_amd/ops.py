@@ -34,6 +34,12 @@ def graph_epoch() -> int:
     return _GRAPH_EPOCH
 
 
+def scratch_launches() -> int:
+    """``hp_scratch_launches``: launches so far of kernels that use scratch (spilled tile variants).  A captured hipGraph with
+    such a launch replays wrongly on this runtime: a predictor whose eager call moves this count stays on eager launches."""
+    return int(lib().hp_scratch_launches())
+
+
 def bump_graph_epoch() -> None:
     global _GRAPH_EPOCH
     _GRAPH_EPOCH += 1

@@ -154,6 +154,9 @@ class _RenderAndCompare:
         resists capture (kept pixels are large and change what is launched; profiling records events)."""
         if not self.use_graphs or self.keep_pixels or self.debug or self._profiling():
             return fn(*inputs)
+        if getattr(self, "_no_graphs", False):
+            return fn(*inputs)
+        scratch0 = ops.scratch_launches()
         from .graphs import GraphCache
 
         # what invalidates captured launches: the process-wide launch-plan epoch and this store's scratch generation (a
@@ -165,6 +168,11 @@ class _RenderAndCompare:
         # single-lane call (on) and a lane of TwoLanePredictor (off) on the same shapes
         consts = tuple(consts) + (("tail_split", bool(self.backbone.tail_split)), ("msaa", self.renderer.msaa), ("aniso", self.renderer.aniso))
         out = self._graphs.run(consts, inputs, fn, keepalive=self._graph_keepalive)
+        if ops.scratch_launches() != scratch0:
+            # this predictor launches a tile variant that spills registers to scratch (EfficientNet's narrow layers, odd
+            # resolutions); a graph holding such a launch replays wrongly.  The count moves on the host at launch time, i.e.
+            # during the eager first call of a signature: nothing of it has been captured yet -- stay eager from here on
+            self._no_graphs, self._graphs = True, None
         if self.store.scratch_generation() != epoch[1]:
             # the eager first call of a signature larger than the reservation grew the scratch: every graph captured
             # before holds freed pointers -- start over (this call's result is valid: it ran eagerly)

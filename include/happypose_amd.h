@@ -393,6 +393,12 @@ int hp_net_set_act_scale(hp_net* net, int enabled);
 int hp_net_status(hp_net* net, void* stream, int* flags);
 /* diagnostics: workgroups per CU the runtime grants conv tile variant 0 (128x128) / 1 (128x64) */
 int hp_conv_occupancy(int variant);
+/* hipGraph safety: launches so far, in this process, of kernels whose code object uses scratch (private segment > 0:
+ * register spills of a rarely used tile variant; counted on the host at launch time, so also while a stream captures,
+ * never during a replay).  A captured graph that contains such a launch replays wrongly on this runtime; the host layer
+ * (happypose_amd/pose_predictor.py::_run_refine, no counterpart in the reference) compares the count around a predictor's
+ * eager call and keeps that predictor on eager launches when it moved.  Stays 0 on the benchmarked configurations. */
+long long hp_scratch_launches(void);
 int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_launches, double* conv_flops,
                            double* mfma_flops);
 /* Several networks on several streams (the two half-batch lanes of a predictor run concurrently, so their summed

@@ -1351,3 +1351,27 @@ def test_lane_streams_are_shared_and_concurrent(dev, world):
     assert m1.streams[0].cuda_stream != m1.streams[1].cuda_stream
     assert TwoLanePredictor._concurrent(dev, *m1.streams)
     del junk
+
+
+def test_scratch_kernels_keep_graphs_off(dev, world):
+    """A tile variant that spills to scratch (EfficientNet's narrow 1x1 layers run one) must not end up in a captured
+    hipGraph: a predictor whose eager call moves ``hp_scratch_launches`` stays on eager launches -- and gives the eager result."""
+    from happypose_amd import ops
+    from happypose_amd.models import create_pose_model_cosypose
+
+    sc = world["scene"]
+    w = _weights("efficientnet-b3", 6)
+    images, K = torch.as_tensor(sc["images"][:, :3].copy(), device=dev), torch.as_tensor(sc["K"], device=dev)
+    T0 = torch.as_tensor(sc["TCO_hyp"], device=dev)
+    labels = _labels(world, sc["hyp_obj_ids"])
+    im_ids = torch.zeros(len(labels), dtype=torch.int32, device=dev)
+    eager = create_pose_model_cosypose(dict(backbone_str="efficientnet-b3"), world["renderer"], state_dict=w, max_batch=16)
+    n0 = ops.scratch_launches()
+    ref = eager.forward(images, K, labels, T0, n_iterations=2, im_ids=im_ids)["iteration=2"].TCO_output
+    if ops.scratch_launches() == n0:
+        pytest.skip("no spilling kernel on this path in this build")
+    g = create_pose_model_cosypose(dict(backbone_str="efficientnet-b3"), world["renderer"], state_dict=w, max_batch=16, graphs=True)
+    for _ in range(3):
+        out = g.forward(images, K, labels, T0, n_iterations=2, im_ids=im_ids)["iteration=2"].TCO_output
+        assert torch.equal(out, ref)
+    assert g._graphs is None and g._no_graphs  # nothing was captured
