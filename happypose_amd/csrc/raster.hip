@@ -514,31 +514,41 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
       b1 = y1 / a.band_rows;
     }
   }
-  // Appends are aggregated twice: lanes -> wave (ballot) -> workgroup (LDS counters), so only
-  // one global atomic per band per workgroup reaches L2 (same-address L2 atomics serialise).
+  // Appends are aggregated per workgroup: a lane takes its slot(s) from LDS counters (one returning LDS atomic per band it
+  // touches -- a triangle of these meshes touches one or two), one global atomic per band and workgroup reserves the
+  // workgroup's range in the band's list (same-address L2 atomics serialise).  (The first version walked the band RANGE of
+  // every wave with ballots: mesh order is not screen order, so a wave spanned 20-40 of the 60 four-row bands.)  The order
+  // of a list is arbitrary either way; the z-buffer minimum does not depend on it.
   __shared__ int wg_cnt[kMaxBands], wg_base[kMaxBands];
-  __shared__ int wave_base[kBinThreads / 64][kMaxBands];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   for (int b = tid; b < a.n_bands; b += kBinThreads) wg_cnt[b] = 0;
   __syncthreads();
-  int lo = b0 <= b1 ? b0 : a.n_bands, hi = b0 <= b1 ? b1 : -1;  // bands touched by this wave
+  int slot0 = 0, slot1 = 0;  // local slots in the first two bands
+  if (b0 <= b1) {
+    slot0 = atomicAdd(&wg_cnt[b0], 1);
+    if (b1 > b0) slot1 = atomicAdd(&wg_cnt[b0 + 1], 1);
+  }
+  int extra[6];  // bands b0 + 2 .. b0 + 7 of a triangle taller than two bands
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-  for (int b = lo; b <= hi; ++b) {
-    const unsigned long long m = __ballot(b0 <= b && b <= b1);
-    if (m != 0 && lane == 0) wave_base[wave][b] = atomicAdd(&wg_cnt[b], __popcll(m));
+  for (int k = 0; k < 6; ++k) extra[k] = (b0 <= b1 && b0 + 2 + k <= b1) ? atomicAdd(&wg_cnt[b0 + 2 + k], 1) : 0;
+  for (int b = b0 + 8; b <= b1; ++b) {  // rare: beyond eight bands a triangle appends itself with a global atomic per band
+    const int slot = atomicAdd(&a.bin_count[lv * a.n_bands + b], 1);
+    if (slot < a.bin_cap) a.bin_list[((int64_t)lv * a.n_bands + b) * a.bin_cap + slot] = f;
   }
   __syncthreads();
   for (int b = tid; b < a.n_bands; b += kBinThreads)
     if (wg_cnt[b] > 0) wg_base[b] = atomicAdd(&a.bin_count[lv * a.n_bands + b], wg_cnt[b]);
   __syncthreads();
-  for (int b = lo; b <= hi; ++b) {
-    const bool mine = b0 <= b && b <= b1;
-    const unsigned long long m = __ballot(mine);
-    if (mine) {
-      const int slot = wg_base[b] + wave_base[wave][b] + __popcll(m & ((1ull << lane) - 1ull));
+  if (b0 <= b1) {
+    auto put = [&](int b, int local) {
+      const int slot = wg_base[b] + local;
       if (slot < a.bin_cap) a.bin_list[((int64_t)lv * a.n_bands + b) * a.bin_cap + slot] = f;
-    }
+    };
+    put(b0, slot0);
+    if (b1 > b0) put(b0 + 1, slot1);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (b0 + 2 + k <= b1) put(b0 + 2 + k, extra[k]);
   }
 }
 
