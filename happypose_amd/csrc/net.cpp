@@ -54,6 +54,7 @@ struct ConvLayer {
   DevBuf w_w2;             // the same for conv_wino2.hip (64 x 64 items)
   DevBuf w, w_wino, w_split, w_isplit, bias, lut, pre_scale, pre_shift;  // w_isplit: hi/lo halves for conv_igemm_split.hip  // w_wino: Winograd-transformed weights (3x3 s1 layers)
                                                                // w_split: fp16 hi/lo halves (conv_split.hip)
+  bool wino_ok = false, wsplit_ok = false, w2_ok = false;  // eligible for w_wino / w_wsplit / w_w2 (built on first use)
   int cout_pad = 0;        // weight rows / bias padded to whole 64-wide tiles
   float pre_smax = 1.f, pre_bmax = 0.f;  // bound of the BN + ReLU prologue: |x_act| <= pre_smax max|x| + pre_bmax (ConvArgs::amax_a / amax_b)
   int se = 0;              // the input is gated by the squeeze-excitation vector of this block (1x1 projections)
@@ -447,20 +448,17 @@ int pack_conv(Net& n, ConvLayer& L) {
     ConvArgs probe{};
     probe.stride = L.stride; probe.pad = L.pad; probe.Cin = L.cin; probe.Cout = L.cout;
     probe.H = L.H; probe.W = L.W; probe.Ho = L.Ho; probe.Wo = L.Wo;
+    // The Winograd weight sets (exact-fp32 U = G g G^T, and the two split-fp16 forms) are LAZY: only eligibility is
+    // recorded here; ensure_wino_weights() transforms a set the first time a forward's algorithm can reach it (the
+    // guard's exact-fp32 fallback, hp_net_set_conv_algo, HP_WINO_SPLIT / HP_WINO2).  The default plan never touches
+    // them: hp_net_create used to spend 2 x 150 MB and 3 x 58 transform launches per WideResNet-34 on kernels that
+    // lost to the direct split kernels.
     if (conv_wino_applicable(probe, L.kh, L.kw)) {
-      if ((rc = L.w_wino.alloc(conv_wino_weight_floats(L.cout, L.cin) * 4))) return rc;
-      if ((rc = conv_wino_transform_weights((const float*)L.w.p, (float*)L.w_wino.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
-      HP_CHECK_HIP(hipStreamSynchronize(nullptr));
+      L.wino_ok = true;
       static const bool no_wsplit = std::getenv("HP_CONV_NO_WINO_SPLIT") != nullptr;
       if (!no_wsplit && L.cin >= 64 && L.cin % 32 == 0 && L.cout_pad == L.cout && L.relu != HP_ACT_SWISH && !L.se) {
-        if ((rc = L.w_wsplit.alloc(conv_wino_split_weight_bytes(L.cout, L.cin)))) return rc;
-        if ((rc = conv_wino_split_transform_weights((const float*)L.w.p, L.w_wsplit.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
-        HP_CHECK_HIP(hipStreamSynchronize(nullptr));
-        if (L.cout % 64 == 0) {
-          if ((rc = L.w_w2.alloc(conv_wino2_weight_bytes(L.cout, L.cin)))) return rc;
-          if ((rc = conv_wino2_transform_weights((const float*)L.w.p, L.w_w2.p, L.cout, L.cin, L.Kpad, nullptr))) return rc;
-          HP_CHECK_HIP(hipStreamSynchronize(nullptr));
-        }
+        L.wsplit_ok = true;
+        L.w2_ok = L.cout % 64 == 0;
       }
     }
     if (conv_split_applicable(probe, L.kh, L.kw) && L.cout_pad == L.cout && L.relu != HP_ACT_SWISH && !L.se) {
@@ -742,6 +740,45 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   return HP_OK;
 }
 
+// Builds the Winograd weight sets a forward under `algo` can reach and that do not exist yet (see pack_conv): allocation
+// plus a transform launch on `stream`, i.e. ordered before the forward's own launches.  Not possible while the stream
+// captures (hipMalloc): the Python layer runs the first call after an algorithm switch eagerly (ops.bump_graph_epoch).
+static int ensure_wino_weights(hp_net* net, int algo, hipStream_t stream) {
+  const bool exact = algo == HP_CONV_ALGO_WINOGRAD_1WAVE || algo == HP_CONV_ALGO_WINOGRAD;
+  const bool split = conv_use_split(algo, 0, 0, 0, 0);
+  int rc;
+  bool capturing_checked = false;
+  auto can_build = [&]() -> int {
+    if (capturing_checked) return HP_OK;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    HP_CHECK_HIP(hipStreamIsCapturing(stream, &st));
+    if (st != hipStreamCaptureStatusNone)
+      return fail(HP_ERR_ARG, "hp_net_forward: Winograd weights of this algorithm are not built yet; run one eager forward before capturing");
+    capturing_checked = true;
+    return HP_OK;
+  };
+  for (auto& Lp : net->convs) {
+    ConvLayer& L = *Lp;
+    // exact-fp32 set: the Winograd algorithms, and under AUTO the layers without split-fp16 weights
+    if (L.wino_ok && !L.w_wino.p && (exact || (algo == HP_CONV_ALGO_AUTO && !L.w_split.p))) {
+      if ((rc = can_build())) return rc;
+      if ((rc = L.w_wino.alloc(conv_wino_weight_floats(L.cout, L.cin) * 4))) return rc;
+      if ((rc = conv_wino_transform_weights((const float*)L.w.p, (float*)L.w_wino.p, L.cout, L.cin, L.Kpad, stream))) return rc;
+    }
+    if (split && L.w2_ok && !L.w_w2.p && conv_use_wino2(algo, L.W)) {
+      if ((rc = can_build())) return rc;
+      if ((rc = L.w_w2.alloc(conv_wino2_weight_bytes(L.cout, L.cin)))) return rc;
+      if ((rc = conv_wino2_transform_weights((const float*)L.w.p, L.w_w2.p, L.cout, L.cin, L.Kpad, stream))) return rc;
+    }
+    if (split && L.wsplit_ok && !L.w_wsplit.p && conv_use_wino_split(algo, L.W)) {
+      if ((rc = can_build())) return rc;
+      if ((rc = L.w_wsplit.alloc(conv_wino_split_weight_bytes(L.cout, L.cin)))) return rc;
+      if ((rc = conv_wino_split_transform_weights((const float*)L.w.p, L.w_wsplit.p, L.cout, L.cin, L.Kpad, stream))) return rc;
+    }
+  }
+  return HP_OK;
+}
+
 // d_x: fp32 input [batch][h][w][c_pad]; or (fp16 plan only) d_x16: fp16 input [batch][h][w][cin16 of the stem]
 static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int batch, float* d_pose, float* d_logits,
                          float* d_features, hipStream_t stream) {
@@ -777,6 +814,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
   // the guard of an EARLIER forward fired (read without synchronising): from now on exact-fp32 kernels only
   if (net->h_status && *(volatile unsigned*)net->h_status) net->exact_only = true;
   const int net_algo = net->exact_only ? HP_CONV_ALGO_WINOGRAD : (net->algo >= 0 ? net->algo : conv_algo());
+  if (!f16 && (rc = ensure_wino_weights(net, net_algo, stream))) return rc;
   static const bool no_act_scale = std::getenv("HP_CONV_NO_ACT_SCALE") != nullptr;  // A/B: the round-2 arithmetic (no activation scale)
   unsigned* const amax_words = (f16 || no_act_scale || !net->act_scale) ? nullptr : (unsigned*)net->amax.p;
   if (amax_words && (rc = launch_zero_words(amax_words, ((int)net->ops.size() + 1) * kAmaxSlots * kAmaxStride, stream))) return rc;
@@ -1209,6 +1247,12 @@ extern "C" int hp_net_status(hp_net* net, void* stream, int* flags) {
     *(volatile unsigned*)net->h_status = 0u;
   }
   if (net->exact_only) *flags |= HP_STATUS_EXACT_ONLY;
+  return HP_OK;
+}
+
+extern "C" int hp_net_force_exact(hp_net* net, int enabled) {
+  HP_REQUIRE(net, "hp_net_force_exact: null net");
+  net->exact_only = enabled != 0;
   return HP_OK;
 }
 

@@ -664,7 +664,7 @@ __device__ __forceinline__ BandLds carve_lds(unsigned char* base, int npix_max, 
   l.zb = reinterpret_cast<unsigned long long*>(base);
   base += (size_t)npix_max * ns * 8;
   l.ex = reinterpret_cast<unsigned short*>(base);
-  base += (size_t)npix_max * 2;
+  base += (size_t)((npix_max * 2 + 15) & ~15);  // odd render widths: keep plist / nsum / the folds 16-B aligned
   l.plist = reinterpret_cast<unsigned short*>(base);
   base += (size_t)((npix_max * band_list_per_pixel(ns) * 2 + 15) & ~15);
   l.nsum = reinterpret_cast<uint32_t*>(base);
@@ -674,7 +674,7 @@ __device__ __forceinline__ BandLds carve_lds(unsigned char* base, int npix_max, 
   return l;
 }
 static size_t band_lds_bytes(int npix_max, int ns, int rows, int w, bool crop) {
-  return (size_t)npix_max * ns * 8 + (size_t)npix_max * 2 + (size_t)((npix_max * band_list_per_pixel(ns) * 2 + 15) & ~15) +
+  return (size_t)npix_max * ns * 8 + (size_t)((npix_max * 2 + 15) & ~15) + (size_t)((npix_max * band_list_per_pixel(ns) * 2 + 15) & ~15) +
          (ns > 1 ? (size_t)npix_max * 4 : 0) + (crop ? (size_t)(rows + w) * sizeof(Fold) : 0) + 16;
 }
 

@@ -248,7 +248,7 @@ def create_pose_model_cosypose(cfg, renderer: BatchRenderer, mesh_db=None, state
     :func:`create_model_pose`."""
     if n_lanes >= 2:
         model = _two_lanes(lambda r, mb: create_pose_model_cosypose(cfg, r, mesh_db, state_dict, mb, precision), renderer,
-                           max_batch)
+                           max_batch, n_lanes)
         model.use_graphs = graphs
         return model
     assert n_lanes == 1

@@ -513,6 +513,13 @@ class Net:
         self._exact_only = exact
         return flags.value
 
+    def force_exact(self, on: bool = True) -> None:
+        """``hp_net_force_exact``: put the network on (or take it off) the exact-fp32 kernels the guard switches to."""
+        check(lib().hp_net_force_exact(self.handle, int(bool(on))), "hp_net_force_exact")
+        if bool(on) != self._exact_only:
+            bump_graph_epoch()
+        self._exact_only = bool(on)
+
     def profile_collect(self):
         """``(conv_ms, n_launches, conv_flops, mfma_flops)`` of the conv launches recorded since
         the last call (HIP events on the launch stream; waits for them): algorithmic FLOPs of the

@@ -226,6 +226,12 @@ class _EstimatorBase:
         if D.sharding_active(self.shard_hypotheses):
             flag = D.all_ranks_max(flag, self.device)
         if flag:
+            # every network of every rank (and of every lane) goes exact BEFORE the repeat: only the one whose guard
+            # fired has switched by itself, and a stage merged from two arithmetics -- or one rank left alone on the
+            # slower kernels, stalling every later all-gather -- is not "identical to a single-process run"
+            backbone = getattr(model, "backbone", None)
+            if backbone is not None and hasattr(backbone, "force_exact"):
+                backbone.force_exact(True)
             out = stage()
         return out
 
@@ -274,7 +280,9 @@ class _EstimatorBase:
         table = {k: [torch.cat(parts) if parts else torch.zeros((0,) + shape, **f) for parts, (_, _, shape) in zip(v, self._ITER_COLS)]
                  for k, v in cols.items()}
         if sharded:
-            packed = torch.cat([t.reshape(n_local, -1).float() for k in table for t in table[k]], dim=1) if n_iterations else \
+            # explicit widths: an EMPTY shard (more ranks than rows) must still pack to [0, 49 * n_iterations]
+            packed = torch.cat([t.reshape(n_local, width).float() for k in table
+                                for t, (_, width, _) in zip(table[k], self._ITER_COLS)], dim=1) if n_iterations else \
                 torch.zeros((n_local, 0), **f)
             full = D.gather_rows(packed.contiguous(), s, B)
             c0 = 0
@@ -356,11 +364,10 @@ class PoseEstimator(_EstimatorBase):
         f = dict(dtype=torch.float32, device=self.device)
         logits = torch.cat(logits_l) if logits_l else torch.zeros((0, 1), **f)
         scores = torch.cat(scores_l) if scores_l else torch.zeros((0, 1), **f)
-        if sharded:  # one all-gather of [n_local, 2] rows
-            tail = logits.shape[1:]
-            full = D.gather_rows(torch.cat([logits.reshape(e - s, -1), scores.reshape(e - s, -1)], dim=1), s, N)
-            w = full.shape[1] // 2
-            logits, scores = full[:, :w].reshape((N,) + tuple(tail)), full[:, w:].reshape((N,) + tuple(tail))
+        if sharded:  # one all-gather of [n_local, 2] rows; the coarse model has ONE logit per row (views_logits_head of a
+            # one-view model, MP/models/pose_rigid.py:144-148), so the width does not depend on what a rank happens to hold
+            full = D.gather_rows(torch.cat([logits.reshape(e - s, 1), scores.reshape(e - s, 1)], dim=1), s, N)
+            logits, scores = full[:, 0:1], full[:, 1:2]  # [N, 1] like the unsharded concatenation
         debug_data = {"images_crop": torch.cat(crops_l), "renders": torch.cat(renders_l)} if return_debug_data else {}
         df["pose_logit"] = logits.cpu().numpy()
         df["pose_score"] = scores.cpu().numpy()

@@ -463,6 +463,10 @@ class _LaneBackbones:
         for n in self.nets:
             n.set_tail_split(on)
 
+    def force_exact(self, on: bool = True):
+        for n in self.nets:
+            n.force_exact(on)
+
     def status(self, streams=None) -> int:
         flags = 0
         for i, n in enumerate(self.nets):
@@ -606,11 +610,12 @@ class TwoLanePredictor:
         return self
 
     def _cuts(self, bsz: int):
-        """Contiguous shares of a batch, one per lane (the first lanes take the remainder; two lanes: bsz // 2 + the rest
-        as before would put the odd row on lane 1 -- kept: lane 0 gets floor, the last lane the remainder)."""
+        """Contiguous shares of a batch, one per lane, ``distributed.shard_range`` semantics: the first ``bsz % n`` lanes
+        take one row more, so no lane exceeds ``ceil(bsz / n)`` -- what its backbone arena and rasteriser scratch were
+        reserved for (``models._two_lanes``)."""
         n = len(self.lanes)
-        q = bsz // n
-        edges = [i * q for i in range(n)] + [bsz]
+        q, r = divmod(bsz, n)
+        edges = [i * q + min(i, r) for i in range(n)] + [bsz]
         return [slice(edges[i], edges[i + 1]) for i in range(n)]
 
     def numerics_status(self) -> int:

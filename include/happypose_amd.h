@@ -391,6 +391,11 @@ int hp_net_set_act_scale(hp_net* net, int enabled);
 #define HP_STATUS_NONFINITE 1
 #define HP_STATUS_EXACT_ONLY 2
 int hp_net_status(hp_net* net, void* stream, int* flags);
+/* Sets (1) or clears (0) the sticky exact-fp32 state the guard enters by itself.  Multi-rank callers use it to keep the
+ * ranks uniform: when ANY rank's guard fired, every rank forces its networks exact before the stage is repeated, so that
+ * the merged rows come from one arithmetic and no rank is left alone on the slower kernels (pose_estimator.py::_guarded;
+ * no counterpart in the reference, whose ranks all run ATen's fp32 convolutions).  0 returns to the default kernels. */
+int hp_net_force_exact(hp_net* net, int enabled);
 /* diagnostics: workgroups per CU the runtime grants conv tile variant 0 (128x128) / 1 (128x64) */
 int hp_conv_occupancy(int variant);
 /* hipGraph safety: launches so far, in this process, of kernels whose code object uses scratch (private segment > 0:

@@ -83,7 +83,8 @@ ESTIMATOR_WORKER = textwrap.dedent("""
     from happypose_amd.tensor_collection import PandasTensorCollection
 
     rank, local_rank, world = D.init_distributed("gloo")
-    n_det, n_hyp = int(os.environ["HP_N"]), 3
+    n_det, n_hyp = int(os.environ["HP_N"]), int(os.environ.get("HP_NHYP", "3"))
+    n_pose_hyp = int(os.environ.get("HP_NPOSE", "2"))
     rs = np.random.RandomState(0)
     LABELS = [f"obj{i}" for i in range(4)]
 
@@ -114,8 +115,19 @@ ESTIMATOR_WORKER = textwrap.dedent("""
         def forward_coarse(self, images, K, labels, TCO_input, cuda_timer=False, return_debug_data=False, im_ids=None):
             logit = (TCO_input[:, :3, :3].reshape(len(labels), -1) * torch.arange(9.0)).sum(1, keepdim=True) + self._obj(labels)[:, None]
             return {"logits": logit, "scores": torch.sigmoid(logit), "render_time": 0.0, "model_time": 0.0, "time": 0.0}
+        # the guard: `fire` lists the ranks whose NEXT status query reports a non-finite forward (once)
+        fire = ()
+        exact = False
         def numerics_status(self):
+            if rank in FakeModel.fire:
+                FakeModel.fire = ()
+                return 1
             return 0
+        @property
+        def backbone(self):
+            return self
+        def force_exact(self, on=True):
+            FakeModel.exact = bool(on)
 
     def fake_init(store, boxes, K, im_ids, obj_ids, R=None, box_ids=None, rot_ids=None, n_points=None):
         n = len(obj_ids)
@@ -164,15 +176,22 @@ ESTIMATOR_WORKER = textwrap.dedent("""
                                          bboxes=torch.as_tensor(rs.uniform(10, 200, size=(n_det, 4)).astype(np.float32)))
     rs = np.random.RandomState(2); d1 = det(); rs = np.random.RandomState(2); d2 = det()
     mp = PoseEstimator(refiner_model=FakeModel(), coarse_model=FakeModel(), bsz_objects=4, bsz_images=16, SO3_grid_size=72)
-    g_sh, x_sh = mp.run_inference_pipeline(obs, detections=d1, n_refiner_iterations=2, n_pose_hypotheses=2)
+    g_sh, x_sh = mp.run_inference_pipeline(obs, detections=d1, n_refiner_iterations=2, n_pose_hypotheses=n_pose_hyp)
     mp.shard_hypotheses = False
-    g_1, x_1 = mp.run_inference_pipeline(obs, detections=d2, n_refiner_iterations=2, n_pose_hypotheses=2)
+    g_1, x_1 = mp.run_inference_pipeline(obs, detections=d2, n_refiner_iterations=2, n_pose_hypotheses=n_pose_hyp)
     same(g_sh, g_1)
     same(x_sh["coarse"]["preds"], x_1["coarse"]["preds"])
     same(x_sh["coarse_filter"]["preds"], x_1["coarse_filter"]["preds"])
     same(x_sh["scoring"]["preds"], x_1["scoring"]["preds"])
     assert torch.equal(x_sh["coarse"]["data"]["logits"], x_1["coarse"]["data"]["logits"])
     assert torch.equal(x_sh["coarse"]["data"]["TCO"], x_1["coarse"]["data"]["TCO"])
+    # the guard fires on ONE rank only: every rank repeats the stage AND every rank's networks go exact first
+    est.shard_hypotheses = None
+    FakeModel.fire, FakeModel.exact, FakeModel.calls = (world - 1,), False, 0
+    rs = np.random.RandomState(1); h3 = hyp()
+    f_g, _ = est.run_inference_pipeline(obs, data_TCO_init=h3, n_coarse_iterations=0, n_refiner_iterations=3)
+    assert FakeModel.exact, "a rank whose own guard stayed silent must be forced exact as well"
+    same(f_g, f_1)
     # every rank holds the same final table: compare a checksum across ranks
     chk = torch.tensor([float(g_sh.poses.double().sum()), float(f_sh.poses.double().sum())], dtype=torch.float64)
     lo, hi = chk.clone(), chk.clone()
@@ -214,18 +233,21 @@ def test_shard_and_all_gather_gloo(tmp_path, world, n_total):
         assert p.returncode == 0 and f"rank {r} ok" in out, out[-2000:]
 
 
-@pytest.mark.parametrize("world,n_det", [(2, 5), (3, 4), (2, 1)])
-def test_estimators_shard_behind_the_entry_point_gloo(tmp_path, world, n_det):
+@pytest.mark.parametrize("world,n_det,n_hyp,n_pose_hyp", [(2, 5, 3, 2), (3, 4, 3, 2), (2, 1, 3, 2), (3, 1, 1, 1), (2, 1, 1, 1)])
+def test_estimators_shard_behind_the_entry_point_gloo(tmp_path, world, n_det, n_hyp, n_pose_hyp):
     """``run_inference_pipeline`` with torch.distributed initialised: every rank computes its shard of the hypothesis
     rows (refiner, coarse grid, scoring) and the merged result equals the unsharded run bit for bit, infos included --
-    the estimator's bookkeeping driven by stand-in predictors (the real ones need the GPU: tests/test_gpu_pipeline.py)."""
+    the estimator's bookkeeping driven by stand-in predictors (the real ones need the GPU: tests/test_gpu_pipeline.py).
+    The (3, 1, 1, 1) / (2, 1, 1, 1) cases have MORE RANKS THAN ROWS: the refiner table has one row (the MegaPose example
+    setup: one detection, ``n_pose_hypotheses=1``), so ranks hold empty shards."""
     script = tmp_path / "worker_est.py"
     script.write_text(ESTIMATOR_WORKER)
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HP_ROOT=str(ROOT), HP_N=str(n_det), OMP_NUM_THREADS="1")
+                   MASTER_PORT=str(port), HP_ROOT=str(ROOT), HP_N=str(n_det), HP_NHYP=str(n_hyp), HP_NPOSE=str(n_pose_hyp),
+                   OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
