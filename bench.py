@@ -78,18 +78,20 @@ def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32",
     return ds, renderer, scene, weights, model
 
 
-def bench_e2e(args, device, rank, world):
+def e2e_run(device, rank, world, lanes, coarse_precision, steps, warmup, run_detector=False):
     """End-to-end frames/s of SURVEY.md 8(d): the whole ``PoseEstimator.run_inference_pipeline`` of the
     ``megapose-1.0-RGB-multi-hypothesis`` configuration (TB/utils/load_model.py:26-34) on one 640x480 frame
     with 8 detections per GPU: coarse scoring of 8 x 576 SO(3)-grid poses, top-5 hypotheses per detection,
     5 refiner iterations over the 40 hypotheses (4 views x RGB + normals, 27 channels), re-scoring, top-1 --
-    host orchestration (pandas bookkeeping, chunking) included."""
+    host orchestration (pandas bookkeeping, chunking) included: what ``MP/evaluation/prediction_runner.py:228-236,
+    265-291`` times.  ``run_detector``: the frame additionally goes through the Mask-RCNN detector (random weights: its
+    detections are timed and discarded, the pose stages run on the projected-object boxes so that their work is the same
+    in every run).  Returns the measurements of rank 0's line (``None`` on the other ranks)."""
     from happypose_amd.models import create_model_pose, pose_model_param_shapes
     from happypose_amd.pose_estimator import ObservationTensor, PoseEstimator, make_detections_from_object_data
     from happypose_amd.renderer import BatchRenderer
     from happypose_amd.synthetic import make_object_dataset, make_scene, predictor_weights
 
-    coarse_precision = args.precision or "f32"
     ds = make_object_dataset(8, seed=1, tex_size=1024)
     renderer = BatchRenderer(ds, device=device)
     store = renderer.store
@@ -100,9 +102,16 @@ def bench_e2e(args, device, rank, world):
                 depth_augmentation=False)
     wc = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 9, pose_dim=0, n_views_logits=1), seed=0)
     wr = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 27), seed=1)
-    coarse = create_model_pose(ccfg, renderer, state_dict=wc, max_batch=576, precision=coarse_precision, n_lanes=args.lanes)
-    refiner = create_model_pose(rcfg, renderer, state_dict=wr, max_batch=64, precision="f32", n_lanes=args.lanes)
-    est = PoseEstimator(refiner_model=refiner, coarse_model=coarse, bsz_objects=8, bsz_images=576, SO3_grid_size=576)
+    coarse = create_model_pose(ccfg, renderer, state_dict=wc, max_batch=576, precision=coarse_precision, n_lanes=lanes)
+    refiner = create_model_pose(rcfg, renderer, state_dict=wr, max_batch=64, precision="f32", n_lanes=lanes)
+    detector = None
+    if run_detector:
+        from happypose_amd.detector import Detector, synthetic_maskrcnn
+
+        detector = Detector(synthetic_maskrcnn(device, n_classes=len(store.labels) + 1, seed=3),
+                            {f"{l}": i + 1 for i, l in enumerate(store.labels)})
+    est = PoseEstimator(refiner_model=refiner, coarse_model=coarse, detector_model=detector, bsz_objects=8, bsz_images=576,
+                        SO3_grid_size=576)
 
     # detections = bounding boxes of the projected objects (what a detector would hand over)
     pts = store.mesh_db.points[scene["det_obj_ids"]].astype(np.float64)
@@ -114,8 +123,14 @@ def bench_e2e(args, device, rank, world):
     det = make_detections_from_object_data([store.labels[i] for i in scene["det_obj_ids"]], boxes).to(device)
     obs = ObservationTensor(torch.as_tensor(scene["images"][:, :3].copy(), device=device),
                             torch.as_tensor(scene["K"], device=device))
+    det_s = [0.0]
 
     def step():
+        if detector is not None:  # timed, its (random-weight) detections discarded
+            t_d = time.perf_counter()
+            detector.get_detections(observation=obs, detection_th=0.0, output_masks=True)
+            torch.cuda.synchronize(device)
+            det_s[0] += time.perf_counter() - t_d
         final, extra = est.run_inference_pipeline(obs, detections=det, n_refiner_iterations=N_ITERS, n_pose_hypotheses=5)
         return final, extra
 
@@ -124,17 +139,22 @@ def bench_e2e(args, device, rank, world):
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     from happypose_amd import ops as _ops
 
     for m in (coarse, refiner):
         m.backbone.set_profiling(True)
+    det_s[0] = 0.0
+    stage_s = {"coarse": 0.0, "refiner": 0.0, "scoring": 0.0}
     fence()
     _ops.profile_mark_reference(device)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         final, extra = step()
+        stage_s["coarse"] += extra["coarse"]["data"]["time"]
+        stage_s["refiner"] += extra["refiner"]["data"]["time"]
+        stage_s["scoring"] += extra["scoring"]["data"]["time"]
     fence()
     elapsed = time.perf_counter() - t0
     # the time during which ANY conv kernel of either backbone ran (lanes and backbones overlap: their sum is not a share)
@@ -148,7 +168,22 @@ def bench_e2e(args, device, rank, world):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
+        return None
+    stage_ms = {k: 1e3 * v / steps for k, v in stage_s.items()}
+    if detector is not None:
+        stage_ms["detection"] = 1e3 * det_s[0] / steps
+    stage_ms["host_and_bookkeeping"] = 1e3 * elapsed / steps - sum(stage_ms.values())
+    return {"elapsed": elapsed, "steps": steps, "prof": prof, "conv_union_ms": conv_union_ms, "stage_ms_per_frame": stage_ms,
+            "timing_str": extra["timing_str"]}
+
+
+def bench_e2e(args, device, rank, world):
+    """``--workload E2E``: the line of :func:`e2e_run`."""
+    coarse_precision = args.precision or "f32"
+    r = e2e_run(device, rank, world, args.lanes, coarse_precision, args.steps, args.warmup, run_detector=args.run_detector)
+    if r is None:
         return
+    elapsed, prof, conv_union_ms = r["elapsed"], r["prof"], r["conv_union_ms"]
     # dominant backbone = the one with more conv time (the coarse net unless it runs in fp16); roofline of the issued
     # instruction, v_mfma_f32_32x32x16_f16: executed fp16-MFMA FLOPs (fp32-MFMA-time equivalents x 16) / conv time
     names = ("coarse", "refiner")
@@ -167,13 +202,15 @@ def bench_e2e(args, device, rank, world):
         "data": "synthetic",
         "config": {"workload": "E2E: PoseEstimator.run_inference_pipeline, megapose-1.0-RGB-multi-hypothesis shape: one 640x480 "
                                "frame per GPU, 8 detections, coarse 8 x 576 views (vanilla_resnet34 on 9 ch), top-5 hypotheses, "
-                               "5 refiner iterations x 40 hypotheses x 4 views (vanilla_resnet34 on 27 ch), re-scoring, top-1",
+                               "5 refiner iterations x 40 hypotheses x 4 views (vanilla_resnet34 on 27 ch), re-scoring, top-1"
+                               + (", Mask-RCNN detector on the frame first (run_detector)" if args.run_detector else ""),
                    "detections_per_gpu": N_DET, "parallelism": f"frame-replica x{world}"},
         "roofline": {"bound": "mfma", "kernel": f"all conv launches of the {names[dom]} backbone (the one with more conv time)", "per_backbone": per_net,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                      "launches": int(sum(p[1] for p in prof)), "conv_time_share": conv_union_ms * 1e-3 / elapsed,
                      "conv_time_sum_over_wall": conv_ms * 1e-3 / elapsed},
-        "stage_seconds_last_frame": extra["timing_str"],
+        "stage_ms_per_frame": r["stage_ms_per_frame"],
+        "stage_seconds_last_frame": r["timing_str"],
     }
     print(json.dumps(line), flush=True)
 
@@ -206,13 +243,13 @@ def recorded_traffic(kind="conv"):
         return None, None
 
 
-def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2, renderer_kw=None):
+def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2, renderer_kw=None, arch="resnet34"):
     """A short run of another BASELINE.json config in the same process (C3: MegaPose RGB-D refiner, fp32; C5: coarse
     scoring in fp16; C2 again in another render state): ``{value, unit, ms_per_step, frac, algorithmic_tflops, steps}`` --
     the driver-visible twin of ``bench.py --workload C3|C5`` / ``--render-state single-sample``."""
     from happypose_amd import ops as _ops
 
-    ds, renderer, scene, weights, model = build_world(device, "resnet34", seed=0, workload=workload, precision=precision, n_lanes=n_lanes,
+    ds, renderer, scene, weights, model = build_world(device, arch, seed=0, workload=workload, precision=precision, n_lanes=n_lanes,
                                                       renderer_kw=renderer_kw)
     store = renderer.store
     B = len(scene["TCO_hyp"])
@@ -258,7 +295,39 @@ def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2, rend
     return {"value": B * steps / elapsed, "unit": "refined poses/s" if workload != "C5" else "views/s", "dtype": precision,
             "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "frac": executed_f16 / PEAK_F16_MFMA_TFLOPS,
             "algorithmic_tflops": conv_flops / sec / 1e12 if sec > 0 else 0.0, "conv_time_share": sec / elapsed,
-            "hypotheses_per_step": B, "lanes": n_lanes}
+            "hypotheses_per_step": B, "lanes": n_lanes, "scratch_launches": int(_ops.scratch_launches())}
+
+
+def estimator_timing(model, images, K, labels, TCO0, device, steps, poses_direct):
+    """``CosyPoseEstimator.forward_refiner`` (bsz_objects = the whole table) on the job the headline times through
+    ``model.forward``: ms per step, and the largest difference of its final poses to the direct call's (0: same launches)."""
+    import pandas as pd
+
+    from happypose_amd.pose_estimator import CosyPoseEstimator, ObservationTensor
+    from happypose_amd.tensor_collection import PandasTensorCollection
+
+    B = len(labels)
+    est = CosyPoseEstimator(refiner_model=model, coarse_model=model, bsz_objects=B)
+    obs = ObservationTensor(images, K)
+    infos = pd.DataFrame({"label": list(labels), "batch_im_id": np.zeros(B, dtype=np.int64), "instance_id": np.arange(B) // N_HYP,
+                          "hypothesis_id": np.arange(B) % N_HYP})
+    data = PandasTensorCollection(infos=infos, poses=TCO0)
+
+    def step():
+        preds, _ = est.forward_refiner(obs, data, n_iterations=N_ITERS)
+        return preds[f"iteration={N_ITERS}"].poses
+
+    for _ in range(2):
+        out = step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize(device)
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    return {"ms_per_step": ms, "steps": steps, "value": B / (ms * 1e-3), "unit": "refined poses/s",
+            "max_abs_pose_diff_vs_direct_call": float((out - poses_direct[:B]).abs().max()),
+            "entry": "CosyPoseEstimator.forward_refiner(observation, data_TCO_input[128], n_iterations=5), bsz_objects=128"}
 
 
 def effective_cpu_count() -> int:
@@ -422,6 +491,7 @@ def main():
     ap.add_argument("--render-state", default="reference", choices=["reference", "single-sample"],
                     help="reference = the reference renderer's state (4x MSAA, mipmap + anisotropic-16; product default); single-sample = "
                          "one sample per pixel, bilinear level 0 (what rounds 1-2 measured)")
+    ap.add_argument("--run-detector", action="store_true", help="E2E: the frame also goes through the Mask-RCNN detector (random weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the 3-step C3 / C5 runs appended to the C2 line")
     ap.add_argument("--no-cpu-1thread", action="store_true")
@@ -549,6 +619,30 @@ def main():
         fence()
         all_gather_us = (time.perf_counter() - t_ag) / 20 * 1e6
 
+    # the same job through the ENTRY POINT: CosyPoseEstimator.forward_refiner (CP/integrated/pose_estimator.py:249-356) on the
+    # 128-row hypothesis table, bsz_objects = 128 -- pandas bookkeeping, chunking, the per-iteration result tables and the
+    # guard's status query included (north_star: "run_inference_pipeline() stays the drop-in entry point")
+    estimator = None
+    if args.workload == "C2" and world == 1:
+        estimator = estimator_timing(model, images, K, labels, TCO0, device, max(3, args.steps // 2), poses)
+
+    ranks_block = None
+    if world > 1:  # what the collective actually ran on: gathered from every rank
+        import ctypes
+
+        bus = ctypes.create_string_buffer(64)
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipDeviceGetPCIBusId(bus, 64, ctypes.c_int(device.index or 0))
+        except OSError:
+            pass
+        mine = {"rank": rank, "local_rank": local_rank, "device": str(device), "name": torch.cuda.get_device_name(device),
+                "pci_bus_id": bus.value.decode() or None, "hostname": os.uname().nodename, "pid": os.getpid()}
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, mine)
+        ranks_block = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
+                       "ranks": gathered, "distinct_devices": len({(g["hostname"], g["pci_bus_id"]) for g in gathered})}
+
     # the same job restricted to the exact-fp32 kernels (fp32 MFMA: Winograd / direct), a quarter of the steps, so the
     # line also carries the number of the build whose every multiply is an fp32 FMA (reported beside `value`)
     exact = None
@@ -648,6 +742,11 @@ def main():
             line["roofline"]["sustained"] = {"error": str(e)}
         if all_gather_us is not None:
             line["all_gather_us"] = all_gather_us
+        if ranks_block is not None:
+            line["ranks"] = ranks_block
+        if estimator is not None:
+            line["estimator_ms_per_step"] = estimator["ms_per_step"]
+            line["estimator"] = dict(estimator, overhead_vs_predictor=estimator["ms_per_step"] / line["ms_per_step"] - 1.0)
         if precision == "f32":
             line["dtype_note"] = ("fp32 tensors and fp32 accumulation everywhere; the convolutions multiply fp16 hi/lo halves of the fp32 "
                                   "operands (three fp16 MFMAs per product, 22 significant bits: per-layer error vs fp64 as the exact-fp32 "
@@ -680,6 +779,26 @@ def main():
                     line[key] = quick_workload(device, wl, prec, n_lanes, steps=5 if wl == "C2" else 3, renderer_kw=rk)
                 except Exception as e:  # never lose the headline line to an extra
                     line[key] = {"error": f"{type(e).__name__}: {e}"}
+            if args.arch == "resnet34" and precision == "f32":
+                # C2 on the backbone the released CosyPose checkpoints use (CP/models/efficientnet.py), 3 steps
+                try:
+                    line["c2_efficientnet_b3"] = quick_workload(device, "C2", "f32", n_lanes, steps=3, arch="efficientnet-b3")
+                except Exception as e:
+                    line["c2_efficientnet_b3"] = {"error": f"{type(e).__name__}: {e}"}
+                # the whole PoseEstimator.run_inference_pipeline on one frame (bench.py --workload E2E), detector included
+                try:
+                    import gc
+
+                    gc.collect()
+                    r = e2e_run(device, 0, 1, n_lanes, "f32", steps=3, warmup=2, run_detector=True)
+                    line["e2e"] = {"value": r["steps"] / r["elapsed"], "unit": "frames/s", "ms_per_frame": 1e3 * r["elapsed"] / r["steps"],
+                                   "steps": r["steps"], "stage_ms_per_frame": r["stage_ms_per_frame"],
+                                   "conv_time_share": r["conv_union_ms"] * 1e-3 / r["elapsed"],
+                                   "job": "PoseEstimator.run_inference_pipeline: Mask-RCNN detector (random weights, timed, its detections "
+                                          "discarded) + 8 detections x 576-pose coarse grid, top-5, 5 refiner iterations x 40 hypotheses x 4 "
+                                          "views, re-scoring, top-1; pandas bookkeeping included"}
+                except Exception as e:
+                    line["e2e"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and args.workload == "C2" and world == 1:  # the CPU baseline is a 1-GPU-run item
             rk = dict(msaa=renderer.msaa, aniso=renderer.aniso)  # the same render state on both sides
             base, cpu_poses = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds, render_kw=rk)

@@ -30,6 +30,9 @@
 // are gone.  Inside a workgroup the work is re-organised in four passes: coverage (triangle-parallel, LDS z-buffer) ->
 // compaction of the covered pixels -> shading of the compacted list (every lane has a fragment; the 8-bit colour codes go
 // back into the z-buffer slots) -> pixel-parallel output pass (crop taps + record assembly, coalesced stores).
+#include <cmath>
+#include <mutex>
+
 #include "common.h"
 #include "crop_math.h"
 
@@ -63,13 +66,29 @@ constexpr int kSamplesMsaa = 5;
 #endif
 constexpr int kMaxViews = 8;  // views per item a record layout can describe
 constexpr int kBandKeysMsaa = HP_RASTER_BAND_KEYS_MSAA;
-__device__ __forceinline__ float sample_x(int ns, int sm) {
-  const float sx[5] = {0.375f, 0.875f, 0.125f, 0.625f, 0.5f};
-  return ns == 1 ? 0.5f : sx[sm];
-}
-__device__ __forceinline__ float sample_y(int ns, int sm) {
-  const float sy[5] = {0.125f, 0.375f, 0.625f, 0.875f, 0.5f};
-  return ns == 1 ? 0.5f : sy[sm];
+// The renderer conventions nobody can pin without Panda3D (hp_raster_conventions in the header), as the kernels see them:
+// the record itself plus what the host derives from it once per launch.  Kernel arguments (SGPRs): with the default record
+// every expression below evaluates the operations of the former compile-time constants on the same values -- bit-identical.
+struct RasterConv {
+  float sx[5], sy[5];          // the four colour samples + the pixel centre (slot 4)
+  float lo_x, hi_x, lo_y, hi_y;  // smallest / largest sample offset per axis (bounding-box growth)
+  float dxa[4], dya[4];        // |offset of sample s from the pixel centre| (conservative reject of the coverage walk)
+  float aniso_max, lod_bias, ratio_bias;
+  int aniso_round, lod_from;
+  int n_axis[3]; float n_sign[3];
+};
+__device__ __forceinline__ float sample_x(const RasterConv& cv, int ns, int sm) { return ns == 1 ? 0.5f : cv.sx[sm]; }
+__device__ __forceinline__ float sample_y(const RasterConv& cv, int ns, int sm) { return ns == 1 ? 0.5f : cv.sy[sm]; }
+// probe count and level of detail of the anisotropic filter from the footprint (pmax >= pmin, texel units)
+__device__ __forceinline__ void aniso_footprint(const RasterConv& cv, float pmax, float pmin, int nlev, float& nf, float& lod) {
+  const float r = pmax / pmin + cv.ratio_bias;
+  nf = pmin > 0.0f ? (cv.aniso_round == 0 ? ceilf(r) : cv.aniso_round == 1 ? rintf(r) : floorf(r)) : cv.aniso_max;
+  if (!(nf >= 1.0f)) nf = 1.0f;
+  if (nf > cv.aniso_max) nf = cv.aniso_max;
+  const float la = cv.lod_from == 0 ? pmax / nf : cv.lod_from == 1 ? pmin : pmax;
+  lod = la > 0.0f ? log2f(la) + cv.lod_bias : 0.0f;
+  if (!(lod > 0.0f)) lod = 0.0f;
+  if (lod > (float)(nlev - 1)) lod = (float)(nlev - 1);
 }
 constexpr int kBigQueue = 512;
 constexpr int kBigArea = 128;  // bbox pixels above which a triangle is walked cooperatively
@@ -120,6 +139,7 @@ struct RasterArgs {
   const float* images; int Bi, Ct, IH, IW, sr, crop_nc, crop_depth_mode;
   const float* boxes; const int32_t* im_ids;
   unsigned w_magic;                    // p / w = (p * w_magic) >> 32 for p < 2^16
+  RasterConv cv;                       // hp_raster_set_conventions, copied at launch
 };
 
 __device__ __forceinline__ void edge_fn(const float* P0, int i0, const float* P1, int i1, float* e) {
@@ -202,19 +222,15 @@ __device__ __forceinline__ void tex_fetch_level(const uint8_t* tex, int tw, int 
 }
 
 // trilinear + anisotropic fetch (HP_RASTER_TEX_ANISO; oracle.c tex_fetch_aniso, same operations in the same order)
-__device__ __forceinline__ void tex_fetch_aniso(const uint8_t* tex, int tw, int th, int nlev, float u, float v, float ux,
+__device__ __forceinline__ void tex_fetch_aniso(const RasterConv& cv, const uint8_t* tex, int tw, int th, int nlev, float u, float v, float ux,
                                                 float vx, float uy, float vy, float* rgb) {
   const float px = sqrtf(fmaf(ux * (float)tw, ux * (float)tw, vx * (float)th * (vx * (float)th)));
   const float py = sqrtf(fmaf(uy * (float)tw, uy * (float)tw, vy * (float)th * (vy * (float)th)));
   const bool along_x = px >= py;
   const float pmax = along_x ? px : py, pmin = along_x ? py : px;
-  float nf = pmin > 0.0f ? ceilf(pmax / pmin) : 16.0f;
-  if (!(nf >= 1.0f)) nf = 1.0f;
-  if (nf > 16.0f) nf = 16.0f;
+  float nf, lod;
+  aniso_footprint(cv, pmax, pmin, nlev, nf, lod);
   const int N = (int)nf;
-  float lod = pmax > 0.0f ? log2f(pmax / nf) : 0.0f;
-  if (!(lod > 0.0f)) lod = 0.0f;
-  if (lod > (float)(nlev - 1)) lod = (float)(nlev - 1);
   const int l0 = (int)lod;
   const float fl = lod - (float)l0;
   const float du = along_x ? ux : uy, dv = along_x ? vx : vy;
@@ -290,19 +306,15 @@ __device__ __forceinline__ void bi_finish_p2(float fx, float fy, const BiTexels&
   }
 }
 
-__device__ __forceinline__ void tex_fetch_aniso_p2(const uint8_t* tex, const MipTable& mt, int tw, int th, int nlev, float u, float v,
+__device__ __forceinline__ void tex_fetch_aniso_p2(const RasterConv& cv, const uint8_t* tex, const MipTable& mt, int tw, int th, int nlev, float u, float v,
                                                    float ux, float vx, float uy, float vy, float* rgb) {
   const float px = sqrtf(fmaf(ux * (float)tw, ux * (float)tw, vx * (float)th * (vx * (float)th)));
   const float py = sqrtf(fmaf(uy * (float)tw, uy * (float)tw, vy * (float)th * (vy * (float)th)));
   const bool along_x = px >= py;
   const float pmax = along_x ? px : py, pmin = along_x ? py : px;
-  float nf = pmin > 0.0f ? ceilf(pmax / pmin) : 16.0f;
-  if (!(nf >= 1.0f)) nf = 1.0f;
-  if (nf > 16.0f) nf = 16.0f;
+  float nf, lod;
+  aniso_footprint(cv, pmax, pmin, nlev, nf, lod);
   const int N = (int)nf;
-  float lod = pmax > 0.0f ? log2f(pmax / nf) : 0.0f;
-  if (!(lod > 0.0f)) lod = 0.0f;
-  if (lod > (float)(nlev - 1)) lod = (float)(nlev - 1);
   const int l0 = (int)lod;
   const float fl = lod - (float)l0;
   const float du = along_x ? ux : uy, dv = along_x ? vx : vy;
@@ -385,8 +397,8 @@ __device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const TriVerts& t,
     if (!(umax >= 0.0f) || !(umin <= (float)a.w) || !(vmax >= 0.0f) || !(vmin <= (float)a.h)) return false;
     float xa = ceilf(umin - 0.5f), xb = floorf(umax - 0.5f);
     float ya = ceilf(vmin - 0.5f), yb = floorf(vmax - 0.5f);
-    if (a.msaa) {  // some sample of pixel j inside [umin, umax]: offsets run from 0.125 to 0.875
-      xa = ceilf(umin - 0.875f); xb = floorf(umax - 0.125f); ya = ceilf(vmin - 0.875f); yb = floorf(vmax - 0.125f);
+    if (a.msaa) {  // some sample of pixel j inside [umin, umax]: offsets run from lo to hi (0.125 to 0.875 in the default pattern)
+      xa = ceilf(umin - a.cv.hi_x); xb = floorf(umax - a.cv.lo_x); ya = ceilf(vmin - a.cv.hi_y); yb = floorf(vmax - a.cv.lo_y);
     }
     x0 = xa < 0.0f ? 0 : (int)xa; x1 = xb > (float)(a.w - 1) ? a.w - 1 : (int)xb;
     y0 = ya < 0.0f ? 0 : (int)ya; y1 = yb > (float)(a.h - 1) ? a.h - 1 : (int)yb;
@@ -412,14 +424,14 @@ __device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const TriVer
 }
 
 template <int NS>
-__device__ __forceinline__ void shade_pixel(const TriSetup& s, int i, int j, uint32_t f,
+__device__ __forceinline__ void shade_pixel(const RasterConv& cv, const TriSetup& s, int i, int j, uint32_t f,
                                             unsigned long long* zb, int row0, int w) {
 #ifdef HP_RABL_COUNT
   int n_in = 0;
 #endif
 #pragma unroll
   for (int sm = 0; sm < NS; ++sm) {
-    const float pv = (float)i + sample_y(NS, sm), pu = (float)j + sample_x(NS, sm);
+    const float pv = (float)i + sample_y(cv, NS, sm), pu = (float)j + sample_x(cv, NS, sm);
     float l0 = fmaf(s.e0[0], pu, fmaf(s.e0[1], pv, s.e0[2]));
     float l1 = fmaf(s.e1[0], pu, fmaf(s.e1[1], pv, s.e1[2]));
     float l2 = fmaf(s.e2[0], pu, fmaf(s.e2[1], pv, s.e2[2]));
@@ -597,8 +609,8 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
       const float vx = fmaf(bx[0], t0.y, fmaf(bx[1], t1.y, bx[2] * t2.y));
       const float uy = fmaf(by[0], t0.x, fmaf(by[1], t1.x, by[2] * t2.x));
       const float vy = fmaf(by[0], t0.y, fmaf(by[1], t1.y, by[2] * t2.y));
-      if (cx.mips->p2) tex_fetch_aniso_p2(a.tex + toff, *cx.mips, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
-      else tex_fetch_aniso(a.tex + toff, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
+      if (cx.mips->p2) tex_fetch_aniso_p2(a.cv, a.tex + toff, *cx.mips, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
+      else tex_fetch_aniso(a.cv, a.tex + toff, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
     } else {
       tex_fetch(a.tex + toff, tw, th, tu, tv, alb);
     }
@@ -641,9 +653,11 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
 #pragma unroll
   for (int c = 0; c < 3; ++c) o_rgb[c] = quant8(alb[c] * lit[c], q8);
   if (cx.need_normal) {
-    o_n[0] = quant8(normal_code(nc[0]), q8);
-    o_n[1] = quant8(normal_code(-nc[1]), q8);
-    o_n[2] = quant8(normal_code(-nc[2]), q8);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {  // default: (nx, -ny, -nz), GL eye space seen from the OpenCV camera frame
+      const int ax = a.cv.n_axis[c];
+      o_n[c] = quant8(normal_code(a.cv.n_sign[c] * (ax == 0 ? nc[0] : ax == 1 ? nc[1] : nc[2])), q8);
+    }
   } else {
     o_n[0] = o_n[1] = o_n[2] = 0.f;
   }
@@ -865,7 +879,7 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
         if (q < kBigQueue) { big_q[q] = f; continue; }
       }
       for (int i = s.y0; i <= s.y1; ++i)
-        for (int j = s.x0; j <= s.x1; ++j) shade_pixel<NS>(s, i, j, (uint32_t)f, zb, row0, a.w);
+        for (int j = s.x0; j <= s.x1; ++j) shade_pixel<NS>(a.cv, s, i, j, (uint32_t)f, zb, row0, a.w);
     }
   } else {
     // Multisampling.  The bounding box is grown by the sample spread, so most of its pixels have no sample inside the
@@ -905,7 +919,10 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
         for (int e = 0; e < 3; ++e) {
           const float ax = fabsf(ee[e][0]), ay = fabsf(ee[e][1]);
           const float sl = 4e-6f * fmaf(ax, (float)(s.x1 + 1), fmaf(ay, (float)(s.y1 + 1), fabsf(ee[e][2])));
-          m[e] = fmaxf(fmaf(0.125f, ax, 0.375f * ay), fmaf(0.375f, ax, 0.125f * ay)) * 1.001f + sl;
+          // the largest |edge function difference| between a sample and the pixel centre (default pattern: offsets (0.125, 0.375), (0.375, 0.125))
+          const float m01 = fmaxf(fmaf(a.cv.dxa[0], ax, a.cv.dya[0] * ay), fmaf(a.cv.dxa[1], ax, a.cv.dya[1] * ay));
+          const float m23 = fmaxf(fmaf(a.cv.dxa[2], ax, a.cv.dya[2] * ay), fmaf(a.cv.dxa[3], ax, a.cv.dya[3] * ay));
+          m[e] = fmaxf(m01, m23) * 1.001f + sl;
         }
       }
 #ifdef HP_RABL_COUNT
@@ -956,7 +973,7 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
           t.z0 = __shfl(s.z0, owner); t.z1 = __shfl(s.z1, owner); t.z2 = __shfl(s.z2, owner);
           const int tf = __shfl(f, owner);
 #ifndef HP_RABL_NO_POP
-          if (lane < n) shade_pixel<NS>(t, row0 + er, ep - er * a.w, (uint32_t)tf, zb, row0, a.w);
+          if (lane < n) shade_pixel<NS>(a.cv, t, row0 + er, ep - er * a.w, (uint32_t)tf, zb, row0, a.w);
 #else
           if (lane < n && t.e0[0] == 12345.f && tf == 77) zb[0] = 0;
 #endif
@@ -975,7 +992,7 @@ __global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) voi
     const int bw = s.x1 - s.x0 + 1;
     const int area = bw * (s.y1 - s.y0 + 1);
     for (int p = tid; p < area; p += kThreads)
-      shade_pixel<NS>(s, s.y0 + p / bw, s.x0 + p % bw, (uint32_t)f, zb, row0, a.w);
+      shade_pixel<NS>(a.cv, s, s.y0 + p / bw, s.x0 + p % bw, (uint32_t)f, zb, row0, a.w);
   }
   if (!band_empty) __syncthreads();
 
@@ -1341,9 +1358,32 @@ extern "C" int hp_mesh_store_reserve_raster(hp_mesh_store* store, int n_views, i
 extern "C" int64_t hp_mesh_store_scratch_generation(const hp_mesh_store* store) { return store ? store->scratch_generation : -1; }
 
 namespace hp {
+static const hp_raster_conventions kDefaultConventions = {{0.375f, 0.875f, 0.125f, 0.625f}, {0.125f, 0.375f, 0.625f, 0.875f}, 16, 0, 0, 0.0f, 0.0f,
+                                                          {0, 1, 2}, {1.0f, -1.0f, -1.0f}};
+static hp_raster_conventions g_conventions = kDefaultConventions;  // process-wide, read at launch time
+static std::mutex g_conventions_mutex;
+
+static RasterConv derive_conventions() {
+  hp_raster_conventions c;
+  { std::lock_guard<std::mutex> lock(g_conventions_mutex); c = g_conventions; }
+  RasterConv r{};
+  r.lo_x = r.lo_y = 1.0f; r.hi_x = r.hi_y = 0.0f;
+  for (int k = 0; k < 4; ++k) {
+    r.sx[k] = c.msaa_x[k]; r.sy[k] = c.msaa_y[k];
+    r.lo_x = std::fmin(r.lo_x, c.msaa_x[k]); r.hi_x = std::fmax(r.hi_x, c.msaa_x[k]);
+    r.lo_y = std::fmin(r.lo_y, c.msaa_y[k]); r.hi_y = std::fmax(r.hi_y, c.msaa_y[k]);
+    r.dxa[k] = std::fabs(c.msaa_x[k] - 0.5f); r.dya[k] = std::fabs(c.msaa_y[k] - 0.5f);
+  }
+  r.sx[4] = r.sy[4] = 0.5f;
+  r.aniso_max = (float)c.aniso_max; r.lod_bias = c.lod_bias; r.ratio_bias = c.aniso_ratio_bias; r.aniso_round = c.aniso_round; r.lod_from = c.lod_from;
+  for (int k = 0; k < 3; ++k) { r.n_axis[k] = c.normal_axis[k]; r.n_sign[k] = c.normal_sign[k]; }
+  return r;
+}
+
 // Common launch path of hp_rasterize (strided planes) and hp_render_inputs (network-input records + fused crop).
 static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool crop, hipStream_t st) {
   const int h = a.h, w = a.w;
+  a.cv = derive_conventions();
   a.msaa = (a.flags & HP_RASTER_MSAA4) && (a.rec || a.rgb || a.nrm) ? 1 : 0;  // depth-only renders have nothing to multisample
   const int ns = a.msaa ? kSamplesMsaa : 1;
   static const int rows_env = std::getenv("HP_RASTER_ROWS") ? std::atoi(std::getenv("HP_RASTER_ROWS")) : 0;
@@ -1400,6 +1440,31 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
   return check_launch("raster_kernel");
 }
 }  // namespace hp
+
+extern "C" int hp_raster_set_conventions(const hp_raster_conventions* c) {
+  using namespace hp;
+  hp_raster_conventions v = c ? *c : kDefaultConventions;
+  for (int k = 0; k < 4; ++k)
+    HP_REQUIRE(v.msaa_x[k] > 0.0f && v.msaa_x[k] < 1.0f && v.msaa_y[k] > 0.0f && v.msaa_y[k] < 1.0f,
+               "hp_raster_set_conventions: sample positions must lie inside the pixel, in (0, 1)");
+  HP_REQUIRE(v.aniso_max >= 1 && v.aniso_max <= 16, "hp_raster_set_conventions: aniso_max must be in 1..16");
+  HP_REQUIRE(v.aniso_round >= 0 && v.aniso_round <= 2 && v.lod_from >= 0 && v.lod_from <= 2, "hp_raster_set_conventions: unknown rule");
+  HP_REQUIRE(std::isfinite(v.lod_bias) && std::isfinite(v.aniso_ratio_bias), "hp_raster_set_conventions: biases must be finite");
+  for (int k = 0; k < 3; ++k)
+    HP_REQUIRE(v.normal_axis[k] >= 0 && v.normal_axis[k] <= 2 && (v.normal_sign[k] == 1.0f || v.normal_sign[k] == -1.0f),
+               "hp_raster_set_conventions: normal_axis in 0..2, normal_sign +1 / -1");
+  std::lock_guard<std::mutex> lock(g_conventions_mutex);
+  g_conventions = v;
+  return HP_OK;
+}
+
+extern "C" int hp_raster_get_conventions(hp_raster_conventions* out) {
+  using namespace hp;
+  HP_REQUIRE(out != nullptr, "hp_raster_get_conventions: null argument");
+  std::lock_guard<std::mutex> lock(g_conventions_mutex);
+  *out = g_conventions;
+  return HP_OK;
+}
 
 extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
                             const int32_t* d_obj_ids, const float* d_TCO, const float* d_K,

@@ -336,3 +336,60 @@ class Detector:
         return add_instance_id(detections)
 
     __call__ = get_detections
+
+
+def maskrcnn_param_shapes(num_classes: int, n_anchors: int = 3) -> Dict[str, tuple]:
+    """state-dict key -> shape of ``DetectorMaskRCNN`` (``MP/models/mask_rcnn.py:22-42`` = torchvision 0.14.1
+    ``MaskRCNN`` on a ResNet-50 FPN backbone), in registration order: body (7x7 stem, bottlenecks 3-4-6-3 with the
+    downsample on the first block of a stage), FPN inner 1x1 / layer 3x3 blocks, RPN head, box head / predictor, mask head /
+    predictor.  What a checkpoint of the reference holds; used to make random-weight detectors for benchmarks."""
+    s: Dict[str, tuple] = {}
+
+    def bn(prefix, c):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{prefix}.{leaf}"] = (c,)
+        s[f"{prefix}.num_batches_tracked"] = ()
+
+    s["backbone.body.conv1.weight"] = (64, 3, 7, 7)
+    bn("backbone.body.bn1", 64)
+    c_in = 64
+    for stage, (width, blocks) in enumerate(((64, 3), (128, 4), (256, 6), (512, 3)), start=1):
+        for blk in range(blocks):
+            q = f"backbone.body.layer{stage}.{blk}"
+            for j, (co, ci, k) in enumerate(((width, c_in, 1), (width, width, 3), (4 * width, width, 1)), start=1):
+                s[f"{q}.conv{j}.weight"] = (co, ci, k, k)
+                bn(f"{q}.bn{j}", co)
+            if blk == 0:
+                s[f"{q}.downsample.0.weight"] = (4 * width, c_in, 1, 1)
+                bn(f"{q}.downsample.1", 4 * width)
+            c_in = 4 * width
+    for i, width in enumerate((64, 128, 256, 512)):
+        s[f"backbone.fpn.inner_blocks.{i}.0.weight"] = (256, 4 * width, 1, 1)
+        s[f"backbone.fpn.inner_blocks.{i}.0.bias"] = (256,)
+    for i in range(4):
+        s[f"backbone.fpn.layer_blocks.{i}.0.weight"] = (256, 256, 3, 3)
+        s[f"backbone.fpn.layer_blocks.{i}.0.bias"] = (256,)
+    for name, shape in (("rpn.head.conv.0.0", (256, 256, 3, 3)), ("rpn.head.cls_logits", (n_anchors, 256, 1, 1)),
+                        ("rpn.head.bbox_pred", (4 * n_anchors, 256, 1, 1)),
+                        ("roi_heads.box_head.fc6", (1024, 256 * 7 * 7)), ("roi_heads.box_head.fc7", (1024, 1024)),
+                        ("roi_heads.box_predictor.cls_score", (num_classes, 1024)),
+                        ("roi_heads.box_predictor.bbox_pred", (4 * num_classes, 1024)),
+                        *[(f"roi_heads.mask_head.{i}.0", (256, 256, 3, 3)) for i in range(4)],
+                        ("roi_heads.mask_predictor.conv5_mask", (256, 256, 2, 2)),
+                        ("roi_heads.mask_predictor.mask_fcn_logits", (num_classes, 256, 1, 1))):
+        s[name + ".weight"] = shape
+        s[name + ".bias"] = (shape[0],)
+    return s
+
+
+def synthetic_maskrcnn(device, n_classes: int, seed: int = 3, input_size=(480, 640)) -> MaskRCNN:
+    """A ``MaskRCNN`` on name-keyed random weights (there are no checkpoints offline): the backbone + FPN + RPN time does
+    not depend on the weights, the head time does through the number of proposals that survive, so the box / objectness
+    layers are scaled to keep a realistic few hundred proposals alive.  Benchmarks only."""
+    from .synthetic import named_weights
+
+    w = named_weights(maskrcnn_param_shapes(n_classes), seed=seed)
+    for k, f in (("rpn.head.bbox_pred.weight", 0.02), ("rpn.head.bbox_pred.bias", 0.5), ("roi_heads.box_predictor.bbox_pred.weight", 0.05),
+                 ("roi_heads.box_predictor.cls_score.weight", 0.3), ("rpn.head.cls_logits.weight", 2.0)):
+        w[k] = (w[k] * f).astype(np.float32)
+    return MaskRCNN(w, n_classes, input_size=input_size, max_batch=1, device=device)

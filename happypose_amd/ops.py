@@ -134,6 +134,43 @@ def nchw_strides(c: int, h: int, w: int) -> Strides:
     return Strides(c * h * w, 0, h * w, w, 1)
 
 
+class RasterConventions(C.Structure):
+    """``hp_raster_conventions`` (include/happypose_amd.h)."""
+    _fields_ = [("msaa_x", C.c_float * 4), ("msaa_y", C.c_float * 4), ("aniso_max", C.c_int), ("aniso_round", C.c_int),
+                ("lod_from", C.c_int), ("lod_bias", C.c_float), ("aniso_ratio_bias", C.c_float), ("normal_axis", C.c_int * 3), ("normal_sign", C.c_float * 3)]
+
+
+RASTER_CONVENTION_DEFAULTS = dict(msaa_x=(0.375, 0.875, 0.125, 0.625), msaa_y=(0.125, 0.375, 0.625, 0.875), aniso_max=16,
+                                  aniso_round=0, lod_from=0, lod_bias=0.0, aniso_ratio_bias=0.0, normal_axis=(0, 1, 2), normal_sign=(1.0, -1.0, -1.0))
+
+
+def set_raster_conventions(conv: Optional[Dict] = None) -> None:
+    """``hp_raster_set_conventions``: the three renderer conventions nobody can pin without Panda3D -- multisample positions,
+    the anisotropic filter's probe-count / level-of-detail rule, the axis / sign map of the eye-normal code
+    (``TB/renderer/panda3d_scene_renderer.py:68-71,221-230``, ``TB/renderer/utils.py:63-79``).  ``conv``: ``None`` = defaults,
+    or a dict overriding any of :data:`RASTER_CONVENTION_DEFAULTS`.  Process-wide, read at launch time; captured graphs are
+    dropped (``bump_graph_epoch``).  ``tools/calibrate_renderer.py`` fits the record to Panda3D renders."""
+    if conv is None:
+        check(lib().hp_raster_set_conventions(None), "hp_raster_set_conventions")
+    else:
+        d = dict(RASTER_CONVENTION_DEFAULTS)
+        unknown = set(conv) - set(d)
+        if unknown:
+            raise KeyError(f"unknown raster convention(s): {sorted(unknown)}")
+        d.update(conv)
+        c = RasterConventions((C.c_float * 4)(*d["msaa_x"]), (C.c_float * 4)(*d["msaa_y"]), int(d["aniso_max"]), int(d["aniso_round"]),
+                              int(d["lod_from"]), float(d["lod_bias"]), float(d["aniso_ratio_bias"]), (C.c_int * 3)(*d["normal_axis"]), (C.c_float * 3)(*d["normal_sign"]))
+        check(lib().hp_raster_set_conventions(C.byref(c)), "hp_raster_set_conventions")
+    bump_graph_epoch()
+
+
+def get_raster_conventions() -> Dict:
+    c = RasterConventions()
+    check(lib().hp_raster_get_conventions(C.byref(c)), "hp_raster_get_conventions")
+    return dict(msaa_x=tuple(c.msaa_x), msaa_y=tuple(c.msaa_y), aniso_max=c.aniso_max, aniso_round=c.aniso_round, lod_from=c.lod_from,
+                lod_bias=c.lod_bias, aniso_ratio_bias=c.aniso_ratio_bias, normal_axis=tuple(c.normal_axis), normal_sign=tuple(c.normal_sign))
+
+
 def rasterize(store: MeshStore, obj_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor,
               resolution: Tuple[int, int], render_normals=False, render_depth=False,
               render_binary_mask=False, ambient: Optional[torch.Tensor] = None,

@@ -251,23 +251,22 @@ class _EstimatorBase:
         t_start = time.time()
         B = len(data_TCO_input)
         s, e, sharded = self._shard(B)
-        # bookkeeping columns of the reference (``MP/inference/pose_estimator.py:196-197``), by GLOBAL row so that they
-        # do not depend on the number of ranks
-        df_all = data_TCO_input.infos.copy()
-        df_all[f"{tag}_batch_idx"] = np.arange(B) // bsz
-        df_all[f"{tag}_instance_idx"] = np.arange(B) % bsz
         cols: Dict[str, List[List[torch.Tensor]]] = {f"iteration={n}": [[] for _ in self._ITER_COLS]
                                                      for n in range(1, n_iterations + 1)}
         all_outputs = []
         model_time = 0.0
+        infos = data_TCO_input.infos
+        labels_all = infos["label"].tolist()
+        im_all_host = np.ascontiguousarray(infos["batch_im_id"].values)
+        poses_all = data_TCO_input.poses
         for a in range(s, e, bsz):
-            ids = np.arange(a, min(e, a + bsz))
-            chunk = data_TCO_input[ids]
-            df_ = chunk.infos
-            im_ids = torch.as_tensor(df_["batch_im_id"].values, device=self.device)
+            b = min(e, a + bsz)
+            # slices of the table's columns: the launches of a chunk are on their way before any pandas work happens
+            # (the frames below are built while the GPU runs; `data_TCO_input[ids]` cost a gather + a frame per chunk)
+            im_ids = torch.as_tensor(im_all_host[a:b], device=self.device)
             t0 = time.time()
-            outputs_ = model(images=observation.images, K=observation.K, TCO=chunk.poses,
-                             n_iterations=n_iterations, labels=df_["label"].tolist(), im_ids=im_ids, **kw)
+            outputs_ = model(images=observation.images, K=observation.K, TCO=poses_all[a:b],
+                             n_iterations=n_iterations, labels=labels_all[a:b], im_ids=im_ids, **kw)
             model_time += time.time() - t0
             if keep_all_outputs:
                 all_outputs.append(outputs_)
@@ -275,9 +274,15 @@ class _EstimatorBase:
                 o = outputs_[f"iteration={n}"]
                 for dst, t in zip(cols[f"iteration={n}"], (o.TCO_output, o.TCO_input, o.K_crop, o.boxes_rend, o.boxes_crop)):
                     dst.append(t)
+        # bookkeeping columns of the reference (``MP/inference/pose_estimator.py:196-197``), by GLOBAL row so that they
+        # do not depend on the number of ranks
+        df_all = infos.copy()
+        df_all[f"{tag}_batch_idx"] = np.arange(B) // bsz
+        df_all[f"{tag}_instance_idx"] = np.arange(B) % bsz
         n_local = e - s
         f = dict(dtype=torch.float32, device=self.device)
-        table = {k: [torch.cat(parts) if parts else torch.zeros((0,) + shape, **f) for parts, (_, _, shape) in zip(v, self._ITER_COLS)]
+        table = {k: [(parts[0] if len(parts) == 1 else torch.cat(parts)) if parts else torch.zeros((0,) + shape, **f)
+                     for parts, (_, _, shape) in zip(v, self._ITER_COLS)]
                  for k, v in cols.items()}
         if sharded:
             # explicit widths: an EMPTY shard (more ranks than rows) must still pack to [0, 49 * n_iterations]

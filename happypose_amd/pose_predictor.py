@@ -312,7 +312,12 @@ class PosePredictor(_RenderAndCompare):
     def _refine_device(self, images, K, im_ids, obj_ids, TCO_input, *, n_iterations: int):
         """The device program of ``forward``: only launches on tensors (capturable as a hipGraph).  One record per
         iteration."""
-        recs = []
+        return list(self._refine_iter(images, K, im_ids, obj_ids, TCO_input, n_iterations=n_iterations))
+
+    def _refine_iter(self, images, K, im_ids, obj_ids, TCO_input, *, n_iterations: int):
+        """``_refine_device`` as a generator: yields an iteration's record once its launches are enqueued, so that
+        ``TwoLanePredictor`` can enqueue its lanes' chains alternately (a lane whose whole chain is enqueued only after
+        the other's starts milliseconds late whenever the caller synchronises between calls, as the estimators do)."""
         for _ in range(n_iterations):
             prep, x, pose, logits, render_time = self._one_pass(
                 images, K, im_ids, obj_ids, TCO_input, n_img_channels=self._n_img,
@@ -327,12 +332,11 @@ class PosePredictor(_RenderAndCompare):
             else:
                 TCO_output = TCO_norm.clone()
             images_crop, renders = self._pixels(x, self._n_img, self._n_single_render_channels * self.n_rendered_views)
-            recs.append(dict(TCO_input=TCO_norm, TCO_output=TCO_output, TCV_O=prep["TCV_O"], tCR=prep["tCR"],
-                             KV_crop=prep["K_crop"], K_crop=prep["K_crop_main"] if self._skip_tco else None,
-                             boxes_rend=prep["boxes_rend"], boxes_crop=prep["boxes_crop"],
-                             pose=pose, logits=logits, images_crop=images_crop, renders=renders, render_time=render_time))
+            yield dict(TCO_input=TCO_norm, TCO_output=TCO_output, TCV_O=prep["TCV_O"], tCR=prep["tCR"],
+                       KV_crop=prep["K_crop"], K_crop=prep["K_crop_main"] if self._skip_tco else None,
+                       boxes_rend=prep["boxes_rend"], boxes_crop=prep["boxes_crop"],
+                       pose=pose, logits=logits, images_crop=images_crop, renders=renders, render_time=render_time)
             TCO_input = TCO_output
-        return recs
 
     def _build_outputs(self, recs, labels, K, per_hyp, im_ids) -> Dict[str, PosePredictorOutput]:
         outputs: Dict[str, PosePredictorOutput] = {}
@@ -412,18 +416,19 @@ class CosyPosePosePredictor(_RenderAndCompare):
 
     def _refine_device(self, images, K, im_ids, obj_ids, TCO_input, *, n_iterations: int):
         """The device program of ``forward`` (see ``PosePredictor._refine_device``)."""
-        recs = []
+        return list(self._refine_iter(images, K, im_ids, obj_ids, TCO_input, n_iterations=n_iterations))
+
+    def _refine_iter(self, images, K, im_ids, obj_ids, TCO_input, *, n_iterations: int):
         for _ in range(n_iterations):
             prep, x, pose, _, render_time = self._one_pass(
                 images, K, im_ids, obj_ids, TCO_input, n_img_channels=3, multiview_type="TCO", normalize=False,
                 render_normals=False, render_depth=False, depth_mode=0, want_pose=True, want_logits=False)
             TCO_output = ops.pose_update(TCO_input, prep["K_crop"], pose, None)
             images_crop, renders = self._pixels(x, 3, 3)
-            recs.append(dict(TCO_input=TCO_input, TCO_output=TCO_output, TCV_O=prep["TCV_O"], tCR=prep["tCR"],
-                             KV_crop=prep["K_crop"], boxes_rend=prep["boxes_rend"], boxes_crop=prep["boxes_crop"],
-                             pose=pose, images_crop=images_crop, renders=renders, render_time=render_time))
+            yield dict(TCO_input=TCO_input, TCO_output=TCO_output, TCV_O=prep["TCV_O"], tCR=prep["tCR"],
+                       KV_crop=prep["K_crop"], boxes_rend=prep["boxes_rend"], boxes_crop=prep["boxes_crop"],
+                       pose=pose, images_crop=images_crop, renders=renders, render_time=render_time)
             TCO_input = TCO_output
-        return recs
 
     def _build_outputs(self, recs, labels, K, per_hyp, im_ids) -> Dict[str, PosePredictorOutput]:
         outputs: Dict[str, PosePredictorOutput] = {}
@@ -646,6 +651,9 @@ class TwoLanePredictor:
         # add its reduction (C2: 24.5 ms with, 22.5 ms without)
         self.backbone.set_tail_split(False)  # per network: other predictors are not affected
         try:
+            eager = not self.use_graphs or any(l.keep_pixels or l.debug or l._profiling() or getattr(l, "_no_graphs", False)
+                                               for l in self.lanes)
+            plan = []
             for lane, stream, sl in zip(self.lanes, self.streams, cuts):
                 lane.use_graphs = self.use_graphs
                 stream.wait_stream(cur)
@@ -653,8 +661,19 @@ class TwoLanePredictor:
                     n_l = sl.stop - sl.start
                     ids_l = torch.arange(n_l, dtype=torch.int32, device=self.device) if per_hyp else im_ids[sl]
                     img_l, K_l = (images[sl], K[sl]) if per_hyp else (images, K)
+                    if eager:  # enqueue the chains ALTERNATELY, one iteration at a time (see _refine_iter)
+                        plan.append((lane, stream, sl, img_l, K_l, ids_l,
+                                     lane._refine_iter(img_l, K_l, ids_l, obj_ids[sl], TCO_input[sl], n_iterations=n_iterations), []))
+                        continue
                     recs = lane._run_refine((n_iterations,), [img_l, K_l, ids_l, obj_ids[sl], TCO_input[sl]],
                                             lambda *t, lane=lane: lane._refine_device(*t, n_iterations=n_iterations))
+                    parts.append(lane._build_outputs(recs, labels[sl], K_l, per_hyp, None if per_hyp else ids_l))
+            for _ in range(n_iterations if eager else 0):
+                for lane, stream, sl, img_l, K_l, ids_l, gen, recs in plan:
+                    with torch.cuda.stream(stream):
+                        recs.append(next(gen))
+            for lane, stream, sl, img_l, K_l, ids_l, gen, recs in plan:
+                with torch.cuda.stream(stream):
                     parts.append(lane._build_outputs(recs, labels[sl], K_l, per_hyp, None if per_hyp else ids_l))
         finally:
             self.backbone.set_tail_split(True)

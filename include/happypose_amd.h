@@ -113,6 +113,32 @@ typedef struct {
   int64_t s_item, s_view, s_chan, s_row, s_col;
 } hp_strides;
 
+/* The three conventions of the reference's renderer that OpenGL / Panda3D leave to the implementation and that cannot be
+ * pinned without Panda3D: where the four multisample positions sit, how the anisotropic filter
+ * derives its probe count and level of detail from the pixel footprint, and which eye-space axis (and sign) each
+ * channel of the normal-code render shows (TB/renderer/panda3d_scene_renderer.py:68-71,221-230, TB/renderer/utils.py:63-79).
+ * They are a RECORD, not compile-time constants, so that an owner of a Panda3D installation can fit them:
+ * tools/calibrate_renderer.py scores candidate records against Panda3D renders of the reference's own test scene
+ * (tests/test_batch_renderer_panda3d.py:43-69); oracle/csrc/oracle.c mirrors the record (hp_oracle_set_raster_conventions).
+ * hp_raster_set_conventions(NULL) restores the defaults below; the record is process-wide and read at launch time (launches
+ * already enqueued keep the values they were launched with; captured hipGraphs must be re-captured after a change). */
+typedef struct {
+  float msaa_x[4], msaa_y[4];  /* sample positions inside the pixel, each in (0, 1).  Default: the standard 4x pattern
+                                  (0.375, 0.125) (0.875, 0.375) (0.125, 0.625) (0.625, 0.875) */
+  int aniso_max;               /* cap of the probe count, 1..16 ("texture-anisotropic-degree").  Default 16 */
+  int aniso_round;             /* probes from the footprint ratio r = Pmax / Pmin: 0 ceil(r) (default, the extension's sketch),
+                                  1 nearest integer (ties to even), 2 floor(r) */
+  int lod_from;                /* level of detail = log2 of: 0 Pmax / N (default), 1 Pmin, 2 Pmax (no anisotropic compensation) */
+  float lod_bias;              /* added to the level of detail before clamping.  Default 0 */
+  float aniso_ratio_bias;      /* added to r before it is rounded to the probe count.  Default 0 */
+  int normal_axis[3];          /* channel c of the normal-code render shows component normal_axis[c] of the unit normal in the
+                                  CAMERA frame of this library (OpenCV: x right, y down, z forward) ... */
+  float normal_sign[3];        /* ... times normal_sign[c] (+1 / -1).  Default axes {0, 1, 2}, signs {+1, -1, -1}: GL eye space
+                                  (x right, y up, z backward) as R, G, B */
+} hp_raster_conventions;
+int hp_raster_set_conventions(const hp_raster_conventions* conventions /* NULL = defaults */);
+int hp_raster_get_conventions(hp_raster_conventions* out);
+
 int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
                  const int32_t* d_obj_ids /* [n / views_per_item] */,
                  const float* d_TCO /* [n][16] */, const float* d_K /* [n][9] */,

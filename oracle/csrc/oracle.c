@@ -115,6 +115,22 @@ void hp_oracle_roi_align(const float* images, int Bi, int C, int H, int W,
                        * positions are implementation-defined in OpenGL and Panda3D is absent here.  Depth and mask are
                        * left at the pixel centre (a fifth, non-averaged sample): every consumer back-projects pixel centres. */
 
+/* The renderer conventions that cannot be pinned without Panda3D (include/happypose_amd.h: hp_raster_conventions -- the same
+ * record, mirrored here so that kernel == oracle holds for EVERY candidate a calibration tries): multisample positions, the
+ * anisotropic filter's probe-count / level-of-detail rule, and the axis / sign map of the eye-normal code.  Process-wide. */
+typedef struct {
+  float msaa_x[4], msaa_y[4];
+  int aniso_max, aniso_round, lod_from;
+  float lod_bias, aniso_ratio_bias;
+  int normal_axis[3];
+  float normal_sign[3];
+} hp_oracle_raster_conventions;
+static const hp_oracle_raster_conventions HP_ORACLE_CONV_DEFAULT = {{0.375f, 0.875f, 0.125f, 0.625f}, {0.125f, 0.375f, 0.625f, 0.875f},
+                                                                     16, 0, 0, 0.0f, 0.0f, {0, 1, 2}, {1.0f, -1.0f, -1.0f}};
+static hp_oracle_raster_conventions g_conv = {{0.375f, 0.875f, 0.125f, 0.625f}, {0.125f, 0.375f, 0.625f, 0.875f},
+                                              16, 0, 0, 0.0f, 0.0f, {0, 1, 2}, {1.0f, -1.0f, -1.0f}};
+void hp_oracle_set_raster_conventions(const hp_oracle_raster_conventions* c) { g_conv = c ? *c : HP_ORACLE_CONV_DEFAULT; }
+
 typedef struct {
   const float* verts;    /* [Vtot][3] metres, object frame */
   const float* normals;  /* [Vtot][3] unit, object frame */
@@ -197,11 +213,13 @@ static inline void tex_fetch_aniso(const uint8_t* tex, int tw, int th, int nlev,
   const float py = sqrtf(fmaf(uy * (float)tw, uy * (float)tw, vy * (float)th * (vy * (float)th)));
   const int along_x = px >= py;
   const float pmax = along_x ? px : py, pmin = along_x ? py : px;
-  float nf = pmin > 0.0f ? ceilf(pmax / pmin) : 16.0f;
+  const float ratio = pmax / pmin + g_conv.aniso_ratio_bias, amax = (float)g_conv.aniso_max;
+  float nf = pmin > 0.0f ? (g_conv.aniso_round == 0 ? ceilf(ratio) : g_conv.aniso_round == 1 ? rintf(ratio) : floorf(ratio)) : amax;
   if (!(nf >= 1.0f)) nf = 1.0f;   /* NaN / zero footprints */
-  if (nf > 16.0f) nf = 16.0f;
+  if (nf > amax) nf = amax;
   const int N = (int)nf;
-  float lod = pmax > 0.0f ? log2f(pmax / nf) : 0.0f;
+  const float la = g_conv.lod_from == 0 ? pmax / nf : g_conv.lod_from == 1 ? pmin : pmax;
+  float lod = la > 0.0f ? log2f(la) + g_conv.lod_bias : 0.0f;
   if (!(lod > 0.0f)) lod = 0.0f;  /* magnification: level 0 */
   if (lod > (float)(nlev - 1)) lod = (float)(nlev - 1);
   const int l0 = (int)lod;
@@ -303,9 +321,7 @@ static void shade_centre(const hp_oracle_meshes* M, const float* sv3, const floa
   }
   for (int c = 0; c < 3; ++c) o_rgb[c] = quant8(alb[c] * lit[c], q8);
   /* eye-normal colour code; Panda/GL eye space is (x right, y up, z backward) */
-  o_n[0] = quant8(normal_code(nc[0]), q8);
-  o_n[1] = quant8(normal_code(-nc[1]), q8);
-  o_n[2] = quant8(normal_code(-nc[2]), q8);
+  for (int c = 0; c < 3; ++c) o_n[c] = quant8(normal_code(g_conv.normal_sign[c] * nc[g_conv.normal_axis[c]]), q8);
 }
 
 void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_ids,
@@ -320,7 +336,12 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
   {
     const int msaa = (flags & HP_R_MSAA4) && (rgb || nrm);
     const int ns = msaa ? 5 : 1;                 /* keys per pixel: 4 colour samples + the centre, or the centre alone */
-    static const float SX[5] = {0.375f, 0.875f, 0.125f, 0.625f, 0.5f}, SY[5] = {0.125f, 0.375f, 0.625f, 0.875f, 0.5f};
+    float SX[5], SY[5], lo_x = 1.0f, hi_x = 0.0f, lo_y = 1.0f, hi_y = 0.0f;  /* the four colour samples + the centre */
+    for (int k = 0; k < 4; ++k) {
+      SX[k] = g_conv.msaa_x[k]; SY[k] = g_conv.msaa_y[k];
+      lo_x = fminf(lo_x, SX[k]); hi_x = fmaxf(hi_x, SX[k]); lo_y = fminf(lo_y, SY[k]); hi_y = fmaxf(hi_y, SY[k]);
+    }
+    SX[4] = SY[4] = 0.5f;
     uint64_t* zbuf = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)h * w * ns);
     float* sv3 = NULL; size_t sv_cap = 0;
 #pragma omp for schedule(dynamic, 1)
@@ -372,8 +393,8 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
             /* pixel centre j+0.5 in [umin, umax]  <=>  j in [ceil(umin-0.5), floor(umax-0.5)] */
             float a = ceilf(umin - 0.5f), b = floorf(umax - 0.5f);
             float c = ceilf(vmin - 0.5f), d = floorf(vmax - 0.5f);
-            if (msaa) { /* some sample of pixel j inside [umin, umax]: the offsets run from 0.125 to 0.875 */
-              a = ceilf(umin - 0.875f); b = floorf(umax - 0.125f); c = ceilf(vmin - 0.875f); d = floorf(vmax - 0.125f);
+            if (msaa) { /* some sample of pixel j inside [umin, umax]: the offsets run from lo to hi (default 0.125 to 0.875) */
+              a = ceilf(umin - hi_x); b = floorf(umax - lo_x); c = ceilf(vmin - hi_y); d = floorf(vmax - lo_y);
             }
             x0 = a < 0.0f ? 0 : (int)a; x1 = b > (float)(w - 1) ? w - 1 : (int)b;
             y0 = c < 0.0f ? 0 : (int)c; y1 = d > (float)(h - 1) ? h - 1 : (int)d;

@@ -48,6 +48,26 @@ def lib():
     return _lib
 
 
+class RasterConventions(C.Structure):
+    """``hp_oracle_raster_conventions`` (oracle.c) -- field for field ``hp_raster_conventions`` of the product header."""
+    _fields_ = [("msaa_x", C.c_float * 4), ("msaa_y", C.c_float * 4), ("aniso_max", C.c_int), ("aniso_round", C.c_int),
+                ("lod_from", C.c_int), ("lod_bias", C.c_float), ("aniso_ratio_bias", C.c_float), ("normal_axis", C.c_int * 3), ("normal_sign", C.c_float * 3)]
+
+
+def set_raster_conventions(conv=None) -> None:
+    """``conv``: ``None`` (defaults) or a dict with any of msaa_x, msaa_y, aniso_max, aniso_round, lod_from, lod_bias,
+    normal_axis, normal_sign (missing keys = defaults) -- the same dict ``happypose_amd.ops.set_raster_conventions`` takes."""
+    if conv is None:
+        lib().hp_oracle_set_raster_conventions(None)
+        return
+    d = dict(msaa_x=(0.375, 0.875, 0.125, 0.625), msaa_y=(0.125, 0.375, 0.625, 0.875), aniso_max=16, aniso_round=0, lod_from=0,
+             lod_bias=0.0, aniso_ratio_bias=0.0, normal_axis=(0, 1, 2), normal_sign=(1.0, -1.0, -1.0))
+    d.update(conv)
+    c = RasterConventions((C.c_float * 4)(*d["msaa_x"]), (C.c_float * 4)(*d["msaa_y"]), int(d["aniso_max"]), int(d["aniso_round"]),
+                          int(d["lod_from"]), float(d["lod_bias"]), float(d["aniso_ratio_bias"]), (C.c_int * 3)(*d["normal_axis"]), (C.c_float * 3)(*d["normal_sign"]))
+    lib().hp_oracle_set_raster_conventions(C.byref(c))
+
+
 def set_threads(n: int) -> None:
     """Thread count of the C oracle's OpenMP loops."""
     lib().hp_oracle_set_threads(int(n))
