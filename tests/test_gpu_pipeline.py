@@ -443,6 +443,50 @@ def test_c2_full_size_two_lanes_vs_oracle(dev):
     assert _pose_err(out["iteration=5"].TCO_output.cpu().numpy(), scene["TCO_hyp"])[1] > 10 * R_TOL
 
 
+BATCH_DT, BATCH_DR = 5e-6, 2e-5  # the same hypothesis in different batches (stated in INTEGRATION.md, "Batch dependence")
+
+
+@pytest.mark.parametrize("gain", [0.002, 0.05])
+def test_same_hypothesis_in_different_batches(dev, gain):
+    """A hypothesis' refined pose depends -- at round-off level -- on its batch-mates: the conv planner picks tiles and
+    K-slices by batch size (a different fp32 summation order) and the split-fp16 kernels scale a layer's activations by ONE
+    power of two per launch, taken from max|y| over the whole batch (DESIGN.md 4.1 "Activation scale").  Both are legitimate
+    (the reference's cuDNN picks algorithms by batch size too) but must be BOUNDED: hypothesis 37 of C2 refined alone
+    (batch 1, one lane), with 7 batch-mates and in the full 128-hypothesis two-lane batch, 5 iterations, low and high head
+    gain -- final poses within BATCH_DT / BATCH_DR of one another (measured: a few 1e-7 m / 1e-6 rad), a quarter of T_TOL /
+    R_TOL, the bound on HIP vs oracle.  Bitwise equality holds between two runs of the SAME batch (test_graph_replay_*,
+    test_two_lane_megapose_is_reproducible)."""
+    bench = _bench()
+    ds, renderer, scene, weights, model = bench.build_world(dev, "resnet34", seed=0, workload="C2", n_lanes=2, update_scale=gain)
+    store = renderer.store
+    images, K = torch.as_tensor(scene["images"], device=dev), torch.as_tensor(scene["K"], device=dev)
+    TCO = torch.as_tensor(scene["TCO_hyp"], device=dev)
+    labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
+    h = 37
+
+    def refine(rows):
+        rows = list(rows)
+        out = model.forward(images, K, [labels[r] for r in rows], TCO[rows], n_iterations=5,
+                            im_ids=torch.zeros(len(rows), dtype=torch.int32, device=dev))
+        assert model.numerics_status() == 0
+        return [out[f"iteration={n}"].TCO_output[rows.index(h)].cpu().numpy()[None] for n in range(1, 6)]
+
+    alone = refine([h])
+    eight = refine(range(32, 40))
+    full = refine(range(128))
+    again = refine(range(128))
+    worst = [0.0, 0.0]
+    for n in range(5):
+        assert np.array_equal(full[n], again[n])                      # same batch: bitwise
+        for a, b in ((alone, eight), (alone, full), (eight, full)):
+            dt, dr = _pose_err(a[n], b[n])
+            worst = [max(worst[0], dt), max(worst[1], dr)]
+            assert dt <= BATCH_DT * (25 if gain > 0.01 else 1) and dr <= BATCH_DR * (25 if gain > 0.01 else 1), (gain, n, dt, dr)
+    print(f"batch dependence at gain {gain}: worst dt {worst[0]:.2e} m, dR {worst[1]:.2e} rad")
+    # the refinement itself moved the pose by orders of magnitude more
+    assert _pose_err(full[4], scene["TCO_hyp"][h][None])[1] > 50 * BATCH_DR
+
+
 def test_c3_full_size_vs_oracle(dev):
     """C3 as benchmarked: MegaPose RGB-D refiner, 64 hypotheses x 4 views x (rgb + normals + depth), ResNet-34 on 32
     channels, two lanes; all 5 iterations against the oracle (the 7x7 / 32-channel stem, 256 renders per iteration)."""
