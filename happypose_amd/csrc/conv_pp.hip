@@ -26,6 +26,7 @@
 //               fp16 out; weights in the plan's packed layout [Cout][(tap, c)].
 // Replaces the same reference ops as conv.hip: ATen conv2d + BatchNorm + ReLU (+ identity) of
 // MP/models/torchvision_resnet.py:110-126 and MP/models/wide_resnet.py:59-65.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -69,59 +70,164 @@ struct PP {
   static int npc(int W) { return (P(W) + PROWS - 1) / PROWS; }
   static constexpr int kPreFloats = 2 * 512;  // pre-activation BN scale / shift of up to 512 input channels, staged once
   static size_t lds_bytes(int W) {
-    const size_t loop = ((size_t)2 * P(W) * LDH + 2 * (size_t)BN * LDH + LDH) * 2 + kPreFloats * 4;
-    const size_t epi = (size_t)BM * (BN + 4) * 4;
-    return loop < epi ? epi : loop;
+    return ((size_t)2 * P(W) * LDH + 2 * (size_t)BN * LDH + LDH) * 2 + kPreFloats * 4;  // the epilogue needs none (direct stores)
   }
 };
 
-// fp16 epilogue: accumulators -> LDS [row][BN + 4] floats -> bias (fp32), residual (fp16), ReLU -> 8 halves per store
-__device__ __forceinline__ void pp_epilogue_f16(const ConvArgs& a, float* cl, pp_floatx16 (&acc)[MT][NT], int64_t m0, int n0,
-                                                int wm, int wn) {
-  constexpr int LDC = BN + 4;
-  const int tid = threadIdx.x, lane = tid & 63;
-  __syncthreads();
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        cl[row * LDC + wn + nt * 32 + (lane & 31)] = acc[mt][nt][r];
-      }
-  __syncthreads();
-  constexpr int C8 = BN / 8;
-  constexpr int ITERS = BM * C8 / kPPThreads;
-  const int c8 = tid % C8;
-  const int n = n0 + 8 * c8;
-  const _Float16* const res = reinterpret_cast<const _Float16*>(a.residual);
-  _Float16* const y = reinterpret_cast<_Float16*>(a.y);
-  pp_floatx4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-  if (a.bias) {
-    b0 = *reinterpret_cast<const pp_floatx4*>(a.bias + n);
-    b1 = *reinterpret_cast<const pp_floatx4*>(a.bias + n + 4);
+// Direct epilogue (round 4).  The MFMAs run TRANSPOSED -- weights as the A operand, pixels as B -- so a lane holds ONE pixel
+// (column l & 31) and 16 output channels per 32 x 32 tile; the weight rows are read in the order sigma(i) = 16 ((i >> 2) & 1) +
+// 4 (i >> 3) + (i & 3), which makes those 16 channels CONSECUTIVE: acc[mt][nt][r] = (pixel m0 + wm + 32 mt + (l & 31), channel
+// n0 + wn + 32 nt + 16 (l >> 5) + r).  Bias, unscale, residual, activation and the NHWC store are 16-B accesses straight from
+// the accumulator registers: no LDS transpose, no workgroup barrier -- each wave leaves on its own, its stores drain while
+// the next tile's prologue runs (the old epilogue: 64 ds_write_b32 + 16 ds_read_b128 per lane between two barriers, ~18 k
+// cycles per 256 x 128 tile, a quarter of a 36-tap tile).  The residual pieces of the whole wave tile are fetched first, into
+// the registers the operand fragments just vacated.
+// 4 x 4 transpose inside a lane quad: lane j's (r0, r1, r2, r3) become element j of lanes 0 .. 3 (two DPP butterfly stages)
+__device__ __forceinline__ void quad_transpose4(int qj, float& r0, float& r1, float& r2, float& r3) {
+  {  // lanes differing in bit 0 exchange across the register pairs (0, 1) and (2, 3)
+    const bool b = qj & 1;
+    const float s01 = b ? r0 : r1, s23 = b ? r2 : r3;
+    const float g01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+    const float g23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+    if (b) { r0 = g01; r2 = g23; } else { r1 = g01; r3 = g23; }
   }
+  {  // lanes differing in bit 1: pairs (0, 2) and (1, 3)
+    const bool b = qj & 2;
+    const float s02 = b ? r0 : r2, s13 = b ? r1 : r3;
+    const float g02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+    const float g13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+    if (b) { r0 = g02; r1 = g13; } else { r2 = g02; r3 = g13; }
+  }
+}
+
+// `between()` runs once, after the first of the wave's two M tiles has been stored (its 32 accumulator registers are dead by
+// then): the persistent loop issues the NEXT item's first loads there, so that they land under the rest of this epilogue.
+template <int MODE, typename Hook>
+__device__ __forceinline__ void pp_epilogue_direct(const ConvArgs& a, pp_floatx16 (&acc)[MT][NT], int64_t m0, int n0, int wm, int wn,
+                                                   float act_inv, int lane, Hook&& between) {
+  const int px = lane & 31, h16 = 16 * (lane >> 5);
+  float chk = 0.f, amax = 0.f;
+  const float* const unscale = MODE == MODE_SPLIT
+      ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(a.w) + (size_t)a.Cout * 18 * a.Cin) : nullptr;
+  if constexpr (MODE == MODE_SPLIT) {
+    // A lane holds 64 contiguous bytes of ONE pixel per 32 x 32 tile; stored as they lie, the 32 lanes of a half-wave would
+    // touch 32 different 512-B rows per instruction (measured: 8-12 % slower than the LDS-transposed epilogue).  A 4 x 4
+    // transpose inside each lane quad (two DPP butterfly stages) gives lane j of a quad piece j (couts 4j .. 4j + 3) of the
+    // quad's four pixels instead: store k then writes pixel k of every quad, 4 lanes x 16 B = 64 contiguous bytes, and the
+    // two half-waves complete the 128-B line -- 8 whole lines per instruction.
+    const int qj = lane & 3, qp = px & ~3;
+    auto quad_transpose = [&](pp_floatx4 (&t)[4]) {
 #pragma unroll
-  for (int k = 0; k < ITERS; ++k) {
-    const int row = tid / C8 + k * (kPPThreads / C8);
-    const int64_t m = m0 + row;
-    if (m < a.M) {
-      pp_floatx4 v0 = *reinterpret_cast<const pp_floatx4*>(cl + row * LDC + 8 * c8) + b0;
-      pp_floatx4 v1 = *reinterpret_cast<const pp_floatx4*>(cl + row * LDC + 8 * c8 + 4) + b1;
-      if (res) {
-        const pp_halfx8 rr = *reinterpret_cast<const pp_halfx8*>(res + m * a.Cout + n);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v0[q] += (float)rr[q]; v1[q] += (float)rr[4 + q]; }
+      for (int c = 0; c < 4; ++c) {
+        float r0 = t[0][c], r1 = t[1][c], r2 = t[2][c], r3 = t[3][c];
+        quad_transpose4(qj, r0, r1, r2, r3);
+        t[0][c] = r0; t[1][c] = r1; t[2][c] = r2; t[3][c] = r3;
       }
-      if (a.relu) {
+    };
+    // after the transpose: t[k] = couts [n + 4 qj, + 4) of pixel row m0 + wm + 32 mt + qp + k
+    pp_floatx4 sc[NT], bias[NT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wn + nt * 32 + h16 + 4 * qj;
+      sc[nt] = *reinterpret_cast<const pp_floatx4*>(unscale + n) * act_inv;
+      bias[nt] = pp_floatx4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bias[nt] = *reinterpret_cast<const pp_floatx4*>(a.bias + n);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      pp_floatx4 res[NT][4];
+      if (a.residual) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int64_t m = m0 + wm + mt * 32 + qp + k;
+          const float* const rp = a.residual + (m < a.M ? m : 0) * a.Cout + n0 + wn + h16 + 4 * qj;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) res[nt][k] = *reinterpret_cast<const pp_floatx4*>(rp + nt * 32);
+        }
       }
-      pp_halfx8 o;
+      if (mt == 1) between();
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { o[q] = (_Float16)v0[q]; o[4 + q] = (_Float16)v1[q]; }
-      *reinterpret_cast<pp_halfx8*>(y + m * a.Cout + n) = o;
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn + nt * 32 + h16 + 4 * qj;
+        pp_floatx4 t[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t[g] = pp_floatx4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+        quad_transpose(t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int64_t m = m0 + wm + mt * 32 + qp + k;
+          pp_floatx4 v = t[k] * sc[nt] + bias[nt];
+          if (a.residual) v += res[nt][k];
+          if (m < a.M) {
+            chk += (v[0] + v[1]) + (v[2] + v[3]);
+            if (a.relu == HP_ACT_RELU) v = __builtin_elementwise_max(v, pp_floatx4{0.f, 0.f, 0.f, 0.f});
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            *reinterpret_cast<pp_floatx4*>(a.y + m * a.Cout + n) = v;
+          }
+        }
+      }
+    }
+    conv_report_nonfinite(a, chk);
+    if (a.amax_out) {  // as conv_epilogue.h: wave maximum, look before the atomic, words spread over L2 channels
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+      if (lane == 0 && amax > 0.f) {
+        const unsigned mine = __float_as_uint(amax);
+        unsigned* const slot = a.amax_out + (blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride;
+        if (mine > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mine);
+      }
+    }
+  } else {
+    // fp16 output: a lane's wave tile row is 4 pieces of 8 couts (nt, g) = 16 B each; the same quad transpose (in fp32, so
+    // that the single rounding to fp16 stays where it was) gives lane j piece j of the quad's four pixels: store k writes 8
+    // whole 128-B lines (pieces 0 / 1 of the two half-waves = couts wn .. wn + 31, pieces 2 / 3 = wn + 32 .. wn + 63)
+    static_assert(NT == 2, "the piece map below assumes two N tiles per wave");
+    const int qj = lane & 3, qp = px & ~3;
+    const _Float16* const resp = reinterpret_cast<const _Float16*>(a.residual);
+    _Float16* const y = reinterpret_cast<_Float16*>(a.y);
+    const int n = n0 + wn + (qj >> 1) * 32 + h16 + 8 * (qj & 1);  // this lane's 8 couts after the transpose
+    pp_floatx4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (a.bias) {
+      b0 = *reinterpret_cast<const pp_floatx4*>(a.bias + n);
+      b1 = *reinterpret_cast<const pp_floatx4*>(a.bias + n + 4);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      pp_halfx8 res[4];
+      if (resp) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int64_t m = m0 + wm + mt * 32 + qp + k;
+          res[k] = *reinterpret_cast<const pp_halfx8*>(resp + (m < a.M ? m : 0) * a.Cout + n);
+        }
+      }
+      if (mt == 1) between();
+      float t[4][8];  // [piece j = 2 nt + g][8 couts]
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) t[j][c] = acc[mt][j >> 1][8 * (j & 1) + c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) quad_transpose4(qj, t[0][c], t[1][c], t[2][c], t[3][c]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // t[k] = this lane's 8 couts of pixel row qp + k
+        const int64_t m = m0 + wm + mt * 32 + qp + k;
+        pp_floatx4 v0 = {t[k][0], t[k][1], t[k][2], t[k][3]}, v1 = {t[k][4], t[k][5], t[k][6], t[k][7]};
+        v0 += b0; v1 += b1;
+        if (resp) {
+          const pp_halfx8 rr = res[k];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v0[q] += (float)rr[q]; v1[q] += (float)rr[4 + q]; }
+        }
+        if (a.relu) {
+          v0 = __builtin_elementwise_max(v0, pp_floatx4{0.f, 0.f, 0.f, 0.f});
+          v1 = __builtin_elementwise_max(v1, pp_floatx4{0.f, 0.f, 0.f, 0.f});
+        }
+        pp_halfx8 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[q] = (_Float16)v0[q]; o[4 + q] = (_Float16)v1[q]; }
+        if (m < a.M) *reinterpret_cast<pp_halfx8*>(y + m * a.Cout + n) = o;
+      }
     }
   }
 }
@@ -146,18 +252,9 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
 #ifdef HP_PP_STAMPS
   const unsigned long long st_k0 = __builtin_readcyclecounter();
 #endif
-  int lin, slice;
-  bool split;
-  if (!splitk_decode(a, lin, slice, split)) return;
-  const int tile_m = fdiv(lin, a.fd_tn), tile_n = lin - tile_m * a.tiles_n;
-  const int64_t m0 = (int64_t)tile_m * BM;
-  const int n0 = tile_n * BN;
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = a.W, H = a.H, Cin = a.Cin;
-  const int ncc_all = Cin / CKC, ntaps = ncc_all * 9;
-  const int cc_begin = split ? slice * ncc_all / a.sk_S : 0;
-  const int ncc = split ? (slice + 1) * ncc_all / a.sk_S : ncc_all;  // end of this item's chunk range
+  const int ncc_all = Cin / CKC;
 
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(a.M * Cin * ESZ), 0x00020000);
@@ -165,20 +262,13 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)((int64_t)a.Cout * wrow * 2), 0x00020000);
 
+  // ---- thread constants that do not depend on the tile
   // patch staging: row = pr0 + PROWS j, channels 8 pk .. 8 pk + 7 of the chunk
   const int pk = tid % TPR, pr0 = tid / TPR;
-  const int64_t gp0 = m0 - (W + 1) + pr0;
-  auto patch_voff = [&](int j) -> unsigned {
-    const int64_t gp = gp0 + PROWS * j;
-    return (pr0 + PROWS * j < P && gp >= 0 && gp < a.M) ? (unsigned)((gp * Cin + 8 * pk) * ESZ) : kOob;
-  };
   // split: this thread's 8 channels land at halves [8 pk, 8 pk + 8) (hi) and 32 + [8 pk, ...) (lo); f16: at [8 pk, ...)
   _Float16* const Pst = patch + pr0 * LDH + 8 * pk;
   // weight staging: row = br0 + 64 i, 16-B piece bk of the 128-B row
   const int bk = tid & 7, br0 = tid >> 3;
-  unsigned wvoff[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) wvoff[i] = (unsigned)(((int64_t)(n0 + br0 + BROWS * i) * wrow + 8 * bk) * 2);
   _Float16* const Bst = Bs + br0 * LDH + 8 * bk;
   if (tid < LDH / 2) reinterpret_cast<unsigned*>(zrow)[tid] = 0u;
   if (PRE) {
@@ -196,38 +286,95 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   auto w_soff = [&](int cc, int tap) -> unsigned {  // byte offset of the (chunk, tap) row piece inside a cout's weights
     return MODE == MODE_SPLIT ? (unsigned)((cc * 9 + tap) * 128) : (unsigned)((tap * Cin + cc * CKC) * 2);
   };
-
-  // fragment bases + validity of the 9 taps per fragment row
+  // fragment bases
   const int wm = ((wave & 3) >> 1) * 64 + (wave >> 2) * 128, wn = (wave & 1) * 64;  // waves w and w + 4 share a SIMD
   const int frow = lane & 31, fk = 8 * (lane >> 5);
-  const _Float16* const Bfr = Bs + (wn + frow) * LDH + fk;
+  // MFMA row i of a 32-cout block multiplies weight row sigma(i): the lane's 16 accumulator rows are then 16 consecutive couts
+  const int srow = 16 * ((frow >> 2) & 1) + 4 * (frow >> 3) + (frow & 3);
+  const _Float16* const Bfr = Bs + (wn + srow) * LDH + fk;
   const _Float16* Afr[MT];
-  unsigned vmask[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    Afr[mt] = patch + (wm + mt * 32 + frow + W + 1) * LDH + fk;
-    const int64_t g = m0 + wm + mt * 32 + frow;
-    unsigned mk = 0;
-    if (g < a.M) {
-      const int rem = (int)g - fdiv((int)g, a.fd_howo) * (H * W);  // stride 1: Ho x Wo = H x W
-      const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * W;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
-        mk |= ((((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W)) ? 1u : 0u) << t;
-      }
-    }
-    vmask[mt] = mk;
-  }
+  for (int mt = 0; mt < MT; ++mt) Afr[mt] = patch + (wm + mt * 32 + frow + W + 1) * LDH + fk;
   const _Float16* const Zfr = zrow + fk;
+  const bool odd = wave >= 4;  // waves 4-7 run one phase behind waves 0-3
+
+  // ---- PERSISTENT loop over work items (round 4).  The grid holds at most one workgroup per CU; workgroup b walks the
+  // virtual blocks b, b + G, b + 2 G, ... of the former one-item-per-workgroup grid (same XCD for all of them: G is a
+  // multiple of 8).  What that buys: the first loads of the NEXT item (its patch chunk and the weights of taps 0 / 1) are
+  // issued before the epilogue of the current one and land under it, the epilogue's stores drain under the next K loop,
+  // and the per-launch set-up above (LDS carve-up, BN vectors, activation scale) is paid once per CU, not once per tile.
+  const int nvb = 8 * (a.sk_regular / 8 + (a.sk_tail_items + 7) / 8);
+  // loop state of the item being multiplied (overwritten by the decode of the next one once the K loop is over)
+  int64_t gp0 = 0;
+  unsigned wvoff[NB];
+  unsigned vmask[MT];
+  int cc_begin = 0, ncc = 0;
+  struct Item { int lin, slice, n0; bool split; int64_t m0; };
+  // Everything an item's set-up and epilogue derive from the thread id is RE-derived per item from a laundered copy of it:
+  // left to itself the compiler hoists those values out of the item loop, keeps them live across the K loop -- where every
+  // register is taken -- and spills them to scratch (which, besides its cost, keeps hipGraph replay off: DESIGN.md 4.5).
+  auto opaque_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+  // The same for the kernel arguments: the set-up and the epilogue read them through a laundered pointer to the kernarg
+  // segment (ConvArgs is its first member), i.e. with scalar loads where they are used, instead of holding ~60 SGPRs of
+  // pointers and sizes live across the K loop (SGPR spills land in VGPR lanes and push the VGPR file over).
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
+  auto opaque_args = [&]() { KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p; };
+#else  // host pass of the single-source compile: never executed
+  typedef const ConvArgs* KArgs;
+  auto opaque_args = [&]() { return &a; };
+#endif
+  auto decode = [&](int vb, Item& it) -> bool {
+    if (vb >= nvb) return false;
+    const KArgs ka = opaque_args();
+    const ConvArgs a = *ka;  // shadows the kernel argument inside this lambda
+    const int t_ = opaque_tid();
+    const int br0 = t_ >> 3, bk = t_ & 7, frow = t_ & 31, wave_ = t_ >> 6;
+    const int wm = ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128;
+    const int pr0 = t_ / TPR;
+    const int rpx = a.sk_regular / 8, tpx = (a.sk_tail_items + 7) / 8;
+    const int xcd = vb % 8, li = vb / 8;
+    it.slice = 0; it.split = false;
+    if (li < rpx) {
+      it.lin = xcd * rpx + li;
+    } else {
+      const int ti = xcd * tpx + (li - rpx);
+      if (li - rpx >= tpx || ti >= a.sk_tail_items) return false;
+      it.lin = a.sk_regular + ti / a.sk_S;
+      it.slice = ti % a.sk_S;
+      it.split = a.sk_S > 1;
+    }
+    const int tile_m = fdiv(it.lin, a.fd_tn), tile_n = it.lin - tile_m * a.tiles_n;
+    it.m0 = (int64_t)tile_m * BM;
+    it.n0 = tile_n * BN;
+    cc_begin = it.split ? it.slice * ncc_all / a.sk_S : 0;
+    ncc = it.split ? (it.slice + 1) * ncc_all / a.sk_S : ncc_all;  // end of this item's chunk range
+    gp0 = it.m0 - (W + 1) + pr0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wvoff[i] = (unsigned)(((int64_t)(it.n0 + br0 + BROWS * i) * wrow + 8 * bk) * 2);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {  // validity of the 9 taps per fragment row
+      const int64_t g = it.m0 + wm + mt * 32 + frow;
+      unsigned mk = 0;
+      if (g < a.M) {
+        const int rem = (int)g - fdiv((int)g, a.fd_howo) * (H * W);  // stride 1: Ho x Wo = H x W
+        const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+          mk |= ((((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W)) ? 1u : 0u) << t;
+        }
+      }
+      vmask[mt] = mk;
+    }
+    return true;
+  };
+  auto patch_voff = [&](int j) -> unsigned {
+    const int64_t gp = gp0 + PROWS * j;
+    return (pr0 + PROWS * j < P && gp >= 0 && gp < a.M) ? (unsigned)((gp * Cin + 8 * pk) * ESZ) : kOob;
+  };
 
   pp_floatx16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // staging registers: the next chunk's patch rows of this thread, the weights of taps t+1 / t+2 (alternating sets)
   pp_floatx4 prf[MODE == MODE_SPLIT ? NPC : 1][2];
@@ -308,22 +455,13 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     t2 = tap + d; c2 = cc;
     if (t2 >= 9) { t2 -= 9; ++c2; }
   };
-
-  // prologue: patch of the first chunk -> buffer 0, weights of tap 0 -> LDS buffer 0, taps 1 and 2 -> registers
+  // first loads of the item the loop state describes: patch of its first chunk, weights of taps 0 and 1 -> registers
+  auto issue_first_loads = [&]() {
 #pragma unroll
-  for (int j = 0; j < NPC; ++j) load_patch(j, cc_begin);
-  load_b(0, cc_begin, 0);
-  load_b(1, cc_begin, 1);
-  store_patch(cc_begin, 0);
-  store_b(0, 0);
-  load_b(0, cc_begin, 2);
-  __syncthreads();
-
-  const bool odd = wave >= 4;  // waves 4-7 run one phase behind waves 0-3
-#ifdef HP_PP_STAMPS
-  const unsigned long long st_t0 = __builtin_readcyclecounter(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  if (odd) __builtin_amdgcn_s_barrier();
+    for (int j = 0; j < NPC; ++j) load_patch(j, cc_begin);
+    load_b(0, cc_begin, 0);
+    load_b(1, cc_begin, 1);
+  };
 
   // one tap: L segment, barrier, C segment, barrier.  Pb = LDS weight buffer (tap parity within the item), PQ = patch
   // buffer (chunk parity within the item) -- compile-time through the two-chunk unrolling below.
@@ -346,7 +484,11 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     pp_halfx8 fa[4][MT], fb[4][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const _Float16* const Ab = ((vmask[i] >> tap) & 1u) ? Afr[i] + PQ * P * LDH + d * LDH : Zfr;
+      // the select stays HERE (two v_cndmask per tap): hoisted out of the K loop it is 36 addresses per item plus the 36
+      // tile-independent ones they are chosen from, all live across the K loop -- the registers the persistent loop needs
+      unsigned vm = vmask[i];
+      asm volatile("" : "+v"(vm));
+      const _Float16* const Ab = ((vm >> tap) & 1u) ? Afr[i] + PQ * P * LDH + d * LDH : Zfr;
 #pragma unroll
       for (int q = 0; q < 4; ++q) fa[q][i] = *reinterpret_cast<const pp_halfx8*>(Ab + q * 16);
     }
@@ -364,7 +506,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[mi], y[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y[ni], x[mi], acc[mi][ni], 0, 0, 0);  // D[cout][pixel]
     };
     if constexpr (MODE == MODE_SPLIT) {
       // fragment q of a row: 0 / 1 = hi halves of channels 0-15 / 16-31, 2 / 3 = their lo halves
@@ -387,46 +529,79 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     tap_step(cc, 3, O{}, Q{}); tap_step(cc, 4, E{}, Q{}); tap_step(cc, 5, O{}, Q{});
     tap_step(cc, 6, E{}, Q{}); tap_step(cc, 7, O{}, Q{}); tap_step(cc, 8, E{}, Q{});
   };
-  int cc = cc_begin;
-  for (; cc + 1 < ncc; cc += 2) {
-    chunk(cc, std::integral_constant<int, 0>{});
-    chunk(cc + 1, std::integral_constant<int, 1>{});
-  }
-  if (cc < ncc) chunk(cc, std::integral_constant<int, 0>{});
-  if (!odd) __builtin_amdgcn_s_barrier();
-  (void)ntaps;
+
+  Item cur{};
+  int vb = blockIdx.x;
+  bool have = decode(vb, cur);
+  if (have) issue_first_loads();
+  while (have) {
+    // ---- prologue of `cur`: its first loads are in flight (issued above, or before the previous item's epilogue)
 #ifdef HP_PP_STAMPS
-  if (tid == 0) {
-    atomicAdd(&g_pp_stamps[0], __builtin_readcyclecounter() - st_t0);
-    atomicAdd(&g_pp_stamps[1], __builtin_amdgcn_s_memrealtime() - st_r0);
-    atomicAdd(&g_pp_stamps[2], (unsigned long long)((ncc - cc_begin) * 9));
-    atomicAdd(&g_pp_stamps[3], 1ull);
-    atomicAdd(&g_pp_stamps[4], st_t0 - st_k0);  // prologue
-  }
-  const unsigned long long st_e0 = __builtin_readcyclecounter();
+    const unsigned long long st_p0 = __builtin_readcyclecounter();
 #endif
-
-  if (split && !splitk_reduce_sc1<BM, BN, MT, NT, kPPThreads>(a, acc, lin - a.sk_regular, slice)) return;
-
-  if constexpr (MODE == MODE_SPLIT) {
-    // scale back (a lane holds one output channel per N tile), then the shared fp32 epilogue
-    const float* const unscale = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(a.w) + (size_t)a.Cout * 18 * Cin);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const float s = unscale[n0 + wn + nt * 32 + (lane & 31)] * act_inv;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= s;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    store_patch(cc_begin, 0);
+    store_b(0, 0);
+    load_b(0, cc_begin, 2);
+    __syncthreads();
+#ifdef HP_PP_STAMPS
+    const unsigned long long st_t0 = __builtin_readcyclecounter(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (odd) __builtin_amdgcn_s_barrier();
+    int cc = cc_begin;
+    for (; cc + 1 < ncc; cc += 2) {
+      chunk(cc, std::integral_constant<int, 0>{});
+      chunk(cc + 1, std::integral_constant<int, 1>{});
     }
-    conv_epilogue<BM, BN, MT, NT, kPPThreads>(a, reinterpret_cast<float*>(lds_raw), acc, m0, n0, wm, wn);
-  } else {
-    pp_epilogue_f16(a, reinterpret_cast<float*>(lds_raw), acc, m0, n0, wm, wn);
-  }
+    if (cc < ncc) chunk(cc, std::integral_constant<int, 0>{});
+    if (!odd) __builtin_amdgcn_s_barrier();  // both wave groups are past their last fragment reads: the LDS buffers are free
 #ifdef HP_PP_STAMPS
-  __syncthreads();
-  if (tid == 0) atomicAdd(&g_pp_stamps[5], __builtin_readcyclecounter() - st_e0);  // slab hand-off + epilogue (full tiles / last arrivers)
+    if (tid == 0) {
+      atomicAdd(&g_pp_stamps[0], __builtin_readcyclecounter() - st_t0);
+      atomicAdd(&g_pp_stamps[1], __builtin_amdgcn_s_memrealtime() - st_r0);
+      atomicAdd(&g_pp_stamps[2], (unsigned long long)((ncc - cc_begin) * 9));
+      atomicAdd(&g_pp_stamps[3], 1ull);
+      atomicAdd(&g_pp_stamps[4], st_t0 - st_p0);  // prologue of this item (waiting for its prefetched loads, staging)
+      if (vb == (int)blockIdx.x) atomicAdd(&g_pp_stamps[6], st_p0 - st_k0);  // per-workgroup set-up before the first item
+    }
+    const unsigned long long st_e0 = __builtin_readcyclecounter();
 #endif
+    // ---- the next item's loop state and first loads, then this item's epilogue (whose stores drain under the next K loop)
+    Item nxt{};
+    vb += (int)gridDim.x;
+    bool finish = true, issued = false;
+    const ConvArgs ea = *opaque_args();  // the epilogue's view of the arguments (see opaque_args)
+    if (cur.split) finish = splitk_reduce_sc1<BM, BN, MT, NT, kPPThreads>(ea, acc, cur.lin - ea.sk_regular, cur.slice);
+    auto prefetch_next = [&]() {  // overwrites the loop state (the K loop of `cur` is over), keeps cur's epilogue constants
+      have = decode(vb, nxt);
+      if (have) issue_first_loads();
+      issued = true;
+    };
+    if (finish) {
+      const int t_ = opaque_tid(), wave_ = t_ >> 6;
+      pp_epilogue_direct<MODE>(ea, acc, cur.m0, cur.n0, ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128, (wave_ & 1) * 64, act_inv, t_ & 63,
+                               prefetch_next);
+    }
+    if (!issued) prefetch_next();
+#ifdef HP_PP_STAMPS
+    if (tid == 0) atomicAdd(&g_pp_stamps[5], __builtin_readcyclecounter() - st_e0);  // slab hand-off + epilogue issue
+#endif
+    cur = nxt;
+  }
+}
+
+static int conv_num_cus() {  // of the current device (queried once: one device per process, as everywhere in this library)
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 8 ? n : 256;
+  }();
+  return cus;
 }
 
 template <int MODE, bool PRE, int NPC>
@@ -448,7 +623,11 @@ int launch_pp_variant(ConvArgs args, hipStream_t stream) {
   const int rc = conv_split_plan_tail(args, args.tiles_m * args.tiles_n, args.Cin / T::CKC, (size_t)BM * BN, 1, stream);
   if (rc) return rc;
   const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
-  hipLaunchKernelGGL((conv3x3_pp<MODE, PRE, NPC>), dim3(8 * per_xcd), dim3(kPPThreads), T::lds_bytes(args.W), stream, args,
+  // persistent grid: one workgroup per CU at most (the LDS admits no second one), a multiple of 8 so that a workgroup's
+  // virtual blocks stay on its XCD; HP_PP_GRID overrides the cap (experiments)
+  static const int cap = std::getenv("HP_PP_GRID") ? std::max(8, std::atoi(std::getenv("HP_PP_GRID")) / 8 * 8) : conv_num_cus() / 8 * 8;
+  const int grid = std::min(8 * per_xcd, cap);
+  hipLaunchKernelGGL((conv3x3_pp<MODE, PRE, NPC>), dim3(grid), dim3(kPPThreads), T::lds_bytes(args.W), stream, args,
                      T::P(args.W));
   return check_launch("conv3x3_pp");
 }
@@ -503,7 +682,7 @@ extern "C" int hp_debug_pp_stamps(double* out4) {  // cycles, 100-MHz ticks, tap
   unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(hp::g_pp_stamps), sizeof(h)) != hipSuccess) return -1;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(hp::g_pp_stamps), z, sizeof(z));
-  for (int i = 0; i < 6; ++i) out4[i] = (double)h[i];
+  for (int i = 0; i < 7; ++i) out4[i] = (double)h[i];
   return 0;
 }
 #endif
