@@ -74,8 +74,12 @@ constexpr int kPoolRows = 3, kPoolCols = 8, kPoolCW = 2 * kPoolCols + 1, kPoolCH
 
 // PRE: 0 none, 1 BN + ReLU on the input (pre_scale / pre_shift [Cin]), 2 squeeze-excitation gate (pre_scale [n][Cin],
 // EfficientNet projections: the gated input is formed in fp32 and then split, as the exact kernels form it)
+// Register budget: double-buffered (NBUF 2) two workgroups per CU = 256 VGPRs; single-buffered (NBUF 1) four per CU = 128
+// VGPRs for the 128-wide tile's cousins that fit, but THREE per CU (168 VGPRs) for the 64-wide tile: at 128 it spilled
+// 36-220 B per lane to scratch (EfficientNet's narrow 1x1 layers, the detector), and a launch that uses scratch also keeps
+// hipGraph replay off for the whole network.
 template <int BN, int PRE, int NBUF, bool POOL>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2 * (3 - NBUF), 2 * (3 - NBUF)))) void conv_igemm_split_f32(ConvArgs a) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 2 : 3, NBUF == 2 ? 2 : 4))) void conv_igemm_split_f32(ConvArgs a) {
   constexpr int MT = 2, NT = BN / 64;  // 4 waves 2 x 2, wave tile 64 x BN/2
   constexpr int NA = 4, NB = BN / 32;  // staged 16-B pieces per thread and K-tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -385,7 +389,9 @@ static int launch_igs_pre(const ConvArgs& a, hipStream_t stream) {
 
 int launch_conv_igemm_split(const ConvArgs& a, int variant, hipStream_t stream) {
   if (variant == 0) return launch_igs_pre<128, 2>(a, stream);
-  if (a.ktiles <= 8) return launch_igs_pre<64, 1>(a, stream);
+  // short K: single-buffered, three workgroups per CU -- except the squeeze-excitation-gated input (PRE 2), whose gate
+  // arithmetic does not fit 168 VGPRs without scratch: those layers take the double-buffered tile
+  if (a.ktiles <= 8 && !(a.pre_scale && !a.pre_shift)) return launch_igs_pre<64, 1>(a, stream);
   return launch_igs_pre<64, 2>(a, stream);
 }
 

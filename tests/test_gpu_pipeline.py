@@ -1413,7 +1413,14 @@ def test_scratch_kernels_keep_graphs_off(dev, world):
     n0 = ops.scratch_launches()
     ref = eager.forward(images, K, labels, T0, n_iterations=2, im_ids=im_ids)["iteration=2"].TCO_output
     if ops.scratch_launches() == n0:
-        pytest.skip("no spilling kernel on this path in this build")
+        # round 4: no tile variant EfficientNet-b3 launches uses scratch any more (the narrow 1x1 layers got their registers),
+        # so hipGraph replay is ALLOWED for it -- and must reproduce the eager result
+        g = create_pose_model_cosypose(dict(backbone_str="efficientnet-b3"), world["renderer"], state_dict=w, max_batch=16, graphs=True)
+        for _ in range(4):
+            out = g.forward(images, K, labels, T0, n_iterations=2, im_ids=im_ids)["iteration=2"].TCO_output
+            assert torch.equal(out, ref)
+        assert g._graphs is not None and not getattr(g, "_no_graphs", False)  # the step was captured and replayed
+        return
     g = create_pose_model_cosypose(dict(backbone_str="efficientnet-b3"), world["renderer"], state_dict=w, max_batch=16, graphs=True)
     for _ in range(3):
         out = g.forward(images, K, labels, T0, n_iterations=2, im_ids=im_ids)["iteration=2"].TCO_output
