@@ -51,7 +51,7 @@ enum { MODE_SPLIT = 0, MODE_F16 = 1 };
 constexpr int kPPThreads = 512;
 constexpr int LDH = 64 + 8;  // LDS row: 64 halves (32 hi + 32 lo, or 64 channels), padded to 36 dwords
 constexpr unsigned kOob = 0xFFFFFFF0u;
-constexpr int BM = 256, BN = 128, MT = 2, NT = 2;
+constexpr int BM = 256, MT = 2;  // block tile 256 x (64 NT): NT = 2 (Cout % 128 == 0) or 1 (the 64-channel layers)
 
 __device__ __forceinline__ pp_floatx4 ldf4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(pp_floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
@@ -60,8 +60,9 @@ __device__ __forceinline__ pp_halfx8 ldh8(__amdgpu_buffer_rsrc_t r, unsigned vof
   return __builtin_bit_cast(pp_halfx8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
-template <int MODE>
+template <int MODE, int NT>
 struct PP {
+  static constexpr int BN = 64 * NT;
   static constexpr int CKC = MODE == MODE_SPLIT ? 32 : 64;  // channels per chunk (= one 128-B LDS row)
   static constexpr int TPR = MODE == MODE_SPLIT ? 4 : 8;    // threads per patch row (8 channels each)
   static constexpr int PROWS = kPPThreads / TPR;            // patch rows per staging pass
@@ -102,7 +103,7 @@ __device__ __forceinline__ void quad_transpose4(int qj, float& r0, float& r1, fl
 
 // `between()` runs once, after the first of the wave's two M tiles has been stored (its 32 accumulator registers are dead by
 // then): the persistent loop issues the NEXT item's first loads there, so that they land under the rest of this epilogue.
-template <int MODE, typename Hook>
+template <int MODE, int NT, typename Hook>
 __device__ __forceinline__ void pp_epilogue_direct(const ConvArgs& a, pp_floatx16 (&acc)[MT][NT], int64_t m0, int n0, int wm, int wn,
                                                    float act_inv, int lane, Hook&& between) {
   const int px = lane & 31, h16 = 16 * (lane >> 5);
@@ -181,7 +182,7 @@ __device__ __forceinline__ void pp_epilogue_direct(const ConvArgs& a, pp_floatx1
     // fp16 output: a lane's wave tile row is 4 pieces of 8 couts (nt, g) = 16 B each; the same quad transpose (in fp32, so
     // that the single rounding to fp16 stays where it was) gives lane j piece j of the quad's four pixels: store k writes 8
     // whole 128-B lines (pieces 0 / 1 of the two half-waves = couts wn .. wn + 31, pieces 2 / 3 = wn + 32 .. wn + 63)
-    static_assert(NT == 2, "the piece map below assumes two N tiles per wave");
+    static_assert(NT == 2, "the piece map below assumes two N tiles per wave (the fp16 plan launches NT = 2 only)");
     const int qj = lane & 3, qp = px & ~3;
     const _Float16* const resp = reinterpret_cast<const _Float16*>(a.residual);
     _Float16* const y = reinterpret_cast<_Float16*>(a.y);
@@ -233,9 +234,10 @@ __device__ __forceinline__ void pp_epilogue_direct(const ConvArgs& a, pp_floatx1
 }
 
 // a.Kpad: MODE_F16 = elements per weight row ([Cout][Kpad] halves, K = (tap, c)); MODE_SPLIT unused (rows are 18 Cin halves)
-template <int MODE, bool PRE, int NPC>
+template <int MODE, bool PRE, int NPC, int NT>
 __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_pp(ConvArgs a, int P) {
-  using T = PP<MODE>;
+  using T = PP<MODE, NT>;
+  constexpr int BN = T::BN;
   constexpr int CKC = T::CKC, TPR = T::TPR, PROWS = T::PROWS, ESZ = T::ESZ;
   constexpr int NB = BN * 8 / kPPThreads;  // 16-B weight pieces per thread and tap (2)
   constexpr int BROWS = kPPThreads / 8;    // weight rows per staging pass (64)
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     return MODE == MODE_SPLIT ? (unsigned)((cc * 9 + tap) * 128) : (unsigned)((tap * Cin + cc * CKC) * 2);
   };
   // fragment bases
-  const int wm = ((wave & 3) >> 1) * 64 + (wave >> 2) * 128, wn = (wave & 1) * 64;  // waves w and w + 4 share a SIMD
+  const int wm = ((wave & 3) >> 1) * 64 + (wave >> 2) * 128, wn = (wave & 1) * (BN / 2);  // waves w and w + 4 share a SIMD
   const int frow = lane & 31, fk = 8 * (lane >> 5);
   // MFMA row i of a 32-cout block multiplies weight row sigma(i): the lane's 16 accumulator rows are then 16 consecutive couts
   const int srow = 16 * ((frow >> 2) & 1) + 4 * (frow >> 3) + (frow & 3);
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     };
     if (finish) {
       const int t_ = opaque_tid(), wave_ = t_ >> 6;
-      pp_epilogue_direct<MODE>(ea, acc, cur.m0, cur.n0, ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128, (wave_ & 1) * 64, act_inv, t_ & 63,
+      pp_epilogue_direct<MODE, NT>(ea, acc, cur.m0, cur.n0, ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128, (wave_ & 1) * (BN / 2), act_inv, t_ & 63,
                                prefetch_next);
     }
     if (!issued) prefetch_next();
@@ -604,14 +606,15 @@ static int conv_num_cus() {  // of the current device (queried once: one device 
   return cus;
 }
 
-template <int MODE, bool PRE, int NPC>
+template <int MODE, bool PRE, int NPC, int NT>
 int launch_pp_variant(ConvArgs args, hipStream_t stream) {
-  using T = PP<MODE>;
+  using T = PP<MODE, NT>;
+  constexpr int BN = T::BN;
   static bool opted = false, spills = false;
   if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC>),
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC, NT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));  // + the static ticket word
-    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC>));
+    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC, NT>));
     opted = true;
   }
   if (spills) count_scratch_launch();
@@ -627,41 +630,53 @@ int launch_pp_variant(ConvArgs args, hipStream_t stream) {
   // virtual blocks stay on its XCD; HP_PP_GRID overrides the cap (experiments)
   static const int cap = std::getenv("HP_PP_GRID") ? std::max(8, std::atoi(std::getenv("HP_PP_GRID")) / 8 * 8) : conv_num_cus() / 8 * 8;
   const int grid = std::min(8 * per_xcd, cap);
-  hipLaunchKernelGGL((conv3x3_pp<MODE, PRE, NPC>), dim3(grid), dim3(kPPThreads), T::lds_bytes(args.W), stream, args,
+  hipLaunchKernelGGL((conv3x3_pp<MODE, PRE, NPC, NT>), dim3(grid), dim3(kPPThreads), T::lds_bytes(args.W), stream, args,
                      T::P(args.W));
   return check_launch("conv3x3_pp");
 }
 
-template <int MODE, bool PRE>
-int launch_pp_npc(const ConvArgs& a, hipStream_t stream) {
-  const int npc = PP<MODE>::npc(a.W);
-  if (npc <= 3) return launch_pp_variant<MODE, PRE, 3>(a, stream);
-  if (npc == 4) return launch_pp_variant<MODE, PRE, 4>(a, stream);
-  if (npc <= 6) return launch_pp_variant<MODE, PRE, 6>(a, stream);
+template <int MODE, bool PRE, int NT>
+int launch_pp_nt(const ConvArgs& a, hipStream_t stream) {
+  const int npc = PP<MODE, NT>::npc(a.W);
+  if (npc <= 3) return launch_pp_variant<MODE, PRE, 3, NT>(a, stream);
+  if (npc == 4) return launch_pp_variant<MODE, PRE, 4, NT>(a, stream);
+  if (npc <= 6) return launch_pp_variant<MODE, PRE, 6, NT>(a, stream);
   return fail(HP_ERR_ARG, "conv3x3_pp: map too wide for the staged patch");
 }
 
-template <int MODE>
+template <int MODE, int NT>
 bool pp_shape_ok(int W, int Cin, int Cout, int stride, int pad, int kh, int kw) {
   static const bool off = std::getenv("HP_CONV_NO_PP") != nullptr;
-  return !off && kh == 3 && kw == 3 && stride == 1 && pad == 1 && Cout % BN == 0 && Cin % PP<MODE>::CKC == 0 && Cin <= 512 &&
-         PP<MODE>::npc(W) <= 6 && PP<MODE>::lds_bytes(W) <= 159 * 1024;
+  using T = PP<MODE, NT>;
+  return !off && kh == 3 && kw == 3 && stride == 1 && pad == 1 && Cout % T::BN == 0 && Cin % T::CKC == 0 && Cin <= 512 &&
+         T::npc(W) <= 6 && T::lds_bytes(W) <= 159 * 1024;
+}
+// 64-wide tiles (round 4, HP_PP_BN64=1): the 64-channel layers of the 60 x 80 maps on the ping-pong skeleton (fp32 / split
+// mode).  Built, parity-green and NOT the default: measured on the same box 169 / 204 us per layer at batch 128 against
+// 154 / 172 for conv3x3_split_f32's 256 x 64 tiles in two 4-wave workgroups per CU (85.6 vs 90.7 us at batch 64, the C2
+// step unchanged: 5255 vs 5257 poses/s) -- with 18 taps per tile these layers are bound by their 64-KB-per-tile output
+// stream, which two workgroups per CU overlap with one another's K loops and one workgroup per CU cannot.
+bool pp_use_bn64(int Cout) {
+  static const bool on = std::getenv("HP_PP_BN64") != nullptr;
+  return on && Cout % 128 != 0;
 }
 
 }  // namespace
 
 // fp32 (split-fp16) entry: a.w = weights split by conv_split_transform_weights
 bool conv_pp_split_applicable(const ConvArgs& a, int kh, int kw) {
-  return pp_shape_ok<MODE_SPLIT>(a.W, a.Cin, a.Cout, a.stride, a.pad, kh, kw);
+  if (pp_use_bn64(a.Cout)) return pp_shape_ok<MODE_SPLIT, 1>(a.W, a.Cin, a.Cout, a.stride, a.pad, kh, kw);
+  return pp_shape_ok<MODE_SPLIT, 2>(a.W, a.Cin, a.Cout, a.stride, a.pad, kh, kw);
 }
 
 int launch_conv_pp_split(const ConvArgs& a, hipStream_t stream) {
-  return a.pre_scale ? launch_pp_npc<MODE_SPLIT, true>(a, stream) : launch_pp_npc<MODE_SPLIT, false>(a, stream);
+  if (pp_use_bn64(a.Cout)) return a.pre_scale ? launch_pp_nt<MODE_SPLIT, true, 1>(a, stream) : launch_pp_nt<MODE_SPLIT, false, 1>(a, stream);
+  return a.pre_scale ? launch_pp_nt<MODE_SPLIT, true, 2>(a, stream) : launch_pp_nt<MODE_SPLIT, false, 2>(a, stream);
 }
 
 // fp16 entry (the fp16 plan): packed weights [Cout][Kpad] with K = (tap, c)
 bool conv_pp_f16_applicable(const ConvArgsH& a) {
-  return pp_shape_ok<MODE_F16>(a.W, a.Cin, a.Cout, a.stride, a.pad, a.kh, a.kw) && a.Ho == a.H && a.Wo == a.W;
+  return pp_shape_ok<MODE_F16, 2>(a.W, a.Cin, a.Cout, a.stride, a.pad, a.kh, a.kw) && a.Ho == a.H && a.Wo == a.W;
 }
 
 int launch_conv_pp_f16(const ConvArgsH& h, hipStream_t stream) {
@@ -672,7 +687,7 @@ int launch_conv_pp_f16(const ConvArgsH& h, hipStream_t stream) {
   a.y = reinterpret_cast<float*>(h.y);
   a.M = h.M; a.H = h.H; a.W = h.W; a.Cin = h.Cin; a.Ho = h.Ho; a.Wo = h.Wo; a.Cout = h.Cout; a.stride = 1; a.pad = 1;
   a.Kpad = h.Kpad; a.relu = h.relu; a.no_tail_split = h.no_tail_split;
-  return h.pre_scale ? launch_pp_npc<MODE_F16, true>(a, stream) : launch_pp_npc<MODE_F16, false>(a, stream);
+  return h.pre_scale ? launch_pp_nt<MODE_F16, true, 2>(a, stream) : launch_pp_nt<MODE_F16, false, 2>(a, stream);
 }
 
 }  // namespace hp

@@ -954,7 +954,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         rc = launch_conv_split(a, stream);
         // three fp16 MFMAs per product over whole 256- / 512-row tiles; an fp16 MFMA FLOP occupies the matrix pipe for
         // 1/16 of an fp32 one, so it is counted as 1/16: mfma_flops / time / fp32 peak stays "how busy is the pipe"
-        const int64_t bm = L.cout % 128 == 0 ? 256 : 512;
+        const int64_t bm = (L.cout % 128 == 0 || (L.stride == 1 && conv_pp_split_applicable(a, L.kh, L.kw))) ? 256 : 512;  // 256-row tiles on the ping-pong kernel
         mfma_flops = 3.0 * 2.0 * (double)((a.M + bm - 1) / bm * bm) * L.cout * L.Kpad / 16.0;
       } else if (wino_ok && L.w_wino.p && conv_wino_launchable(a)) {
         a.w = (const float*)L.w_wino.p;
