@@ -49,3 +49,34 @@ for case in range(n_cases):
           f"relu={int(relu)}  " + "  ".join(f"{a} {e:.1e}" for a, e in errs.items()) + flag)
 print("worst relative difference:", worst)
 assert worst < 6e-5
+
+# fp16 plan: the persistent ping-pong kernel (Cin % 64 == 0, Cout % 128 == 0) and the generic fp16 kernels against torch's
+# fp32 convolution of the same fp16-rounded operands; HP_PP_GRID=8 makes every workgroup walk many items
+worst16 = 0.0
+for case in range(max(8, n_cases // 4)):
+    h, w = int(rs.randint(2, 50)), int(rs.randint(2, 90))
+    cin, cout = 64 * int(rs.randint(1, 5)), 128 * int(rs.randint(1, 4))
+    n = int(rs.choice([1, 3, 17, 40, 129]))
+    if n * h * w * max(cin, cout) > 2e8:
+        n = max(1, int(2e8 // (h * w * max(cin, cout))))
+    pre, res, relu = (bool(rs.randint(2)) for _ in range(3))
+    x = torch.randn(n, h, w, cin, device=dev).half()
+    wt = (torch.randn(cout, 3, 3, cin, device=dev) / np.sqrt(9 * cin)).half()
+    b = torch.randn(cout, device=dev)
+    ps = (torch.rand(cin, device=dev) + 0.5).half() if pre else None
+    pb = (torch.randn(cin, device=dev) * 0.3).half() if pre else None
+    r = torch.randn(n, h, w, cout, device=dev).half() if res else None
+    y = ops.conv2d_nhwc_f16(x, wt, 1, 1, b, r, ps, pb, relu).float()
+    xa = x.float()
+    if pre:
+        xa = torch.relu((x * ps + pb).float())  # the kernel forms the prologue in fp16
+    ref = torch.nn.functional.conv2d(xa.permute(0, 3, 1, 2), wt.float().permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+    if res:
+        ref = ref + r.float()
+    if relu:
+        ref = torch.relu(ref)
+    e = float((y - ref).abs().max() / max(1.0, float(ref.abs().max())))
+    worst16 = max(worst16, e)
+    print(f"f16 {case:3d} n={n:3d} {h:2d}x{w:3d} {cin:3d}->{cout:3d} pre={int(pre)} res={int(res)} relu={int(relu)}  {e:.1e}" + ("" if e < 2e-3 else "   <-- MISMATCH"))
+print("worst fp16 relative difference:", worst16)
+assert worst16 < 2e-3

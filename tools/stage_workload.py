@@ -16,8 +16,9 @@ from happypose_amd import ops  # noqa: E402
 dev = torch.device("cuda:0")
 reps = int(os.environ.get("HP_STAGE_REPS", "5"))
 flags = dict(msaa=bool(int(os.environ.get("HP_STAGE_MSAA", "0"))), aniso=bool(int(os.environ.get("HP_STAGE_ANISO", "0"))))
+only = os.environ.get("HP_STAGE_ONLY", "")  # "raster": time / launch the rasteriser stage alone (per-workload PMC passes)
 out = {}
-for wl in ("C2", "C3"):
+for wl in os.environ.get("HP_STAGE_WORKLOADS", "C2,C3").split(","):
     ds, renderer, scene, weights, model = bench.build_world(dev, "resnet34", seed=0, workload=wl, n_lanes=1)
     store = renderer.store
     B = len(scene["TCO_hyp"])
@@ -52,6 +53,8 @@ for wl in ("C2", "C3"):
     crop_bytes = float(B * 76800 * n_img * 4)
     res = {}
     for name, fn, nbytes in (("crop", crop, crop_bytes), ("raster", raster, raster_bytes), ("render_inputs", fused, raster_bytes + crop_bytes)):
+        if only and name != only:
+            continue
         for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
