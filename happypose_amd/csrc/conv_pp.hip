@@ -670,7 +670,13 @@ bool conv_pp_split_applicable(const ConvArgs& a, int kh, int kw) {
 }
 
 int launch_conv_pp_split(const ConvArgs& a, hipStream_t stream) {
-  if (pp_use_bn64(a.Cout)) return a.pre_scale ? launch_pp_nt<MODE_SPLIT, true, 1>(a, stream) : launch_pp_nt<MODE_SPLIT, false, 1>(a, stream);
+  // HP_PP_SMALL64=<percent>: 256 x 64 tiles also for Cout % 128 == 0 layers whose 256 x 128 tiling has fewer tiles than that
+  // share of the CUs (the 15 x 20 and 8 x 10 layers at 64 samples per lane: 150 / 80 tiles on 256 CUs)
+  static const int small64 = std::getenv("HP_PP_SMALL64") ? std::atoi(std::getenv("HP_PP_SMALL64")) : 0;
+  const bool few = small64 > 0 && a.Cout % 128 == 0 &&
+                   (int64_t)((a.M + BM - 1) / BM) * (a.Cout / 128) * 100 < (int64_t)small64 * conv_num_cus() &&
+                   pp_shape_ok<MODE_SPLIT, 1>(a.W, a.Cin, a.Cout, a.stride, a.pad, 3, 3);
+  if (pp_use_bn64(a.Cout) || few) return a.pre_scale ? launch_pp_nt<MODE_SPLIT, true, 1>(a, stream) : launch_pp_nt<MODE_SPLIT, false, 1>(a, stream);
   return a.pre_scale ? launch_pp_nt<MODE_SPLIT, true, 2>(a, stream) : launch_pp_nt<MODE_SPLIT, false, 2>(a, stream);
 }
 
