@@ -165,6 +165,9 @@ int conv_split_plan_tail(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg
 // ping-pong 3x3 / stride-1 kernel for Cout % 128 == 0 (conv_pp.hip): the two waves of a SIMD alternate between an
 // LDS / staging segment and an MFMA burst; fp32 (split-fp16 weights of conv_split_transform_weights) and fp16 modes
 bool conv_pp_split_applicable(const ConvArgs& a, int kh, int kw);
+// the stride-2 3x3 layers on the same skeleton (conv3x3s2_pp): double-buffered space-to-depth patches, persistent items
+bool conv_pp_s2_applicable(const ConvArgs& a, int kh, int kw);
+int launch_conv_pp_s2_split(const ConvArgs& a, hipStream_t stream);
 int launch_conv_pp_split(const ConvArgs& a, hipStream_t stream);
 struct ConvArgsH;
 bool conv_pp_f16_applicable(const ConvArgsH& a);

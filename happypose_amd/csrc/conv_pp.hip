@@ -597,6 +597,288 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / STRIDE-2 / pad-1 layers (the first conv of layer2 / 3 / 4) on the same skeleton (round 4).  conv3x3s2_split_f32
+// (conv_split.hip) keeps ONE patch buffer: every (phase, chunk) of the space-to-depth walk ends in barrier -> convert + store
+// the next patch -> barrier with the matrix pipe idle, a patch feeds 2.25 taps on average, and prologue / epilogue are exposed
+// (one item per workgroup): SQ counters put the matrix pipe at 0.15 busy (profiles/r04a_conv_pmc_summary.txt).  Here the walk
+// (same entry order e -> (phase, chunk, tap), same pre-split weights: s2_entry / s2_tap of conv_split.hip restated below) runs
+// as ping-pong taps on a DOUBLE-buffered patch: the patch of sub-patch u + 1 is converted and stored by the L segment of
+// u's last tap while the other wave group multiplies, its loads having been issued when u's own patch was stored; items are
+// persistent, the epilogue is pp_epilogue_direct.
+__device__ __forceinline__ void pp_s2_entry(int e, int n, int& ph, int& c, int& t, int& T) {
+  if (e < n) { ph = 0; c = e; t = 0; T = 1; }
+  else if (e < 3 * n) { ph = 1; c = (e - n) >> 1; t = (e - n) & 1; T = 2; }
+  else if (e < 5 * n) { ph = 2; c = (e - 3 * n) >> 1; t = (e - 3 * n) & 1; T = 2; }
+  else { ph = 3; c = (e - 5 * n) >> 2; t = (e - 5 * n) & 3; T = 4; }
+}
+__device__ __forceinline__ void pp_s2_tap(int ph, int t, int& di, int& dj, int& kh, int& kw) {
+  const int p = ph >> 1, q = ph & 1;
+  const int ti = (p && q) ? t >> 1 : t, tj = (p && q) ? t & 1 : t;
+  di = p ? ti - 1 : 0; kh = p ? 2 * ti : 1;  // phase row 1 holds the input rows of kh = 0 (one row up) and kh = 2
+  dj = q ? tj - 1 : 0; kw = q ? 2 * tj : 1;
+}
+
+struct PPS2 {
+  static constexpr int BN = 128, NT = 2, CKC = 32, PROWS = kPPThreads / 4;
+  static int P(int Wo) { return BM + Wo + 1; }
+  static int npc(int Wo) { return (P(Wo) + PROWS - 1) / PROWS; }
+  static constexpr int kPreFloats = 2 * 512;
+  static size_t lds_bytes(int Wo) { return ((size_t)2 * P(Wo) * LDH + 2 * (size_t)BN * LDH + LDH) * 2 + kPreFloats * 4; }
+};
+
+template <bool PRE, int NPC>
+__global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3s2_pp(ConvArgs a, int P) {
+  constexpr int BN = PPS2::BN, NT = PPS2::NT, CKC = PPS2::CKC, PROWS = PPS2::PROWS;
+  constexpr int NB = BN * 8 / kPPThreads, BROWS = kPPThreads / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  _Float16* const patch = reinterpret_cast<_Float16*>(lds_raw);  // [2][P][LDH]
+  _Float16* const Bs = patch + 2 * P * LDH;                        // [2][BN][LDH]
+  _Float16* const zrow = Bs + 2 * BN * LDH;
+  float* const pre_lds = reinterpret_cast<float*>(zrow + LDH);
+  float act_sx = 1.f, act_inv = 1.f;
+  conv_act_scale(a, act_sx, act_inv);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = a.W, H = a.H, C = a.Cin, Wo = a.Wo, Ho = a.Ho;
+  const int n = C / CKC, nent = 9 * n, npatch = 4 * n;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((a.M / (Ho * Wo)) * (int64_t)H * W * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)((size_t)a.Cout * 9 * C * 4), 0x00020000);
+
+  const int pk = tid & 3, pr0 = tid >> 2;
+  _Float16* const Pst = patch + pr0 * LDH + 8 * pk;
+  const int bk = tid & 7, br0 = tid >> 3;
+  _Float16* const Bst = Bs + br0 * LDH + 8 * bk;
+  if (tid < LDH / 2) reinterpret_cast<unsigned*>(zrow)[tid] = 0u;
+  if (PRE) {
+    for (int i = tid; i < C; i += kPPThreads) { pre_lds[i] = a.pre_scale[i] * act_sx; pre_lds[C + i] = a.pre_shift[i] * act_sx; }
+    __syncthreads();
+  }
+  const int wm = ((wave & 3) >> 1) * 64 + (wave >> 2) * 128, wn = (wave & 1) * (BN / 2);
+  const int frow = lane & 31, fk = 8 * (lane >> 5);
+  const int srow = 16 * ((frow >> 2) & 1) + 4 * (frow >> 3) + (frow & 3);  // see conv3x3_pp: 16 consecutive couts per lane
+  const _Float16* const Bfr = Bs + (wn + srow) * LDH + fk;
+  const _Float16* Afr[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) Afr[mt] = patch + (wm + mt * 32 + frow + Wo + 1) * LDH + fk;
+  const _Float16* const Zfr = zrow + fk;
+  const bool odd = wave >= 4;
+
+  auto opaque_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
+  auto opaque_args = [&]() { KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p; };
+#else
+  typedef const ConvArgs* KArgs;
+  auto opaque_args = [&]() { return &a; };
+#endif
+
+  // ---- item state
+  const int nblk = a.tiles_m * a.tiles_n, per_xcd = (nblk + 7) / 8, nvb = 8 * per_xcd;
+  unsigned pbase[NPC], pflag[NPC];  // input pixel (2 oh, 2 ow) of the thread's patch rows; bit 0 inside, 1: row 2 oh + 1, 2: col 2 ow + 1
+  unsigned wvoff[NB];
+  unsigned vmask[MT];
+  struct Item { int n0; int64_t m0; };
+  auto decode = [&](int vb, Item& it) -> bool {
+    if (vb >= nvb) return false;
+    const int lin = (vb % 8) * per_xcd + vb / 8;
+    if (lin >= nblk) return false;
+    const ConvArgs a = *opaque_args();
+    const int t_ = opaque_tid();
+    const int br0 = t_ >> 3, bk = t_ & 7, frow = t_ & 31, wave_ = t_ >> 6, pr0 = t_ >> 2, pk = t_ & 3;
+    const int wm = ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128;
+    const int tile_m = fdiv(lin, a.fd_tn), tile_n = lin - tile_m * a.tiles_n;
+    it.m0 = (int64_t)tile_m * BM;
+    it.n0 = tile_n * BN;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int64_t g = it.m0 - (Wo + 1) + pr0 + PROWS * j;
+      pbase[j] = 0; pflag[j] = 0;
+      if (pr0 + PROWS * j < P && g >= 0 && g < a.M) {
+        const int img = fdiv((int)g, a.fd_howo);
+        const int rem = (int)g - img * (Ho * Wo);
+        const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * Wo;
+        pbase[j] = (unsigned)(((((int64_t)img * H + 2 * oh) * W + 2 * ow) * C + 8 * pk) * 4);
+        pflag[j] = 1u | (2 * oh + 1 < H ? 2u : 0u) | (2 * ow + 1 < W ? 4u : 0u);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wvoff[i] = (unsigned)(((int64_t)(it.n0 + br0 + BROWS * i) * (18 * C) + 8 * bk) * 2);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int64_t g = it.m0 + wm + mt * 32 + frow;
+      unsigned mk = 0;
+      if (g < a.M) {
+        const int rem = (int)g - fdiv((int)g, a.fd_howo) * (Ho * Wo);
+        const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * Wo;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int ih = 2 * oh + t / 3 - 1, iw = 2 * ow + t % 3 - 1;
+          mk |= ((((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W)) ? 1u : 0u) << t;
+        }
+      }
+      vmask[mt] = mk;
+    }
+    return true;
+  };
+
+  pp_floatx16 acc[MT][NT];
+  pp_floatx4 pr[NPC][2];
+  pp_halfx8 rb[2][NB];
+  auto patch_voff = [&](int j, int ph) -> unsigned {
+    const unsigned need = 1u | ((ph & 2) ? 2u : 0u) | ((ph & 1) ? 4u : 0u);
+    return (pflag[j] & need) == need ? pbase[j] : kOob;
+  };
+  auto load_patch = [&](int u) {  // sub-patch u = ph * n + c: raw fp32 rows -> registers
+    const int ph = u / n, c = u - ph * n;
+    const unsigned soff = (unsigned)((((ph >> 1) * W + (ph & 1)) * C + c * CKC) * 4);
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const unsigned vo = patch_voff(j, ph);
+      pr[j][0] = ldf4(xrsrc, vo, soff);
+      pr[j][1] = ldf4(xrsrc, vo, soff + 16);
+    }
+  };
+  auto store_patch = [&](int u) {  // registers -> patch buffer u & 1 (BN + ReLU prologue, activation scale, hi / lo split)
+    const int ph = u / n, c = u - ph * n;
+    _Float16* const dst = Pst + (u & 1) * P * LDH;
+    pp_floatx4 ps[2], pb[2];
+    if (PRE) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ps[h] = *reinterpret_cast<const pp_floatx4*>(pre_lds + c * CKC + 8 * pk + 4 * h);
+        pb[h] = *reinterpret_cast<const pp_floatx4*>(pre_lds + C + c * CKC + 8 * pk + 4 * h);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      if (pr0 + PROWS * j < P) {
+        const bool real = patch_voff(j, ph) != kOob;
+        pp_halfx4 hi[2], lo[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          pp_floatx4 v = pr[j][h];
+          if (PRE) {
+            v = __builtin_elementwise_max(v * ps[h] + pb[h], pp_floatx4{0.f, 0.f, 0.f, 0.f});
+            if (!real) v = pp_floatx4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            v = v * act_sx;
+          }
+          hi[h] = __builtin_convertvector(v, pp_halfx4);
+          lo[h] = __builtin_convertvector(v - __builtin_convertvector(hi[h], pp_floatx4), pp_halfx4);
+        }
+        *reinterpret_cast<pp_halfx8*>(dst + PROWS * j * LDH) = __builtin_shufflevector(hi[0], hi[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<pp_halfx8*>(dst + PROWS * j * LDH + 32) = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+  };
+  auto load_b = [&](int set, int e) {
+    const int e2 = e < nent ? e : nent - 1;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[set][i] = ldh8(wrsrc, wvoff[i], (unsigned)(e2 * 128));
+  };
+  auto store_b = [&](int set, int buf) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<pp_halfx8*>(Bst + buf * BN * LDH + BROWS * i * LDH) = rb[set][i];
+  };
+  auto issue_first_loads = [&]() {
+    load_patch(0);
+    load_b(0, 0);
+    load_b(1, 1);
+  };
+
+  // one entry (tap): L segment, barrier, C segment, barrier.  Pb = weight buffer parity (compile time), patch buffer u & 1
+  auto entry_step = [&](int e, auto par) {
+    constexpr int Pb = decltype(par)::value;
+    int ph, c, t, T;
+    pp_s2_entry(e, n, ph, c, t, T);
+    int di, dj, kh, kw;
+    pp_s2_tap(ph, t, di, dj, kh, kw);
+    const int d = di * Wo + dj, bit = kh * 3 + kw;
+    const int u = ph * n + c;
+    // ---- L
+    store_b(1 - Pb, 1 - Pb);
+    load_b(1 - Pb, e + 3);
+    if (t == T - 1 && u + 1 < npatch) {  // wave-uniform: the next sub-patch goes into the other buffer now ...
+      store_patch(u + 1);
+      if (u + 2 < npatch) load_patch(u + 2);  // ... and its successor's loads take the registers
+    }
+    pp_halfx8 fa[4][MT], fb[4][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      unsigned vm = vmask[i];
+      asm volatile("" : "+v"(vm));
+      const _Float16* const Ab = ((vm >> bit) & 1u) ? Afr[i] + (u & 1) * P * LDH + d * LDH : Zfr;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fa[q][i] = *reinterpret_cast<const pp_halfx8*>(Ab + q * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fb[q][i] = *reinterpret_cast<const pp_halfx8*>(Bfr + Pb * BN * LDH + i * 32 * LDH + q * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C
+    auto mm = [&](const pp_halfx8 (&x)[MT], const pp_halfx8 (&y)[NT]) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y[ni], x[mi], acc[mi][ni], 0, 0, 0);
+    };
+    mm(fa[0], fb[0]); mm(fa[0], fb[2]); mm(fa[2], fb[0]);
+    mm(fa[1], fb[1]); mm(fa[1], fb[3]); mm(fa[3], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  Item cur{};
+  int vb = blockIdx.x;
+  bool have = decode(vb, cur);
+  if (have) issue_first_loads();
+  while (have) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    store_patch(0);
+    if (npatch > 1) load_patch(1);
+    store_b(0, 0);
+    load_b(0, 2);
+    __syncthreads();
+    if (odd) __builtin_amdgcn_s_barrier();
+    for (int e = 0; e < nent; e += 2) {  // 9 n entries, n even
+      entry_step(e, std::integral_constant<int, 0>{});
+      entry_step(e + 1, std::integral_constant<int, 1>{});
+    }
+    if (!odd) __builtin_amdgcn_s_barrier();
+    Item nxt{};
+    vb += (int)gridDim.x;
+    bool issued = false;
+    const ConvArgs ea = *opaque_args();
+    auto prefetch_next = [&]() {
+      have = decode(vb, nxt);
+      if (have) issue_first_loads();
+      issued = true;
+    };
+    {
+      const int t_ = opaque_tid(), wave_ = t_ >> 6;
+      pp_epilogue_direct<MODE_SPLIT, NT>(ea, acc, cur.m0, cur.n0, ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128, (wave_ & 1) * (BN / 2), act_inv,
+                                         t_ & 63, prefetch_next);
+    }
+    if (!issued) prefetch_next();
+    cur = nxt;
+  }
+}
+
 static int conv_num_cus() {  // of the current device (queried once: one device per process, as everywhere in this library)
   static const int cus = [] {
     int dev = 0, n = 256;
@@ -661,6 +943,42 @@ bool pp_use_bn64(int Cout) {
   return on && Cout % 128 != 0;
 }
 
+
+template <bool PRE, int NPC>
+int launch_pp_s2_variant(ConvArgs args, hipStream_t stream) {
+  static bool opted = false, spills = false;
+  if (!opted) {
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_pp<PRE, NPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     159 * 1024));
+    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3s2_pp<PRE, NPC>));
+    opted = true;
+  }
+  if (spills) count_scratch_launch();
+  args.tiles_m = (int)((args.M + BM - 1) / BM);
+  args.tiles_n = args.Cout / PPS2::BN;
+  args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
+  args.fd_wo = make_fastdiv((unsigned)args.Wo);
+  args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
+  const int nblk = args.tiles_m * args.tiles_n;
+  const int grid = std::min(8 * ((nblk + 7) / 8), conv_num_cus() / 8 * 8);
+  hipLaunchKernelGGL((conv3x3s2_pp<PRE, NPC>), dim3(grid), dim3(kPPThreads), PPS2::lds_bytes(args.Wo), stream, args, PPS2::P(args.Wo));
+  return check_launch("conv3x3s2_pp");
+}
+
+}  // namespace
+
+// stride-2 entry (fp32 / split mode): a.w = weights split by conv_split_transform_weights(..., stride 2)
+bool conv_pp_s2_applicable(const ConvArgs& a, int kh, int kw) {
+  static const bool off = std::getenv("HP_CONV_NO_PP") != nullptr || std::getenv("HP_CONV_NO_PP_S2") != nullptr;
+  return !off && kh == 3 && kw == 3 && a.stride == 2 && a.pad == 1 && a.Cin % 64 == 0 && a.Cin <= 512 && a.Cout % PPS2::BN == 0 &&
+         a.Ho == (a.H - 1) / 2 + 1 && a.Wo == (a.W - 1) / 2 + 1 && PPS2::npc(a.Wo) <= 3 && PPS2::lds_bytes(a.Wo) <= 159 * 1024;
+}
+
+int launch_conv_pp_s2_split(const ConvArgs& a, hipStream_t stream) {
+  return a.pre_scale ? launch_pp_s2_variant<true, 3>(a, stream) : launch_pp_s2_variant<false, 3>(a, stream);
+}
+
+namespace {
 }  // namespace
 
 // fp32 (split-fp16) entry: a.w = weights split by conv_split_transform_weights

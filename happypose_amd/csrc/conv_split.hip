@@ -927,8 +927,10 @@ int conv_split_transform_weights(const float* d_w, void* d_ws, int cout, int cin
 
 int launch_conv_split(const ConvArgs& a, hipStream_t stream) {
   const bool pre = a.pre_scale != nullptr;
-  if (a.stride == 2)
+  if (a.stride == 2) {
+    if (conv_pp_s2_applicable(a, 3, 3)) return launch_conv_pp_s2_split(a, stream);  // ping-pong skeleton (conv_pp.hip)
     return pre ? launch_split_s2_variant<4, 2, true, 3>(a, stream) : launch_split_s2_variant<4, 2, false, 3>(a, stream);
+  }
   static const bool t128 = std::getenv("HP_SPLIT_128") != nullptr;  // experiment: 128 x 128 tiles, 4 waves, two workgroups per CU
   if (t128 && a.Cout % 128 == 0 && SplitTile<2, 2>::npc(a.W) <= 7)
     return pre ? launch_split_npc<2, 2, true>(a, stream) : launch_split_npc<2, 2, false>(a, stream);
