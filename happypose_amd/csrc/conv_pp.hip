@@ -642,7 +642,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = a.W, H = a.H, C = a.Cin, Wo = a.Wo, Ho = a.Ho;
-  const int n = C / CKC, nent = 9 * n, npatch = 4 * n;
+  const int n = C / CKC;  // 32-channel chunks of the layer; an item covers chunks [c0, c0 + nl) (all of them unless K-sliced)
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x), 0, (int)((a.M / (Ho * Wo)) * (int64_t)H * W * C * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc =
@@ -676,17 +676,37 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   auto opaque_args = [&]() { return &a; };
 #endif
 
-  // ---- item state
-  const int nblk = a.tiles_m * a.tiles_n, per_xcd = (nblk + 7) / 8, nvb = 8 * per_xcd;
+  // ---- item state.  K slices (tail items of conv_split_plan_tail, as in conv3x3_pp) cut the CHUNK range: a slice walks all
+  // four phases of its chunks, so its entries are whole patches; slice bounds are even (pairs of chunks = the planner's unit)
+  const int nvb = 8 * (a.sk_regular / 8 + (a.sk_tail_items + 7) / 8);
+  int c0 = 0, nl = n, nent = 9 * n, npatch = 4 * n;
   unsigned pbase[NPC], pflag[NPC];  // input pixel (2 oh, 2 ow) of the thread's patch rows; bit 0 inside, 1: row 2 oh + 1, 2: col 2 ow + 1
   unsigned wvoff[NB];
   unsigned vmask[MT];
-  struct Item { int n0; int64_t m0; };
+  struct Item { int lin, slice, n0; bool split; int64_t m0; };
   auto decode = [&](int vb, Item& it) -> bool {
     if (vb >= nvb) return false;
-    const int lin = (vb % 8) * per_xcd + vb / 8;
-    if (lin >= nblk) return false;
     const ConvArgs a = *opaque_args();
+    {
+      const int rpx = a.sk_regular / 8, tpx = (a.sk_tail_items + 7) / 8;
+      const int xcd = vb % 8, li = vb / 8;
+      it.slice = 0; it.split = false;
+      if (li < rpx) {
+        it.lin = xcd * rpx + li;
+      } else {
+        const int ti = xcd * tpx + (li - rpx);
+        if (li - rpx >= tpx || ti >= a.sk_tail_items) return false;
+        it.lin = a.sk_regular + ti / a.sk_S;
+        it.slice = ti % a.sk_S;
+        it.split = a.sk_S > 1;
+      }
+    }
+    const int lin = it.lin;
+    {
+      const int U = n / 2;
+      const int u0 = it.split ? it.slice * U / a.sk_S : 0, u1 = it.split ? (it.slice + 1) * U / a.sk_S : U;
+      c0 = 2 * u0; nl = 2 * (u1 - u0); nent = 9 * nl; npatch = 4 * nl;
+    }
     const int t_ = opaque_tid();
     const int br0 = t_ >> 3, bk = t_ & 7, frow = t_ & 31, wave_ = t_ >> 6, pr0 = t_ >> 2, pk = t_ & 3;
     const int wm = ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128;
@@ -732,8 +752,8 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     const unsigned need = 1u | ((ph & 2) ? 2u : 0u) | ((ph & 1) ? 4u : 0u);
     return (pflag[j] & need) == need ? pbase[j] : kOob;
   };
-  auto load_patch = [&](int u) {  // sub-patch u = ph * n + c: raw fp32 rows -> registers
-    const int ph = u / n, c = u - ph * n;
+  auto load_patch = [&](int u) {  // sub-patch u = ph * nl + (c - c0) of the item: raw fp32 rows -> registers
+    const int ph = u / nl, c = c0 + (u - ph * nl);
     const unsigned soff = (unsigned)((((ph >> 1) * W + (ph & 1)) * C + c * CKC) * 4);
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
@@ -743,7 +763,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     }
   };
   auto store_patch = [&](int u) {  // registers -> patch buffer u & 1 (BN + ReLU prologue, activation scale, hi / lo split)
-    const int ph = u / n, c = u - ph * n;
+    const int ph = u / nl, c = c0 + (u - ph * nl);
     _Float16* const dst = Pst + (u & 1) * P * LDH;
     pp_floatx4 ps[2], pb[2];
     if (PRE) {
@@ -775,10 +795,13 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
       }
     }
   };
-  auto load_b = [&](int set, int e) {
+  auto load_b = [&](int set, int e) {  // e = local entry of the item -> row of the layer's entry-ordered weights
     const int e2 = e < nent ? e : nent - 1;
+    int ph, cl, t, T;
+    pp_s2_entry(e2, nl, ph, cl, t, T);
+    const int eg = (ph == 0 ? 0 : ph == 1 ? n : ph == 2 ? 3 * n : 5 * n) + (c0 + cl) * T + t;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[set][i] = ldh8(wrsrc, wvoff[i], (unsigned)(e2 * 128));
+    for (int i = 0; i < NB; ++i) rb[set][i] = ldh8(wrsrc, wvoff[i], (unsigned)(eg * 128));
   };
   auto store_b = [&](int set, int buf) {
 #pragma unroll
@@ -794,11 +817,11 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   auto entry_step = [&](int e, auto par) {
     constexpr int Pb = decltype(par)::value;
     int ph, c, t, T;
-    pp_s2_entry(e, n, ph, c, t, T);
+    pp_s2_entry(e, nl, ph, c, t, T);  // c = chunk index inside the item
     int di, dj, kh, kw;
     pp_s2_tap(ph, t, di, dj, kh, kw);
     const int d = di * Wo + dj, bit = kh * 3 + kw;
-    const int u = ph * n + c;
+    const int u = ph * nl + c;
     // ---- L
     store_b(1 - Pb, 1 - Pb);
     load_b(1 - Pb, e + 3);
@@ -862,14 +885,15 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     if (!odd) __builtin_amdgcn_s_barrier();
     Item nxt{};
     vb += (int)gridDim.x;
-    bool issued = false;
+    bool issued = false, finish = true;
     const ConvArgs ea = *opaque_args();
+    if (cur.split) finish = splitk_reduce_sc1<BM, BN, MT, NT, kPPThreads>(ea, acc, cur.lin - ea.sk_regular, cur.slice);
     auto prefetch_next = [&]() {
       have = decode(vb, nxt);
       if (have) issue_first_loads();
       issued = true;
     };
-    {
+    if (finish) {
       const int t_ = opaque_tid(), wave_ = t_ >> 6;
       pp_epilogue_direct<MODE_SPLIT, NT>(ea, acc, cur.m0, cur.n0, ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128, (wave_ & 1) * (BN / 2), act_inv,
                                          t_ & 63, prefetch_next);
@@ -959,8 +983,11 @@ int launch_pp_s2_variant(ConvArgs args, hipStream_t stream) {
   args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
   args.fd_wo = make_fastdiv((unsigned)args.Wo);
   args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
-  const int nblk = args.tiles_m * args.tiles_n;
-  const int grid = std::min(8 * ((nblk + 7) / 8), conv_num_cus() / 8 * 8);
+  // K slices over PAIRS of 32-channel chunks (a slice's entry count stays even); same policy as conv3x3_pp
+  const int rc = conv_split_plan_tail(args, args.tiles_m * args.tiles_n, args.Cin / (2 * PPS2::CKC), (size_t)BM * PPS2::BN, 1, stream);
+  if (rc) return rc;
+  const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
+  const int grid = std::min(8 * per_xcd, conv_num_cus() / 8 * 8);
   hipLaunchKernelGGL((conv3x3s2_pp<PRE, NPC>), dim3(grid), dim3(kPPThreads), PPS2::lds_bytes(args.Wo), stream, args, PPS2::P(args.Wo));
   return check_launch("conv3x3s2_pp");
 }

@@ -37,7 +37,7 @@ def main(fetch_dir, write_dir, out, layer_launches=None):
     res = {"conv_kernel_launches": launches, "conv_launches": layer_launches, "fetch_bytes_per_launch": fetch / layer_launches,
            "write_bytes_per_launch": write / layer_launches, "hbm_bytes_per_launch": (fetch + write) / layer_launches,
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over `bench.py --steps 4 --warmup 1`; "
-                     "FETCH_SIZE x 2 (gfx950 wide-read correction), units of 1024 B, summed over all conv kernels and divided by the number of conv layer launches (25 forwards x 36 layers x 2 lanes)",
+                     "FETCH_SIZE x 2 (gfx950 wide-read correction), units of 1024 B, summed over all conv kernels and divided by the number of conv launches of the profiled command (timed steps, warm-up and the estimator pass alike: every launch of a layer moves the same bytes)",
            "per_kernel": rows}
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)

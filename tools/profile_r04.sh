@@ -25,7 +25,7 @@ fi
 if [ "$WHAT" = "traffic" ] || [ "$WHAT" = "all" ]; then
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/trf_fetch -o p --output-format csv -- python3 bench.py $SHORT > $OUT/trf_fetch.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/trf_write -o p --output-format csv -- python3 bench.py $SHORT > $OUT/trf_write.log 2>&1
-  python3 tools/pmc_traffic.py $(dirname $(find $OUT/trf_fetch -name p_counter_collection.csv | head -1)) $(dirname $(find $OUT/trf_write -name p_counter_collection.csv | head -1)) $OUT/conv_hbm_traffic.json 1800
+  python3 tools/pmc_traffic.py $(dirname $(find $OUT/trf_fetch -name p_counter_collection.csv | head -1)) $(dirname $(find $OUT/trf_write -name p_counter_collection.csv | head -1)) $OUT/conv_hbm_traffic.json
 fi
 if [ "$WHAT" = "raster" ] || [ "$WHAT" = "all" ]; then
   export HP_STAGE_MSAA=1 HP_STAGE_ANISO=1 HP_STAGE_ONLY=raster
