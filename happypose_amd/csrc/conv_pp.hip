@@ -60,18 +60,23 @@ __device__ __forceinline__ pp_halfx8 ldh8(__amdgpu_buffer_rsrc_t r, unsigned vof
   return __builtin_bit_cast(pp_halfx8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
-template <int MODE, int NT>
+// WIDE (round 4, fp32 / split mode only): 512 x 64 block tile for the 64-channel layers -- eight waves of 64 x 64, stacked in
+// M (waves 0-3 rows 0-255, their SIMD partners 4-7 rows 256-511), ONE patch buffer (two would not fit) swapped between
+// chunks in a two-phase bubble.
+template <int MODE, int NT, bool WIDE = false>
 struct PP {
-  static constexpr int BN = 64 * NT;
+  static constexpr int BN = WIDE ? 64 : 64 * NT;
+  static constexpr int BMT = WIDE ? 512 : BM;   // rows of the block tile
+  static constexpr int NPB = WIDE ? 1 : 2;      // patch buffers
   static constexpr int CKC = MODE == MODE_SPLIT ? 32 : 64;  // channels per chunk (= one 128-B LDS row)
   static constexpr int TPR = MODE == MODE_SPLIT ? 4 : 8;    // threads per patch row (8 channels each)
   static constexpr int PROWS = kPPThreads / TPR;            // patch rows per staging pass
   static constexpr int ESZ = MODE == MODE_SPLIT ? 4 : 2;    // bytes per activation element
-  static int P(int W) { return BM + 2 * W + 2; }
+  static int P(int W) { return BMT + 2 * W + 2; }
   static int npc(int W) { return (P(W) + PROWS - 1) / PROWS; }
   static constexpr int kPreFloats = 2 * 512;  // pre-activation BN scale / shift of up to 512 input channels, staged once
   static size_t lds_bytes(int W) {
-    return ((size_t)2 * P(W) * LDH + 2 * (size_t)BN * LDH + LDH) * 2 + kPreFloats * 4;  // the epilogue needs none (direct stores)
+    return ((size_t)NPB * P(W) * LDH + 2 * (size_t)BN * LDH + LDH) * 2 + kPreFloats * 4;  // the epilogue needs none (direct stores)
   }
 };
 
@@ -234,16 +239,17 @@ __device__ __forceinline__ void pp_epilogue_direct(const ConvArgs& a, pp_floatx1
 }
 
 // a.Kpad: MODE_F16 = elements per weight row ([Cout][Kpad] halves, K = (tap, c)); MODE_SPLIT unused (rows are 18 Cin halves)
-template <int MODE, bool PRE, int NPC, int NT>
+template <int MODE, bool PRE, int NPC, int NT, bool WIDE = false>
 __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_pp(ConvArgs a, int P) {
-  using T = PP<MODE, NT>;
-  constexpr int BN = T::BN;
+  using T = PP<MODE, NT, WIDE>;
+  constexpr int BN = T::BN, BMT = T::BMT, NPB = T::NPB;
+  static_assert(!WIDE || (MODE == MODE_SPLIT && NT == 2), "the 512 x 64 tile exists for the fp32 path only");
   constexpr int CKC = T::CKC, TPR = T::TPR, PROWS = T::PROWS, ESZ = T::ESZ;
   constexpr int NB = BN * 8 / kPPThreads;  // 16-B weight pieces per thread and tap (2)
   constexpr int BROWS = kPPThreads / 8;    // weight rows per staging pass (64)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   _Float16* const patch = reinterpret_cast<_Float16*>(lds_raw);  // [2][P][LDH]
-  _Float16* const Bs = patch + 2 * P * LDH;                        // [2][BN][LDH]
+  _Float16* const Bs = patch + NPB * P * LDH;                      // [2][BN][LDH]
   _Float16* const zrow = Bs + 2 * BN * LDH;                        // [LDH] zeros: what a masked tap reads
   float act_sx = 1.f, act_inv = 1.f;  // ConvArgs::amax_in: power-of-two scale of the staged activations (split mode)
   if constexpr (MODE == MODE_SPLIT) conv_act_scale(a, act_sx, act_inv);
@@ -289,7 +295,9 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     return MODE == MODE_SPLIT ? (unsigned)((cc * 9 + tap) * 128) : (unsigned)((tap * Cin + cc * CKC) * 2);
   };
   // fragment bases
-  const int wm = ((wave & 3) >> 1) * 64 + (wave >> 2) * 128, wn = (wave & 1) * (BN / 2);  // waves w and w + 4 share a SIMD
+  // waves w and w + 4 share a SIMD; WIDE: eight 64-row slabs of the 512-row tile, every wave all 64 couts
+  const int wm = WIDE ? (wave & 3) * 64 + (wave >> 2) * 256 : ((wave & 3) >> 1) * 64 + (wave >> 2) * 128;
+  const int wn = WIDE ? 0 : (wave & 1) * (BN / 2);
   const int frow = lane & 31, fk = 8 * (lane >> 5);
   // MFMA row i of a 32-cout block multiplies weight row sigma(i): the lane's 16 accumulator rows are then 16 consecutive couts
   const int srow = 16 * ((frow >> 2) & 1) + 4 * (frow >> 3) + (frow & 3);
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     const ConvArgs a = *ka;  // shadows the kernel argument inside this lambda
     const int t_ = opaque_tid();
     const int br0 = t_ >> 3, bk = t_ & 7, frow = t_ & 31, wave_ = t_ >> 6;
-    const int wm = ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128;
+    const int wm = WIDE ? (wave_ & 3) * 64 + (wave_ >> 2) * 256 : ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128;
     const int pr0 = t_ / TPR;
     const int rpx = a.sk_regular / 8, tpx = (a.sk_tail_items + 7) / 8;
     const int xcd = vb % 8, li = vb / 8;
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
       it.split = a.sk_S > 1;
     }
     const int tile_m = fdiv(it.lin, a.fd_tn), tile_n = it.lin - tile_m * a.tiles_n;
-    it.m0 = (int64_t)tile_m * BM;
+    it.m0 = (int64_t)tile_m * BMT;
     it.n0 = tile_n * BN;
     cc_begin = it.split ? it.slice * ncc_all / a.sk_S : 0;
     ncc = it.split ? (it.slice + 1) * ncc_all / a.sk_S : ncc_all;  // end of this item's chunk range
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
     for (int j = 0; j < NPC; ++j)  // next chunk's patch: one staging pass per tap (taps 0 .. NPC - 1)
       if (j == tap) load_patch(j, next_chunk ? cc + 1 : cc);
-    if (tap == 8 && next_chunk) store_patch(cc + 1, 1 - PQ);
+    if (!WIDE && tap == 8 && next_chunk) store_patch(cc + 1, 1 - PQ);
     const int d = (tap / 3 - 1) * W + (tap % 3 - 1);
     pp_halfx8 fa[4][MT], fb[4][NT];
 #pragma unroll
@@ -526,10 +534,21 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     constexpr int C0 = decltype(c0)::value;
     using E = std::integral_constant<int, C0>;      // even taps
     using O = std::integral_constant<int, 1 - C0>;  // odd taps
-    using Q = std::integral_constant<int, C0>;      // patch buffer
+    using Q = std::integral_constant<int, WIDE ? 0 : C0>;  // patch buffer
     tap_step(cc, 0, E{}, Q{}); tap_step(cc, 1, O{}, Q{}); tap_step(cc, 2, E{}, Q{});
     tap_step(cc, 3, O{}, Q{}); tap_step(cc, 4, E{}, Q{}); tap_step(cc, 5, O{}, Q{});
     tap_step(cc, 6, E{}, Q{}); tap_step(cc, 7, O{}, Q{}); tap_step(cc, 8, E{}, Q{});
+    if (WIDE && cc + 1 < ncc) {
+      // single patch buffer: this wave group is past its C of tap 8, i.e. BOTH groups have read their tap-8 fragments (the
+      // other group's L ran beside that C).  Group A stores its rows of the next chunk while B multiplies tap 8; B stores
+      // while A waits; then A reads tap 0.  The same three statements for both groups, one barrier apart as everything
+      // else: two phases without an MFMA per SIMD and chunk swap (~1.4 k of the ~17 k cycles of a chunk).
+      store_patch(cc + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
 
   Item cur{};
@@ -578,7 +597,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     vb += (int)gridDim.x;
     bool finish = true, issued = false;
     const ConvArgs ea = *opaque_args();  // the epilogue's view of the arguments (see opaque_args)
-    if (cur.split) finish = splitk_reduce_sc1<BM, BN, MT, NT, kPPThreads>(ea, acc, cur.lin - ea.sk_regular, cur.slice);
+    if (cur.split) finish = splitk_reduce_sc1<BMT, BN, MT, NT, kPPThreads>(ea, acc, cur.lin - ea.sk_regular, cur.slice);
     auto prefetch_next = [&]() {  // overwrites the loop state (the K loop of `cur` is over), keeps cur's epilogue constants
       have = decode(vb, nxt);
       if (have) issue_first_loads();
@@ -586,8 +605,8 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     };
     if (finish) {
       const int t_ = opaque_tid(), wave_ = t_ >> 6;
-      pp_epilogue_direct<MODE, NT>(ea, acc, cur.m0, cur.n0, ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128, (wave_ & 1) * (BN / 2), act_inv, t_ & 63,
-                               prefetch_next);
+      pp_epilogue_direct<MODE, NT>(ea, acc, cur.m0, cur.n0, WIDE ? (wave_ & 3) * 64 + (wave_ >> 2) * 256 : ((wave_ & 3) >> 1) * 64 + (wave_ >> 2) * 128,
+                                   WIDE ? 0 : (wave_ & 1) * (BN / 2), act_inv, t_ & 63, prefetch_next);
     }
     if (!issued) prefetch_next();
 #ifdef HP_PP_STAMPS
@@ -912,15 +931,15 @@ static int conv_num_cus() {  // of the current device (queried once: one device 
   return cus;
 }
 
-template <int MODE, bool PRE, int NPC, int NT>
+template <int MODE, bool PRE, int NPC, int NT, bool WIDE = false>
 int launch_pp_variant(ConvArgs args, hipStream_t stream) {
-  using T = PP<MODE, NT>;
-  constexpr int BN = T::BN;
+  using T = PP<MODE, NT, WIDE>;
+  constexpr int BN = T::BN, BM = T::BMT;  // shadows the 256-row constant in this launcher
   static bool opted = false, spills = false;
   if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC, NT>),
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC, NT, WIDE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));  // + the static ticket word
-    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC, NT>));
+    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC, NT, WIDE>));
     opted = true;
   }
   if (spills) count_scratch_launch();
@@ -936,7 +955,7 @@ int launch_pp_variant(ConvArgs args, hipStream_t stream) {
   // virtual blocks stay on its XCD; HP_PP_GRID overrides the cap (experiments)
   static const int cap = std::getenv("HP_PP_GRID") ? std::max(8, std::atoi(std::getenv("HP_PP_GRID")) / 8 * 8) : conv_num_cus() / 8 * 8;
   const int grid = std::min(8 * per_xcd, cap);
-  hipLaunchKernelGGL((conv3x3_pp<MODE, PRE, NPC, NT>), dim3(grid), dim3(kPPThreads), T::lds_bytes(args.W), stream, args,
+  hipLaunchKernelGGL((conv3x3_pp<MODE, PRE, NPC, NT, WIDE>), dim3(grid), dim3(kPPThreads), T::lds_bytes(args.W), stream, args,
                      T::P(args.W));
   return check_launch("conv3x3_pp");
 }
@@ -962,6 +981,14 @@ bool pp_shape_ok(int W, int Cin, int Cout, int stride, int pad, int kh, int kw) 
 // 154 / 172 for conv3x3_split_f32's 256 x 64 tiles in two 4-wave workgroups per CU (85.6 vs 90.7 us at batch 64, the C2
 // step unchanged: 5255 vs 5257 poses/s) -- with 18 taps per tile these layers are bound by their 64-KB-per-tile output
 // stream, which two workgroups per CU overlap with one another's K loops and one workgroup per CU cannot.
+// 512 x 64 tiles (WIDE) for the 64-channel layers: HP_PP_WIDE64=0 switches them back to conv3x3_split_f32's two 4-wave workgroups
+bool pp_wide64_ok(const ConvArgs& a, int kh, int kw) {
+  static const bool off = std::getenv("HP_CONV_NO_PP") != nullptr || (std::getenv("HP_PP_WIDE64") && std::atoi(std::getenv("HP_PP_WIDE64")) == 0);
+  using T = PP<MODE_SPLIT, 2, true>;
+  return !off && kh == 3 && kw == 3 && a.stride == 1 && a.pad == 1 && a.Cout % 128 != 0 && a.Cout % 64 == 0 && a.Cin % T::CKC == 0 &&
+         a.Cin <= 512 && T::npc(a.W) <= 6 && T::lds_bytes(a.W) <= 159 * 1024;
+}
+
 bool pp_use_bn64(int Cout) {
   static const bool on = std::getenv("HP_PP_BN64") != nullptr;
   return on && Cout % 128 != 0;
@@ -1011,6 +1038,7 @@ namespace {
 // fp32 (split-fp16) entry: a.w = weights split by conv_split_transform_weights
 bool conv_pp_split_applicable(const ConvArgs& a, int kh, int kw) {
   if (pp_use_bn64(a.Cout)) return pp_shape_ok<MODE_SPLIT, 1>(a.W, a.Cin, a.Cout, a.stride, a.pad, kh, kw);
+  if (pp_wide64_ok(a, kh, kw)) return true;
   return pp_shape_ok<MODE_SPLIT, 2>(a.W, a.Cin, a.Cout, a.stride, a.pad, kh, kw);
 }
 
@@ -1021,6 +1049,8 @@ int launch_conv_pp_split(const ConvArgs& a, hipStream_t stream) {
   const bool few = small64 > 0 && a.Cout % 128 == 0 &&
                    (int64_t)((a.M + BM - 1) / BM) * (a.Cout / 128) * 100 < (int64_t)small64 * conv_num_cus() &&
                    pp_shape_ok<MODE_SPLIT, 1>(a.W, a.Cin, a.Cout, a.stride, a.pad, 3, 3);
+  if (!pp_use_bn64(a.Cout) && pp_wide64_ok(a, 3, 3))
+    return a.pre_scale ? launch_pp_variant<MODE_SPLIT, true, 6, 2, true>(a, stream) : launch_pp_variant<MODE_SPLIT, false, 6, 2, true>(a, stream);
   if (pp_use_bn64(a.Cout) || few) return a.pre_scale ? launch_pp_nt<MODE_SPLIT, true, 1>(a, stream) : launch_pp_nt<MODE_SPLIT, false, 1>(a, stream);
   return a.pre_scale ? launch_pp_nt<MODE_SPLIT, true, 2>(a, stream) : launch_pp_nt<MODE_SPLIT, false, 2>(a, stream);
 }
