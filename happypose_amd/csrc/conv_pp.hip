@@ -168,7 +168,17 @@ __device__ __forceinline__ void pp_epilogue_direct(const ConvArgs& a, pp_floatx1
             chk += (v[0] + v[1]) + (v[2] + v[3]);
             if (a.relu == HP_ACT_RELU) v = __builtin_elementwise_max(v, pp_floatx4{0.f, 0.f, 0.f, 0.f});
             amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#if defined(HP_PP_NT_STORES)   // experiment: non-temporal output stores
+            __builtin_nontemporal_store(v, reinterpret_cast<pp_floatx4*>(a.y + m * a.Cout + n));
+#elif defined(HP_PP_SC1_STORES)  // experiment: write-through (sc1) output stores
+            {
+              typedef unsigned int pp_uintx4 __attribute__((ext_vector_type(4)));
+              const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0x7FFFFFFF, 0x00020000);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pp_uintx4, v), yr, (int)((m * a.Cout + n) * 4), 0, 16);
+            }
+#else
             *reinterpret_cast<pp_floatx4*>(a.y + m * a.Cout + n) = v;
+#endif
           }
         }
       }
