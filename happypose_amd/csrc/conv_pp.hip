@@ -253,7 +253,7 @@ template <int MODE, bool PRE, int NPC, int NT, bool WIDE = false>
 __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_pp(ConvArgs a, int P) {
   using T = PP<MODE, NT, WIDE>;
   constexpr int BN = T::BN, BMT = T::BMT, NPB = T::NPB;
-  static_assert(!WIDE || (MODE == MODE_SPLIT && NT == 2), "the 512 x 64 tile exists for the fp32 path only");
+  static_assert(!WIDE || NT == 2, "the 512 x 64 tile: every wave covers all 64 couts (two N tiles)");
   constexpr int CKC = T::CKC, TPR = T::TPR, PROWS = T::PROWS, ESZ = T::ESZ;
   constexpr int NB = BN * 8 / kPPThreads;  // 16-B weight pieces per thread and tap (2)
   constexpr int BROWS = kPPThreads / 8;    // weight rows per staging pass (64)
@@ -1066,7 +1066,17 @@ int launch_conv_pp_split(const ConvArgs& a, hipStream_t stream) {
 }
 
 // fp16 entry (the fp16 plan): packed weights [Cout][Kpad] with K = (tap, c)
+// fp16 plan, 64-channel layers with ONE 64-channel chunk (Cin == 64: the 60 x 80 layers of ResNet-34): the 512 x 64 tile needs
+// no chunk swap at all -- nine taps on one staged patch.  HP_PP_WIDE64=0 leaves them on conv3x3_patch_f16.
+static bool pp_f16_wide64_ok(const ConvArgsH& a) {
+  static const bool off = std::getenv("HP_CONV_NO_PP") != nullptr || (std::getenv("HP_PP_WIDE64") && std::atoi(std::getenv("HP_PP_WIDE64")) == 0);
+  using T = PP<MODE_F16, 2, true>;
+  return !off && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Cout % 128 != 0 && a.Cout % 64 == 0 && a.Cin == 64 &&
+         a.Ho == a.H && a.Wo == a.W && T::npc(a.W) <= 11 && T::lds_bytes(a.W) <= 159 * 1024;
+}
+
 bool conv_pp_f16_applicable(const ConvArgsH& a) {
+  if (pp_f16_wide64_ok(a)) return true;
   return pp_shape_ok<MODE_F16, 2>(a.W, a.Cin, a.Cout, a.stride, a.pad, a.kh, a.kw) && a.Ho == a.H && a.Wo == a.W;
 }
 
@@ -1078,6 +1088,8 @@ int launch_conv_pp_f16(const ConvArgsH& h, hipStream_t stream) {
   a.y = reinterpret_cast<float*>(h.y);
   a.M = h.M; a.H = h.H; a.W = h.W; a.Cin = h.Cin; a.Ho = h.Ho; a.Wo = h.Wo; a.Cout = h.Cout; a.stride = 1; a.pad = 1;
   a.Kpad = h.Kpad; a.relu = h.relu; a.no_tail_split = h.no_tail_split;
+  if (pp_f16_wide64_ok(h))
+    return h.pre_scale ? launch_pp_variant<MODE_F16, true, 11, 2, true>(a, stream) : launch_pp_variant<MODE_F16, false, 11, 2, true>(a, stream);
   return h.pre_scale ? launch_pp_nt<MODE_F16, true, 2>(a, stream) : launch_pp_nt<MODE_F16, false, 2>(a, stream);
 }
 
