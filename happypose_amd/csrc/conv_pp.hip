@@ -701,7 +701,6 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
   auto opaque_args = [&]() { KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p; };
 #else
-  typedef const ConvArgs* KArgs;
   auto opaque_args = [&]() { return &a; };
 #endif
 
