@@ -182,9 +182,11 @@ bool conv_stem_split_applicable(const ConvArgs& a, int kh, int kw, int run_mode)
 int launch_conv_stem_split_pool(ConvArgs args, hipStream_t stream);
 // the MegaPose stems (7x7 s2 p3 -> 64, + ReLU + 3x3 s2 max-pool) with the input region of a pooled tile staged once per
 // channel slab (conv_stem7.hip); fp32 (split-fp16 arithmetic) or the fp16 plan; weights packed on the host at plan time
+int conv_num_cus();  // compute units of the current device (conv_pp.hip)
 bool conv_stem7_applicable(int kh, int kw, int stride, int pad, int cin_mem, int cout, int relu, int f16);
 size_t conv_stem7_pack_weights(const float* h_w, int cin_real, int cin_mem, int f16, void* h_out);
 int launch_conv_stem7_pool(const ConvArgs& a, int f16, hipStream_t stream);
+int conv_stem7_f16_krow(int cin_real);
 bool conv_igemm_split_pool_launchable(const ConvArgs& a, int cout_pad);
 int launch_conv_igemm_split_pool(const ConvArgs& a, hipStream_t stream);
 // plan-time choice between the split-fp16 kernel and the exact-fp32 ones for a 3x3 stride-1 layer

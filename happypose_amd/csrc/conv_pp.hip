@@ -45,6 +45,15 @@ typedef float pp_floatx4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long g_pp_stamps[8];
 #endif
 
+int conv_num_cus() {  // of the current device (queried once: one device per process, as everywhere in this library)
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 8 ? n : 256;
+  }();
+  return cus;
+}
+
 namespace {
 
 enum { MODE_SPLIT = 0, MODE_F16 = 1 };
@@ -931,14 +940,6 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 
-static int conv_num_cus() {  // of the current device (queried once: one device per process, as everywhere in this library)
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 8 ? n : 256;
-  }();
-  return cus;
-}
 
 template <int MODE, bool PRE, int NPC, int NT, bool WIDE = false>
 int launch_pp_variant(ConvArgs args, hipStream_t stream) {

@@ -19,7 +19,9 @@
 // step ahead in registers.  4 waves x (64 rows x 64 couts); two workgroups per CU overlap one another's staging and
 // pooled epilogue (conv tile -> LDS -> 3x3 / s2 maxima, conv pixels outside the map excluded as with PyTorch's -inf
 // padding -> bias -> ReLU -> 16-B stores).  The conv map is never written.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -313,6 +315,310 @@ int launch_stem7(ConvArgs args, hipStream_t stream) {
   return check_launch("conv_stem7x7s2_pool");
 }
 
+
+// ---- fp16 plan with <= 9 real input channels (the MegaPose coarse model: 9), round 4: a PERSISTENT two-group kernel ------
+// What the tile kernel above costs on that input (C5, 576 views per launch, profiles/r04d_*: 1.55 ms, matrix pipe 0.42 busy on
+// K padded 9 -> 16 channels): every 48-pooled-pixel tile re-reads all 7 x 64 x 128 weight halves from L2 (6.6 GB per launch),
+// zero-fills and stages its input behind an exposed HBM round trip, and the two workgroups of a CU run in lockstep -- both
+// staging, both multiplying, both pooling at the same time.  Here:
+//   * one 512-thread workgroup per CU walks tiles b, b + G, ...; the weights of all seven filter rows stay in LDS (77 KB);
+//   * K order (kw, c) over a TWELVE-slot pixel: the staged row is [pixel][12] halves, so the fragment of conv pixel dc starts
+//     48 dc bytes into the row: one aligned, conflict-free ds_read_b128 (kRowPix).  35 k-steps per tile instead of 49
+//     (s7p::KSTEPS).  (A ten-slot pixel was built first: its fragments are only 8-byte aligned -- two ds_read_b64 at half
+//     the rate with 2-way bank conflicts whatever the row pitch, and the four multiplying waves ask the LDS for more
+//     cycles than their MFMAs take.)
+//   * the two wave groups (waves 0-3 / 4-7: one wave per SIMD each) alternate ROLES per phase, two workgroup barriers per
+//     phase: M = the 35 k-steps of a tile back to back, fragments fetched two k-steps ahead, and the global loads of the
+//     group's next tile issued at its head; O = the pooled epilogue of the tile just multiplied, then those loads go to LDS.
+//     A SIMD always has one wave in its MFMA stream and one doing everything else (the ping-pong of conv_pp.hip, at tile
+//     granularity);
+//   * wave-local pooling: a wave's 64 GEMM rows are the 7 x 9 conv pixels under its 3 x 4 pooled pixels (the column
+//     shared with the neighbour is computed twice), the MFMAs run transposed (weights as A: a lane holds one pixel and
+//     16 consecutive couts), so bias + ReLU + fp16 rounding happen in registers (max commutes with all three), the tile
+//     goes to LDS as 32-B pieces, 32 couts at a time, and the wave pools what it wrote itself -- no barrier inside the
+//     epilogue; the epilogue tile aliases the group's input region.
+namespace s7p {
+constexpr int kT = 512;
+constexpr int CPP = 12;                  // staged slots per pixel: channels 0-8, the shifted copy of channel 8, two zeros
+constexpr int CMAX = 9;                  // real input channels this layout holds
+constexpr int PXB = 2 * CPP;             // bytes per staged pixel
+constexpr int NPX = 72;                  // staged pixels per row: 71 + the one the last k-step's zero-weight slots read
+constexpr int PITCH = 1744;              // bytes per staged row (72 x 24 = 1728): with kRowPix below the fragment reads are conflict-free
+constexpr int IN_BYTES = IR * PITCH;     // 19 rows
+// K slots of a filter row: pixel kw, channel c -> 12 kw + c.  Six pixels and channels 0-7 of the seventh fill 80 slots = 5
+// k-steps; the one product left over, (kw 6, channel 8), rides in the first pixel's spare slot 9: the staging writes channel 8
+// of pixel q + 6 there (a shifted copy), and slot 9 carries the weight of (kw 6, channel 8).  35 k-steps per tile, not 42.
+constexpr int KSTEPS = 5;
+constexpr int WROWB = (KSTEPS * 16 + 8) * 2;   // bytes per (kh, cout) weight row: 80 halves + 16 B (bank spread)
+constexpr int W_BYTES = 7 * BN * WROWB;  // 78848
+constexpr int EPITCH = (BN + 8) * 2;     // bytes per pixel of the epilogue tile: 64 halves + 16 B
+constexpr int EPI_BYTES = 4 * 64 * EPITCH;     // per group: four waves x 64 pixels
+constexpr int GRP_BYTES = (IN_BYTES > EPI_BYTES ? IN_BYTES : EPI_BYTES);  // the epilogue tile aliases the group's input
+constexpr size_t kLds = (size_t)W_BYTES + 2 * GRP_BYTES;
+constexpr int NIT = (IR * NPX + 255) / 256;    // staged pixels per thread of a group
+static_assert(GRP_BYTES % 16 == 0 && W_BYTES % 16 == 0 && PITCH % 16 == 0, "16-B aligned carve-up");
+static_assert(kLds <= 160 * 1024, "one workgroup per CU");
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+// GEMM row r = 32 mt + (lane & 31) of a wave -> conv pixel 9 dr + dcl of its 7 x 9 block (63 pixels, one twice).  A
+// ds_read_b128 is served in groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: MI355X_MICROARCH.md); the 16
+// fragments of a group start at (2 dr PITCH + 48 dcl) and must fall into 16 different 16-B bank granules mod 256 B.  The
+// table gives every group 16 different granules except the last one (three 2-way pairs); generated by spreading the
+// occurrences of each granule over the four groups.
+__device__ constexpr unsigned char kRowPix[64] = {
+    0, 1, 2, 3, 11, 12, 13, 14, 15, 16, 17, 46, 4, 5, 6, 7, 36, 20, 21, 29, 8, 9, 10, 18, 19, 27, 28, 37, 30, 38, 39, 48,
+    22, 23, 24, 25, 33, 34, 35, 54, 56, 58, 42, 43, 26, 55, 45, 57, 51, 52, 60, 61, 47, 31, 32, 40, 41, 49, 50, 59, 44, 53, 62, 62};
+}  // namespace s7p
+
+// a.x: fp16 [n][H][W][16] (channels >= 9 are never used); a.w: [7][64][88] halves (conv_stem7_pack_weights, layout 2);
+// a.y: pooled fp16 map [n][Hp][Wp][64]
+__global__ __launch_bounds__(s7p::kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_stem7x7s2_pool_f16_pp(ConvArgs a) {
+  using namespace s7p;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, wl = wave & 3, gt = tid & 255;
+  unsigned char* const Wl = lds_raw;
+  unsigned char* const Grp = lds_raw + W_BYTES + grp * GRP_BYTES;
+  const int H = a.H, W = a.W;
+  const _Float16* const xg = reinterpret_cast<const _Float16*>(a.x);
+  _Float16* const yg = reinterpret_cast<_Float16*>(a.y);
+  const int Hp = (a.Ho - 1) / 2 + 1, Wp = (a.Wo - 1) / 2 + 1;
+
+  for (int i = tid; i < W_BYTES / 16; i += kT) reinterpret_cast<uintx4*>(Wl)[i] = reinterpret_cast<const uintx4*>(a.w)[i];
+
+  // tiles of this workgroup: virtual indices v = b + G j (same XCD for all j: G % 8 == 0), XCD-contiguous renumbering
+  const int nblk = a.tiles_m, per_xcd = (nblk + 7) / 8, G = (int)gridDim.x;
+  const int T = (8 * per_xcd - (int)blockIdx.x + G - 1) / G;
+  struct Tile { int img, ty, tx; bool ok; };
+  auto tile_of = [&](int j) -> Tile {
+    Tile t{0, 0, 0, false};
+    if (j < 0 || j >= T) return t;
+    const int v = (int)blockIdx.x + G * j, lin = (v & 7) * per_xcd + (v >> 3);
+    if (lin >= nblk) return t;
+    t.img = fdiv(lin, a.fd_howo);
+    const int rem = lin - t.img * a.sk_S2;
+    t.ty = fdiv(rem, a.fd_wo); t.tx = rem - t.ty * a.sk_S3;
+    t.ok = true;
+    return t;
+  };
+
+  // ---- fragment bases (bytes); the wave's 7 x 9 block starts at conv column 8 wl of the tile
+  const int frow = lane & 31, hsel = lane >> 5;
+  int boff[2], pix[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    pix[mt] = kRowPix[32 * mt + frow];
+    const int dr = pix[mt] / 9, dcl = pix[mt] - 9 * dr;
+    boff[mt] = 2 * dr * PITCH + 2 * (8 * wl + dcl) * PXB + 16 * hsel;
+  }
+  // MFMA row i of a 32-cout block multiplies weight row sigma(i) (conv_pp.hip): the lane's 16 accumulator rows are couts
+  // 16 hsel .. 16 hsel + 15 of the block
+  const int srow = 16 * ((frow >> 2) & 1) + 4 * (frow >> 3) + (frow & 3);
+  const int aoff = srow * WROWB + 16 * hsel;
+
+  // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for the staging loads a group
+  // has in flight across its M role and for the pooled stores of the O role (an HBM round trip per phase)
+  auto lds_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  s7_floatx16 acc[2][2];
+  s7_floatx4 bias_r[2][4];  // the lane's 2 x 16 couts (fetched once: inside the epilogue the loads would queue behind the staging loads)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bias_r[nt][q] = a.bias ? *reinterpret_cast<const s7_floatx4*>(a.bias + 32 * nt + 16 * hsel + 4 * q) : s7_floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // staging registers: the group's NEXT tile, pixel = 16 B (channels 0-7) + 8 B (8-11) of its 32-B record.  The loads are issued
+  // at the head of the M role (two phases before the tile is multiplied) and land under its MFMA stream; the O role that
+  // follows only moves them to LDS.  (Issued at the head of the O role they cost the phase an exposed HBM round trip.)
+  uintx4 sv[NIT];
+  unsigned sw[NIT];  // the dword holding channel 8 (a third load per pixel -- channel 8 of the pixel six to the right, so that the
+                     // record could be composed in registers and stored as three ds_write_b64 -- cost 450 us per launch: TA-bound)
+  auto issue_loads = [&](const Tile& ts) {
+    if (!ts.ok) return;
+#ifdef HP_S7_ABL_NOLOAD
+    if (a.M > 0) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) { sv[k] = uintx4{0u, 0u, 0u, 0u}; sw[k] = 0u; }
+      return;
+    }
+#endif
+    const int ih_base = 2 * (2 * PR * ts.ty - 1) - 3, iw_base = 2 * (2 * PC * ts.tx - 1) - 3;
+    const _Float16* const ximg = xg + (int64_t)ts.img * H * W * 16;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = gt + 256 * k, rr = idx / NPX, cc = idx - rr * NPX;
+      const int ih = ih_base + rr, iw = iw_base + cc;
+      const bool ok = idx < IR * NPX && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      const _Float16* const p = ximg + ((int64_t)ih * W + iw) * 16;
+      sv[k] = ok ? *reinterpret_cast<const uintx4*>(p) : uintx4{0u, 0u, 0u, 0u};
+      sw[k] = ok ? *reinterpret_cast<const unsigned*>(p + 8) : 0u;
+    }
+  };
+
+  auto role_m = [&](const Tile& t, const Tile& tnext) {
+    issue_loads(tnext);
+    if (t.ok) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    // 35 k-steps, fragments fetched TWO steps ahead of their MFMAs (left to itself the compiler issues each ds_read right
+    // before its use and waits for it: the LDS round trip, ~100+ cycles under the other group's traffic, every step)
+    constexpr int NSTEP = 7 * KSTEPS;
+    s7_halfx8 px[3][2], wt[3][2];
+    auto fetch = [&](int st, int slot) {
+      const int kh = st / KSTEPS, kk = st - kh * KSTEPS;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) px[slot][mt] = *reinterpret_cast<const s7_halfx8*>(Grp + boff[mt] + kh * PITCH + 32 * kk);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        wt[slot][nt] = *reinterpret_cast<const s7_halfx8*>(Wl + (kh * BN + 32 * nt) * WROWB + aoff + 32 * kk);
+    };
+#ifdef HP_S7_ABL_NOMFMA  // diagnostics builds (tools/stem7_ablate.sh): phases compiled out
+    const bool mm_on = t.ok && a.M < 0;
+#else
+    const bool mm_on = t.ok;
+#endif
+#ifndef HP_S7_ABL_NOPRIO
+    __builtin_amdgcn_s_setprio(3);  // the multiplying wave goes first on its SIMD (its partner is in the O role)
+#endif
+    if (mm_on) { fetch(0, 0); fetch(1, 1); }
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      if (mm_on) {
+        if (st + 2 < NSTEP) fetch(st + 2, (st + 2) % 3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wt[st % 3][nt], px[st % 3][mt], acc[mt][nt], 0, 0, 0);  // D[cout][pixel]
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (st == 4 * KSTEPS - 1) lds_barrier();  // the O group's mid-phase barrier
+    }
+#ifndef HP_S7_ABL_NOPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    lds_barrier();
+  };
+
+  auto role_o = [&](const Tile& te, const Tile& ts, bool load_now) {
+    if (load_now) issue_loads(ts);
+    // ---- pooled epilogue of the tile this group multiplied in the previous phase
+#ifdef HP_S7_ABL_NOEPI
+    if (te.ok && a.M < 0) {
+#else
+    if (te.ok) {
+#endif
+      unsigned char* const Ew = Grp + wl * 64 * EPITCH;
+      const int oh0 = 2 * PR * te.ty - 1, ow0 = 2 * PC * te.tx - 1 + 8 * wl;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          s7_halfx8 o[2];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = fmaxf(acc[mt][nt][r] + bias_r[nt][r >> 2][r & 3], 0.f);
+            o[r >> 3][r & 7] = (_Float16)v;
+          }
+          unsigned char* const dst = Ew + pix[mt] * EPITCH + 64 * nt + 32 * hsel;
+          *reinterpret_cast<s7_halfx8*>(dst) = o[0];
+          *reinterpret_cast<s7_halfx8*>(dst + 16) = o[1];
+        }
+      // the wave reads back what it wrote itself (the LDS serves a wave's accesses in order): 12 pooled pixels x 8 pieces of
+      // 8 couts = 96 items, lanes 0-31 take two
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const int item = lane + 64 * rep;
+        if (item < 96) {
+          const int c8 = item & 7, pp = item >> 3, py = pp >> 2, pxl = pp & 3;
+          const int ph = PR * te.ty + py, pw = PC * te.tx + 4 * wl + pxl;
+          if (ph < Hp && pw < Wp) {
+            s7_halfx8 best = {0, 0, 0, 0, 0, 0, 0, 0};  // post-ReLU values: 0 is the identity (the window's centre is always inside)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx) {
+                const int dr = 2 * py + dy, dcl = 2 * pxl + dx;
+                if ((unsigned)(oh0 + dr) < (unsigned)a.Ho && (unsigned)(ow0 + dcl) < (unsigned)a.Wo)
+                  best = __builtin_elementwise_max(best, *reinterpret_cast<const s7_halfx8*>(Ew + (9 * dr + dcl) * EPITCH + 16 * c8));
+              }
+            *reinterpret_cast<s7_halfx8*>(yg + (((int64_t)te.img * Hp + ph) * Wp + pw) * BN + 8 * c8) = best;
+          }
+        }
+      }
+    }
+    lds_barrier();  // every wave of the group is done with the epilogue tile: the input region may be overwritten
+    if (ts.ok) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int idx = gt + 256 * k, rr = idx / NPX, cc = idx - rr * NPX;
+        if (idx < IR * NPX) {
+          unsigned char* const d = Grp + rr * PITCH + cc * PXB;
+          reinterpret_cast<uintx2*>(d)[0] = uintx2{sv[k][0], sv[k][1]};
+          reinterpret_cast<uintx2*>(d)[1] = uintx2{sv[k][2], sv[k][3]};
+          const unsigned short c8 = (unsigned short)(sw[k] & 0xFFFFu);
+          reinterpret_cast<unsigned short*>(d)[8] = c8;                                  // channel 8 ...
+          if (cc >= 6) reinterpret_cast<unsigned short*>(d - 6 * PXB)[9] = c8;           // ... and its copy six pixels to the left
+          if (cc >= NPX - 6) reinterpret_cast<unsigned short*>(d)[9] = 0;                // (nobody writes the last six)
+          reinterpret_cast<unsigned*>(d)[5] = 0u;                                        // slots 10, 11: whatever the record's pad channels hold stays out
+        }
+      }
+    }
+    lds_barrier();
+  };
+
+  // phases p = -1 .. T: group g multiplies tile p when p - g is even, otherwise it finishes tile p - 1 and stages tile p + 1
+  // (tiles of parity g).  Group 1 idles through phase -1.
+  int p = -1;
+  if (grp == 1) { lds_barrier(); lds_barrier(); p = 0; }
+  bool first = true;  // the group's first tile has no M role before it to carry its loads
+  while (true) {
+    role_o(tile_of(p - 1), tile_of(p + 1), first);
+    first = false;
+    if (++p > T) break;
+    role_m(tile_of(p), tile_of(p + 2));
+    if (++p > T) break;
+  }
+}
+
+template <int DUMMY = 0>
+int launch_stem7_f16_pp(ConvArgs args, hipStream_t stream) {
+  static bool opted = false;
+  if (!opted) {
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7s2_pool_f16_pp),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)s7p::kLds));
+    opted = true;
+  }
+  const int Hp = (args.Ho - 1) / 2 + 1, Wp = (args.Wo - 1) / 2 + 1;
+  const int tiles_y = (Hp + PR - 1) / PR, tiles_x = (Wp + PC - 1) / PC;
+  const int n_img = (int)(args.M / ((int64_t)args.Ho * args.Wo));
+  args.tiles_m = n_img * tiles_y * tiles_x;
+  args.fd_howo = make_fastdiv((unsigned)(tiles_y * tiles_x));
+  args.fd_wo = make_fastdiv((unsigned)tiles_x);
+  args.sk_S2 = tiles_y * tiles_x;
+  args.sk_S3 = tiles_x;
+  const int per_xcd = (args.tiles_m + 7) / 8;
+  const int grid = std::min(8 * per_xcd, conv_num_cus() / 8 * 8);
+  hipLaunchKernelGGL(conv_stem7x7s2_pool_f16_pp, dim3(grid), dim3(s7p::kT), s7p::kLds, stream, args);
+  return check_launch("conv_stem7x7s2_pool_f16_pp");
+}
+
+// the persistent fp16 kernel takes the layers whose real channels fit its pixel layout (<= 9) (HP_STEM7_F16_OLD=1: the tile kernel)
+bool stem7_f16_pp(int cin_real) {
+  static const bool off = std::getenv("HP_STEM7_F16_OLD") != nullptr;
+  return !off && cin_real > 0 && cin_real <= s7p::CMAX;
+}
+
 int slab_of(int cin, int f16) { return f16 ? 16 : (cin % 8 == 0 ? 8 : 4); }
 
 }  // namespace
@@ -330,6 +636,18 @@ bool conv_stem7_applicable(int kh, int kw, int stride, int pad, int cin_mem, int
 // power-of-two scale-back factors behind them.  Returns the byte size; h_out may be null to query it.
 size_t conv_stem7_pack_weights(const float* h_w /* [64][cin_real][7][7], BN folded */, int cin_real, int cin_mem, int f16,
                                void* h_out) {
+  if (f16 && stem7_f16_pp(cin_real)) {  // layout 2 (conv_stem7x7s2_pool_f16_pp): [kh][cout][88 halves], k = 12 kw + c; (kw 6, c 8) -> slot 9
+    const size_t bytes = (size_t)s7p::W_BYTES;
+    if (!h_out) return bytes;
+    std::vector<_Float16> out(bytes / 2, (_Float16)0.f);
+    for (int o = 0; o < BN; ++o)
+      for (int c = 0; c < cin_real; ++c)
+        for (int kh = 0; kh < 7; ++kh)
+          for (int kw = 0; kw < 7; ++kw)
+            out[((size_t)kh * BN + o) * (s7p::WROWB / 2) + ((kw == 6 && c == 8) ? 9 : kw * s7p::CPP + c)] = (_Float16)h_w[(((size_t)o * cin_real + c) * 7 + kh) * 7 + kw];
+    std::memcpy(h_out, out.data(), bytes);
+    return bytes;
+  }
   const int SC = slab_of(cin_mem, f16), KS = (7 * SC + 15) / 16, NS = cin_mem / SC, nsteps = NS * 7;
   const int wrow = ((f16 ? 1 : 2) * KS * 16 + 31) / 32 * 32;
   const size_t halves = (size_t)nsteps * BN * wrow, bytes = halves * 2 + (f16 ? 0 : BN * 4);
@@ -364,8 +682,13 @@ size_t conv_stem7_pack_weights(const float* h_w /* [64][cin_real][7][7], BN fold
   return bytes;
 }
 
-// a.x / a.Cin = the input as it lies in memory, a.w = conv_stem7_pack_weights, a.y = the POOLED map
+// K elements per filter row the fp16 launch multiplies (7 x 16 channels in 7 k-steps, or 80 slots in 5): bench.py's executed FLOPs
+int conv_stem7_f16_krow(int cin_real) { return stem7_f16_pp(cin_real) ? s7p::KSTEPS * 16 : 112; }
+
+// a.x / a.Cin = the input as it lies in memory, a.w = conv_stem7_pack_weights, a.y = the POOLED map; a.Kpad = the REAL input
+// channel count the weights were packed for (it selects the same layout as conv_stem7_pack_weights did)
 int launch_conv_stem7_pool(const ConvArgs& a, int f16, hipStream_t stream) {
+  if (f16 && stem7_f16_pp(a.Kpad)) return launch_stem7_f16_pp<>(a, stream);
   if (f16) return launch_stem7<MODE_F16, 16>(a, stream);
   return a.Cin % 8 == 0 ? launch_stem7<MODE_SPLIT, 8>(a, stream) : launch_stem7<MODE_SPLIT, 4>(a, stream);
 }

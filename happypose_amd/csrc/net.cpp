@@ -857,9 +857,10 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         ConvArgs s7{};
         s7.x = (const float*)a.x; s7.w = (const float*)L.w_stem7.p; s7.bias = a.bias; s7.y = (float*)net->bufs[next16->out_buf].p;
         s7.M = a.M; s7.H = L.H; s7.W = L.W; s7.Cin = L.cin16; s7.Ho = L.Ho; s7.Wo = L.Wo; s7.Cout = L.cout; s7.relu = L.relu;
+        s7.Kpad = L.cin_real;  // selects the kernel the weights were packed for
         if ((rc = launch_conv_stem7_pool(s7, 1, stream))) return rc;
         pool_fused = true;
-        prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, 2.0 * (double)a.M * (256.0 / 192.0) * L.cout * 7 * 112);
+        prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, 2.0 * (double)a.M * (256.0 / 192.0) * L.cout * 7 * conv_stem7_f16_krow(L.cin_real));
       } else {
         if ((rc = launch_conv_f16(a, stream))) return rc;
         prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout * L.Kpad16);

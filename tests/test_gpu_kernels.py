@@ -13,6 +13,8 @@ Stated tolerances
     -> |err| <= 2e-4 * max|ref| per tensor.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -723,6 +725,21 @@ def test_backbone_f16_vs_f32(dev, arch, cin):
     assert np.abs(outs["f16"][2] - outs["f32"][2]).max() <= 2e-2 * scale
     np.testing.assert_allclose(outs["f16"][0], outs["f32"][0], atol=2e-2 * max(1.0, np.abs(outs["f32"][0]).max()))
     np.testing.assert_allclose(outs["f16"][1], outs["f32"][1], atol=2e-2 * max(1.0, np.abs(outs["f32"][1]).max()))
+
+
+def test_f16_stem_persistent_kernel_vs_tile_kernel(dev):
+    """The persistent two-group fp16 stem (conv_stem7x7s2_pool_f16_pp: <= 9 real channels, the MegaPose coarse model) against
+    the tile kernel it replaces (HP_STEM7_F16_OLD=1), through the whole vanilla_resnet34 backbone: 240 x 320 and three sizes
+    whose pooled maps are not multiples of the 3 x 16 tile, pad channels of the 16-channel record filled with garbage.  The
+    two kernels sum in different orders, so they agree to fp16 rounding noise, not bit for bit: 2e-3 of the feature scale
+    (measured 6e-4).  The switch is read once per process: each side runs in its own interpreter (tools/stem7_ab.py)."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stem7_ab.py")
+    out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    worst = float(out.stdout.strip().splitlines()[-1].split()[-1])
+    assert worst < 2e-3, out.stdout
 
 
 @pytest.mark.parametrize("arch,cin,tag", [("vanilla_resnet34", 27, "vanilla_resnet34_27"),
