@@ -37,6 +37,7 @@ N_DET, N_HYP, N_ITERS = 8, 16, 5
 
 
 WORKLOADS = ("C2", "C3", "C5", "E2E")
+DEFAULT_LANES = {"C2": 2, "C3": 3, "C5": 2, "E2E": 2}  # --lanes
 
 
 def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32", n_lanes=1, update_scale=0.002, renderer_kw=None):
@@ -180,7 +181,7 @@ def e2e_run(device, rank, world, lanes, coarse_precision, steps, warmup, run_det
 def bench_e2e(args, device, rank, world):
     """``--workload E2E``: the line of :func:`e2e_run`."""
     coarse_precision = args.precision or "f32"
-    r = e2e_run(device, rank, world, args.lanes, coarse_precision, args.steps, args.warmup, run_detector=args.run_detector)
+    r = e2e_run(device, rank, world, args.lanes or DEFAULT_LANES["E2E"], coarse_precision, args.steps, args.warmup, run_detector=args.run_detector)
     if r is None:
         return
     elapsed, prof, conv_union_ms = r["elapsed"], r["prof"], r["conv_union_ms"]
@@ -481,8 +482,10 @@ def main():
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS),
                     help="BASELINE.json config (default C2 = the one the headline metric is quoted on)")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the secondary run on the exact-fp32 kernels")
-    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="refiner workloads (C2, C3): 2 = two half-batch chains on two streams (TwoLanePredictor)")
+    ap.add_argument("--lanes", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="shares of the batch as independent chains on their own streams (TwoLanePredictor).  Default: 2, and 3 for "
+                         "C3 (64 hypotheses of 4 views: measured 2747 / 2828 / 2790 poses/s at 2 / 3 / 4 lanes; C2: 5273 / 5330 / "
+                         "4970 with the conv-busy share of the step going from 0.87 to 0.94 to 0.96, left at 2)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16"],
                     help="conv arithmetic (default: f32, the reference's; f16 for C5 as BASELINE.json names it)")
     ap.add_argument("--graphs", default="off", choices=["on", "off"],
@@ -524,7 +527,7 @@ def main():
         return
     precision = args.precision or ("f16" if args.workload == "C5" else "f32")
     peak = PEAK_F16_MFMA_TFLOPS if precision == "f16" else PEAK_F32_MFMA_TFLOPS
-    n_lanes = args.lanes
+    n_lanes = args.lanes or DEFAULT_LANES.get(args.workload, 2)
     rkw = None if args.render_state == "reference" else dict(msaa=False, aniso=False)
     ds, renderer, scene, weights, model = build_world(device, args.arch, seed=rank, workload=args.workload,
                                                       precision=precision, n_lanes=n_lanes, renderer_kw=rkw)
@@ -776,7 +779,7 @@ def main():
                 extras.append(("c2_single_sample_renders", "C2", "f32", dict(msaa=False, aniso=False)))
             for key, wl, prec, rk in extras:
                 try:
-                    line[key] = quick_workload(device, wl, prec, n_lanes, steps=5 if wl == "C2" else 3, renderer_kw=rk)
+                    line[key] = quick_workload(device, wl, prec, args.lanes or DEFAULT_LANES.get(wl, 2), steps=5 if wl == "C2" else 3, renderer_kw=rk)
                 except Exception as e:  # never lose the headline line to an extra
                     line[key] = {"error": f"{type(e).__name__}: {e}"}
             if args.arch == "resnet34" and precision == "f32":
