@@ -481,7 +481,7 @@ __global__ __launch_bounds__(s7p::kT) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int nt = 0; nt < 2; ++nt)
         wt[slot][nt] = *reinterpret_cast<const s7_halfx8*>(Wl + (kh * BN + 32 * nt) * WROWB + aoff + 32 * kk);
     };
-#ifdef HP_S7_ABL_NOMFMA  // diagnostics builds (tools/stem7_ablate.sh): phases compiled out
+#ifdef HP_S7_ABL_NOMFMA  // diagnostics builds (tools/stem_ablate.sh): phases compiled out
     const bool mm_on = t.ok && a.M < 0;
 #else
     const bool mm_on = t.ok;
@@ -543,15 +543,21 @@ __global__ __launch_bounds__(s7p::kT) __attribute__((amdgpu_waves_per_eu(2, 2)))
           const int c8 = item & 7, pp = item >> 3, py = pp >> 2, pxl = pp & 3;
           const int ph = PR * te.ty + py, pw = PC * te.tx + 4 * wl + pxl;
           if (ph < Hp && pw < Wp) {
-            s7_halfx8 best = {0, 0, 0, 0, 0, 0, 0, 0};  // post-ReLU values: 0 is the identity (the window's centre is always inside)
+            // all nine reads issued back to back: a conv pixel outside the map is replaced by the window's centre, which is
+            // always inside (guarded reads compile to nine dependent LDS round trips per item)
+            const unsigned char* const ctr = Ew + (9 * (2 * py + 1) + 2 * pxl + 1) * EPITCH + 16 * c8;
+            s7_halfx8 v[9];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
               for (int dx = 0; dx < 3; ++dx) {
                 const int dr = 2 * py + dy, dcl = 2 * pxl + dx;
-                if ((unsigned)(oh0 + dr) < (unsigned)a.Ho && (unsigned)(ow0 + dcl) < (unsigned)a.Wo)
-                  best = __builtin_elementwise_max(best, *reinterpret_cast<const s7_halfx8*>(Ew + (9 * dr + dcl) * EPITCH + 16 * c8));
+                const bool in = (unsigned)(oh0 + dr) < (unsigned)a.Ho && (unsigned)(ow0 + dcl) < (unsigned)a.Wo;
+                v[3 * dy + dx] = *reinterpret_cast<const s7_halfx8*>(in ? Ew + (9 * dr + dcl) * EPITCH + 16 * c8 : ctr);
               }
+            s7_halfx8 best = v[0];
+#pragma unroll
+            for (int k = 1; k < 9; ++k) best = __builtin_elementwise_max(best, v[k]);
             *reinterpret_cast<s7_halfx8*>(yg + (((int64_t)te.img * Hp + ph) * Wp + pw) * BN + 8 * c8) = best;
           }
         }
