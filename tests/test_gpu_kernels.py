@@ -539,7 +539,10 @@ def _conv_ref(x_nhwc, w_oihw, stride, pad, bias, residual, pre, relu):
 
 @pytest.mark.parametrize("case", [
     dict(n=2, h=60, w=80, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=False, relu=True),
-    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),
+    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),    # conv3x3s2_pp<MODE_F16>: one chunk
+    dict(n=2, h=30, w=40, cin=128, cout=256, k=3, s=2, p=1, bias=True, res=False, pre=False, relu=True),  # two chunks
+    dict(n=3, h=31, w=45, cin=128, cout=128, k=3, s=2, p=1, bias=False, res=True, pre=False, relu=False), # odd size, residual
+    dict(n=1, h=15, w=20, cin=256, cout=512, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),   # few tiles: K slices
     dict(n=2, h=30, w=40, cin=128, cout=256, k=1, s=2, p=0, bias=False, res=False, pre=True, relu=False),
     dict(n=1, h=15, w=20, cin=256, cout=512, k=3, s=2, p=1, bias=False, res=True, pre=False, relu=False),
     dict(n=5, h=9, w=7, cin=32, cout=64, k=3, s=1, p=1, bias=True, res=False, pre=False, relu=False),  # ragged M
@@ -665,7 +668,10 @@ def test_split_conv_dynamic_range(dev, case):
 # accumulation order and the final rounding to fp16 (2^-11 relative)
 @pytest.mark.parametrize("case", [
     dict(n=3, h=60, w=80, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=False, relu=True),
-    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),
+    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),    # conv3x3s2_pp<MODE_F16>: one chunk
+    dict(n=2, h=30, w=40, cin=128, cout=256, k=3, s=2, p=1, bias=True, res=False, pre=False, relu=True),  # two chunks
+    dict(n=3, h=31, w=45, cin=128, cout=128, k=3, s=2, p=1, bias=False, res=True, pre=False, relu=False), # odd size, residual
+    dict(n=1, h=15, w=20, cin=256, cout=512, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),   # few tiles: K slices
     dict(n=2, h=30, w=40, cin=128, cout=256, k=1, s=2, p=0, bias=False, res=False, pre=True, relu=False),
     dict(n=2, h=15, w=20, cin=256, cout=512, k=3, s=1, p=1, bias=False, res=True, pre=False, relu=False),
     dict(n=5, h=9, w=7, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=False, pre=False, relu=False),   # ragged M
