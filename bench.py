@@ -793,15 +793,20 @@ def main():
                     import gc
 
                     gc.collect()
-                    r = e2e_run(device, 0, 1, n_lanes, "f32", steps=3, warmup=2, run_detector=True)
-                    line["e2e"] = {"value": r["steps"] / r["elapsed"], "unit": "frames/s", "ms_per_frame": 1e3 * r["elapsed"] / r["steps"],
-                                   "steps": r["steps"], "stage_ms_per_frame": r["stage_ms_per_frame"],
-                                   "conv_time_share": r["conv_union_ms"] * 1e-3 / r["elapsed"],
-                                   "job": "PoseEstimator.run_inference_pipeline: Mask-RCNN detector (random weights, timed, its detections "
-                                          "discarded) + 8 detections x 576-pose coarse grid, top-5, 5 refiner iterations x 40 hypotheses x 4 "
-                                          "views, re-scoring, top-1; pandas bookkeeping included"}
+                    for key, cprec in (("e2e", "f32"), ("e2e_f16_coarse", "f16")):
+                        # the second one: the coarse / scoring model on the fp16 plan (BASELINE.json config 5 names fp16 for that
+                        # stage), the refiner in fp32 as always
+                        r = e2e_run(device, 0, 1, n_lanes, cprec, steps=3, warmup=2, run_detector=True)
+                        line[key] = {"value": r["steps"] / r["elapsed"], "unit": "frames/s", "ms_per_frame": 1e3 * r["elapsed"] / r["steps"],
+                                     "steps": r["steps"], "stage_ms_per_frame": r["stage_ms_per_frame"],
+                                     "conv_time_share": r["conv_union_ms"] * 1e-3 / r["elapsed"], "coarse_precision": cprec,
+                                     "job": "PoseEstimator.run_inference_pipeline: Mask-RCNN detector (random weights, timed, its detections "
+                                            "discarded) + 8 detections x 576-pose coarse grid, top-5, 5 refiner iterations x 40 hypotheses x 4 "
+                                            "views, re-scoring, top-1; pandas bookkeeping included"}
+                        gc.collect()
                 except Exception as e:
-                    line["e2e"] = {"error": f"{type(e).__name__}: {e}"}
+                    line.setdefault("e2e", {"error": f"{type(e).__name__}: {e}"})
+                    line.setdefault("e2e_f16_coarse", {"error": f"{type(e).__name__}: {e}"})
         if not args.no_cpu_baseline and args.workload == "C2" and world == 1:  # the CPU baseline is a 1-GPU-run item
             rk = dict(msaa=renderer.msaa, aniso=renderer.aniso)  # the same render state on both sides
             base, cpu_poses = cpu_baseline(store, scene, weights, args.arch, args.cpu_seconds, render_kw=rk)
