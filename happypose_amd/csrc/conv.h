@@ -47,6 +47,14 @@ struct ConvArgs {
   // per-launch switches (zero-initialised = defaults), carried here instead of process-wide state so that
   // networks on different host threads / streams cannot race:
   int algo;                // HP_CONV_ALGO_* of the launching network (only the Winograd schedule reads it here)
+  // conv3x3s2_pp only: the block's 1x1 / stride-2 shortcut as EXTRA WORK ITEMS of the 3x3 / stride-2 launch (same input, same
+  // output shape; its input pixel is the 3x3's centre tap).  sc_w = the shortcut's weights in the centre of a zero 3x3 filter,
+  // split by conv_split_transform_weights(..., stride 2); null = no shortcut items.
+  const float* sc_w;
+  const float* sc_bias;
+  float* sc_y;
+  unsigned* sc_amax_out;
+  int sc_relu, sc_items;   // sc_items: filled by the launcher (tiles_m x tiles_n)
   int no_tail_split;       // 1: leave the tiles of a partially filled last round whole (a second lane fills the CUs)
   unsigned* status;        // host-visible word or null: the epilogue stores 1 when it produced a non-finite value
                            // (split-fp16 launches: an activation beyond the fp16 range turned into inf / NaN)

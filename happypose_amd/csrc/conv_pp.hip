@@ -685,6 +685,9 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
       const_cast<float*>(a.x), 0, (int)((a.M / (Ho * Wo)) * (int64_t)H * W * C * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)((size_t)a.Cout * 9 * C * 4), 0x00020000);
+  // shortcut items (ConvArgs::sc_w): the same rows of a second weight array; entries [0, nl) of the walk are its centre taps
+  const __amdgpu_buffer_rsrc_t wrsrc_sc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.sc_w ? a.sc_w : a.w), 0, (int)((size_t)a.Cout * 9 * C * 4), 0x00020000);
 
   const int pk = tid & 3, pr0 = tid >> 2;
   _Float16* const Pst = patch + pr0 * LDH + 8 * pk;
@@ -715,34 +718,41 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
 
   // ---- item state.  K slices (tail items of conv_split_plan_tail, as in conv3x3_pp) cut the CHUNK range: a slice walks all
   // four phases of its chunks, so its entries are whole patches; slice bounds are even (pairs of chunks = the planner's unit)
-  const int nvb = 8 * (a.sk_regular / 8 + (a.sk_tail_items + 7) / 8);
+  const int nvb = 8 * (a.sk_regular / 8 + (a.sk_tail_items + 7) / 8 + (a.sc_items + 7) / 8);
   int c0 = 0, nl = n, nent = 9 * n, npatch = 4 * n;
+  bool sc_item = false;  // the item being multiplied is a shortcut item: phase 0 only (one entry, one sub-patch per chunk)
   unsigned pbase[NPC], pflag[NPC];  // input pixel (2 oh, 2 ow) of the thread's patch rows; bit 0 inside, 1: row 2 oh + 1, 2: col 2 ow + 1
   unsigned wvoff[NB];
   unsigned vmask[MT];
-  struct Item { int lin, slice, n0; bool split; int64_t m0; };
+  struct Item { int lin, slice, n0; bool split, sc; int64_t m0; };
   auto decode = [&](int vb, Item& it) -> bool {
     if (vb >= nvb) return false;
     const ConvArgs a = *opaque_args();
     {
       const int rpx = a.sk_regular / 8, tpx = (a.sk_tail_items + 7) / 8;
       const int xcd = vb % 8, li = vb / 8;
-      it.slice = 0; it.split = false;
+      it.slice = 0; it.split = false; it.sc = false;
       if (li < rpx) {
         it.lin = xcd * rpx + li;
-      } else {
+      } else if (li < rpx + tpx) {
         const int ti = xcd * tpx + (li - rpx);
-        if (li - rpx >= tpx || ti >= a.sk_tail_items) return false;
+        if (ti >= a.sk_tail_items) return false;
         it.lin = a.sk_regular + ti / a.sk_S;
         it.slice = ti % a.sk_S;
         it.split = a.sk_S > 1;
+      } else {  // shortcut items follow the tail: they fill the CUs the last (partial) round of 3x3 items leaves idle
+        const int spx = (a.sc_items + 7) / 8, si = xcd * spx + (li - rpx - tpx);
+        if (si >= a.sc_items) return false;
+        it.lin = si;
+        it.sc = true;
       }
     }
     const int lin = it.lin;
     {
       const int U = n / 2;
       const int u0 = it.split ? it.slice * U / a.sk_S : 0, u1 = it.split ? (it.slice + 1) * U / a.sk_S : U;
-      c0 = 2 * u0; nl = 2 * (u1 - u0); nent = 9 * nl; npatch = 4 * nl;
+      sc_item = it.sc;
+      c0 = 2 * u0; nl = 2 * (u1 - u0); nent = (it.sc ? 1 : 9) * nl; npatch = (it.sc ? 1 : 4) * nl;
     }
     const int t_ = opaque_tid();
     const int br0 = t_ >> 3, bk = t_ & 7, frow = t_ & 31, wave_ = t_ >> 6, pr0 = t_ >> 2, pk = t_ & 3;
@@ -838,7 +848,7 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     pp_s2_entry(e2, nl, ph, cl, t, T);
     const int eg = (ph == 0 ? 0 : ph == 1 ? n : ph == 2 ? 3 * n : 5 * n) + (c0 + cl) * T + t;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[set][i] = ldh8(wrsrc, wvoff[i], (unsigned)(eg * 128));
+    for (int i = 0; i < NB; ++i) rb[set][i] = ldh8(sc_item ? wrsrc_sc : wrsrc, wvoff[i], (unsigned)(eg * 128));
   };
   auto store_b = [&](int set, int buf) {
 #pragma unroll
@@ -923,7 +933,10 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     Item nxt{};
     vb += (int)gridDim.x;
     bool issued = false, finish = true;
-    const ConvArgs ea = *opaque_args();
+    ConvArgs ea = *opaque_args();
+    if (cur.sc) {  // the shortcut's output, bias, activation and scale-back factors (behind its own weights)
+      ea.y = ea.sc_y; ea.bias = ea.sc_bias; ea.relu = ea.sc_relu; ea.w = ea.sc_w; ea.residual = nullptr; ea.amax_out = ea.sc_amax_out;
+    }
     if (cur.split) finish = splitk_reduce_sc1<BM, BN, MT, NT, kPPThreads>(ea, acc, cur.lin - ea.sk_regular, cur.slice);
     auto prefetch_next = [&]() {
       have = decode(vb, nxt);
@@ -1023,7 +1036,8 @@ int launch_pp_s2_variant(ConvArgs args, hipStream_t stream) {
   // K slices over PAIRS of 32-channel chunks (a slice's entry count stays even); same policy as conv3x3_pp
   const int rc = conv_split_plan_tail(args, args.tiles_m * args.tiles_n, args.Cin / (2 * PPS2::CKC), (size_t)BM * PPS2::BN, 1, stream);
   if (rc) return rc;
-  const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
+  args.sc_items = args.sc_w ? args.tiles_m * args.tiles_n : 0;
+  const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8 + (args.sc_items + 7) / 8;
   const int grid = std::min(8 * per_xcd, conv_num_cus() / 8 * 8);
   hipLaunchKernelGGL((conv3x3s2_pp<PRE, NPC>), dim3(grid), dim3(kPPThreads), PPS2::lds_bytes(args.Wo), stream, args, PPS2::P(args.Wo));
   return check_launch("conv3x3s2_pp");

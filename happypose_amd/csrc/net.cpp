@@ -52,6 +52,8 @@ struct ConvLayer {
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
   DevBuf w_wsplit;         // Winograd-transformed weights as fp16 hi/lo halves (conv_wino.hip, SPLIT)
   DevBuf w_w2;             // the same for conv_wino2.hip (64 x 64 items)
+  DevBuf w_short;  // a 1x1 / stride-2 shortcut in the centre of a zero 3x3 filter, split like a stride-2 3x3 layer's weights: it runs as
+                   // extra work items of the block's 3x3 / stride-2 launch (ConvArgs::sc_w)
   DevBuf w, w_wino, w_split, w_isplit, bias, lut, pre_scale, pre_shift;  // w_isplit: hi/lo halves for conv_igemm_split.hip  // w_wino: Winograd-transformed weights (3x3 s1 layers)
                                                                // w_split: fp16 hi/lo halves (conv_split.hip)
   bool wino_ok = false, wsplit_ok = false, w2_ok = false;  // eligible for w_wino / w_wsplit / w_w2 (built on first use)
@@ -235,8 +237,9 @@ int build_graph(Net& n) {
         if (ds) add_conv(n, p + ".downsample.0.weight", p + ".downsample.1", "", inpl, planes, 1, stride, 0, 0, H, W, cur, d, -1);
         add_conv(n, p + ".conv2.weight", p + ".bn2", "", planes, planes, 3, 1, 1, 1, Ho, Wo, t, o, ds ? d : cur);
       } else {
-        if (ds) add_conv(n, p + ".downsample.weight", "", p + ".bn1", inpl, planes, 1, stride, 0, 0, H, W, cur, d, -1);
         add_conv(n, p + ".conv1.weight", p + ".bn2", p + ".bn1", inpl, planes, 3, stride, 1, 1, H, W, cur, t, -1);
+        // (the module computes the shortcut first: same values; behind conv1 it can ride in conv1's launch, forward_chunk)
+        if (ds) add_conv(n, p + ".downsample.weight", "", p + ".bn1", inpl, planes, 1, stride, 0, 0, H, W, cur, d, -1);
         add_conv(n, p + ".conv2.weight", "", "", planes, planes, 3, 1, 1, 0, Ho, Wo, t, o, ds ? d : cur);
       }
       cur = o; inpl = planes; H = Ho; W = Wo;
@@ -469,6 +472,21 @@ int pack_conv(Net& n, ConvLayer& L) {
       if ((rc = L.w_isplit.alloc(conv_igemm_split_weight_bytes(L.cout_pad, L.Kpad)))) return rc;
       if ((rc = conv_igemm_split_transform_weights((const float*)L.w.p, L.w_isplit.p, L.cout_pad, L.Kpad, nullptr))) return rc;
       HP_CHECK_HIP(hipStreamSynchronize(nullptr));
+    }
+    {  // a 1x1 / stride-2 / pad-0 shortcut whose 3x3 / stride-2 / pad-1 twin the persistent stride-2 kernel would take
+      ConvArgs twin = probe;
+      twin.pad = 1;
+      if (L.kh == 1 && L.kw == 1 && L.stride == 2 && L.pad == 0 && L.res_buf < 0 && conv_pp_s2_applicable(twin, 3, 3) && L.cout_pad == L.cout &&
+          L.cin_real == L.cin && L.relu != HP_ACT_SWISH && !L.se) {
+        std::vector<float> w33((size_t)L.cout * 9 * L.cin, 0.f);  // [cout][(kh, kw)][cin], centre tap = the shortcut
+        for (int o = 0; o < L.cout; ++o)
+          for (int ci = 0; ci < L.cin; ++ci) w33[((size_t)o * 9 + 4) * L.cin + ci] = packed[(size_t)o * L.Kpad + ci];
+        DevBuf tmp;
+        if ((rc = tmp.upload(w33.data(), w33.size() * 4))) return rc;
+        if ((rc = L.w_short.alloc(conv_split_weight_bytes(L.cout, L.cin)))) return rc;
+        if ((rc = conv_split_transform_weights((const float*)tmp.p, L.w_short.p, L.cout, L.cin, 9 * L.cin, 2, nullptr))) return rc;
+        HP_CHECK_HIP(hipStreamSynchronize(nullptr));
+      }
     }
   }
   if (conv_stem7_applicable(L.kh, L.kw, L.stride, L.pad, L.cin, L.cout, L.relu, 0) && !L.run_mode && L.bn_before.empty()) {
@@ -824,6 +842,24 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
   bool front_fused = false; // the expansion conv ran the depthwise conv after it too (mbconv_front.hip): skip that op
   int dw_partials = 0;      // > 0: the depthwise launch left this many pooling partials per image for the SE op after it
   static const bool no_fuse = std::getenv("HP_NO_POOL_FUSION") != nullptr;
+  // A down-sampling block's 1x1 / stride-2 shortcut runs as extra work items of the block's 3x3 / stride-2 launch (conv3x3s2_pp,
+  // ConvArgs::sc_w): as a launch of its own it sits on a floor of 20 - 30 us whatever the kernel.  The plans put the shortcut
+  // right behind the 3x3 op.  HP_NET_NO_SHORTCUT_FUSION=1 / per-layer profiling: separate launches.
+  static const bool no_sc_fusion = std::getenv("HP_NET_NO_SHORTCUT_FUSION") != nullptr;
+  int sc_done = -1;       // op index of a shortcut the 3x3 op before it has already run
+  auto sc_pair = [&](size_t o3, size_t o1) -> bool {  // may op o1 (shortcut) ride in the launch of op o3 (3x3 / stride 2)?
+    if (no_sc_fusion || per_launch || sync_ops || f16 || o3 >= net->ops.size() || o1 >= net->ops.size()) return false;
+    if (net->ops[o3].kind != OP_CONV || net->ops[o1].kind != OP_CONV) return false;
+    const ConvLayer& A = *net->convs[net->ops[o3].conv];
+    const ConvLayer& B = *net->convs[net->ops[o1].conv];
+    if (!B.w_short.p || !A.w_split.p || A.kh != 3 || A.kw != 3 || A.stride != 2 || A.pad != 1 || A.res_buf >= 0 || A.se) return false;
+    if (A.in_buf != B.in_buf || A.cin != B.cin || A.cout != B.cout || A.H != B.H || A.W != B.W || A.Ho != B.Ho || A.Wo != B.Wo) return false;
+    if (A.bn_before != B.bn_before || A.out_buf == B.out_buf) return false;  // one staging prologue serves both
+    ConvArgs t{};
+    t.stride = 2; t.pad = 1; t.Cin = A.cin; t.Cout = A.cout; t.H = A.H; t.W = A.W; t.Ho = A.Ho; t.Wo = A.Wo;
+    t.M = (int64_t)batch * A.Ho * A.Wo;
+    return conv_use_split(net_algo, A.H, A.W, A.cin, A.cout) && conv_split_launchable(t) && conv_pp_s2_applicable(t, 3, 3);
+  };
   for (size_t oi = 0; oi < net->ops.size(); ++oi) {
     const Op& op = net->ops[oi];
     if (sync_ops) {
@@ -866,6 +902,8 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         prof_add(2.0 * (double)a.M * L.cout * L.kh * L.kw * L.cin_real, 2.0 * (double)((a.M + 127) / 128 * 128) * L.cout * L.Kpad16);
       }
       if ((rc = prof_end(false))) return rc;
+    } else if (op.kind == OP_CONV && (int)oi == sc_done) {
+      sc_done = -1;  // this shortcut rode in the previous op's launch
     } else if (op.kind == OP_CONV) {
       ConvLayer& L = *net->convs[op.conv];
       ConvArgs a{};
@@ -952,6 +990,16 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       } else if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_split.p && conv_split_launchable(a)) {
         a.w = (const float*)L.w_split.p;
         a.status = net->d_status;
+        int sc_op = -1;  // the block's shortcut as extra work items of this launch
+        if (sc_pair(oi, oi + 1)) { sc_op = (int)oi + 1; sc_done = sc_op; }
+        if (sc_op >= 0) {
+          const ConvLayer& S = *net->convs[net->ops[sc_op].conv];
+          a.sc_w = (const float*)S.w_short.p; a.sc_bias = (const float*)S.bias.p; a.sc_y = (float*)net->bufs[S.out_buf].p;
+          a.sc_relu = S.relu;
+          a.sc_amax_out = amax_words ? amax_words + (size_t)sc_op * kAmaxSlots * kAmaxStride : nullptr;
+          if (S.out_buf >= 0) buf_amax[S.out_buf] = amax_words ? sc_op : -1;
+          prof_add(2.0 * (double)a.M * S.cout * S.cin_real, 3.0 * 2.0 * (double)((a.M + 255) / 256 * 256) * S.cout * S.cin / 16.0);
+        }
         rc = launch_conv_split(a, stream);
         // three fp16 MFMAs per product over whole 256- / 512-row tiles; an fp16 MFMA FLOP occupies the matrix pipe for
         // 1/16 of an fp32 one, so it is counted as 1/16: mfma_flops / time / fp32 peak stays "how busy is the pipe"

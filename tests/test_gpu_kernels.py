@@ -733,15 +733,17 @@ def test_backbone_f16_vs_f32(dev, arch, cin):
     np.testing.assert_allclose(outs["f16"][1], outs["f32"][1], atol=2e-2 * max(1.0, np.abs(outs["f32"][1]).max()))
 
 
-@pytest.mark.parametrize("case,bound", [("stem7f16", 2e-3), ("stem5", 0.0)])
+@pytest.mark.parametrize("case,bound", [("stem7f16", 2e-3), ("stem5", 0.0), ("shortcut", 2e-5), ("shortcut_mp", 2e-5)])
 def test_persistent_stem_kernels_vs_tile_kernels(dev, case, bound):
     """The persistent two-group stems (conv_stem7x7s2_pool_f16_pp: fp16 plan, <= 9 real channels, the MegaPose coarse model;
     conv_stem5x5s2_pool_split_pp: the CosyPose fp32 stem) against the tile kernels they replace (HP_STEM7_F16_OLD=1 /
     HP_STEM5_OLD=1), through the whole backbone: 240 x 320 and three sizes whose pooled maps are not multiples of the 3 x 16 tile;
     fp16: the pad channels of the 16-channel record filled with garbage.  The fp16 kernels sum in different orders: fp16
     rounding noise, 2e-3 of the feature scale (measured 6e-4); the fp32 kernel issues the same MFMAs in the same order and
-    its epilogue is monotone: identical bits.  The switches are read once per process: each side runs in its own
-    interpreter (tools/stem_ab.py)."""
+    its epilogue is monotone: identical bits.  shortcut / shortcut_mp: the down-sampling blocks' 1 x 1 / stride-2 shortcuts as
+    extra work items of the block's 3 x 3 / stride-2 launch (conv3x3s2_pp, ConvArgs::sc_w) against launches of their own
+    (HP_NET_NO_SHORTCUT_FUSION=1): another kernel, another summation order, fp32 round-off (2e-5 of the feature scale).  The
+    switches are read once per process: each side runs in its own interpreter (tools/stem_ab.py)."""
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stem_ab.py")

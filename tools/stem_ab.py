@@ -1,8 +1,9 @@
-"""A/B of a persistent two-group stem kernel against the tile kernel it replaces, through the whole backbone, at the product size
+"""A/B of a kernel path against the one it replaces (an environment switch), through the whole backbone, at the product size
 and at sizes whose pooled map is not a multiple of the 3 x 16 tile.  The switches are read once per process, so each side runs
 in its own interpreter.
   python tools/stem_ab.py stem7f16   conv_stem7x7s2_pool_f16_pp (vanilla_resnet34, 9 channels, fp16 plan) vs HP_STEM7_F16_OLD=1
   python tools/stem_ab.py stem5      conv_stem5x5s2_pool_split_pp (CosyPose resnet34, 6 channels, fp32)    vs HP_STEM5_OLD=1
+  python tools/stem_ab.py shortcut | shortcut_mp   shortcuts inside the stride-2 launch (resnet34 / vanilla_resnet34) vs HP_NET_NO_SHORTCUT_FUSION=1
 prints the largest feature / pose difference per size, last line "worst <value>"; exit code 0 when below the case's bound
 (fp16: 2e-3 of the feature scale -- different summation order; stem5: 0 -- same MFMA order, monotone epilogue)."""
 import os, subprocess, sys, tempfile
@@ -10,7 +11,11 @@ import numpy as np
 
 SIZES = [(240, 320, 5), (104, 136, 3), (100, 132, 2), (64, 48, 2)]
 CASES = {"stem7f16": ("vanilla_resnet34", 9, "f16", "HP_STEM7_F16_OLD", 2e-3),
-         "stem5": ("resnet34", 6, "f32", "HP_STEM5_OLD", 0.0)}
+         "stem5": ("resnet34", 6, "f32", "HP_STEM5_OLD", 0.0),
+         # the blocks' 1x1 / stride-2 shortcuts as work items of the 3x3 / stride-2 launch vs launches of their own (another kernel:
+         # another summation order, fp32 round-off)
+         "shortcut": ("resnet34", 6, "f32", "HP_NET_NO_SHORTCUT_FUSION", 2e-5),
+         "shortcut_mp": ("vanilla_resnet34", 27, "f32", "HP_NET_NO_SHORTCUT_FUSION", 2e-5)}
 
 
 def dump(case, path):
