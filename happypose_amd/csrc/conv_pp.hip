@@ -725,10 +725,10 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   unsigned wvoff[NB];
   unsigned vmask[MT];
   struct Item { int lin, slice, n0; bool split, sc; int64_t m0; };
-  auto decode = [&](int vb, Item& it) -> bool {
-    if (vb >= nvb) return false;
+  auto decode = [&](int& vb, Item& it) -> bool {  // advances vb past empty slots of the tail / shortcut regions
     const ConvArgs a = *opaque_args();
-    {
+    for (;; vb += (int)gridDim.x) {
+      if (vb >= nvb) return false;
       const int rpx = a.sk_regular / 8, tpx = (a.sk_tail_items + 7) / 8;
       const int xcd = vb % 8, li = vb / 8;
       it.slice = 0; it.split = false; it.sc = false;
@@ -736,16 +736,17 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
         it.lin = xcd * rpx + li;
       } else if (li < rpx + tpx) {
         const int ti = xcd * tpx + (li - rpx);
-        if (ti >= a.sk_tail_items) return false;
+        if (ti >= a.sk_tail_items) continue;  // (not the end: this workgroup's shortcut items may follow)
         it.lin = a.sk_regular + ti / a.sk_S;
         it.slice = ti % a.sk_S;
         it.split = a.sk_S > 1;
       } else {  // shortcut items follow the tail: they fill the CUs the last (partial) round of 3x3 items leaves idle
         const int spx = (a.sc_items + 7) / 8, si = xcd * spx + (li - rpx - tpx);
-        if (si >= a.sc_items) return false;
+        if (si >= a.sc_items) continue;
         it.lin = si;
         it.sc = true;
       }
+      break;
     }
     const int lin = it.lin;
     {

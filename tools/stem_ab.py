@@ -9,7 +9,8 @@ prints the largest feature / pose difference per size, last line "worst <value>"
 import os, subprocess, sys, tempfile
 import numpy as np
 
-SIZES = [(240, 320, 5), (104, 136, 3), (100, 132, 2), (64, 48, 2)]
+SIZES = [(240, 320, 5), (104, 136, 3), (100, 132, 2), (64, 48, 2), (240, 320, 64)]  # the last one in ONE chunk of 64 (a lane of C2:
+# K-sliced tail items and more work items than workgroups); the others in chunks of <= 4
 CASES = {"stem7f16": ("vanilla_resnet34", 9, "f16", "HP_STEM7_F16_OLD", 2e-3),
          "stem5": ("resnet34", 6, "f32", "HP_STEM5_OLD", 0.0),
          # the blocks' 1x1 / stride-2 shortcuts as work items of the 3x3 / stride-2 launch vs launches of their own (another kernel:
@@ -30,14 +31,14 @@ def dump(case, path):
     out = {}
     for (h, wd, n) in SIZES:
         x = np.random.RandomState(h).uniform(-1, 1, size=(n, h, wd, cin)).astype(np.float32)
-        net = ops.Net(arch, cin, w, max_batch=4, device=dev, h=h, w=wd, precision=prec)
+        net = ops.Net(arch, cin, w, max_batch=64 if n > 8 else 4, device=dev, h=h, w=wd, precision=prec)
         xin = net.new_input(n)
         xin[..., :cin] = torch.as_tensor(x, device=dev).to(xin.dtype)
         if prec == "f16":
             xin[..., cin:] = 7.0  # the pad channels of the 16-channel record must not matter to either kernel (zero weights)
         pose, logits, feats = net.forward(xin, want_pose=True, want_logits=True, want_features=True)
-        out[f"f_{h}x{wd}"] = feats.cpu().numpy()
-        out[f"p_{h}x{wd}"] = pose.cpu().numpy()
+        out[f"f_{h}x{wd}_{n}"] = feats.cpu().numpy()
+        out[f"p_{h}x{wd}_{n}"] = pose.cpu().numpy()
     np.savez(path, **out)
 
 
