@@ -1,4 +1,6 @@
 // C-ABI glue: error reporting, device queries and the device-resident mesh store.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -44,6 +46,56 @@ int upload(T** dst, const T* src, size_t count) {
   HP_CHECK_HIP(hipMalloc((void**)dst, count * sizeof(T)));
   HP_CHECK_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
   return HP_OK;
+}
+
+// Back-face culling record of one object (MeshStore::cull).  The reference renders two-sided
+// (TB/renderer/panda3d_scene_renderer.py:102), so a triangle facing away from the camera may only be dropped when it provably
+// cannot be seen: the object is a CLOSED, consistently oriented surface (every directed edge occurs once and so does its
+// reverse, vertices welded by exact position: texture seams duplicate vertices) and the camera is outside it (the binning
+// pass checks the bounding sphere per view).  Then every ray from the camera meets a front face first.
+void mesh_cull_record(const float* v, int64_t nv, const int32_t* f, int64_t nf, float* out8) {
+  for (int k = 0; k < 8; ++k) out8[k] = 0.f;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int64_t i = 0; i < nv; ++i)
+    for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], (double)v[3 * i + c]); hi[c] = std::max(hi[c], (double)v[3 * i + c]); }
+  const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), cz = 0.5 * (lo[2] + hi[2]);
+  double r2 = 0.0;
+  for (int64_t i = 0; i < nv; ++i) {
+    const double dx = v[3 * i] - cx, dy = v[3 * i + 1] - cy, dz = v[3 * i + 2] - cz;
+    r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+  }
+  out8[0] = (float)cx; out8[1] = (float)cy; out8[2] = (float)cz; out8[3] = (float)(std::sqrt(r2) * 1.0001 + 1e-7);
+  // weld by exact position
+  std::vector<int32_t> order((size_t)nv), canon((size_t)nv);
+  for (int64_t i = 0; i < nv; ++i) order[i] = (int32_t)i;
+  auto less = [&](int32_t a, int32_t b) { return std::memcmp(v + 3 * (int64_t)a, v + 3 * (int64_t)b, 12) < 0; };
+  std::sort(order.begin(), order.end(), less);
+  for (int64_t i = 0; i < nv; ++i)
+    canon[order[i]] = (i > 0 && std::memcmp(v + 3 * (int64_t)order[i], v + 3 * (int64_t)order[i - 1], 12) == 0) ? canon[order[i - 1]] : order[i];
+  std::vector<uint64_t> edges;
+  edges.reserve((size_t)nf * 3);
+  double vol = 0.0;
+  for (int64_t t = 0; t < nf; ++t) {
+    const int32_t a = canon[f[3 * t]], b = canon[f[3 * t + 1]], c = canon[f[3 * t + 2]];
+    if (a == b || b == c || a == c) continue;  // degenerate after welding: no area, no edges
+    const float* pa = v + 3 * (int64_t)a; const float* pb = v + 3 * (int64_t)b; const float* pc = v + 3 * (int64_t)c;
+    vol += (double)pa[0] * ((double)pb[1] * pc[2] - (double)pb[2] * pc[1]) - (double)pa[1] * ((double)pb[0] * pc[2] - (double)pb[2] * pc[0]) +
+           (double)pa[2] * ((double)pb[0] * pc[1] - (double)pb[1] * pc[0]);
+    edges.push_back(((uint64_t)(uint32_t)a << 32) | (uint32_t)b);
+    edges.push_back(((uint64_t)(uint32_t)b << 32) | (uint32_t)c);
+    edges.push_back(((uint64_t)(uint32_t)c << 32) | (uint32_t)a);
+  }
+  if (edges.empty()) return;
+  std::sort(edges.begin(), edges.end());
+  for (size_t i = 1; i < edges.size(); ++i)
+    if (edges[i] == edges[i - 1]) return;  // a directed edge used twice: not a consistently oriented manifold
+  for (uint64_t e : edges) {
+    const uint64_t rev = (e << 32) | (e >> 32);
+    if (!std::binary_search(edges.begin(), edges.end(), rev)) return;  // a boundary edge: open surface
+  }
+  const double r = std::sqrt(r2);
+  if (std::fabs(vol) < 1e-9 * r * r * r) return;
+  out8[4] = vol > 0.0 ? 1.f : -1.f;
 }
 
 }  // namespace
@@ -103,6 +155,12 @@ extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float
   rc |= upload(&s->faces, h_faces, (size_t)n_faces_total * 3);
   rc |= upload(&s->tex, h_tex, (size_t)(tex_bytes > 0 ? tex_bytes : 0));
   rc |= upload(&s->obj, h_obj, (size_t)n_obj * 8);
+  {
+    std::vector<float> cull((size_t)n_obj * 8);
+    for (int o = 0; o < n_obj; ++o)
+      mesh_cull_record(h_verts + 3 * h_obj[8 * o], h_obj[8 * o + 1], h_faces + 3 * h_obj[8 * o + 2], h_obj[8 * o + 3], cull.data() + 8 * o);
+    rc |= upload(&s->cull, cull.data(), cull.size());
+  }
   if (h_points) rc |= upload(&s->points, h_points, (size_t)n_obj * n_pad * 3);
   if (rc) {
     hp_mesh_store_destroy(s);
@@ -114,7 +172,7 @@ extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float
 extern "C" void hp_mesh_store_destroy(hp_mesh_store* s) {
   if (!s) return;
   (void)hipFree(s->verts); (void)hipFree(s->normals); (void)hipFree(s->uvs); (void)hipFree(s->colors);
-  (void)hipFree(s->faces); (void)hipFree(s->tex); (void)hipFree(s->obj); (void)hipFree(s->points);
+  (void)hipFree(s->faces); (void)hipFree(s->tex); (void)hipFree(s->obj); (void)hipFree(s->points); (void)hipFree(s->cull);
   (void)hipFree(s->bin_list); (void)hipFree(s->bin_count); (void)hipFree(s->xverts);
   (void)hipFree(s->verts4); (void)hipFree(s->normals4);
   delete s;

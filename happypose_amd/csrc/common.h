@@ -49,6 +49,10 @@ struct MeshStore {
   uint8_t* tex = nullptr;
   int64_t* obj = nullptr;  // [n_obj][8]
   float* points = nullptr; // [n_obj][n_pad][3]
+  // [n_obj][8] back-face culling record of the rasteriser's binning pass: bounding sphere (cx, cy, cz, r) in the vertices' units,
+  // orientation sign (+1 / -1: the object is a closed, consistently oriented surface with positive / negative signed volume;
+  // 0: not provably closed -> never culled), 3 unused (api.cpp: mesh_cull_record)
+  float* cull = nullptr;
   // rasteriser scratch: per-(view, band) triangle lists (grown on demand, see raster.hip)
   int32_t* bin_list = nullptr;
   size_t bin_list_bytes = 0;

@@ -30,6 +30,7 @@
 // are gone.  Inside a workgroup the work is re-organised in four passes: coverage (triangle-parallel, LDS z-buffer) ->
 // compaction of the covered pixels -> shading of the compacted list (every lane has a fragment; the 8-bit colour codes go
 // back into the z-buffer slots) -> pixel-parallel output pass (crop taps + record assembly, coalesced stores).
+#include <atomic>
 #include <cmath>
 #include <mutex>
 
@@ -104,6 +105,7 @@ struct RasterArgs {
   const int32_t* faces;
   const uint8_t* tex;
   const int64_t* obj;
+  const float* cull;      // MeshStore::cull ([n_obj][8]) or null: back faces of closed objects are not binned (raster_bin_kernel)
   const int32_t* obj_ids;
   const float* TCO;
   const float* K;
@@ -515,6 +517,17 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
   const int item = view / a.views_per_item;
   const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
   const int nf = x.finite ? (int)ob[3] : 0;
+  // the view may cull: the object is closed (MeshStore::cull), the camera is outside its bounding sphere, and the whole
+  // sphere lies beyond the near plane (a clipped object shows its inside)
+  float cull_sign = 0.f;
+  if (a.cull && x.finite && x.Kv[0] > 0.f && x.Kv[4] > 0.f) {
+    const float* const cu = a.cull + 8 * (int64_t)a.obj_ids[item];
+    const float cx = fmaf(x.T[0], cu[0], fmaf(x.T[1], cu[1], fmaf(x.T[2], cu[2], x.T[3])));
+    const float cy = fmaf(x.T[4], cu[0], fmaf(x.T[5], cu[1], fmaf(x.T[6], cu[2], x.T[7])));
+    const float cz = fmaf(x.T[8], cu[0], fmaf(x.T[9], cu[1], fmaf(x.T[10], cu[2], x.T[11])));
+    const float r = cu[3] * 1.001f + 1e-6f;  // (a scaled rotation is not expected in T; the margin covers its rounding)
+    if (cx * cx + cy * cy + cz * cz > r * r && cz - r > kZNear) cull_sign = cu[4];
+  }
   int b0 = 1, b1 = 0;  // empty band range
   if (f < nf) {
     const int32_t* fbase = a.faces + 3 * ob[2];
@@ -524,6 +537,25 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
     if (tri_bbox(a, load_tri_verts(a.xverts + 2 * (int64_t)lv * a.max_verts, tri), V0, V1, V2, x0, x1, y0, y1)) {
       b0 = y0 / a.band_rows;
       b1 = y1 / a.band_rows;
+      // Back faces of a CLOSED object seen from outside are never visible (the renders are two-sided like the reference's,
+      // panda3d_scene_renderer.py:102: every ray meets a front face of the closed surface first, and the canonical edge
+      // functions make that surface watertight).  V = K (T p): the triple product V0 . (V1 x V2) has the sign of the camera-space
+      // one (fx, fy > 0); it is negative for a triangle that faces the camera when the object's signed volume is positive.
+      // Dropped only when the sign is clear of the rounding of the product (|det| > 1e-5 sum |terms|, ~40x its error bound).
+      if (cull_sign != 0.f) {
+        // V0 . ((V1 - V0) x (V2 - V0)): the edge vectors of these pixel-sized triangles are small and nearly exact, so the
+        // cross product does not cancel the way V1 x V2 does in pixel-homogeneous coordinates (|terms| ~ 1e5 x |det| there)
+        const float ax = V1[0] - V0[0], ay = V1[1] - V0[1], az = V1[2] - V0[2];
+        const float bx = V2[0] - V0[0], by = V2[1] - V0[1], bz = V2[2] - V0[2];
+        const float t0 = ay * bz, t1 = az * by, t2 = az * bx, t3 = ax * bz, t4 = ax * by, t5 = ay * bx;
+        const float det = fmaf(V0[0], t0 - t1, fmaf(V0[1], t2 - t3, V0[2] * (t4 - t5)));
+        // rounding of the edge vectors (relative 2^-24 of the vertices) and of the products
+        const float emag = 1.2e-7f * (fabsf(V0[0]) + fabsf(V0[1]) + fabsf(V0[2]));
+        const float mag = fabsf(V0[0]) * (fabsf(t0) + fabsf(t1) + emag * (fabsf(ay) + fabsf(az) + fabsf(by) + fabsf(bz))) +
+                          fabsf(V0[1]) * (fabsf(t2) + fabsf(t3) + emag * (fabsf(ax) + fabsf(az) + fabsf(bx) + fabsf(bz))) +
+                          fabsf(V0[2]) * (fabsf(t4) + fabsf(t5) + emag * (fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by)));
+        if (det * cull_sign > 1e-5f * mag) { b0 = 1; b1 = 0; }
+      }
     }
   }
   // Appends are aggregated per workgroup: a lane takes its slot(s) from LDS counters (one returning LDS atomic per band it
@@ -1338,6 +1370,17 @@ static int raster_scratch(hp::MeshStore* ms, int n, int n_bands, hipStream_t st,
   return rc;
 }
 
+// hp_raster_set_backface_culling / HP_RASTER_NO_CULL=1 (the initial state): bin every triangle, the round-3 behaviour
+static std::atomic<int> g_cull{-1};
+static bool raster_cull_enabled() {
+  int v = g_cull.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = std::getenv("HP_RASTER_NO_CULL") ? 0 : 1;
+    g_cull.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+
 static int raster_bands(int h, int w, int msaa) {
   const int band_rows = msaa ? hp::kBandKeysMsaa / (hp::kSamplesMsaa * w) : hp::kBandPixels / w;
   return (h + band_rows - 1) / band_rows;
@@ -1458,6 +1501,12 @@ extern "C" int hp_raster_set_conventions(const hp_raster_conventions* c) {
   return HP_OK;
 }
 
+extern "C" int hp_raster_set_backface_culling(int on) {
+  const int prev = raster_cull_enabled() ? 1 : 0;
+  g_cull.store(on ? 1 : 0, std::memory_order_relaxed);
+  return prev;
+}
+
 extern "C" int hp_raster_get_conventions(hp_raster_conventions* out) {
   using namespace hp;
   HP_REQUIRE(out != nullptr, "hp_raster_get_conventions: null argument");
@@ -1488,7 +1537,7 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_rasterize: depth_norm_z missing");
   RasterArgs a{};
   a.verts4 = store->verts4; a.normals4 = store->normals4; a.uvs = store->uvs; a.colors = store->colors;
-  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj;
+  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj; a.cull = raster_cull_enabled() ? store->cull : nullptr;
   a.obj_ids = d_obj_ids; a.TCO = d_TCO; a.K = d_K; a.ambient = d_ambient;
   a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
   a.rgb = d_rgb; a.nrm = d_nrm; a.depth = d_depth; a.mask = d_mask;
@@ -1534,7 +1583,7 @@ extern "C" int hp_render_inputs(const hp_mesh_store* store, int n_items, int vie
   }
   RasterArgs a{};
   a.verts4 = store->verts4; a.normals4 = store->normals4; a.uvs = store->uvs; a.colors = store->colors;
-  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj;
+  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj; a.cull = raster_cull_enabled() ? store->cull : nullptr;
   a.obj_ids = d_obj_ids; a.TCO = d_TCV_O; a.K = d_KV; a.ambient = d_ambient;
   a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
   a.n = n_items * views_per_item; a.views_per_item = views_per_item; a.n_lights = n_lights; a.h = h; a.w = w;

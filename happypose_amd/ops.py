@@ -164,6 +164,13 @@ def set_raster_conventions(conv: Optional[Dict] = None) -> None:
     bump_graph_epoch()
 
 
+def set_backface_culling(on: bool = True) -> bool:
+    """``hp_raster_set_backface_culling``: drop triangles that face away from the camera when that cannot change the image
+    (closed objects seen from outside; the renders stay two-sided like the reference's for everything else).  Returns the
+    previous setting.  Default on; ``HP_RASTER_NO_CULL=1`` starts with it off."""
+    return bool(lib().hp_raster_set_backface_culling(1 if on else 0))
+
+
 def get_raster_conventions() -> Dict:
     c = RasterConventions()
     check(lib().hp_raster_get_conventions(C.byref(c)), "hp_raster_get_conventions")

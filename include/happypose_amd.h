@@ -138,6 +138,12 @@ typedef struct {
 } hp_raster_conventions;
 int hp_raster_set_conventions(const hp_raster_conventions* conventions /* NULL = defaults */);
 int hp_raster_get_conventions(hp_raster_conventions* out);
+/* Back-face culling in the binning pass (process-wide, read at launch time; default on, HP_RASTER_NO_CULL=1 starts with it off).
+ * The reference renders two-sided (TB/renderer/panda3d_scene_renderer.py:102).  A triangle facing away from the camera is
+ * dropped only when that cannot change the image: the object is a closed, consistently oriented surface (checked at
+ * hp_mesh_store_create on position-welded vertices), the camera is outside its bounding sphere and the sphere lies beyond
+ * the near plane.  Returns the previous setting. */
+int hp_raster_set_backface_culling(int on);
 
 int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
                  const int32_t* d_obj_ids /* [n / views_per_item] */,

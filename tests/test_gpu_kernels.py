@@ -231,7 +231,11 @@ def test_rasterizer_outliers_are_boundary_pixels(dev, scene_store):
     from happypose_amd import ops
     from oracle import native
 
-    gpu, ref = _render_both(scene_store, n=12, seed=5)
+    prev = ops.set_backface_culling(False)  # this test is about the conventions: the two-sided render (culling: the next test)
+    try:
+        gpu, ref = _render_both(scene_store, n=12, seed=5)
+    finally:
+        ops.set_backface_culling(prev)
     rgb, nrm = gpu[0].cpu().numpy(), gpu[1].cpu().numpy()
     e = 3e-5
     d0 = ops.RASTER_CONVENTION_DEFAULTS
@@ -261,6 +265,58 @@ def test_rasterizer_outliers_are_boundary_pixels(dev, scene_store):
     assert unexplained_rgb.sum() <= max(2, 0.02 * out_rgb.sum()), (int(unexplained_rgb.sum()), int(out_rgb.sum()))
     assert unexplained_nrm.sum() <= max(2, 0.02 * out_nrm.sum()), (int(unexplained_nrm.sum()), int(out_nrm.sum()))
     assert sens_rgb.mean() < 0.05  # the perturbations are round-off sized: they must not touch ordinary pixels
+
+
+def test_rasterizer_backface_culling_keeps_the_image(dev, scene_store):
+    """``hp_raster_set_backface_culling`` (default on): the binning pass drops triangles that face away from the camera when the
+    object is a closed, consistently oriented surface seen from outside -- the reference renders two-sided
+    (TB/renderer/panda3d_scene_renderer.py:102), and of a closed surface only front faces are ever visible.  Culled and two-sided
+    renders of the test scene (reference render state, 12 views, three objects, 0.3 - 1.6 m) are identical except for hairline
+    cracks along texture seams (duplicated vertices: the canonical edge functions are keyed by vertex index, not position),
+    through which the two-sided render shows the inside of the far wall and the culled one the background: < 2e-5 of the
+    pixels, depth / mask included.  An OPEN surface (the same mesh without a strip of faces) is never culled: bit-identical."""
+    from happypose_amd import ops
+
+    T = _poses(12, 5, zlo=0.3, zhi=1.6)
+    K = np.tile(np.array([[900.0, 0, 160], [0, 900.0, 120], [0, 0, 1]], np.float32), (12, 1, 1))
+    obj = (np.arange(12) % 3).astype(np.int32)
+
+    def render(store, cull):
+        prev = ops.set_backface_culling(cull)
+        try:
+            out = ops.rasterize(store, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), (240, 320), render_normals=True,
+                                render_depth=True, msaa=True, aniso=True)
+        finally:
+            ops.set_backface_culling(prev)
+        return [o.cpu().numpy() for o in out[:3]]
+
+    a, b = render(scene_store, True), render(scene_store, False)
+    diff = np.zeros(a[0].shape[:1] + a[0].shape[2:], bool)
+    for x, y in zip(a, b):
+        diff |= (x != y).reshape(x.shape[0], -1, *x.shape[-2:]).any(1)
+    assert diff.mean() < 2e-5, diff.mean()
+    assert (a[2] > 0).mean() > 0.02  # the objects are in view
+    # an open surface: remove a strip of faces from every object and rebuild the store
+    open_store = _open_copy(dev)
+    c, d = render(open_store, True), render(open_store, False)
+    for x, y in zip(c, d):
+        assert np.array_equal(x, y)
+
+
+def _open_copy(dev):
+    """The scene_store objects with a strip of faces removed: open surfaces (a boundary edge = never culled)."""
+    import dataclasses
+
+    from happypose_amd.mesh_store import RigidObject, RigidObjectDataset
+    from happypose_amd.ops import MeshStore
+    from happypose_amd.synthetic import make_mesh
+
+    objs = []
+    for i in range(3):
+        mesh = make_mesh(1000 + i, n_lat=72, n_lon=112, diameter=float(np.random.RandomState(1).uniform(0.10, 0.25)), tex_size=256)
+        mesh = dataclasses.replace(mesh, faces=np.ascontiguousarray(mesh.faces[400:]))
+        objs.append(RigidObject(label=f"obj_{i + 1:06d}", mesh_path=mesh, mesh_units="m"))
+    return MeshStore(RigidObjectDataset(objs), dev)
 
 
 def _oracle_only(scene_store, n, seed):
