@@ -58,7 +58,7 @@ constexpr unsigned long long kKeyEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kBandPixels = HP_RASTER_BAND_PIXELS;  // LDS z-buffer of a band, 8 B per pixel
 // HP_RASTER_MSAA4 (the reference's framebuffer state, see oracle.c HP_R_MSAA4): five keys per pixel -- the four colour
 // samples of the standard 4x pattern and the pixel centre (depth / mask stay centre-sampled) -- in a 50-KB z-buffer:
-// 4 rows of 320 pixels per band, three 512-thread workgroups per CU (12800 keys / one workgroup per CU: 1.4x slower).
+// 4 rows of 320 pixels per band, two 512-thread workgroups per CU (band_threads below has the measured alternative).
 // The coverage pass tests 5 samples on a bounding box that grows by the sample spread: ~10x its single-sample work,
 // 3.6x the whole rasteriser (128 views: 240 -> 880 us)
 constexpr int kSamplesMsaa = 5;
@@ -93,9 +93,20 @@ __device__ __forceinline__ void aniso_footprint(const RasterConv& cv, float pmax
 }
 constexpr int kBigQueue = 512;
 constexpr int kBigArea = 128;  // bbox pixels above which a triangle is walked cooperatively
-constexpr int kThreads = HP_RASTER_THREADS;  // band kernel
+// The multisampled band kernel's shape is a pair of build options (late round 4): -DHP_RASTER_THREADS_MSAA=256
+// -DHP_RASTER_BAND_KEYS_MSAA=3200 = 256 threads on 2-row bands, FOUR workgroups per CU instead of two at the same 16 waves.  A
+// band is a chain of dependent gathers (list -> corners -> vertices -> z-buffer -> attributes -> texels) on a few hundred
+// triangles -- one pass of its threads either way -- so the chains in flight per CU are what counts: 608 -> 563 us per 128 C2
+// views (C3 unchanged; 128 threads x 1 row 678, 256 x 1 row 740, 192 x 2 rows 622, 512 x 3 rows 675).  NOT the default: with
+// it (and back-face culling on) the two-lane MegaPose step replayed from a hipGraph differs from the eager one
+// (tests/test_gpu_pipeline.py::test_graph_replay_matches_eager[megapose-2]; every eager / oracle test passes, repeated eager
+// renders are bit-identical) -- cause not found, so the round-3 shape stays.
+#ifndef HP_RASTER_THREADS_MSAA
+#define HP_RASTER_THREADS_MSAA 512
+#endif
+constexpr __host__ __device__ int band_threads(int ns) { return ns == 1 ? HP_RASTER_THREADS : HP_RASTER_THREADS_MSAA; }
 constexpr int kBinThreads = 1024;  // binning kernel
-constexpr int kMaxBands = 256;
+constexpr int kMaxBands = 512;  // 480 one-row multisampled bands of a 640-wide render
 
 struct RasterArgs {
   const float4* verts4;   // xyz + pad
@@ -788,7 +799,8 @@ __device__ __forceinline__ void crop_taps(const float* __restrict__ img, int HW,
 // HALF: fp16 destinations (the input of an fp16 network plan) -- its own instantiation so that the fp32 path's register
 // budget (80 VGPRs: three 512-thread workgroups per CU) does not carry the 16-half record assembly
 template <int NS, bool HALF, bool ANISO>
-__global__ __launch_bounds__(kThreads, (NS == 1 && !HALF && !ANISO) ? 6 : 4) void raster_kernel(RasterArgs a, int npix_max) {
+__global__ __launch_bounds__(band_threads(NS), (NS == 1 && !HALF && !ANISO) ? 6 : 4) void raster_kernel(RasterArgs a, int npix_max) {
+  constexpr int kThreads = band_threads(NS);  // (shadows the single-sample constant)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int big_q[kBigQueue];
   __shared__ int big_n, n_cov, span_max[2];
@@ -1478,7 +1490,7 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
     hipLaunchKernelGGL(raster_xform_kernel, dim3((a.max_verts + 255) / 256, nv), dim3(256), 0, st, a);
     hipLaunchKernelGGL(raster_bin_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
     const int total = nv * a.n_bands;
-    hipLaunchKernelGGL(kernels[ki], dim3(8 * ((total + 7) / 8)), dim3(kThreads), lds, st, a, npix_max);
+    hipLaunchKernelGGL(kernels[ki], dim3(8 * ((total + 7) / 8)), dim3(band_threads(ns)), lds, st, a, npix_max);
   }
   return check_launch("raster_kernel");
 }
