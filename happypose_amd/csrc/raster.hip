@@ -98,9 +98,11 @@ constexpr int kBigArea = 128;  // bbox pixels above which a triangle is walked c
 // band is a chain of dependent gathers (list -> corners -> vertices -> z-buffer -> attributes -> texels) on a few hundred
 // triangles -- one pass of its threads either way -- so the chains in flight per CU are what counts: 608 -> 563 us per 128 C2
 // views (C3 unchanged; 128 threads x 1 row 678, 256 x 1 row 740, 192 x 2 rows 622, 512 x 3 rows 675).  NOT the default: with
-// it (and back-face culling on) the two-lane MegaPose step replayed from a hipGraph differs from the eager one
-// (tests/test_gpu_pipeline.py::test_graph_replay_matches_eager[megapose-2]; every eager / oracle test passes, repeated eager
-// renders are bit-identical) -- cause not found, so the round-3 shape stays.
+// it (and back-face culling on) a TWO-LANE MegaPose step is not reproducible -- the same step run twice on the same model
+// gives different poses, and tests/test_gpu_pipeline.py::test_graph_replay_matches_eager[megapose-2] fails -- while one lane is
+// bit-reproducible and every eager / oracle test passes.  The default shape is reproducible in both.  Cause not found (the lanes
+// share no buffers; it has the signature of the co-scheduling sensitivity recorded in DESIGN.md section 0b), so the round-3
+// shape stays.
 #ifndef HP_RASTER_THREADS_MSAA
 #define HP_RASTER_THREADS_MSAA 512
 #endif
