@@ -160,6 +160,18 @@ extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float
     for (int o = 0; o < n_obj; ++o)
       mesh_cull_record(h_verts + 3 * h_obj[8 * o], h_obj[8 * o + 1], h_faces + 3 * h_obj[8 * o + 2], h_obj[8 * o + 3], cull.data() + 8 * o);
     rc |= upload(&s->cull, cull.data(), cull.size());
+    std::vector<float4> planes((size_t)n_faces_total);
+    for (int o = 0; o < n_obj; ++o) {
+      const float* v = h_verts + 3 * h_obj[8 * o];
+      const int32_t* f = h_faces + 3 * h_obj[8 * o + 2];
+      for (int64_t t = 0; t < h_obj[8 * o + 3]; ++t) {
+        const float* a = v + 3 * (int64_t)f[3 * t]; const float* b = v + 3 * (int64_t)f[3 * t + 1]; const float* c = v + 3 * (int64_t)f[3 * t + 2];
+        const double e1[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]}, e2[3] = {(double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2]};
+        const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        planes[(size_t)(h_obj[8 * o + 2] + t)] = make_float4((float)n[0], (float)n[1], (float)n[2], (float)(n[0] * a[0] + n[1] * a[1] + n[2] * a[2]));
+      }
+    }
+    rc |= upload(&s->face_planes, planes.data(), planes.size());
   }
   if (h_points) rc |= upload(&s->points, h_points, (size_t)n_obj * n_pad * 3);
   if (rc) {
@@ -172,7 +184,7 @@ extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float
 extern "C" void hp_mesh_store_destroy(hp_mesh_store* s) {
   if (!s) return;
   (void)hipFree(s->verts); (void)hipFree(s->normals); (void)hipFree(s->uvs); (void)hipFree(s->colors);
-  (void)hipFree(s->faces); (void)hipFree(s->tex); (void)hipFree(s->obj); (void)hipFree(s->points); (void)hipFree(s->cull);
+  (void)hipFree(s->faces); (void)hipFree(s->tex); (void)hipFree(s->obj); (void)hipFree(s->points); (void)hipFree(s->cull); (void)hipFree(s->face_planes);
   (void)hipFree(s->bin_list); (void)hipFree(s->bin_count); (void)hipFree(s->xverts);
   (void)hipFree(s->verts4); (void)hipFree(s->normals4);
   delete s;

@@ -53,6 +53,7 @@ struct MeshStore {
   // orientation sign (+1 / -1: the object is a closed, consistently oriented surface with positive / negative signed volume;
   // 0: not provably closed -> never culled), 3 unused (api.cpp: mesh_cull_record)
   float* cull = nullptr;
+  float4* face_planes = nullptr;  // [faces of all objects] (n, n . a) of every face, n = (b - a) x (c - a) in the vertices' units: the facing test
   // rasteriser scratch: per-(view, band) triangle lists (grown on demand, see raster.hip)
   int32_t* bin_list = nullptr;
   size_t bin_list_bytes = 0;

@@ -57,13 +57,13 @@ constexpr float kZFar = 10.0f;
 constexpr unsigned long long kKeyEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kBandPixels = HP_RASTER_BAND_PIXELS;  // LDS z-buffer of a band, 8 B per pixel
 // HP_RASTER_MSAA4 (the reference's framebuffer state, see oracle.c HP_R_MSAA4): five keys per pixel -- the four colour
-// samples of the standard 4x pattern and the pixel centre (depth / mask stay centre-sampled) -- in a 50-KB z-buffer:
-// 4 rows of 320 pixels per band, two 512-thread workgroups per CU (band_threads below has the measured alternative).
+// samples of the standard 4x pattern and the pixel centre (depth / mask stay centre-sampled) -- in a 25-KB z-buffer:
+// 2 rows of 320 pixels per band, four 256-thread workgroups per CU (band_threads below; rounds 2-3: 4 rows, 512 threads).
 // The coverage pass tests 5 samples on a bounding box that grows by the sample spread: ~10x its single-sample work,
 // 3.6x the whole rasteriser (128 views: 240 -> 880 us)
 constexpr int kSamplesMsaa = 5;
 #ifndef HP_RASTER_BAND_KEYS_MSAA
-#define HP_RASTER_BAND_KEYS_MSAA 6400
+#define HP_RASTER_BAND_KEYS_MSAA 3200
 #endif
 constexpr int kMaxViews = 8;  // views per item a record layout can describe
 constexpr int kBandKeysMsaa = HP_RASTER_BAND_KEYS_MSAA;
@@ -93,18 +93,13 @@ __device__ __forceinline__ void aniso_footprint(const RasterConv& cv, float pmax
 }
 constexpr int kBigQueue = 512;
 constexpr int kBigArea = 128;  // bbox pixels above which a triangle is walked cooperatively
-// The multisampled band kernel's shape is a pair of build options (late round 4): -DHP_RASTER_THREADS_MSAA=256
-// -DHP_RASTER_BAND_KEYS_MSAA=3200 = 256 threads on 2-row bands, FOUR workgroups per CU instead of two at the same 16 waves.  A
-// band is a chain of dependent gathers (list -> corners -> vertices -> z-buffer -> attributes -> texels) on a few hundred
-// triangles -- one pass of its threads either way -- so the chains in flight per CU are what counts: 608 -> 563 us per 128 C2
-// views (C3 unchanged; 128 threads x 1 row 678, 256 x 1 row 740, 192 x 2 rows 622, 512 x 3 rows 675).  NOT the default: with
-// it (and back-face culling on) a TWO-LANE MegaPose step is not reproducible -- the same step run twice on the same model
-// gives different poses, and tests/test_gpu_pipeline.py::test_graph_replay_matches_eager[megapose-2] fails -- while one lane is
-// bit-reproducible and every eager / oracle test passes.  The default shape is reproducible in both.  Cause not found (the lanes
-// share no buffers; it has the signature of the co-scheduling sensitivity recorded in DESIGN.md section 0b), so the round-3
-// shape stays.
+// The multisampled band kernel (late round 4): 256 threads on 2-row bands (3200 keys, 25 KB of z-buffer) instead of 512 threads on
+// 4 rows -- FOUR workgroups per CU instead of two at the same 16 waves.  A band is a chain of dependent gathers (list ->
+// corners -> vertices -> z-buffer -> attributes -> texels) on a few hundred triangles -- one pass of its threads either way --
+// so the chains in flight per CU are what counts: 608 -> 563 us per 128 C2 views (C3 unchanged; 128 threads x 1 row 678,
+// 256 x 1 row 740, 192 x 2 rows 622, 512 x 3 rows 675).  -DHP_RASTER_THREADS_MSAA=512 -DHP_RASTER_BAND_KEYS_MSAA=6400: rounds 2-3.
 #ifndef HP_RASTER_THREADS_MSAA
-#define HP_RASTER_THREADS_MSAA 512
+#define HP_RASTER_THREADS_MSAA 256
 #endif
 constexpr __host__ __device__ int band_threads(int ns) { return ns == 1 ? HP_RASTER_THREADS : HP_RASTER_THREADS_MSAA; }
 constexpr int kBinThreads = 1024;  // binning kernel
@@ -119,6 +114,7 @@ struct RasterArgs {
   const uint8_t* tex;
   const int64_t* obj;
   const float* cull;      // MeshStore::cull ([n_obj][8]) or null: back faces of closed objects are not binned (raster_bin_kernel)
+  const float4* face_planes;  // MeshStore::face_planes
   const int32_t* obj_ids;
   const float* TCO;
   const float* K;
@@ -523,6 +519,9 @@ __global__ __launch_bounds__(256) void raster_xform_kernel(RasterArgs a) {
 // Pass 1: one lane per (view, triangle) -> append the triangle to the list of every band its
 // bounding box touches.  Appends are aggregated per wave (one atomic per band per wave).
 __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
+#ifdef HP_RASTER_ACQUIRE
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   const int lv = blockIdx.y;               // view within the chunk
   const int view = a.view0 + lv;
   const int f = blockIdx.x * kBinThreads + threadIdx.x;
@@ -532,14 +531,18 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
   const int nf = x.finite ? (int)ob[3] : 0;
   // the view may cull: the object is closed (MeshStore::cull), the camera is outside its bounding sphere, and the whole
   // sphere lies beyond the near plane (a clipped object shows its inside)
-  float cull_sign = 0.f;
-  if (a.cull && x.finite && x.Kv[0] > 0.f && x.Kv[4] > 0.f) {
+  float cull_sign = 0.f, cam[3] = {0.f, 0.f, 0.f};
+  if (a.cull && x.finite) {
     const float* const cu = a.cull + 8 * (int64_t)a.obj_ids[item];
     const float cx = fmaf(x.T[0], cu[0], fmaf(x.T[1], cu[1], fmaf(x.T[2], cu[2], x.T[3])));
     const float cy = fmaf(x.T[4], cu[0], fmaf(x.T[5], cu[1], fmaf(x.T[6], cu[2], x.T[7])));
     const float cz = fmaf(x.T[8], cu[0], fmaf(x.T[9], cu[1], fmaf(x.T[10], cu[2], x.T[11])));
     const float r = cu[3] * 1.001f + 1e-6f;  // (a scaled rotation is not expected in T; the margin covers its rounding)
     if (cx * cx + cy * cy + cz * cz > r * r && cz - r > kZNear) cull_sign = cu[4];
+    // the camera centre in the object's frame: - R^T t
+    cam[0] = -(x.T[0] * x.T[3] + x.T[4] * x.T[7] + x.T[8] * x.T[11]);
+    cam[1] = -(x.T[1] * x.T[3] + x.T[5] * x.T[7] + x.T[9] * x.T[11]);
+    cam[2] = -(x.T[2] * x.T[3] + x.T[6] * x.T[7] + x.T[10] * x.T[11]);
   }
   int b0 = 1, b1 = 0;  // empty band range
   if (f < nf) {
@@ -552,22 +555,18 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
       b1 = y1 / a.band_rows;
       // Back faces of a CLOSED object seen from outside are never visible (the renders are two-sided like the reference's,
       // panda3d_scene_renderer.py:102: every ray meets a front face of the closed surface first, and the canonical edge
-      // functions make that surface watertight).  V = K (T p): the triple product V0 . (V1 x V2) has the sign of the camera-space
-      // one (fx, fy > 0); it is negative for a triangle that faces the camera when the object's signed volume is positive.
-      // Dropped only when the sign is clear of the rounding of the product (|det| > 1e-5 sum |terms|, ~40x its error bound).
+      // functions make that surface watertight).  The first version took the facing from the screen-space vertices of the
+      // vertex pass (the sign of V0 . ((V1 - V0) x (V2 - V0))): correct, but in two-lane steps the decision was then NOT
+      // reproducible for a few triangles per launch (single-pixel colour differences from run to run; with a decision that does
+      // not read those records, or without culling, bit-identical) -- so it reads object-space data only.
       if (cull_sign != 0.f) {
-        // V0 . ((V1 - V0) x (V2 - V0)): the edge vectors of these pixel-sized triangles are small and nearly exact, so the
-        // cross product does not cancel the way V1 x V2 does in pixel-homogeneous coordinates (|terms| ~ 1e5 x |det| there)
-        const float ax = V1[0] - V0[0], ay = V1[1] - V0[1], az = V1[2] - V0[2];
-        const float bx = V2[0] - V0[0], by = V2[1] - V0[1], bz = V2[2] - V0[2];
-        const float t0 = ay * bz, t1 = az * by, t2 = az * bx, t3 = ax * bz, t4 = ax * by, t5 = ay * bx;
-        const float det = fmaf(V0[0], t0 - t1, fmaf(V0[1], t2 - t3, V0[2] * (t4 - t5)));
-        // rounding of the edge vectors (relative 2^-24 of the vertices) and of the products
-        const float emag = 1.2e-7f * (fabsf(V0[0]) + fabsf(V0[1]) + fabsf(V0[2]));
-        const float mag = fabsf(V0[0]) * (fabsf(t0) + fabsf(t1) + emag * (fabsf(ay) + fabsf(az) + fabsf(by) + fabsf(bz))) +
-                          fabsf(V0[1]) * (fabsf(t2) + fabsf(t3) + emag * (fabsf(ax) + fabsf(az) + fabsf(bx) + fabsf(bz))) +
-                          fabsf(V0[2]) * (fabsf(t4) + fabsf(t5) + emag * (fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by)));
-        if (det * cull_sign > 1e-5f * mag) { b0 = 1; b1 = 0; }
+        // the camera is on the inner side of the face's plane, by 100x the rounding of the test (object-space data only: the
+        // face's plane from hp_mesh_store_create and the camera centre - R^T t; nothing a previous launch wrote)
+        const float4 pl = a.face_planes[ob[2] + f];
+        const float t0 = pl.x * cam[0], t1 = pl.y * cam[1], t2 = pl.z * cam[2];
+        const float sd = (t0 + t1) + (t2 - pl.w);
+        const float mag = fabsf(t0) + fabsf(t1) + fabsf(t2) + fabsf(pl.w);
+        if (sd * cull_sign < -1e-5f * mag) { b0 = 1; b1 = 0; }
       }
     }
   }
@@ -803,6 +802,9 @@ __device__ __forceinline__ void crop_taps(const float* __restrict__ img, int HW,
 template <int NS, bool HALF, bool ANISO>
 __global__ __launch_bounds__(band_threads(NS), (NS == 1 && !HALF && !ANISO) ? 6 : 4) void raster_kernel(RasterArgs a, int npix_max) {
   constexpr int kThreads = band_threads(NS);  // (shadows the single-sample constant)
+#ifdef HP_RASTER_ACQUIRE
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int big_q[kBigQueue];
   __shared__ int big_n, n_cov, span_max[2];
@@ -1357,8 +1359,15 @@ __global__ __launch_bounds__(band_threads(NS), (NS == 1 && !HALF && !ANISO) ? 6 
 // captured launch would keep the pointer that is freed here) -- run the call once eagerly, or reserve.
 static int raster_scratch(hp::MeshStore* ms, int n, int n_bands, hipStream_t st, int* chunk_out) {
   const size_t per_view = (size_t)n_bands * (size_t)ms->max_faces * sizeof(int32_t);
-  const size_t budget = (size_t)512 << 20;
-  int chunk = (int)(budget / (per_view ? per_view : 1));
+  // List budget: 8 GB of the 288 (what is allocated is what the largest call needs: 7.7 MB per multisampled 240 x 320 view); it was
+  // 512 MB through round 3 (five chunks for a lane's 576 coarse views).  One chunk per call saves the repeated launches;
+  // HP_RASTER_CHUNK_VIEWS=<n> forces chunks (the tests' way to run the chunked path), HP_RASTER_CHUNK_SYNC=1 synchronises the
+  // stream after every chunk (diagnostics).
+  static const size_t budget_mb = std::getenv("HP_RASTER_LIST_BUDGET_MB") ? (size_t)std::atoll(std::getenv("HP_RASTER_LIST_BUDGET_MB")) : 8192;
+  const size_t budget = budget_mb << 20;
+  int chunk = (int)std::min<size_t>(budget / (per_view ? per_view : 1), 1u << 30);
+  static const int chunk_env = std::getenv("HP_RASTER_CHUNK_VIEWS") ? std::atoi(std::getenv("HP_RASTER_CHUNK_VIEWS")) : 0;
+  if (chunk_env > 0 && chunk_env < chunk) chunk = chunk_env;
   if (chunk < 1) chunk = 1;
   if (chunk > n) chunk = n;
   *chunk_out = chunk;
@@ -1493,6 +1502,8 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
     hipLaunchKernelGGL(raster_bin_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
     const int total = nv * a.n_bands;
     hipLaunchKernelGGL(kernels[ki], dim3(8 * ((total + 7) / 8)), dim3(band_threads(ns)), lds, st, a, npix_max);
+    static const bool chunk_sync = std::getenv("HP_RASTER_CHUNK_SYNC") != nullptr;  // diagnostics (see raster_scratch)
+    if (chunk_sync && v0 + chunk < n) (void)hipStreamSynchronize(st);
   }
   return check_launch("raster_kernel");
 }
@@ -1551,7 +1562,7 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_rasterize: depth_norm_z missing");
   RasterArgs a{};
   a.verts4 = store->verts4; a.normals4 = store->normals4; a.uvs = store->uvs; a.colors = store->colors;
-  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj; a.cull = raster_cull_enabled() ? store->cull : nullptr;
+  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj; a.cull = raster_cull_enabled() ? store->cull : nullptr; a.face_planes = store->face_planes;
   a.obj_ids = d_obj_ids; a.TCO = d_TCO; a.K = d_K; a.ambient = d_ambient;
   a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
   a.rgb = d_rgb; a.nrm = d_nrm; a.depth = d_depth; a.mask = d_mask;
@@ -1597,7 +1608,7 @@ extern "C" int hp_render_inputs(const hp_mesh_store* store, int n_items, int vie
   }
   RasterArgs a{};
   a.verts4 = store->verts4; a.normals4 = store->normals4; a.uvs = store->uvs; a.colors = store->colors;
-  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj; a.cull = raster_cull_enabled() ? store->cull : nullptr;
+  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj; a.cull = raster_cull_enabled() ? store->cull : nullptr; a.face_planes = store->face_planes;
   a.obj_ids = d_obj_ids; a.TCO = d_TCV_O; a.K = d_KV; a.ambient = d_ambient;
   a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
   a.n = n_items * views_per_item; a.views_per_item = views_per_item; a.n_lights = n_lights; a.h = h; a.w = w;

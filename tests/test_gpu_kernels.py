@@ -303,6 +303,33 @@ def test_rasterizer_backface_culling_keeps_the_image(dev, scene_store):
         assert np.array_equal(x, y)
 
 
+def test_rasterizer_chunked_launch_is_bit_identical(dev, scene_store, tmp_path):
+    """``hp_rasterize`` renders in chunks of views when the per-(view, band) triangle lists of a call would exceed the list
+    budget (8 GB: never at the benchmark sizes any more).  The chunked path -- scratch re-used from chunk to chunk, ``view0``
+    offsets -- must give the bits of the one-chunk launch: ``HP_RASTER_CHUNK_VIEWS=5`` (read once per process: a second
+    interpreter) against this process, 12 views in the reference render state."""
+    import subprocess
+    import sys
+
+    gpu, _ = _render_both(scene_store, n=12, seed=5)
+    here = [g.cpu().numpy() for g in gpu[:3]]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_gpu_kernels as t\n"
+        "from happypose_amd.ops import MeshStore\n"
+        "from happypose_amd.synthetic import make_object_dataset\n"
+        "store = MeshStore(make_object_dataset(3, seed=1, tex_size=256), torch.device('cuda:0'))\n"
+        "gpu, _ = t._render_both(store, n=12, seed=5)\n"
+        "np.savez(%r, *[g.cpu().numpy() for g in gpu[:3]])\n" % (root, os.path.join(root, "tests"), str(tmp_path / "chunked.npz")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env={**os.environ, "HP_RASTER_CHUNK_VIEWS": "5"})
+    assert out.returncode == 0, out.stdout + out.stderr
+    there = np.load(tmp_path / "chunked.npz")
+    for k, x in enumerate(here):
+        assert np.array_equal(x, there[f"arr_{k}"]), k
+
+
 def _open_copy(dev):
     """The scene_store objects with a strip of faces removed: open surfaces (a boundary edge = never culled)."""
     import dataclasses
@@ -595,8 +622,8 @@ def _conv_ref(x_nhwc, w_oihw, stride, pad, bias, residual, pre, relu):
 
 @pytest.mark.parametrize("case", [
     dict(n=2, h=60, w=80, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=False, relu=True),
-    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),    # conv3x3s2_pp<MODE_F16>: one chunk
-    dict(n=2, h=30, w=40, cin=128, cout=256, k=3, s=2, p=1, bias=True, res=False, pre=False, relu=True),  # two chunks
+    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),    # 3x3 / stride 2, one 64-channel chunk
+    dict(n=2, h=30, w=40, cin=128, cout=256, k=3, s=2, p=1, bias=True, res=False, pre=False, relu=True),  # two 64-channel chunks
     dict(n=3, h=31, w=45, cin=128, cout=128, k=3, s=2, p=1, bias=False, res=True, pre=False, relu=False), # odd size, residual
     dict(n=1, h=15, w=20, cin=256, cout=512, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),   # few tiles: K slices
     dict(n=2, h=30, w=40, cin=128, cout=256, k=1, s=2, p=0, bias=False, res=False, pre=True, relu=False),
@@ -724,8 +751,8 @@ def test_split_conv_dynamic_range(dev, case):
 # accumulation order and the final rounding to fp16 (2^-11 relative)
 @pytest.mark.parametrize("case", [
     dict(n=3, h=60, w=80, cin=64, cout=64, k=3, s=1, p=1, bias=True, res=True, pre=False, relu=True),
-    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),    # conv3x3s2_pp<MODE_F16>: one chunk
-    dict(n=2, h=30, w=40, cin=128, cout=256, k=3, s=2, p=1, bias=True, res=False, pre=False, relu=True),  # two chunks
+    dict(n=3, h=60, w=80, cin=64, cout=128, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),    # 3x3 / stride 2, one 64-channel chunk
+    dict(n=2, h=30, w=40, cin=128, cout=256, k=3, s=2, p=1, bias=True, res=False, pre=False, relu=True),  # two 64-channel chunks
     dict(n=3, h=31, w=45, cin=128, cout=128, k=3, s=2, p=1, bias=False, res=True, pre=False, relu=False), # odd size, residual
     dict(n=1, h=15, w=20, cin=256, cout=512, k=3, s=2, p=1, bias=True, res=False, pre=True, relu=True),   # few tiles: K slices
     dict(n=2, h=30, w=40, cin=128, cout=256, k=1, s=2, p=0, bias=False, res=False, pre=True, relu=False),
