@@ -102,9 +102,9 @@ _PROTOS = {
     "hp_net_set_conv_algo": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_net_status": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "hp_net_force_exact": (C.c_int, [C.c_void_p, C.c_int]),
-    "hp_raster_set_conventions": (C.c_int, [C.c_void_p]),
-    "hp_raster_get_conventions": (C.c_int, [C.c_void_p]),
-    "hp_raster_set_backface_culling": (C.c_int, [C.c_int]),
+    "hp_mesh_store_set_raster_conventions": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hp_mesh_store_get_raster_conventions": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hp_mesh_store_set_backface_culling": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_profile_mark_reference": (C.c_int, [C.c_void_p]),
     "hp_net_profile_intervals": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "hp_conv_select_algo": (C.c_int, [C.c_int]),

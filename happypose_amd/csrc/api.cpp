@@ -48,13 +48,18 @@ int upload(T** dst, const T* src, size_t count) {
   return HP_OK;
 }
 
-// Back-face culling record of one object (MeshStore::cull).  The reference renders two-sided
+// Back-face culling data of one object (MeshStore::cull, the flag in MeshStore::faces4).  The reference renders two-sided
 // (TB/renderer/panda3d_scene_renderer.py:102), so a triangle facing away from the camera may only be dropped when it provably
-// cannot be seen: the object is a CLOSED, consistently oriented surface (every directed edge occurs once and so does its
-// reverse, vertices welded by exact position: texture seams duplicate vertices) and the camera is outside it (the binning
-// pass checks the bounding sphere per view).  Then every ray from the camera meets a front face first.
-void mesh_cull_record(const float* v, int64_t nv, const int32_t* f, int64_t nf, float* out8) {
+// cannot be seen.  Per CONNECTED COMPONENT of the position-welded mesh (texture seams duplicate vertices; faces are connected
+// through shared edges): if the component is a closed, consistently oriented surface (every directed edge occurs once and so
+// does its reverse) with a signed volume safely away from zero, then from any camera position outside the component every ray
+// meets one of its outward-facing faces before any inward-facing one -- the inward-facing faces of THAT component are never
+// visible, whatever the other components do (nested shells, a part with flipped winding, open sheets: each gets its own
+// flag).  flag = +1 / -1: outward = the winding's front / back side; 0: never culled.  The rasteriser culls only when the
+// camera is outside the object's bounding sphere (hence outside every component) and the sphere lies beyond the near plane.
+void mesh_cull_flags(const float* v, int64_t nv, const int32_t* f, int64_t nf, float* out8, int32_t* flags) {
   for (int k = 0; k < 8; ++k) out8[k] = 0.f;
+  for (int64_t t = 0; t < nf; ++t) flags[t] = 0;
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   for (int64_t i = 0; i < nv; ++i)
     for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], (double)v[3 * i + c]); hi[c] = std::max(hi[c], (double)v[3 * i + c]); }
@@ -72,30 +77,55 @@ void mesh_cull_record(const float* v, int64_t nv, const int32_t* f, int64_t nf, 
   std::sort(order.begin(), order.end(), less);
   for (int64_t i = 0; i < nv; ++i)
     canon[order[i]] = (i > 0 && std::memcmp(v + 3 * (int64_t)order[i], v + 3 * (int64_t)order[i - 1], 12) == 0) ? canon[order[i - 1]] : order[i];
-  std::vector<uint64_t> edges;
-  edges.reserve((size_t)nf * 3);
-  double vol = 0.0;
+  // union-find over the faces: two faces sharing an (undirected) welded edge are connected
+  std::vector<int32_t> parent((size_t)nf);
+  for (int64_t t = 0; t < nf; ++t) parent[t] = (int32_t)t;
+  auto find = [&](int32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+  struct Edge { uint64_t key; int32_t face; };
+  std::vector<Edge> directed, undirected;
+  directed.reserve((size_t)nf * 3); undirected.reserve((size_t)nf * 3);
+  std::vector<char> degenerate((size_t)nf, 0);
+  std::vector<double> fvol((size_t)nf, 0.0);
   for (int64_t t = 0; t < nf; ++t) {
-    const int32_t a = canon[f[3 * t]], b = canon[f[3 * t + 1]], c = canon[f[3 * t + 2]];
-    if (a == b || b == c || a == c) continue;  // degenerate after welding: no area, no edges
-    const float* pa = v + 3 * (int64_t)a; const float* pb = v + 3 * (int64_t)b; const float* pc = v + 3 * (int64_t)c;
-    vol += (double)pa[0] * ((double)pb[1] * pc[2] - (double)pb[2] * pc[1]) - (double)pa[1] * ((double)pb[0] * pc[2] - (double)pb[2] * pc[0]) +
-           (double)pa[2] * ((double)pb[0] * pc[1] - (double)pb[1] * pc[0]);
-    edges.push_back(((uint64_t)(uint32_t)a << 32) | (uint32_t)b);
-    edges.push_back(((uint64_t)(uint32_t)b << 32) | (uint32_t)c);
-    edges.push_back(((uint64_t)(uint32_t)c << 32) | (uint32_t)a);
+    const int32_t c3[3] = {canon[f[3 * t]], canon[f[3 * t + 1]], canon[f[3 * t + 2]]};
+    if (c3[0] == c3[1] || c3[1] == c3[2] || c3[0] == c3[2]) { degenerate[t] = 1; continue; }  // no area, no edges
+    const float* pa = v + 3 * (int64_t)c3[0]; const float* pb = v + 3 * (int64_t)c3[1]; const float* pc = v + 3 * (int64_t)c3[2];
+    fvol[t] = (double)pa[0] * ((double)pb[1] * pc[2] - (double)pb[2] * pc[1]) - (double)pa[1] * ((double)pb[0] * pc[2] - (double)pb[2] * pc[0]) +
+              (double)pa[2] * ((double)pb[0] * pc[1] - (double)pb[1] * pc[0]);
+    for (int e = 0; e < 3; ++e) {
+      const uint32_t a = (uint32_t)c3[e], b = (uint32_t)c3[(e + 1) % 3];
+      directed.push_back({((uint64_t)a << 32) | b, (int32_t)t});
+      undirected.push_back({((uint64_t)std::min(a, b) << 32) | std::max(a, b), (int32_t)t});
+    }
   }
-  if (edges.empty()) return;
-  std::sort(edges.begin(), edges.end());
-  for (size_t i = 1; i < edges.size(); ++i)
-    if (edges[i] == edges[i - 1]) return;  // a directed edge used twice: not a consistently oriented manifold
-  for (uint64_t e : edges) {
-    const uint64_t rev = (e << 32) | (e >> 32);
-    if (!std::binary_search(edges.begin(), edges.end(), rev)) return;  // a boundary edge: open surface
+  if (directed.empty()) return;
+  auto by_key = [](const Edge& x, const Edge& y) { return x.key < y.key; };
+  std::sort(undirected.begin(), undirected.end(), by_key);
+  for (size_t i = 1; i < undirected.size(); ++i)
+    if (undirected[i].key == undirected[i - 1].key) {
+      const int32_t ra = find(undirected[i].face), rb = find(undirected[i - 1].face);
+      if (ra != rb) parent[ra] = rb;
+    }
+  std::sort(directed.begin(), directed.end(), by_key);
+  std::vector<char> bad((size_t)nf, 0);  // per component root
+  for (size_t i = 0; i < directed.size(); ++i) {
+    if (i > 0 && directed[i].key == directed[i - 1].key) bad[find(directed[i].face)] = 1;  // a directed edge used twice
+    const uint64_t rev = (directed[i].key << 32) | (directed[i].key >> 32);
+    const Edge probe{rev, 0};
+    if (!std::binary_search(directed.begin(), directed.end(), probe, by_key)) bad[find(directed[i].face)] = 1;  // boundary edge
   }
-  const double r = std::sqrt(r2);
-  if (std::fabs(vol) < 1e-9 * r * r * r) return;
-  out8[4] = vol > 0.0 ? 1.f : -1.f;
+  std::vector<double> vol((size_t)nf, 0.0), mag((size_t)nf, 0.0);
+  for (int64_t t = 0; t < nf; ++t)
+    if (!degenerate[t]) { const int32_t r = find((int32_t)t); vol[r] += fvol[t]; mag[r] += std::fabs(fvol[t]); }
+  bool any = false;
+  for (int64_t t = 0; t < nf; ++t) {
+    if (degenerate[t]) continue;
+    const int32_t r = find((int32_t)t);
+    if (bad[r] || !(std::fabs(vol[r]) > 1e-9 * mag[r]) || mag[r] == 0.0) continue;
+    flags[t] = vol[r] > 0.0 ? 1 : -1;
+    any = true;
+  }
+  out8[4] = any ? 1.f : 0.f;
 }
 
 }  // namespace
@@ -133,10 +163,12 @@ extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float
   }
   hp_mesh_store* s = new hp_mesh_store();
   s->n_obj = n_obj;
+  hp::raster_store_defaults(s);
   s->n_pad = h_points ? n_pad : 0;
   for (int o = 0; o < n_obj; ++o) {
     if (h_obj[8 * o + 1] > s->max_verts) s->max_verts = h_obj[8 * o + 1];
     if (h_obj[8 * o + 3] > s->max_faces) s->max_faces = h_obj[8 * o + 3];
+    if (h_obj[8 * o + 4] < 0) s->any_untextured = true;
   }
   int rc = 0;
   rc |= upload(&s->verts, h_verts, (size_t)n_verts_total * 3);
@@ -152,26 +184,18 @@ extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float
   }
   rc |= upload(&s->uvs, h_uvs, (size_t)n_verts_total * 2);
   rc |= upload(&s->colors, h_colors, (size_t)n_verts_total * 4);
-  rc |= upload(&s->faces, h_faces, (size_t)n_faces_total * 3);
   rc |= upload(&s->tex, h_tex, (size_t)(tex_bytes > 0 ? tex_bytes : 0));
   rc |= upload(&s->obj, h_obj, (size_t)n_obj * 8);
   {
     std::vector<float> cull((size_t)n_obj * 8);
+    std::vector<int32_t> flags((size_t)n_faces_total);
+    std::vector<int4> f4((size_t)n_faces_total);
     for (int o = 0; o < n_obj; ++o)
-      mesh_cull_record(h_verts + 3 * h_obj[8 * o], h_obj[8 * o + 1], h_faces + 3 * h_obj[8 * o + 2], h_obj[8 * o + 3], cull.data() + 8 * o);
+      mesh_cull_flags(h_verts + 3 * h_obj[8 * o], h_obj[8 * o + 1], h_faces + 3 * h_obj[8 * o + 2], h_obj[8 * o + 3], cull.data() + 8 * o,
+                      flags.data() + h_obj[8 * o + 2]);
+    for (int64_t t = 0; t < n_faces_total; ++t) f4[t] = make_int4(h_faces[3 * t], h_faces[3 * t + 1], h_faces[3 * t + 2], flags[t]);
     rc |= upload(&s->cull, cull.data(), cull.size());
-    std::vector<float4> planes((size_t)n_faces_total);
-    for (int o = 0; o < n_obj; ++o) {
-      const float* v = h_verts + 3 * h_obj[8 * o];
-      const int32_t* f = h_faces + 3 * h_obj[8 * o + 2];
-      for (int64_t t = 0; t < h_obj[8 * o + 3]; ++t) {
-        const float* a = v + 3 * (int64_t)f[3 * t]; const float* b = v + 3 * (int64_t)f[3 * t + 1]; const float* c = v + 3 * (int64_t)f[3 * t + 2];
-        const double e1[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]}, e2[3] = {(double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2]};
-        const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-        planes[(size_t)(h_obj[8 * o + 2] + t)] = make_float4((float)n[0], (float)n[1], (float)n[2], (float)(n[0] * a[0] + n[1] * a[1] + n[2] * a[2]));
-      }
-    }
-    rc |= upload(&s->face_planes, planes.data(), planes.size());
+    rc |= upload(&s->faces4, f4.data(), f4.size());
   }
   if (h_points) rc |= upload(&s->points, h_points, (size_t)n_obj * n_pad * 3);
   if (rc) {
@@ -184,8 +208,8 @@ extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float
 extern "C" void hp_mesh_store_destroy(hp_mesh_store* s) {
   if (!s) return;
   (void)hipFree(s->verts); (void)hipFree(s->normals); (void)hipFree(s->uvs); (void)hipFree(s->colors);
-  (void)hipFree(s->faces); (void)hipFree(s->tex); (void)hipFree(s->obj); (void)hipFree(s->points); (void)hipFree(s->cull); (void)hipFree(s->face_planes);
-  (void)hipFree(s->bin_list); (void)hipFree(s->bin_count); (void)hipFree(s->xverts);
+  (void)hipFree(s->faces4); (void)hipFree(s->tex); (void)hipFree(s->obj); (void)hipFree(s->points); (void)hipFree(s->cull);
+  (void)hipFree(s->bin_list); (void)hipFree(s->bin_count); (void)hipFree(s->recs);
   (void)hipFree(s->verts4); (void)hipFree(s->normals4);
   delete s;
 }

@@ -45,28 +45,37 @@ struct MeshStore {
   float4* normals4 = nullptr;
   float* uvs = nullptr;
   uint8_t* colors = nullptr;
-  int32_t* faces = nullptr;
   uint8_t* tex = nullptr;
   int64_t* obj = nullptr;  // [n_obj][8]
   float* points = nullptr; // [n_obj][n_pad][3]
-  // [n_obj][8] back-face culling record of the rasteriser's binning pass: bounding sphere (cx, cy, cz, r) in the vertices' units,
-  // orientation sign (+1 / -1: the object is a closed, consistently oriented surface with positive / negative signed volume;
-  // 0: not provably closed -> never culled), 3 unused (api.cpp: mesh_cull_record)
+  // [n_obj][8] view-level back-face culling record of the rasteriser's set-up pass: bounding sphere (cx, cy, cz, r) in the vertices'
+  // units, entry 4: 1 when at least one face of the object may be culled (api.cpp: mesh_cull_flags), 3 unused
   float* cull = nullptr;
-  float4* face_planes = nullptr;  // [faces of all objects] (n, n . a) of every face, n = (b - a) x (c - a) in the vertices' units: the facing test
-  // rasteriser scratch: per-(view, band) triangle lists (grown on demand, see raster.hip)
+  // [faces of all objects] {i0, i1, i2, cull flag}: the corner indices (object-local) and the face's orientation flag -- +1 / -1:
+  // the face belongs to a CLOSED, consistently oriented connected component whose signed volume is positive / negative (its
+  // back side can never be seen from outside the object); 0: never culled
+  int4* faces4 = nullptr;
+  // rasteriser scratch (grown on demand, see raster.hip): per-(view, band) triangle lists, their counters (all zero between
+  // launches: the band kernel clears what it has consumed) and the per-(view, sub-triangle) set-up records
   int32_t* bin_list = nullptr;
   size_t bin_list_bytes = 0;
   int32_t* bin_count = nullptr;
   size_t bin_count_bytes = 0;
-  float4* xverts = nullptr;  // per-(view, vertex) screen-space vertices of the current chunk (2 float4 each)
-  size_t xverts_bytes = 0;
+  uint4* recs = nullptr;      // [view][2 * max_faces][8]: 128-B set-up record of every sub-triangle (raster.hip: FaceRec)
+  size_t recs_bytes = 0;
   int64_t scratch_generation = 0;  // bumped whenever the scratch above is reallocated (captured graphs hold the old pointers)
+  // renderer state of THIS store (no process-wide state: two stores may differ): the conventions record of
+  // hp_mesh_store_set_raster_conventions and the back-face culling switch of hp_mesh_store_set_backface_culling
+  hp_raster_conventions conventions;
+  int backface_culling = 1;
+  bool any_untextured = false;  // some object has no texture: its vertex colours are interpolated (needs the barycentric planes)
   int n_obj = 0;
   int n_pad = 0;
   int64_t max_verts = 0;  // max vertices of a single object
   int64_t max_faces = 0;
 };
+
+void raster_store_defaults(MeshStore* s);  // raster.hip: default conventions record, culling on
 
 }  // namespace hp
 

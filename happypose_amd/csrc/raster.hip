@@ -3,33 +3,25 @@
 //
 // Replaces Panda3dBatchRenderer.render -> worker processes -> Panda3D/OpenGL
 // (TB/renderer/panda3d_batch_renderer.py:194-286, TB/renderer/panda3d_scene_renderer.py:320-390).
-// The arithmetic (operation order included) follows the CPU definition in
-// oracle/csrc/oracle.c so that coverage decisions agree pixel for pixel.
+// The arithmetic (operation order included) follows the CPU definition in oracle/csrc/oracle.c
+// ("the rasteriser's geometry, round 5") so that coverage and depth agree bit for bit.
 //
-// Mapping to the hardware
-//   * one workgroup (256 threads = 4 waves) per (view, horizontal band of the image); the
-//     band's 64-bit z-buffer {depth bits : triangle id} lives in LDS (<= 76.8 KB, two
-//     workgroups per CU) and is updated with ds_min_u64 -- no z-buffer traffic to HBM;
-//   * a thread owns a triangle: it transforms the three vertices itself (9+6 FMAs each, the
-//     mesh is L2/MALL resident and shared by every view of the object), rejects it against
-//     the band, sets up the three homogeneous edge functions and walks its (tiny: ~3 px)
-//     bounding box; triangles with a large footprint are queued in LDS and walked by the
-//     whole workgroup so one lane never serialises thousands of pixels;
-//   * the resolve pass is pixel-parallel: consecutive lanes take consecutive columns, so
-//     NCHW planes are written with fully coalesced 256-B wave stores; texture, uv and
-//     normal gathers hit L2;
-//   * HBM traffic is therefore the output tensor (+ first touch of mesh/texture) -- the
-//     kernel's roofline is HBM bandwidth ("rasteriser").
-//   * workgroups are renumbered so that each XCD gets a contiguous range of views:
-//     consecutive hypotheses share an object, hence the mesh stays in that XCD's L2.
-//
-// Round 3: ONE WRITER PER PIXEL RECORD.  The kernel can also produce the observed crop (roi_align of the frame, crop_math.h)
-// for its pixels and stores the crop channels and the render channels of a view as one run of the network-input record
-// (hp_render_inputs): the separate crop launch and the 12-B-of-24/32-B partial-sector stores of two kernels (a
-// read-modify-write in the memory system: rocprofv3 counted 3x the algorithmic bytes, profiles/r03a_raster_hbm_traffic.json)
-// are gone.  Inside a workgroup the work is re-organised in four passes: coverage (triangle-parallel, LDS z-buffer) ->
-// compaction of the covered pixels -> shading of the compacted list (every lane has a fragment; the 8-bit colour codes go
-// back into the z-buffer slots) -> pixel-parallel output pass (crop taps + record assembly, coalesced stores).
+// Round 5: the geometry is defined the way OpenGL hardware defines it -- vertices snapped to a 1/256-px grid, exact integer
+// edge functions with a top-left fill rule, 1/z and the attributes as PLANES in window coordinates -- and the work is split
+// so that nothing is derived twice:
+//   * raster_setup_kernel, one lane per (view, triangle): camera transform of the three corners (the mesh is L2 / MALL
+//     resident and shared by every view of the object), near-plane clipping (rare), snapping, back-face culling of closed
+//     components on the EXACT sign of the snapped area, plane set-up, one 128-B record per sub-triangle (FaceRec below) and
+//     the append of its id to the list of every band of rows it can touch;
+//   * raster_kernel, one workgroup per (view, band): coverage is a walk over the candidate pixels of each listed record with
+//     nine integer multiply-adds per pixel and three adds per sample (the per-sample IEEE division, the nine-product
+//     homogeneous edge set-up per (triangle, band) and per shading invocation, and the list -> corner indices -> vertex
+//     records chain of rounds 1-4 are gone); the band's 64-bit z-buffer {~bits(1/z) : id} lives in LDS (ds_min_u64); shading
+//     evaluates the record's planes at the pixel centre (six FMAs and one division for u, v and their screen derivatives)
+//     and goes straight to the texture; the output pass is pixel-parallel (coalesced NCHW planes or NHWC record runs).
+//   * HBM traffic = the output tensor + the records (64 - 96 B per visible triangle and view) + first touch of mesh / texture.
+//   * workgroups are renumbered so that each XCD gets a contiguous range of views: consecutive hypotheses share an object,
+//     hence mesh, texture and records stay in that XCD's L2.
 #include <atomic>
 #include <cmath>
 #include <mutex>
@@ -37,10 +29,6 @@
 #include "common.h"
 #include "crop_math.h"
 
-// Band size: a band is one workgroup.  Only the bands the object covers carry work, so the launch is as long as the busiest
-// CU's sequence of busy bands.  LDS per workgroup: 8 B (z key / colour codes) + 2 B (codes) + 2 B (covered-pixel list) per
-// pixel + the crop folds: 10 rows of 320 pixels = 49 KB -> three 512-thread workgroups per CU, which is also what the
-// fp32 kernel's 80 VGPRs allow (24 waves per CU).
 #ifndef HP_RASTER_BAND_PIXELS
 #define HP_RASTER_BAND_PIXELS 3200
 #endif
@@ -54,32 +42,32 @@ namespace hp {
 
 constexpr float kZNear = 0.1f;
 constexpr float kZFar = 10.0f;
+constexpr int kSub = 256;                  // sub-pixel grid of the snapped vertices and of the sample positions
+constexpr float kGuardSub = 4194304.0f;    // guard band: +-2^22 sub-pixel units = +-16384 px
+constexpr int kSmallLimit = 8192;          // |corner - origin| <= 32 px on both axes: 32-bit edge functions (v_mad_i32_i24)
 constexpr unsigned long long kKeyEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kBandPixels = HP_RASTER_BAND_PIXELS;  // LDS z-buffer of a band, 8 B per pixel
 // HP_RASTER_MSAA4 (the reference's framebuffer state, see oracle.c HP_R_MSAA4): five keys per pixel -- the four colour
 // samples of the standard 4x pattern and the pixel centre (depth / mask stay centre-sampled) -- in a 25-KB z-buffer:
-// 2 rows of 320 pixels per band, four 256-thread workgroups per CU (band_threads below; rounds 2-3: 4 rows, 512 threads).
-// The coverage pass tests 5 samples on a bounding box that grows by the sample spread: ~10x its single-sample work,
-// 3.6x the whole rasteriser (128 views: 240 -> 880 us)
+// 2 rows of 320 pixels per band, four 256-thread workgroups per CU (band_threads below); renders wider than 640 px take
+// 512 threads on 6400 keys.
 constexpr int kSamplesMsaa = 5;
 #ifndef HP_RASTER_BAND_KEYS_MSAA
 #define HP_RASTER_BAND_KEYS_MSAA 3200
 #endif
 constexpr int kMaxViews = 8;  // views per item a record layout can describe
 constexpr int kBandKeysMsaa = HP_RASTER_BAND_KEYS_MSAA;
+constexpr int kBandKeysMsaaWide = 6400;
 // The renderer conventions nobody can pin without Panda3D (hp_raster_conventions in the header), as the kernels see them:
-// the record itself plus what the host derives from it once per launch.  Kernel arguments (SGPRs): with the default record
-// every expression below evaluates the operations of the former compile-time constants on the same values -- bit-identical.
+// the store's record plus what the host derives from it once per launch.  Kernel arguments (SGPRs).
 struct RasterConv {
-  float sx[5], sy[5];          // the four colour samples + the pixel centre (slot 4)
-  float lo_x, hi_x, lo_y, hi_y;  // smallest / largest sample offset per axis (bounding-box growth)
-  float dxa[4], dya[4];        // |offset of sample s from the pixel centre| (conservative reject of the coverage walk)
+  int sxi[5], syi[5];            // sample offsets inside the pixel in 1/256 px: the four colour samples + the centre (slot 4)
+  float sxf[5], syf[5];          // the same in pixels (exact)
+  int lo_x, hi_x, lo_y, hi_y;    // smallest / largest offset among the samples THIS launch tests (bounding-box growth)
   float aniso_max, lod_bias, ratio_bias;
   int aniso_round, lod_from;
   int n_axis[3]; float n_sign[3];
 };
-__device__ __forceinline__ float sample_x(const RasterConv& cv, int ns, int sm) { return ns == 1 ? 0.5f : cv.sx[sm]; }
-__device__ __forceinline__ float sample_y(const RasterConv& cv, int ns, int sm) { return ns == 1 ? 0.5f : cv.sy[sm]; }
 // probe count and level of detail of the anisotropic filter from the footprint (pmax >= pmin, texel units)
 __device__ __forceinline__ void aniso_footprint(const RasterConv& cv, float pmax, float pmin, int nlev, float& nf, float& lod) {
   const float r = pmax / pmin + cv.ratio_bias;
@@ -92,17 +80,13 @@ __device__ __forceinline__ void aniso_footprint(const RasterConv& cv, float pmax
   if (lod > (float)(nlev - 1)) lod = (float)(nlev - 1);
 }
 constexpr int kBigQueue = 512;
-constexpr int kBigArea = 128;  // bbox pixels above which a triangle is walked cooperatively
-// The multisampled band kernel (late round 4): 256 threads on 2-row bands (3200 keys, 25 KB of z-buffer) instead of 512 threads on
-// 4 rows -- FOUR workgroups per CU instead of two at the same 16 waves.  A band is a chain of dependent gathers (list ->
-// corners -> vertices -> z-buffer -> attributes -> texels) on a few hundred triangles -- one pass of its threads either way --
-// so the chains in flight per CU are what counts: 608 -> 563 us per 128 C2 views (C3 unchanged; 128 threads x 1 row 678,
-// 256 x 1 row 740, 192 x 2 rows 622, 512 x 3 rows 675).  -DHP_RASTER_THREADS_MSAA=512 -DHP_RASTER_BAND_KEYS_MSAA=6400: rounds 2-3.
+constexpr int kBigArea = 128;  // candidate pixels above which a triangle is walked cooperatively
 #ifndef HP_RASTER_THREADS_MSAA
 #define HP_RASTER_THREADS_MSAA 256
 #endif
-constexpr __host__ __device__ int band_threads(int ns) { return ns == 1 ? HP_RASTER_THREADS : HP_RASTER_THREADS_MSAA; }
-constexpr int kBinThreads = 1024;  // binning kernel
+// NS: keys per pixel (1 / 5); WIDE: the multisampled instantiation for renders wider than 640 px (512 threads, 6400 keys)
+constexpr __host__ __device__ int band_threads(int ns, bool wide = false) { return ns == 1 ? HP_RASTER_THREADS : wide ? 512 : HP_RASTER_THREADS_MSAA; }
+constexpr int kBinThreads = 1024;  // set-up kernel
 constexpr int kMaxBands = 512;  // 480 one-row multisampled bands of a 640-wide render
 
 struct RasterArgs {
@@ -110,11 +94,10 @@ struct RasterArgs {
   const float4* normals4;
   const float* uvs;
   const uint8_t* colors;
-  const int32_t* faces;
+  const int4* faces4;     // {i0, i1, i2, cull flag} (MeshStore::faces4)
   const uint8_t* tex;
   const int64_t* obj;
-  const float* cull;      // MeshStore::cull ([n_obj][8]) or null: back faces of closed objects are not binned (raster_bin_kernel)
-  const float4* face_planes;  // MeshStore::face_planes
+  const float* cull;      // MeshStore::cull ([n_obj][8]) or null: back faces of closed components are not set up
   const int32_t* obj_ids;
   const float* TCO;
   const float* K;
@@ -131,13 +114,14 @@ struct RasterArgs {
   int band_rows, n_bands;
   int msaa;             // 1: five keys per pixel (HP_RASTER_MSAA4 and a colour / normal output), 0: the centre only
   float depth_max;
-  // per-(view, band) triangle lists built by raster_bin_kernel
-  int32_t* bin_count;   // [chunk views][n_bands]
+  // per-(view, band) lists of sub-triangle ids built by raster_setup_kernel
+  int32_t* bin_count;   // [chunk views][n_bands]; zero between launches (the band kernel clears what it consumed)
   int32_t* bin_list;    // [chunk views][n_bands][bin_cap]
-  int bin_cap, view0, max_faces, max_verts;
-  // screen-space vertices of the chunk's views, written by raster_xform_kernel:
-  // [view][vertex] {X, Y, Z, X/Z}, {Y/Z, -, -, -}
-  float4* xverts;
+  int bin_cap, view0, max_faces;
+  // set-up records of the chunk's views: [view][rec_slots = 2 * max_faces] x 128 B (FaceRec)
+  uint4* recs;
+  int rec_slots;
+  int need_attr;        // the shading needs barycentrics (normals, point lights or vertex colours): sector 2 of the records
   // ---- record mode (rec != nullptr): the network input [item][row][col][rec_col elements], fp32 or fp16.  View v of an
   // item writes its render channels (rgb, normals, depth as requested) at element v_c0[v] of the pixel record and, when
   // v_crop_n[v] > 0, the observed crop's source channels [v_crop_src0[v], + v_crop_n[v]) at element v_crop_c0[v]
@@ -150,28 +134,8 @@ struct RasterArgs {
   const float* images; int Bi, Ct, IH, IW, sr, crop_nc, crop_depth_mode;
   const float* boxes; const int32_t* im_ids;
   unsigned w_magic;                    // p / w = (p * w_magic) >> 32 for p < 2^16
-  RasterConv cv;                       // hp_raster_set_conventions, copied at launch
+  RasterConv cv;                       // the store's conventions record, derived at launch
 };
-
-__device__ __forceinline__ void edge_fn(const float* P0, int i0, const float* P1, int i1, float* e) {
-  const float* P = P0;
-  const float* Q = P1;
-  float sgn = 1.0f;
-  if (i1 < i0) { P = P1; Q = P0; sgn = -1.0f; }
-  e[0] = sgn * fmaf(P[1], Q[2], -(P[2] * Q[1]));
-  e[1] = sgn * fmaf(P[2], Q[0], -(P[0] * Q[2]));
-  e[2] = sgn * fmaf(P[0], Q[1], -(P[1] * Q[0]));
-}
-
-// vertices are stored as float4 (xyz + pad): one 16-B gather per vertex
-__device__ __forceinline__ void xform_vertex(const float* T, const float* Kv, const float4 p, float* o) {
-  float cx = fmaf(T[0], p.x, fmaf(T[1], p.y, fmaf(T[2], p.z, T[3])));
-  float cy = fmaf(T[4], p.x, fmaf(T[5], p.y, fmaf(T[6], p.z, T[7])));
-  float cz = fmaf(T[8], p.x, fmaf(T[9], p.y, fmaf(T[10], p.z, T[11])));
-  o[0] = fmaf(Kv[0], cx, fmaf(Kv[1], cy, Kv[2] * cz));
-  o[1] = fmaf(Kv[4], cy, Kv[5] * cz);
-  o[2] = cz;
-}
 
 __device__ __forceinline__ float quant8(float c, int on) {
   c = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
@@ -266,12 +230,6 @@ __device__ __forceinline__ void tex_fetch_aniso(const RasterConv& cv, const uint
 // ---- the same filter, organised for the machine (power-of-two textures; others take tex_fetch_aniso above): the mip
 // levels' offsets / sizes come from a per-workgroup table (LDS) and the probes are processed in PAIRS so that the 16 texel
 // loads of two trilinear probes are in flight together (the rolled loop pays one L2 round trip per probe).
-#ifdef HP_RABL_COUNT
-// tools/raster_walk_count.py: [0] low half: walk iterations (wave level), high half: probe-pair iterations (wave level), [1] sum of bbox
-// areas, [2] triangles, [3] survivors, [4] wave batches, [5] shading invocations with the anisotropic filter, [6] their probes,
-// [7] those blending two levels
-__device__ unsigned long long hp_dbg_cnt[8];
-#endif
 struct MipTable {
   int off[16], w[16], h[16];
   int sh[16];        // log2(w) + 2 when the texture's sizes are powers of two (row pitch in bytes as a shift)
@@ -334,15 +292,9 @@ __device__ __forceinline__ void tex_fetch_aniso_p2(const RasterConv& cv, const u
   const int off0 = mt.off[l0], w0 = mt.w[l0], h0 = mt.h[l0], s0 = mt.sh[l0];
   const int off1 = mt.off[l1], w1 = mt.w[l1], h1 = mt.h[l1], s1 = mt.sh[l1];
   const float* const tt = mt.tt[N - 1];
-#ifdef HP_RABL_COUNT
-  atomicAdd(&hp_dbg_cnt[5], 1ull); atomicAdd(&hp_dbg_cnt[6], (unsigned long long)N); if (two) atomicAdd(&hp_dbg_cnt[7], 1ull);
-#endif
   float acc[3] = {0.0f, 0.0f, 0.0f};
   for (int i = 1; i <= N; i += 2) {
     const bool second = i + 1 <= N;
-#ifdef HP_RABL_COUNT
-    if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&hp_dbg_cnt[0], 1ull << 32);
-#endif
     const float ta = tt[i - 1];
     const float tb = tt[second ? i : i - 1];
     const float sua = fmaf(ta, du, u), sva = fmaf(ta, dv, v), sub = fmaf(tb, du, u), svb = fmaf(tb, dv, v);
@@ -373,103 +325,120 @@ __device__ __forceinline__ void tex_fetch_aniso_p2(const RasterConv& cv, const u
   for (int c = 0; c < 3; ++c) rgb[c] = acc[c] / (float)N;
 }
 
-struct TriSetup {
-  float e0[3], e1[3], e2[3];
-  float z0, z1, z2;  // camera-space depth of the three corners
-  float det;
-  int x0, x1, y0, y1;  // inclusive pixel bbox clipped to the band; empty if x0 > x1
-};
+// ---- set-up records ---------------------------------------------------------------------------------------------------
+// One 128-B record (8 x uint4, one cache line) per sub-triangle and view, written by raster_setup_kernel at
+// recs[(view * rec_slots + id) * 8], id = f, or n_faces + f for the second half of a near-clipped quad:
+//   q0 = {ox | oy << 16, flags (bit 0: big), rx0 | ry0 << 16, rx1 | ry1 << 16}     coverage: origin pixel, corners relative to
+//   q1 = {rx2 | ry2 << 16, W.q0, W.qx, W.qy}                                         (256 ox, 256 oy) as int16 pairs, 1 / z plane
+//   q2 = {NU.q0, NU.qx, NU.qy, NV.q0}                                               shading: numerator planes of u and v,
+//   q3 = {NV.qx, NV.qy, v0, v1}                                                      original vertex ids (object-local)
+//   q4 = {NB1.q0, NB1.qx, NB1.qy, NB2.q0}                                           (need_attr) numerator planes of the
+//   q5 = {NB2.qx, NB2.qy, v2, 0}                                                     barycentrics b1, b2
+//   q6 = {rx0, ry0, rx1, ry1}, q7 = {rx2, ry2, 0, 0}                                (big) the corners as int32
+// A plane q(fx, fy) = q0 + qx fx + qy fy, (fx, fy) = pixels from the origin pixel's top-left corner.  Corners are
+// orientation-normalised (interior = positive side of the three edge functions).
+struct PlaneQ { float q0, qx, qy; };
+struct Corner { float c[3]; float b[3]; };  // camera-space corner + barycentrics w.r.t. the original triangle
 
-// the six 16-B records of a triangle's corners ({X, Y, Z, X/Z}, {Y/Z, ...} per vertex), loaded ahead of their use
-struct TriVerts { float4 p0, p1, p2; float v0, v1, v2; };
-__device__ __forceinline__ TriVerts load_tri_verts(const float4* xv, const int32_t* tri) {
-  TriVerts t;
-  t.p0 = xv[2 * tri[0]]; t.p1 = xv[2 * tri[1]]; t.p2 = xv[2 * tri[2]];
-  t.v0 = xv[2 * tri[0] + 1].x; t.v1 = xv[2 * tri[1] + 1].x; t.v2 = xv[2 * tri[2] + 1].x;
-  return t;
+__device__ __forceinline__ int snap_sub(float s) {
+  float r = s * (float)kSub;
+  if (!(r >= -kGuardSub)) r = -kGuardSub;  // NaN lands here
+  if (!(r <= kGuardSub)) r = kGuardSub;
+  return (int)rintf(r);
+}
+__device__ __forceinline__ float plane_at(const PlaneQ& p, float fx, float fy) { return fmaf(p.qy, fy, fmaf(p.qx, fx, p.q0)); }
+__device__ __forceinline__ PlaneQ make_plane(float qa, float qb, float qc, const float (&px)[3], const float (&py)[3], float inv) {
+  const float dx1 = px[1] - px[0], dy1 = py[1] - py[0], dx2 = px[2] - px[0], dy2 = py[2] - py[0];
+  const float dq1 = qb - qa, dq2 = qc - qa;
+  PlaneQ p;
+  p.qx = fmaf(dq1, dy2, -(dq2 * dy1)) * inv;
+  p.qy = fmaf(dq2, dx1, -(dq1 * dx2)) * inv;
+  p.q0 = fmaf(-p.qy, py[0], fmaf(-p.qx, px[0], qa));
+  return p;
 }
 
-// Screen-space vertices + inclusive pixel bbox (clipped to the image).  Returns false when the
-// triangle is outside the clip range or the image.
-__device__ __forceinline__ bool tri_bbox(const RasterArgs& a, const TriVerts& t, float (&V0)[3],
-                                         float (&V1)[3], float (&V2)[3], int& x0, int& x1, int& y0, int& y1) {
-  const float4 p0 = t.p0, p1 = t.p1, p2 = t.p2;
-  V0[0] = p0.x; V0[1] = p0.y; V0[2] = p0.z;
-  V1[0] = p1.x; V1[1] = p1.y; V1[2] = p1.z;
-  V2[0] = p2.x; V2[1] = p2.y; V2[2] = p2.z;
-  float zmin = fminf(V0[2], fminf(V1[2], V2[2])), zmax = fmaxf(V0[2], fmaxf(V1[2], V2[2]));
-  if (!(zmax >= kZNear) || !(zmin <= kZFar)) return false;
-  x0 = 0; x1 = a.w - 1; y0 = 0; y1 = a.h - 1;
-  if (zmin > 1e-6f) {
-    const float u0 = p0.w, u1 = p1.w, u2 = p2.w;  // X / Z, Y / Z: divided once per vertex and view
-    const float v0 = t.v0, v1 = t.v1, v2 = t.v2;
-    float umin = fminf(u0, fminf(u1, u2)), umax = fmaxf(u0, fmaxf(u1, u2));
-    float vmin = fminf(v0, fminf(v1, v2)), vmax = fmaxf(v0, fmaxf(v1, v2));
-    if (!(umax >= 0.0f) || !(umin <= (float)a.w) || !(vmax >= 0.0f) || !(vmin <= (float)a.h)) return false;
-    float xa = ceilf(umin - 0.5f), xb = floorf(umax - 0.5f);
-    float ya = ceilf(vmin - 0.5f), yb = floorf(vmax - 0.5f);
-    if (a.msaa) {  // some sample of pixel j inside [umin, umax]: offsets run from lo to hi (0.125 to 0.875 in the default pattern)
-      xa = ceilf(umin - a.cv.hi_x); xb = floorf(umax - a.cv.lo_x); ya = ceilf(vmin - a.cv.hi_y); yb = floorf(vmax - a.cv.lo_y);
-    }
-    x0 = xa < 0.0f ? 0 : (int)xa; x1 = xb > (float)(a.w - 1) ? a.w - 1 : (int)xb;
-    y0 = ya < 0.0f ? 0 : (int)ya; y1 = yb > (float)(a.h - 1) ? a.h - 1 : (int)yb;
-  }
-  return y0 <= y1 && x0 <= x1;
-}
-
-// Returns false when the triangle cannot touch rows [row0, row1] of this view.
-__device__ __forceinline__ bool setup_triangle(const RasterArgs& a, const TriVerts& t, const int32_t* tri, int row0,
-                                               int row1, TriSetup& s) {
-  float V0[3], V1[3], V2[3];
-  if (!tri_bbox(a, t, V0, V1, V2, s.x0, s.x1, s.y0, s.y1)) return false;
-  if (s.y0 < row0) s.y0 = row0;
-  if (s.y1 > row1) s.y1 = row1;
-  if (s.y0 > s.y1) return false;
-  edge_fn(V1, tri[1], V2, tri[2], s.e0);
-  edge_fn(V2, tri[2], V0, tri[0], s.e1);
-  edge_fn(V0, tri[0], V1, tri[1], s.e2);
-  s.det = fmaf(V0[0], s.e0[0], fmaf(V0[1], s.e0[1], V0[2] * s.e0[2]));
-  if (!(s.det != 0.0f) || !isfinite(s.det)) return false;
-  s.z0 = V0[2]; s.z1 = V1[2]; s.z2 = V2[2];
-  return true;
-}
-
-template <int NS>
-__device__ __forceinline__ void shade_pixel(const RasterConv& cv, const TriSetup& s, int i, int j, uint32_t f,
-                                            unsigned long long* zb, int row0, int w) {
-#ifdef HP_RABL_COUNT
-  int n_in = 0;
-#endif
+// Set-up of one sub-triangle (oracle.c setup_subtri: same operations in the same order).  Writes its record and returns the
+// rows [row_lo, row_hi] its candidate pixels span; false when nothing can be covered (or the face is culled).
+// cull_flag: 0, or the face's orientation flag (+1 / -1) when this view may cull: a closed component's face whose inward
+// side is turned to the camera.  The camera looks along +z with x right and y down, so a face whose winding normal
+// (b - a) x (c - a) points at the camera has NEGATIVE snapped area.
+__device__ __forceinline__ bool setup_subtri(const RasterArgs& a, const float (&Kv)[9], const Corner& c0, const Corner& c1, const Corner& c2,
+                                             const float2 (&uv)[3], const int4 tri, int cull_flag, uint4* rec, int& row_lo, int& row_hi) {
+  int x[3], y[3];
+  float wk[3];
+  const Corner* const cs[3] = {&c0, &c1, &c2};
 #pragma unroll
-  for (int sm = 0; sm < NS; ++sm) {
-    const float pv = (float)i + sample_y(cv, NS, sm), pu = (float)j + sample_x(cv, NS, sm);
-    float l0 = fmaf(s.e0[0], pu, fmaf(s.e0[1], pv, s.e0[2]));
-    float l1 = fmaf(s.e1[0], pu, fmaf(s.e1[1], pv, s.e1[2]));
-    float l2 = fmaf(s.e2[0], pu, fmaf(s.e2[1], pv, s.e2[2]));
-    float sum = l0 + l1 + l2;
-    bool in_pos = (l0 >= 0.0f) & (l1 >= 0.0f) & (l2 >= 0.0f) & (sum > 0.0f);
-    bool in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (sum < 0.0f);
-    if (!(in_pos | in_neg)) continue;
-#ifdef HP_RABL_COUNT
-    ++n_in;
-#endif
-    // depth = the vertex depths interpolated with the perspective-correct barycentrics (oracle.c explains why not det / sum)
-#ifdef HP_RABL_NO_SAMPLE_DIV
-    float Z = fmaf(l0, s.z0, fmaf(l1, s.z1, l2 * s.z2)) * sum;
-#else
-    float Z = fmaf(l0, s.z0, fmaf(l1, s.z1, l2 * s.z2)) / sum;
-#endif
-    if (!(Z >= kZNear) || !(Z <= kZFar)) continue;
-    unsigned long long key = ((unsigned long long)__float_as_uint(Z) << 32) | f;
-#ifndef HP_RABL_NO_SAMPLE_ATOMIC
-    atomicMin(&zb[((i - row0) * w + j) * NS + sm], key);
-#else
-    if (key == 12345ull) zb[0] = key;
-#endif
+  for (int k = 0; k < 3; ++k) {
+    const float cx = cs[k]->c[0], cy = cs[k]->c[1], cz = cs[k]->c[2];
+    const float Xh = fmaf(Kv[0], cx, fmaf(Kv[1], cy, Kv[2] * cz));
+    const float Yh = fmaf(Kv[4], cy, Kv[5] * cz);
+    wk[k] = 1.0f / cz;
+    x[k] = snap_sub(Xh * wk[k]);
+    y[k] = snap_sub(Yh * wk[k]);
   }
-#ifdef HP_RABL_COUNT
-  if (NS > 1) { atomicAdd(&hp_dbg_cnt[7], (unsigned long long)(n_in > 0) << 32); atomicAdd(&hp_dbg_cnt[6], (unsigned long long)n_in << 32); }
-#endif
+  long long area2 = (long long)(x[1] - x[0]) * (long long)(y[2] - y[0]) - (long long)(x[2] - x[0]) * (long long)(y[1] - y[0]);
+  if (area2 == 0) return false;
+  if (cull_flag != 0 && ((area2 > 0) == (cull_flag > 0))) return false;
+  float b1[3] = {c1.b[0], c1.b[1], c1.b[2]}, b2[3] = {c2.b[0], c2.b[1], c2.b[2]};
+  if (area2 < 0) {  // normalise the orientation: swap corners 1 and 2
+    int t = x[1]; x[1] = x[2]; x[2] = t; t = y[1]; y[1] = y[2]; y[2] = t;
+    float tf = wk[1]; wk[1] = wk[2]; wk[2] = tf;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { tf = b1[c]; b1[c] = b2[c]; b2[c] = tf; }
+    area2 = -area2;
+  }
+  const float* const bb[3] = {c0.b, b1, b2};
+  const int xmin = min(x[0], min(x[1], x[2])), xmax = max(x[0], max(x[1], x[2]));
+  const int ymin = min(y[0], min(y[1], y[2])), ymax = max(y[0], max(y[1], y[2]));
+  // origin pixel: the one holding the bounding box's minimum, clamped into the image (x >> 8 = floor division)
+  const int j0 = min(max(xmin >> 8, 0), a.w - 1), i0 = min(max(ymin >> 8, 0), a.h - 1);
+  // candidate pixels: some sample offset s in [lo, hi] with xmin <= 256 j + s <= xmax (ceil(a / 256) = -((-a) >> 8))
+  const int ja = max(-((a.cv.hi_x - xmin) >> 8), j0), j1 = min((xmax - a.cv.lo_x) >> 8, a.w - 1);
+  const int ia = max(-((a.cv.hi_y - ymin) >> 8), i0), i1 = min((ymax - a.cv.lo_y) >> 8, a.h - 1);
+  if (ja > j1 || ia > i1) return false;
+  int rx[3], ry[3];
+  float px[3], py[3];
+  int amax = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    rx[k] = x[k] - kSub * j0; ry[k] = y[k] - kSub * i0;
+    amax = max(amax, max(abs(rx[k]), abs(ry[k])));
+    px[k] = (float)rx[k] * (1.0f / (float)kSub);
+    py[k] = (float)ry[k] * (1.0f / (float)kSub);
+  }
+  const bool big = amax > kSmallLimit;
+  const float det = (float)area2 * (1.0f / (float)(kSub * kSub));
+  const float inv = 1.0f / det;
+  const PlaneQ W = make_plane(wk[0], wk[1], wk[2], px, py, inv);
+  float q[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q[k] = fmaf(bb[k][0], uv[0].x, fmaf(bb[k][1], uv[1].x, bb[k][2] * uv[2].x)) * wk[k];
+  const PlaneQ NU = make_plane(q[0], q[1], q[2], px, py, inv);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q[k] = fmaf(bb[k][0], uv[0].y, fmaf(bb[k][1], uv[1].y, bb[k][2] * uv[2].y)) * wk[k];
+  const PlaneQ NV = make_plane(q[0], q[1], q[2], px, py, inv);
+  auto pk = [](int lo, int hi) { return (uint32_t)(lo & 0xFFFF) | ((uint32_t)hi << 16); };
+  auto fb = [](float f) { return __float_as_uint(f); };
+  rec[0] = make_uint4(pk(j0, i0), big ? 1u : 0u, pk(rx[0], ry[0]), pk(rx[1], ry[1]));
+  rec[1] = make_uint4(pk(rx[2], ry[2]), fb(W.q0), fb(W.qx), fb(W.qy));
+  rec[2] = make_uint4(fb(NU.q0), fb(NU.qx), fb(NU.qy), fb(NV.q0));
+  rec[3] = make_uint4(fb(NV.qx), fb(NV.qy), (uint32_t)tri.x, (uint32_t)tri.y);
+  if (a.need_attr) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] = bb[k][1] * wk[k];
+    const PlaneQ NB1 = make_plane(q[0], q[1], q[2], px, py, inv);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] = bb[k][2] * wk[k];
+    const PlaneQ NB2 = make_plane(q[0], q[1], q[2], px, py, inv);
+    rec[4] = make_uint4(fb(NB1.q0), fb(NB1.qx), fb(NB1.qy), fb(NB2.q0));
+    rec[5] = make_uint4(fb(NB2.qx), fb(NB2.qy), (uint32_t)tri.z, 0u);
+  }
+  if (big) {
+    rec[6] = make_uint4((uint32_t)rx[0], (uint32_t)ry[0], (uint32_t)rx[1], (uint32_t)ry[1]);
+    rec[7] = make_uint4((uint32_t)rx[2], (uint32_t)ry[2], 0u, 0u);
+  }
+  row_lo = ia; row_hi = i1;
+  return true;
 }
 
 struct ViewXform { float T[12], Kv[9]; bool finite; };
@@ -491,37 +460,23 @@ __device__ __forceinline__ ViewXform load_view(const RasterArgs& a, int view) {
   return x;
 }
 
-// Pass 0: one lane per (view, vertex): camera + intrinsics transform and the perspective division,
-// once instead of once per (triangle corner, band, covered pixel).  Same operations in the same
-// order as xform_vertex / the divisions of the per-triangle code it replaces.
-__global__ __launch_bounds__(256) void raster_xform_kernel(RasterArgs a) {
-  const int lv = blockIdx.y, view = a.view0 + lv;
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  // the band counters of this view start at zero for the binning pass that follows in stream order (a
-  // hipMemsetAsync did this: captured in a hipGraph, the memset node is skipped from the second replay on --
-  // counters kept growing past the lists)
-  if (blockIdx.x == 0)
-    for (int b = threadIdx.x; b < a.n_bands; b += 256) a.bin_count[(int64_t)lv * a.n_bands + b] = 0;
-  const int item = view / a.views_per_item;
-  const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
-  if (v >= (int)ob[1]) return;
-  float T[12], Kv[9], o[3];
+// the point of the edge I -> O on the plane z = near, interpolated FROM the inside corner TO the outside one
+__device__ __forceinline__ Corner isect_near(const Corner& I, const Corner& O) {
+  const float t = (I.c[2] - kZNear) / (I.c[2] - O.c[2]);
+  Corner r;
+  r.c[0] = fmaf(t, O.c[0] - I.c[0], I.c[0]);
+  r.c[1] = fmaf(t, O.c[1] - I.c[1], I.c[1]);
+  r.c[2] = kZNear;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) T[k] = a.TCO[16 * (int64_t)view + k];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) Kv[k] = a.K[9 * (int64_t)view + k];
-  xform_vertex(T, Kv, a.verts4[ob[0] + v], o);
-  float4* dst = a.xverts + 2 * ((int64_t)lv * a.max_verts + v);
-  dst[0] = make_float4(o[0], o[1], o[2], o[0] / o[2]);
-  dst[1] = make_float4(o[1] / o[2], 0.f, 0.f, 0.f);
+  for (int c = 0; c < 3; ++c) r.b[c] = fmaf(t, O.b[c] - I.b[c], I.b[c]);
+  return r;
 }
 
-// Pass 1: one lane per (view, triangle) -> append the triangle to the list of every band its
-// bounding box touches.  Appends are aggregated per wave (one atomic per band per wave).
-__global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
-#ifdef HP_RASTER_ACQUIRE
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
+// Pass 1: one lane per (view, triangle): camera transform, near-plane clipping, snapping, culling, plane set-up -> the
+// sub-triangle's record, and its id appended to the list of every band its candidate rows touch (appends are aggregated
+// per workgroup: one returning LDS atomic per touched band and lane, one global atomic per band and workgroup).  A view
+// with a non-finite pose or intrinsics sets nothing up: zero images (panda3d_batch_renderer.py:81-111).
+__global__ __launch_bounds__(kBinThreads) void raster_setup_kernel(RasterArgs a) {
   const int lv = blockIdx.y;               // view within the chunk
   const int view = a.view0 + lv;
   const int f = blockIdx.x * kBinThreads + threadIdx.x;
@@ -529,52 +484,64 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
   const int item = view / a.views_per_item;
   const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
   const int nf = x.finite ? (int)ob[3] : 0;
-  // the view may cull: the object is closed (MeshStore::cull), the camera is outside its bounding sphere, and the whole
-  // sphere lies beyond the near plane (a clipped object shows its inside)
-  float cull_sign = 0.f, cam[3] = {0.f, 0.f, 0.f};
+  // the view may cull: some component of the object is closed (MeshStore::cull), the camera is outside the object's bounding
+  // sphere, and the whole sphere lies beyond the near plane (a clipped object shows its inside)
+  bool view_cull = false;
   if (a.cull && x.finite) {
     const float* const cu = a.cull + 8 * (int64_t)a.obj_ids[item];
     const float cx = fmaf(x.T[0], cu[0], fmaf(x.T[1], cu[1], fmaf(x.T[2], cu[2], x.T[3])));
     const float cy = fmaf(x.T[4], cu[0], fmaf(x.T[5], cu[1], fmaf(x.T[6], cu[2], x.T[7])));
     const float cz = fmaf(x.T[8], cu[0], fmaf(x.T[9], cu[1], fmaf(x.T[10], cu[2], x.T[11])));
     const float r = cu[3] * 1.001f + 1e-6f;  // (a scaled rotation is not expected in T; the margin covers its rounding)
-    if (cx * cx + cy * cy + cz * cz > r * r && cz - r > kZNear) cull_sign = cu[4];
-    // the camera centre in the object's frame: - R^T t
-    cam[0] = -(x.T[0] * x.T[3] + x.T[4] * x.T[7] + x.T[8] * x.T[11]);
-    cam[1] = -(x.T[1] * x.T[3] + x.T[5] * x.T[7] + x.T[9] * x.T[11]);
-    cam[2] = -(x.T[2] * x.T[3] + x.T[6] * x.T[7] + x.T[10] * x.T[11]);
+    view_cull = cu[4] != 0.f && cx * cx + cy * cy + cz * cz > r * r && cz - r > kZNear;
   }
-  int b0 = 1, b1 = 0;  // empty band range
+  int b0 = 1, b1 = 0;  // band range of the (first) sub-triangle: empty
+  int c0 = 1, c1 = 0;  // ... of the second half of a near-clipped quad (rare)
+  uint4* const recs = a.recs + (int64_t)lv * a.rec_slots * 8;
   if (f < nf) {
-    const int32_t* fbase = a.faces + 3 * ob[2];
-    int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
-    float V0[3], V1[3], V2[3];
-    int x0, x1, y0, y1;
-    if (tri_bbox(a, load_tri_verts(a.xverts + 2 * (int64_t)lv * a.max_verts, tri), V0, V1, V2, x0, x1, y0, y1)) {
-      b0 = y0 / a.band_rows;
-      b1 = y1 / a.band_rows;
-      // Back faces of a CLOSED object seen from outside are never visible (the renders are two-sided like the reference's,
-      // panda3d_scene_renderer.py:102: every ray meets a front face of the closed surface first, and the canonical edge
-      // functions make that surface watertight).  The first version took the facing from the screen-space vertices of the
-      // vertex pass (the sign of V0 . ((V1 - V0) x (V2 - V0))): correct, but in two-lane steps the decision was then NOT
-      // reproducible for a few triangles per launch (single-pixel colour differences from run to run; with a decision that does
-      // not read those records, or without culling, bit-identical) -- so it reads object-space data only.
-      if (cull_sign != 0.f) {
-        // the camera is on the inner side of the face's plane, by 100x the rounding of the test (object-space data only: the
-        // face's plane from hp_mesh_store_create and the camera centre - R^T t; nothing a previous launch wrote)
-        const float4 pl = a.face_planes[ob[2] + f];
-        const float t0 = pl.x * cam[0], t1 = pl.y * cam[1], t2 = pl.z * cam[2];
-        const float sd = (t0 + t1) + (t2 - pl.w);
-        const float mag = fabsf(t0) + fabsf(t1) + fabsf(t2) + fabsf(pl.w);
-        if (sd * cull_sign < -1e-5f * mag) { b0 = 1; b1 = 0; }
+    const int4 tri = a.faces4[ob[2] + f];
+    const int64_t voff = ob[0];
+    const float4 p0 = a.verts4[voff + tri.x], p1 = a.verts4[voff + tri.y], p2 = a.verts4[voff + tri.z];
+    const float2 uv[3] = {*reinterpret_cast<const float2*>(a.uvs + 2 * (voff + tri.x)), *reinterpret_cast<const float2*>(a.uvs + 2 * (voff + tri.y)),
+                          *reinterpret_cast<const float2*>(a.uvs + 2 * (voff + tri.z))};
+    const float4 pp[3] = {p0, p1, p2};
+    Corner V[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      V[k].c[0] = fmaf(x.T[0], pp[k].x, fmaf(x.T[1], pp[k].y, fmaf(x.T[2], pp[k].z, x.T[3])));
+      V[k].c[1] = fmaf(x.T[4], pp[k].x, fmaf(x.T[5], pp[k].y, fmaf(x.T[6], pp[k].z, x.T[7])));
+      V[k].c[2] = fmaf(x.T[8], pp[k].x, fmaf(x.T[9], pp[k].y, fmaf(x.T[10], pp[k].z, x.T[11])));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) V[k].b[c] = c == k ? 1.0f : 0.0f;
+    }
+    const float zmin = fminf(V[0].c[2], fminf(V[1].c[2], V[2].c[2])), zmax = fmaxf(V[0].c[2], fmaxf(V[1].c[2], V[2].c[2]));
+    if ((zmax >= kZNear) && (zmin <= kZFar)) {
+      int lo, hi;
+      if (zmin >= kZNear) {
+        if (setup_subtri(a, x.Kv, V[0], V[1], V[2], uv, tri, view_cull ? tri.w : 0, recs + (int64_t)f * 8, lo, hi)) {
+          b0 = lo / a.band_rows; b1 = hi / a.band_rows;
+        }
+      } else {
+        // near-plane clipping (oracle.c): rotate the corners cyclically so that corner 0 is inside and corner 2 outside, then
+        // the polygon is [V0, I(0->1), I(0->2)] or [V0, V1, I(1->2), I(0->2)]
+        const bool in0 = V[0].c[2] >= kZNear, in1 = V[1].c[2] >= kZNear, in2 = V[2].c[2] >= kZNear;
+        const int n_in = (int)in0 + (int)in1 + (int)in2;
+        const int r = n_in == 1 ? (in0 ? 0 : in1 ? 1 : 2) : (!in0 ? 1 : !in1 ? 2 : 0);
+        const Corner R0 = r == 0 ? V[0] : r == 1 ? V[1] : V[2];
+        const Corner R1 = r == 0 ? V[1] : r == 1 ? V[2] : V[0];
+        const Corner R2 = r == 0 ? V[2] : r == 1 ? V[0] : V[1];
+        if (n_in == 1) {
+          const Corner P1 = isect_near(R0, R1), P2 = isect_near(R0, R2);
+          if (setup_subtri(a, x.Kv, R0, P1, P2, uv, tri, 0, recs + (int64_t)f * 8, lo, hi)) { b0 = lo / a.band_rows; b1 = hi / a.band_rows; }
+        } else {
+          const Corner P2 = isect_near(R1, R2), P3 = isect_near(R0, R2);
+          if (setup_subtri(a, x.Kv, R0, R1, P2, uv, tri, 0, recs + (int64_t)f * 8, lo, hi)) { b0 = lo / a.band_rows; b1 = hi / a.band_rows; }
+          if (setup_subtri(a, x.Kv, R0, P2, P3, uv, tri, 0, recs + (int64_t)(nf + f) * 8, lo, hi)) { c0 = lo / a.band_rows; c1 = hi / a.band_rows; }
+        }
       }
     }
   }
-  // Appends are aggregated per workgroup: a lane takes its slot(s) from LDS counters (one returning LDS atomic per band it
-  // touches -- a triangle of these meshes touches one or two), one global atomic per band and workgroup reserves the
-  // workgroup's range in the band's list (same-address L2 atomics serialise).  (The first version walked the band RANGE of
-  // every wave with ballots: mesh order is not screen order, so a wave spanned 20-40 of the 60 four-row bands.)  The order
-  // of a list is arbitrary either way; the z-buffer minimum does not depend on it.
+  // Appends.  The order of a list is arbitrary; the z-buffer minimum {depth : id} does not depend on it.
   __shared__ int wg_cnt[kMaxBands], wg_base[kMaxBands];
   const int tid = threadIdx.x;
   for (int b = tid; b < a.n_bands; b += kBinThreads) wg_cnt[b] = 0;
@@ -590,6 +557,10 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
   for (int b = b0 + 8; b <= b1; ++b) {  // rare: beyond eight bands a triangle appends itself with a global atomic per band
     const int slot = atomicAdd(&a.bin_count[lv * a.n_bands + b], 1);
     if (slot < a.bin_cap) a.bin_list[((int64_t)lv * a.n_bands + b) * a.bin_cap + slot] = f;
+  }
+  for (int b = c0; b <= c1; ++b) {      // rarer: the second half of a near-clipped quad
+    const int slot = atomicAdd(&a.bin_count[lv * a.n_bands + b], 1);
+    if (slot < a.bin_cap) a.bin_list[((int64_t)lv * a.n_bands + b) * a.bin_cap + slot] = nf + f;
   }
   __syncthreads();
   for (int b = tid; b < a.n_bands; b += kBinThreads)
@@ -608,51 +579,46 @@ __global__ __launch_bounds__(kBinThreads) void raster_bin_kernel(RasterArgs a) {
   }
 }
 
-// One fragment-shader invocation: colour and normal code of triangle f at the CENTRE of pixel (i, j) (attributes
+// One fragment-shader invocation: colour and normal code of sub-triangle `id` at the CENTRE of pixel (i, j) (attributes
 // extrapolated when the centre lies outside the triangle: multisampled edge pixels) -- oracle.c shade_centre.
 struct ShadeCtx {
-  const float* T; const float* Kv; const float* amb; const float4* xv; const int32_t* fbase;
+  const float* T; const float* Kv; const float* amb; const uint4* recs;
   int64_t voff, toff; int tw, th, view, q8, nlev, aniso;
   const MipTable* mips;  // per-workgroup table of the object's mip levels (LDS)
   bool need_normal;      // the view renders normals or has point lights: otherwise the normal is never looked at
 };
 template <bool ANISO>
-__device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx& cx, int f, int i, int j, float* o_rgb, float* o_n) {
-  const float* T = cx.T; const float* Kv = cx.Kv; const float* amb = cx.amb; const float4* xv = cx.xv;
-  const int32_t* fbase = cx.fbase;
+__device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx& cx, int id, int i, int j, float* o_rgb, float* o_n) {
+  const float* T = cx.T; const float* Kv = cx.Kv; const float* amb = cx.amb;
   const int64_t voff = cx.voff, toff = cx.toff;
   const int tw = cx.tw, th = cx.th, view = cx.view, q8 = cx.q8;
-  int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
-  float e0[3], e1[3], e2[3];
-  const float4 q0 = xv[2 * tri[0]], q1 = xv[2 * tri[1]], q2 = xv[2 * tri[2]];
-  const float V0[3] = {q0.x, q0.y, q0.z}, V1[3] = {q1.x, q1.y, q1.z}, V2[3] = {q2.x, q2.y, q2.z};
-  edge_fn(V1, tri[1], V2, tri[2], e0);
-  edge_fn(V2, tri[2], V0, tri[0], e1);
-  edge_fn(V0, tri[0], V1, tri[1], e2);
-  const float pu = (float)j + 0.5f, pv = (float)i + 0.5f;
-  float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
-  float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
-  float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
-  float sum = l0 + l1 + l2;
-  float b0 = l0 / sum, b1 = l1 / sum, b2 = l2 / sum;
-  const float Z = fmaf(l0, V0[2], fmaf(l1, V1[2], l2 * V2[2])) / sum;  // = the key's depth when the centre is covered
-  const int64_t g0 = voff + tri[0], g1 = voff + tri[1], g2 = voff + tri[2];
+  const uint4* const r = cx.recs + (int64_t)id * 8;
+  const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+  const int ox = (int)(short)(r0.x & 0xFFFFu), oy = (int)r0.x >> 16;
+  const PlaneQ W{__uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w)};
+  const float fx = (float)(j - ox) + 0.5f, fy = (float)(i - oy) + 0.5f;
+  const float Wc = plane_at(W, fx, fy);
+  const float iw = 1.0f / Wc;
+  const bool need_b = cx.need_normal || toff < 0;
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  int64_t g0 = 0, g1 = 0, g2 = 0;
+  if (need_b) {
+    const uint4 r4 = r[4], r5 = r[5];
+    const PlaneQ NB1{__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z)};
+    const PlaneQ NB2{__uint_as_float(r4.w), __uint_as_float(r5.x), __uint_as_float(r5.y)};
+    b1 = plane_at(NB1, fx, fy) * iw; b2 = plane_at(NB2, fx, fy) * iw;
+    b0 = (1.0f - b1) - b2;
+    g0 = voff + (int)r3.z; g1 = voff + (int)r3.w; g2 = voff + (int)r5.z;
+  }
   float alb[3];
   if (toff >= 0) {
-    const float2 t0 = *reinterpret_cast<const float2*>(a.uvs + 2 * g0);
-    const float2 t1 = *reinterpret_cast<const float2*>(a.uvs + 2 * g1);
-    const float2 t2 = *reinterpret_cast<const float2*>(a.uvs + 2 * g2);
-    float tu = fmaf(b0, t0.x, fmaf(b1, t1.x, b2 * t2.x));
-    float tv = fmaf(b0, t0.y, fmaf(b1, t1.y, b2 * t2.y));
+    const PlaneQ NU{__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z)};
+    const PlaneQ NV{__uint_as_float(r2.w), __uint_as_float(r3.x), __uint_as_float(r3.y)};
+    const float tu = plane_at(NU, fx, fy) * iw, tv = plane_at(NV, fx, fy) * iw;
     if (ANISO && cx.nlev > 1) {
-      // screen-space derivatives of the perspective-correct barycentrics: b_i = l_i / sum, l_i affine in (x, y)
-      const float sx = e0[0] + e1[0] + e2[0], sy = e0[1] + e1[1] + e2[1];
-      const float bx[3] = {(e0[0] - b0 * sx) / sum, (e1[0] - b1 * sx) / sum, (e2[0] - b2 * sx) / sum};
-      const float by[3] = {(e0[1] - b0 * sy) / sum, (e1[1] - b1 * sy) / sum, (e2[1] - b2 * sy) / sum};
-      const float ux = fmaf(bx[0], t0.x, fmaf(bx[1], t1.x, bx[2] * t2.x));
-      const float vx = fmaf(bx[0], t0.y, fmaf(bx[1], t1.y, bx[2] * t2.y));
-      const float uy = fmaf(by[0], t0.x, fmaf(by[1], t1.x, by[2] * t2.x));
-      const float vy = fmaf(by[0], t0.y, fmaf(by[1], t1.y, by[2] * t2.y));
+      // screen-space derivatives of the perspective-correct coordinates: u = N_u / W, both affine in (x, y)
+      const float ux = fmaf(-tu, W.qx, NU.qx) * iw, vx = fmaf(-tv, W.qx, NV.qx) * iw;
+      const float uy = fmaf(-tu, W.qy, NU.qy) * iw, vy = fmaf(-tv, W.qy, NV.qy) * iw;
       if (cx.mips->p2) tex_fetch_aniso_p2(a.cv, a.tex + toff, *cx.mips, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
       else tex_fetch_aniso(a.cv, a.tex + toff, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
     } else {
@@ -678,6 +644,7 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
   }
   float lit[3] = {amb[0], amb[1], amb[2]};
   if (a.n_lights > 0) {
+    const float pu = (float)j + 0.5f, pv = (float)i + 0.5f, Z = iw;
     float py = (pv - Kv[5]) * Z / Kv[4];
     float px = ((pu - Kv[2]) * Z - Kv[1] * py) / Kv[0];
     for (int l = 0; l < a.n_lights; ++l) {
@@ -797,26 +764,49 @@ __device__ __forceinline__ void crop_taps(const float* __restrict__ img, int HW,
   }
 }
 
+// ---- coverage ---------------------------------------------------------------------------------------------------------
+// The three edge functions of a record in the form E_k(X, Y) = A_k X + B_k Y + C_k on sub-pixel coordinates relative to the
+// origin, the top-left rule folded into C_k (- 1 on the edges that do not own their points): inside <=> all E_k >= 0.
+// Values: |A|, |B| <= 2^15, |C| < 2^29, X, Y < 2^14 for a small record -- everything fits 32 bits, operands fit 24.
+struct EdgeSet { int A[3], B[3], C[3]; };
+__device__ __forceinline__ void edge_setup(const int (&rx)[3], const int (&ry)[3], EdgeSet& e) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int ia = (k + 1) % 3, ib = (k + 2) % 3;
+    const int ex = rx[ib] - rx[ia], ey = ry[ib] - ry[ia];
+    const bool owns = ey > 0 || (ey == 0 && ex < 0);
+    e.A[k] = -ey; e.B[k] = ex;
+    e.C[k] = __mul24(ey, rx[ia]) - __mul24(ex, ry[ia]) - (owns ? 0 : 1);
+  }
+}
+
+// candidate pixels of a record inside the band: columns [jlo, jhi], rows [ilo, ihi] relative to the origin pixel
+__device__ __forceinline__ bool candidate_range(const RasterArgs& a, const int (&rx)[3], const int (&ry)[3], int ox, int oy, int row0, int row1,
+                                                int& jlo, int& jhi, int& ilo, int& ihi) {
+  const int xmin = min(rx[0], min(rx[1], rx[2])), xmax = max(rx[0], max(rx[1], rx[2]));
+  const int ymin = min(ry[0], min(ry[1], ry[2])), ymax = max(ry[0], max(ry[1], ry[2]));
+  jlo = max(-((a.cv.hi_x - xmin) >> 8), 0); jhi = min((xmax - a.cv.lo_x) >> 8, a.w - 1 - ox);
+  ilo = max(max(-((a.cv.hi_y - ymin) >> 8), 0), row0 - oy); ihi = min(min((ymax - a.cv.lo_y) >> 8, a.h - 1 - oy), row1 - oy);
+  return jlo <= jhi && ilo <= ihi;
+}
+
 // HALF: fp16 destinations (the input of an fp16 network plan) -- its own instantiation so that the fp32 path's register
-// budget (80 VGPRs: three 512-thread workgroups per CU) does not carry the 16-half record assembly
-template <int NS, bool HALF, bool ANISO>
-__global__ __launch_bounds__(band_threads(NS), (NS == 1 && !HALF && !ANISO) ? 6 : 4) void raster_kernel(RasterArgs a, int npix_max) {
-  constexpr int kThreads = band_threads(NS);  // (shadows the single-sample constant)
-#ifdef HP_RASTER_ACQUIRE
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
+// budget does not carry the 16-half record assembly
+template <int NS, bool HALF, bool ANISO, bool WIDE>
+__global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO) ? 6 : 4) void raster_kernel(RasterArgs a, int npix_max) {
+  constexpr int kThreads = band_threads(NS, WIDE);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int big_q[kBigQueue];
   __shared__ int big_n, n_cov, span_max[2];
   __shared__ MipTable mips;
-  __shared__ uint32_t cov_q[NS == 1 ? 1 : kThreads / 64][NS == 1 ? 1 : 128];  // multisampling: (lane, pixel) pairs awaiting their sample tests
 
   // XCD-aware renumbering: dispatch order b -> XCD b % 8; give each XCD a contiguous range.
   const int total = a.n * a.n_bands;  // a.n = views of this chunk
   const int per_xcd = (total + 7) / 8;
   const int lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (lin >= total) return;
-  const int view = a.view0 + lin / a.n_bands;
+  const int lv = lin / a.n_bands;
+  const int view = a.view0 + lv;
   const int band = lin % a.n_bands;
   const int row0 = band * a.band_rows;
   const int row1 = min(a.h, row0 + a.band_rows) - 1;
@@ -825,26 +815,17 @@ __global__ __launch_bounds__(band_threads(NS), (NS == 1 && !HALF && !ANISO) ? 6 
   const BandLds L = carve_lds(smem, npix_max, NS, a.band_rows);
   unsigned long long* const zb = L.zb;
 
-  float T[12], Kv[9];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) T[k] = a.TCO[16 * (int64_t)view + k];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) Kv[k] = a.K[9 * (int64_t)view + k];
-  bool finite = true;
-#pragma unroll
-  for (int k = 0; k < 12; ++k) finite &= isfinite(T[k]);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) finite &= isfinite(a.TCO[16 * (int64_t)view + 12 + k]);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) finite &= isfinite(Kv[k]);
+  // the band's list: the first entry's loads are issued before anything else (a non-finite view set nothing up: cnt = 0)
+  const int cnt = min(a.bin_count[lin], a.bin_cap);
+  const int32_t* const list = a.bin_list + (int64_t)lin * a.bin_cap;
+  const uint4* const recs = a.recs + (int64_t)lv * a.rec_slots * 8;
+  int id_n = tid < cnt ? list[tid] : 0;
+  uint4 q0_n = recs[(int64_t)id_n * 8], q1_n = recs[(int64_t)id_n * 8 + 1];
 
   const int item = view / a.views_per_item, vi = view % a.views_per_item;
   const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
-  const int64_t voff = ob[0], foff = ob[2], toff = ob[4];
-  const int nf = finite ? (int)ob[3] : 0;
+  const int64_t voff = ob[0], toff = ob[4];
   const int tw = (int)ob[5], th = (int)ob[6];
-  const float4* xv = a.xverts + 2 * (int64_t)(lin / a.n_bands) * a.max_verts;
-  const int32_t* fbase = a.faces + 3 * foff;
 
   // ---- fused crop: folded roi_align weights of the band's rows and of every column (crop_math.h) ----
   const int ncrop = (a.rec && a.images && vi < kMaxViews) ? a.v_crop_n[vi] : 0;
@@ -885,9 +866,6 @@ __global__ __launch_bounds__(band_threads(NS), (NS == 1 && !HALF && !ANISO) ? 6 
     const int N = (tid >> 4) + 1, i = (tid & 15) + 1;
     mips.tt[N - 1][i - 1] = (float)i / (float)(N + 1) - 0.5f;
   }
-  // ---- coverage + depth: only the triangles binned to this band ----
-  const int cnt = nf > 0 ? min(a.bin_count[lin], a.bin_cap) : 0;
-  const int32_t* list = a.bin_list + (int64_t)lin * a.bin_cap;
   // a band no triangle touches skips the z-buffer passes altogether: the output pass streams the background (and the crop)
   const bool band_empty = cnt == 0;
   if (!band_empty) {
@@ -895,152 +873,112 @@ __global__ __launch_bounds__(band_threads(NS), (NS == 1 && !HALF && !ANISO) ? 6 
     if (tid == 0) { big_n = 0; n_cov = 0; }
   }
   __syncthreads();
+  if (!band_empty && tid == 0) a.bin_count[lin] = 0;  // consumed (every thread has read it by now): zero for the next launch
 #ifdef HP_RABL_NO_COVER
   const int cnt_loop = 0;
 #else
   const int cnt_loop = cnt;
 #endif
-  // three-stage software pipeline over the dependent gathers list -> corner indices -> vertex records: while triangle k
-  // is rasterised, the vertex records of k + T, the corner indices of k + 2T and the list entry of k + 3T are in flight
-  // (every stage needs the previous stage's data of the same triangle); indices past the end read entry 0: harmless
-  int f0 = tid < cnt_loop ? list[tid] : 0;
-  int f1 = tid + kThreads < cnt_loop ? list[tid + kThreads] : 0;
-  int f2 = tid + 2 * kThreads < cnt_loop ? list[tid + 2 * kThreads] : 0;
-  int32_t tri0[3] = {fbase[3 * f0], fbase[3 * f0 + 1], fbase[3 * f0 + 2]};
-  int32_t tri1[3] = {fbase[3 * f1], fbase[3 * f1 + 1], fbase[3 * f1 + 2]};
-  TriVerts tv0 = load_tri_verts(xv, tri0);
-  if (NS == 1) {
-    for (int k = tid; k < cnt_loop; k += kThreads) {
-      const int f = f0;
-      const int32_t tri[3] = {tri0[0], tri0[1], tri0[2]};
-      const TriVerts tv = tv0;
-      f0 = f1; tri0[0] = tri1[0]; tri0[1] = tri1[1]; tri0[2] = tri1[2];
-      tv0 = load_tri_verts(xv, tri0);
-      f1 = f2;
-      tri1[0] = fbase[3 * f1]; tri1[1] = fbase[3 * f1 + 1]; tri1[2] = fbase[3 * f1 + 2];
-      f2 = k + 3 * kThreads < cnt_loop ? list[k + 3 * kThreads] : 0;
-      TriSetup s;
-      if (!setup_triangle(a, tv, tri, row0, row1, s)) continue;
-      const int area = (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
-      if (area > kBigArea) {
-        int q = atomicAdd(&big_n, 1);
-        if (q < kBigQueue) { big_q[q] = f; continue; }
-      }
-      for (int i = s.y0; i <= s.y1; ++i)
-        for (int j = s.x0; j <= s.x1; ++j) shade_pixel<NS>(a.cv, s, i, j, (uint32_t)f, zb, row0, a.w);
+  const float w_near = 1.0f / kZNear, w_far = 1.0f / kZFar;
+  // ---- coverage + depth: a lane owns a listed record; the next one's loads are in flight while it walks ----
+  for (int k = tid; k < cnt_loop; k += kThreads) {
+    const int id = id_n;
+    const uint4 q0 = q0_n, q1 = q1_n;
+    if (k + kThreads < cnt_loop) {
+      id_n = list[k + kThreads];
+      q0_n = recs[(int64_t)id_n * 8]; q1_n = recs[(int64_t)id_n * 8 + 1];
     }
-  } else {
-    // Multisampling.  The bounding box is grown by the sample spread, so most of its pixels have no sample inside the
-    // triangle, and the five exact sample tests of the pixels that do are ~100 instructions.  Two measures keep the lanes
-    // of a wave busy: (1) a pixel is dropped when the edge functions at its CENTRE, widened by the largest sample offset
-    // (and by a bound on the rounding of the fp32 evaluation), leave no sample on the inner side of some edge for either
-    // orientation -- the five exact tests would all fail anyway; (2) the surviving (triangle, pixel) pairs of the whole
-    // wave go through a per-wave queue in LDS and are popped 64 at a time, each lane fetching the owner lane's edge
-    // functions with ds_bpermute: the expensive part runs on dense lanes whatever the sizes of the 64 bounding boxes are.
-    // plain LDS accesses (a `volatile` pointer made them FLAT stores with system scope + s_waitcnt vmcnt(0) per walk step,
-    // which also drained the triangle prefetch).  One wave writes and reads its own queue: the LDS executes a wave's
-    // accesses in order, and the wave barriers below keep the compiler from moving them across one another.
-    uint32_t* const q = cov_q[tid >> 6];
-    const int lane = tid & 63;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    int qh = 0, qt = 0;  // wave-uniform
-    for (int kb = 0; kb < cnt_loop; kb += kThreads) {
-      const int k = kb + tid;
-      const int f = f0;
-      const int32_t tri[3] = {tri0[0], tri0[1], tri0[2]};
-      const TriVerts tv = tv0;
-      f0 = f1; tri0[0] = tri1[0]; tri0[1] = tri1[1]; tri0[2] = tri1[2];
-      tv0 = load_tri_verts(xv, tri0);
-      f1 = f2;
-      tri1[0] = fbase[3 * f1]; tri1[1] = fbase[3 * f1 + 1]; tri1[2] = fbase[3 * f1 + 2];
-      f2 = k + 3 * kThreads < cnt_loop ? list[k + 3 * kThreads] : 0;
-      TriSetup s{};
-      bool valid = k < cnt_loop && setup_triangle(a, tv, tri, row0, row1, s);
-      if (valid && (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1) > kBigArea) {
-        int bq = atomicAdd(&big_n, 1);
-        if (bq < kBigQueue) { big_q[bq] = f; valid = false; }
-      }
-      float m[3] = {0.f, 0.f, 0.f};
-      if (valid) {
-        const float* const ee[3] = {s.e0, s.e1, s.e2};
+    const int ox = (int)(short)(q0.x & 0xFFFFu), oy = (int)q0.x >> 16;
+    if (q0.y & 1u) {  // big: corners beyond the 32-bit range of the edge functions -> cooperative walk in 64 bits
+      const int q = atomicAdd(&big_n, 1);
+      if (q < kBigQueue) big_q[q] = id;
+      continue;
+    }
+    const int rx[3] = {(int)(short)(q0.z & 0xFFFFu), (int)(short)(q0.w & 0xFFFFu), (int)(short)(q1.x & 0xFFFFu)};
+    const int ry[3] = {(int)q0.z >> 16, (int)q0.w >> 16, (int)q1.x >> 16};
+    int jlo, jhi, ilo, ihi;
+    if (!candidate_range(a, rx, ry, ox, oy, row0, row1, jlo, jhi, ilo, ihi)) continue;
+    if ((jhi - jlo + 1) * (ihi - ilo + 1) > kBigArea) {
+      const int q = atomicAdd(&big_n, 1);
+      if (q < kBigQueue) { big_q[q] = id; continue; }
+    }
+    EdgeSet e;
+    edge_setup(rx, ry, e);
+    const float W0 = __uint_as_float(q1.y), Wx = __uint_as_float(q1.z), Wy = __uint_as_float(q1.w);
+    // the samples' offsets from the pixel's corner, per edge
+    int off[3][NS];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-          const float ax = fabsf(ee[e][0]), ay = fabsf(ee[e][1]);
-          const float sl = 4e-6f * fmaf(ax, (float)(s.x1 + 1), fmaf(ay, (float)(s.y1 + 1), fabsf(ee[e][2])));
-          // the largest |edge function difference| between a sample and the pixel centre (default pattern: offsets (0.125, 0.375), (0.375, 0.125))
-          const float m01 = fmaxf(fmaf(a.cv.dxa[0], ax, a.cv.dya[0] * ay), fmaf(a.cv.dxa[1], ax, a.cv.dya[1] * ay));
-          const float m23 = fmaxf(fmaf(a.cv.dxa[2], ax, a.cv.dya[2] * ay), fmaf(a.cv.dxa[3], ax, a.cv.dya[3] * ay));
-          m[e] = fmaxf(m01, m23) * 1.001f + sl;
-        }
-      }
-#ifdef HP_RABL_COUNT
-      {
-        const int ar = valid ? (s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1) : 0;
-        atomicAdd(&hp_dbg_cnt[1], (unsigned long long)ar);
-        if (valid) atomicAdd(&hp_dbg_cnt[2], 1ull);
-        if (lane == 0) atomicAdd(&hp_dbg_cnt[4], 1ull);
-      }
-#endif
-      int ci = s.y0, cj = s.x0;
-#ifdef HP_RABL_NO_WALK
-      bool more = valid && s.z0 == 12345.f;
-#else
-      bool more = valid;
-#endif
-      while (__any(more)) {
-        bool surv = false;
-        const int pi = ci, pj = cj;
-        if (more) {
-          const float pu = (float)cj + 0.5f, pv = (float)ci + 0.5f;
-          const float l0 = fmaf(s.e0[0], pu, fmaf(s.e0[1], pv, s.e0[2]));
-          const float l1 = fmaf(s.e1[0], pu, fmaf(s.e1[1], pv, s.e1[2]));
-          const float l2 = fmaf(s.e2[0], pu, fmaf(s.e2[1], pv, s.e2[2]));
-          const bool no_pos = (l0 + m[0] < 0.0f) | (l1 + m[1] < 0.0f) | (l2 + m[2] < 0.0f);
-          const bool no_neg = (l0 - m[0] > 0.0f) | (l1 - m[1] > 0.0f) | (l2 - m[2] > 0.0f);
-          surv = !(no_pos & no_neg);
-          if (++cj > s.x1) { cj = s.x0; ++ci; }
-          more = ci <= s.y1;
-        }
-        const unsigned long long sm = __ballot(surv);
-#ifdef HP_RABL_COUNT
-        if (lane == 0) { atomicAdd(&hp_dbg_cnt[0], 1ull); atomicAdd(&hp_dbg_cnt[3], (unsigned long long)__popcll(sm)); }
-#endif
-        if (surv) q[(qt + __popcll(sm & lt_mask)) & 127] = ((uint32_t)lane << 16) | (uint32_t)((pi - row0) * a.w + pj);  // npix_max < 65536
-        qt += __popcll(sm);
-        __builtin_amdgcn_wave_barrier();
-        while (qt - qh >= 64 || (qt > qh && !__any(more))) {  // a full wave of pairs, or the rest once every box is walked
-          const int n = min(64, qt - qh);
-          const uint32_t e = q[(qh + lane) & 127];
-          __builtin_amdgcn_wave_barrier();
-          const int owner = (int)(e >> 16) & 63;
-          const int ep = (int)(e & 0xFFFFu);
-          const int er = (int)(((unsigned long long)ep * a.w_magic) >> 32);
-          TriSetup t;
+    for (int s = 0; s < NS; ++s) {
+      const int sl = NS == 1 ? 4 : s;
 #pragma unroll
-          for (int c = 0; c < 3; ++c) { t.e0[c] = __shfl(s.e0[c], owner); t.e1[c] = __shfl(s.e1[c], owner); t.e2[c] = __shfl(s.e2[c], owner); }
-          t.z0 = __shfl(s.z0, owner); t.z1 = __shfl(s.z1, owner); t.z2 = __shfl(s.z2, owner);
-          const int tf = __shfl(f, owner);
-#ifndef HP_RABL_NO_POP
-          if (lane < n) shade_pixel<NS>(a.cv, t, row0 + er, ep - er * a.w, (uint32_t)tf, zb, row0, a.w);
-#else
-          if (lane < n && t.e0[0] == 12345.f && tf == 77) zb[0] = 0;
-#endif
-          qh += n;
+      for (int c = 0; c < 3; ++c) off[c][s] = __mul24(e.A[c], a.cv.sxi[sl]) + __mul24(e.B[c], a.cv.syi[sl]);
+    }
+    for (int di = ilo; di <= ihi; ++di) {
+      const float dif = (float)di;
+      unsigned long long* const zrow = zb + (size_t)((oy + di - row0) * a.w + ox) * NS;
+      const int Y0 = di << 8;
+      const int r0 = __mul24(e.B[0], Y0) + e.C[0], r1 = __mul24(e.B[1], Y0) + e.C[1], r2 = __mul24(e.B[2], Y0) + e.C[2];
+      for (int dj = jlo; dj <= jhi; ++dj) {
+        const int X0 = dj << 8;
+        const int e0 = __mul24(e.A[0], X0) + r0, e1 = __mul24(e.A[1], X0) + r1, e2 = __mul24(e.A[2], X0) + r2;
+        const float djf = (float)dj;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int sl = NS == 1 ? 4 : s;
+          if (((e0 + off[0][s]) | (e1 + off[1][s]) | (e2 + off[2][s])) < 0) continue;
+          const float Ws = fmaf(Wy, dif + a.cv.syf[sl], fmaf(Wx, djf + a.cv.sxf[sl], W0));
+          if (!(Ws <= w_near) || !(Ws >= w_far)) continue;
+          atomicMin(&zrow[dj * NS + s], ((unsigned long long)(~__float_as_uint(Ws)) << 32) | (uint32_t)id);
         }
       }
     }
   }
   if (!band_empty) __syncthreads();
+  // ---- large footprints and far-reaching corners: the whole workgroup walks the candidate pixels, edge functions in
+  // double precision (exact: |A X| < 2^43) ----
   const int nbig = band_empty ? 0 : min(big_n, kBigQueue);
   for (int q = 0; q < nbig; ++q) {
-    const int f = big_q[q];
-    int32_t tri[3] = {fbase[3 * f], fbase[3 * f + 1], fbase[3 * f + 2]};
-    TriSetup s;
-    if (!setup_triangle(a, load_tri_verts(xv, tri), tri, row0, row1, s)) continue;
-    const int bw = s.x1 - s.x0 + 1;
-    const int area = bw * (s.y1 - s.y0 + 1);
-    for (int p = tid; p < area; p += kThreads)
-      shade_pixel<NS>(a.cv, s, s.y0 + p / bw, s.x0 + p % bw, (uint32_t)f, zb, row0, a.w);
+    const int id = big_q[q];
+    const uint4* const r = recs + (int64_t)id * 8;
+    const uint4 q0 = r[0], q1 = r[1];
+    const int ox = (int)(short)(q0.x & 0xFFFFu), oy = (int)q0.x >> 16;
+    int rx[3], ry[3];
+    if (q0.y & 1u) {
+      const uint4 q6 = r[6], q7 = r[7];
+      rx[0] = (int)q6.x; ry[0] = (int)q6.y; rx[1] = (int)q6.z; ry[1] = (int)q6.w; rx[2] = (int)q7.x; ry[2] = (int)q7.y;
+    } else {
+      rx[0] = (int)(short)(q0.z & 0xFFFFu); rx[1] = (int)(short)(q0.w & 0xFFFFu); rx[2] = (int)(short)(q1.x & 0xFFFFu);
+      ry[0] = (int)q0.z >> 16; ry[1] = (int)q0.w >> 16; ry[2] = (int)q1.x >> 16;
+    }
+    int jlo, jhi, ilo, ihi;
+    if (!candidate_range(a, rx, ry, ox, oy, row0, row1, jlo, jhi, ilo, ihi)) continue;
+    double A[3], B[3], C[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int ia = (c + 1) % 3, ib = (c + 2) % 3;
+      const int ex = rx[ib] - rx[ia], ey = ry[ib] - ry[ia];
+      const bool owns = ey > 0 || (ey == 0 && ex < 0);
+      A[c] = -(double)ey; B[c] = (double)ex;
+      C[c] = (double)ey * (double)rx[ia] - (double)ex * (double)ry[ia] - (owns ? 0.0 : 1.0);
+    }
+    const float W0 = __uint_as_float(q1.y), Wx = __uint_as_float(q1.z), Wy = __uint_as_float(q1.w);
+    const int bw = jhi - jlo + 1;
+    const int area = bw * (ihi - ilo + 1);
+    for (int p = tid; p < area; p += kThreads) {
+      const int pr = p / bw;
+      const int di = ilo + pr, dj = jlo + (p - pr * bw);
+      unsigned long long* const zpix = zb + (size_t)((oy + di - row0) * a.w + ox + dj) * NS;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int sl = NS == 1 ? 4 : s;
+        const double X = (double)((dj << 8) + a.cv.sxi[sl]), Y = (double)((di << 8) + a.cv.syi[sl]);
+        const double e0 = fma(A[0], X, fma(B[0], Y, C[0])), e1 = fma(A[1], X, fma(B[1], Y, C[1])), e2 = fma(A[2], X, fma(B[2], Y, C[2]));
+        if (e0 < 0.0 || e1 < 0.0 || e2 < 0.0) continue;
+        const float Ws = fmaf(Wy, (float)di + a.cv.syf[sl], fmaf(Wx, (float)dj + a.cv.sxf[sl], W0));
+        if (!(Ws <= w_near) || !(Ws >= w_far)) continue;
+        atomicMin(&zpix[s], ((unsigned long long)(~__float_as_uint(Ws)) << 32) | (uint32_t)id);
+      }
+    }
   }
   if (!band_empty) __syncthreads();
 
@@ -1048,8 +986,9 @@ __global__ __launch_bounds__(band_threads(NS), (NS == 1 && !HALF && !ANISO) ? 6 
   const int q8 = 1;  // colours are 8-bit quantised like the reference's uint8 read-back (HP_RASTER_QUANT8 is implied)
   float amb[3] = {1.0f, 1.0f, 1.0f};
   if (a.ambient) { amb[0] = a.ambient[3 * view]; amb[1] = a.ambient[3 * view + 1]; amb[2] = a.ambient[3 * view + 2]; }
-  const ShadeCtx cx{T, Kv, amb, xv, fbase, voff, toff, tw, th, view, q8, (int)ob[7] > 0 ? (int)ob[7] : 1,
-                    (a.flags & HP_RASTER_TEX_ANISO) != 0, &mips, (a.rec ? a.want_nrm != 0 : a.nrm != nullptr) || a.n_lights > 0};
+  const bool need_normal = (a.rec ? a.want_nrm != 0 : a.nrm != nullptr) || a.n_lights > 0;
+  const ShadeCtx cx{a.TCO + 16 * (int64_t)view, a.K + 9 * (int64_t)view, amb, recs, voff, toff, tw, th, view, q8, (int)ob[7] > 0 ? (int)ob[7] : 1,
+                    (a.flags & HP_RASTER_TEX_ANISO) != 0, &mips, need_normal};
   const bool want_colour = a.rec ? true : (a.rgb != nullptr || a.nrm != nullptr);
   const bool coded = !band_empty;  // colours travel as 8-bit codes through LDS
   if (coded && NS == 1) {
@@ -1234,7 +1173,7 @@ __global__ __launch_bounds__(band_threads(NS), (NS == 1 && !HALF && !ANISO) ? 6 
       const unsigned long long slot = zb[p * NS + (NS - 1)];
       const uint32_t zbits = (uint32_t)(slot >> 32);
       if (zbits != 0xFFFFFFFFu) {
-        const float Z = __uint_as_float(zbits);
+        const float Z = 1.0f / __uint_as_float(~zbits);  // the key holds ~bits(1 / z)
         o_d = Z > a.depth_max ? 0.0f : Z;
       }
       if (coded) {
@@ -1354,60 +1293,67 @@ __global__ __launch_bounds__(band_threads(NS), (NS == 1 && !HALF && !ANISO) ? 6 
 
 }  // namespace hp
 
-// Rasteriser scratch of a mesh store for `n` views of `n_bands` bands: per-(view, band) triangle lists, their counters
-// and the per-(view, vertex) screen-space records.  Grows, never shrinks; refuses to grow under stream capture (a
+// Rasteriser scratch of a mesh store for `n` views of `n_bands` bands: per-(view, band) lists of sub-triangle ids, their
+// counters and the per-(view, sub-triangle) set-up records.  Grows, never shrinks; refuses to grow under stream capture (a
 // captured launch would keep the pointer that is freed here) -- run the call once eagerly, or reserve.
 static int raster_scratch(hp::MeshStore* ms, int n, int n_bands, hipStream_t st, int* chunk_out) {
-  const size_t per_view = (size_t)n_bands * (size_t)ms->max_faces * sizeof(int32_t);
-  // List budget: 8 GB of the 288 (what is allocated is what the largest call needs: 7.7 MB per multisampled 240 x 320 view); it was
-  // 512 MB through round 3 (five chunks for a lane's 576 coarse views).  One chunk per call saves the repeated launches;
-  // HP_RASTER_CHUNK_VIEWS=<n> forces chunks (the tests' way to run the chunked path), HP_RASTER_CHUNK_SYNC=1 synchronises the
-  // stream after every chunk (diagnostics).
-  static const size_t budget_mb = std::getenv("HP_RASTER_LIST_BUDGET_MB") ? (size_t)std::atoll(std::getenv("HP_RASTER_LIST_BUDGET_MB")) : 8192;
-  const size_t budget = budget_mb << 20;
+  const size_t rec_view = (size_t)2 * (size_t)ms->max_faces * 128;
+  const size_t per_view = (size_t)n_bands * (size_t)ms->max_faces * sizeof(int32_t) + rec_view;
+  // Scratch budget: min(8 GB, 1/16 of the device's free memory at the first call); what is allocated is what the largest call
+  // needs (a multisampled 240 x 320 view of a 16 k-face object: 7.7 MB of list address space + 4 MB of records).  A call that
+  // exceeds it renders in chunks of views.  HP_RASTER_LIST_BUDGET_MB overrides; HP_RASTER_CHUNK_VIEWS=<n> forces chunks (the
+  // tests' way to run the chunked path), HP_RASTER_CHUNK_SYNC=1 synchronises the stream after every chunk (diagnostics).
+  static const size_t budget = [] {
+    if (const char* e = std::getenv("HP_RASTER_LIST_BUDGET_MB")) return (size_t)std::atoll(e) << 20;
+    size_t free_b = 0, total_b = 0;
+    size_t b = (size_t)8192 << 20;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 16 < b) b = free_b / 16;
+    return b < ((size_t)64 << 20) ? ((size_t)64 << 20) : b;
+  }();
   int chunk = (int)std::min<size_t>(budget / (per_view ? per_view : 1), 1u << 30);
   static const int chunk_env = std::getenv("HP_RASTER_CHUNK_VIEWS") ? std::atoi(std::getenv("HP_RASTER_CHUNK_VIEWS")) : 0;
   if (chunk_env > 0 && chunk_env < chunk) chunk = chunk_env;
   if (chunk < 1) chunk = 1;
   if (chunk > n) chunk = n;
   *chunk_out = chunk;
-  const size_t need_list = (size_t)chunk * per_view, need_cnt = (size_t)chunk * n_bands * sizeof(int32_t);
-  const size_t need_xv = (size_t)chunk * (size_t)ms->max_verts * 2 * sizeof(float4);
-  if (ms->bin_list_bytes >= need_list && ms->bin_count_bytes >= need_cnt && ms->xverts_bytes >= need_xv) return HP_OK;
+  const size_t need_list = (size_t)chunk * n_bands * (size_t)ms->max_faces * sizeof(int32_t), need_cnt = (size_t)chunk * n_bands * sizeof(int32_t);
+  const size_t need_rec = (size_t)chunk * rec_view;
+  if (ms->bin_list_bytes >= need_list && ms->bin_count_bytes >= need_cnt && ms->recs_bytes >= need_rec) return HP_OK;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (st) (void)hipStreamIsCapturing(st, &cap);
   HP_REQUIRE(cap == hipStreamCaptureStatusNone,
              "hp_rasterize: the rasteriser scratch would have to grow during stream capture (hp_mesh_store_reserve_raster first)");
-  auto grow = [](void** p, size_t* have, size_t need) -> int {
+  auto grow = [](void** p, size_t* have, size_t need, bool zero) -> int {
     if (*have >= need) return HP_OK;
     if (*p) (void)hipFree(*p);  // hipFree waits for the device: nothing in flight reads it any more
     *p = nullptr; *have = 0;
     HP_CHECK_HIP(hipMalloc(p, need));
+    if (zero) HP_CHECK_HIP(hipMemset(*p, 0, need));  // (synchronous: done before any launch that follows)
     *have = need;
     return HP_OK;
   };
-  int rc = grow((void**)&ms->bin_list, &ms->bin_list_bytes, need_list);
-  if (!rc) rc = grow((void**)&ms->bin_count, &ms->bin_count_bytes, need_cnt);
-  if (!rc) rc = grow((void**)&ms->xverts, &ms->xverts_bytes, need_xv);
+  int rc = grow((void**)&ms->bin_list, &ms->bin_list_bytes, need_list, false);
+  if (!rc) rc = grow((void**)&ms->bin_count, &ms->bin_count_bytes, need_cnt, true);  // the kernels keep the counters at zero between launches
+  if (!rc) rc = grow((void**)&ms->recs, &ms->recs_bytes, need_rec, false);
   ms->scratch_generation += 1;
   return rc;
 }
 
-// hp_raster_set_backface_culling / HP_RASTER_NO_CULL=1 (the initial state): bin every triangle, the round-3 behaviour
-static std::atomic<int> g_cull{-1};
-static bool raster_cull_enabled() {
-  int v = g_cull.load(std::memory_order_relaxed);
-  if (v < 0) {
-    v = std::getenv("HP_RASTER_NO_CULL") ? 0 : 1;
-    g_cull.store(v, std::memory_order_relaxed);
-  }
-  return v != 0;
+namespace hp {
+// band layout of a render: rows per band / threads per workgroup / LDS keys
+struct BandPlan { int band_rows, n_bands, npix_max; bool wide; };
+static bool band_plan(int h, int w, int msaa, int rows_env, BandPlan* bp) {
+  bp->wide = false;
+  int budget = msaa ? kBandKeysMsaa / kSamplesMsaa : kBandPixels;  // pixels of a band
+  if (msaa && w > budget) { budget = kBandKeysMsaaWide / kSamplesMsaa; bp->wide = true; }  // 641 .. 1280 px: the 512-thread instantiation
+  if (w > budget) return false;
+  bp->band_rows = rows_env > 0 && !msaa && rows_env * w <= 2 * kBandPixels ? rows_env : budget / w;
+  if (bp->band_rows > h) bp->band_rows = h;
+  bp->n_bands = (h + bp->band_rows - 1) / bp->band_rows;
+  bp->npix_max = bp->band_rows * w;
+  return true;
 }
-
-static int raster_bands(int h, int w, int msaa) {
-  const int band_rows = msaa ? hp::kBandKeysMsaa / (hp::kSamplesMsaa * w) : hp::kBandPixels / w;
-  return (h + band_rows - 1) / band_rows;
-}
+}  // namespace hp
 
 extern "C" int hp_mesh_store_reserve_raster(hp_mesh_store* store, int n_views, int h, int w, int flags) {
   using namespace hp;
@@ -1415,9 +1361,10 @@ extern "C" int hp_mesh_store_reserve_raster(hp_mesh_store* store, int n_views, i
   HP_REQUIRE(n_views >= 0 && h > 0 && w > 0 && w <= kBandPixels, "hp_mesh_store_reserve_raster: bad size");
   if (n_views == 0) return HP_OK;
   int chunk = 0;
-  int rc = raster_scratch(store, n_views, raster_bands(h, w, 0), nullptr, &chunk);
-  if (!rc && (flags & HP_RASTER_MSAA4) && kSamplesMsaa * w <= kBandKeysMsaa)
-    rc = raster_scratch(store, n_views, raster_bands(h, w, 1), nullptr, &chunk);
+  BandPlan bp;
+  HP_REQUIRE(band_plan(h, w, 0, 0, &bp), "hp_mesh_store_reserve_raster: image too wide for one band");
+  int rc = raster_scratch(store, n_views, bp.n_bands, nullptr, &chunk);
+  if (!rc && (flags & HP_RASTER_MSAA4) && band_plan(h, w, 1, 0, &bp)) rc = raster_scratch(store, n_views, bp.n_bands, nullptr, &chunk);
   return rc;
 }
 
@@ -1426,21 +1373,25 @@ extern "C" int64_t hp_mesh_store_scratch_generation(const hp_mesh_store* store) 
 namespace hp {
 static const hp_raster_conventions kDefaultConventions = {{0.375f, 0.875f, 0.125f, 0.625f}, {0.125f, 0.375f, 0.625f, 0.875f}, 16, 0, 0, 0.0f, 0.0f,
                                                           {0, 1, 2}, {1.0f, -1.0f, -1.0f}};
-static hp_raster_conventions g_conventions = kDefaultConventions;  // process-wide, read at launch time
-static std::mutex g_conventions_mutex;
+// state of a new store: the default record, culling on (HP_RASTER_NO_CULL=1: off)
+void raster_store_defaults(MeshStore* s) {
+  s->conventions = kDefaultConventions;
+  s->backface_culling = std::getenv("HP_RASTER_NO_CULL") ? 0 : 1;
+}
 
-static RasterConv derive_conventions() {
-  hp_raster_conventions c;
-  { std::lock_guard<std::mutex> lock(g_conventions_mutex); c = g_conventions; }
+static RasterConv derive_conventions(const hp_raster_conventions& c, int msaa) {
   RasterConv r{};
-  r.lo_x = r.lo_y = 1.0f; r.hi_x = r.hi_y = 0.0f;
-  for (int k = 0; k < 4; ++k) {
-    r.sx[k] = c.msaa_x[k]; r.sy[k] = c.msaa_y[k];
-    r.lo_x = std::fmin(r.lo_x, c.msaa_x[k]); r.hi_x = std::fmax(r.hi_x, c.msaa_x[k]);
-    r.lo_y = std::fmin(r.lo_y, c.msaa_y[k]); r.hi_y = std::fmax(r.hi_y, c.msaa_y[k]);
-    r.dxa[k] = std::fabs(c.msaa_x[k] - 0.5f); r.dya[k] = std::fabs(c.msaa_y[k] - 0.5f);
+  auto sub = [](float s) { const int v = (int)std::rint(s * (float)kSub); return v < 0 ? 0 : v > kSub - 1 ? kSub - 1 : v; };  // hardware keeps sample positions on such a grid
+  for (int k = 0; k < 4; ++k) { r.sxi[k] = sub(c.msaa_x[k]); r.syi[k] = sub(c.msaa_y[k]); }
+  r.sxi[4] = r.syi[4] = kSub / 2;
+  r.lo_x = r.hi_x = r.lo_y = r.hi_y = kSub / 2;  // the centre is always tested
+  for (int k = 0; k < 5; ++k) {
+    r.sxf[k] = (float)r.sxi[k] * (1.0f / (float)kSub); r.syf[k] = (float)r.syi[k] * (1.0f / (float)kSub);
+    if (msaa && k < 4) {
+      r.lo_x = std::min(r.lo_x, r.sxi[k]); r.hi_x = std::max(r.hi_x, r.sxi[k]);
+      r.lo_y = std::min(r.lo_y, r.syi[k]); r.hi_y = std::max(r.hi_y, r.syi[k]);
+    }
   }
-  r.sx[4] = r.sy[4] = 0.5f;
   r.aniso_max = (float)c.aniso_max; r.lod_bias = c.lod_bias; r.ratio_bias = c.aniso_ratio_bias; r.aniso_round = c.aniso_round; r.lod_from = c.lod_from;
   for (int k = 0; k < 3; ++k) { r.n_axis[k] = c.normal_axis[k]; r.n_sign[k] = c.normal_sign[k]; }
   return r;
@@ -1449,29 +1400,30 @@ static RasterConv derive_conventions() {
 // Common launch path of hp_rasterize (strided planes) and hp_render_inputs (network-input records + fused crop).
 static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool crop, hipStream_t st) {
   const int h = a.h, w = a.w;
-  a.cv = derive_conventions();
   a.msaa = (a.flags & HP_RASTER_MSAA4) && (a.rec || a.rgb || a.nrm) ? 1 : 0;  // depth-only renders have nothing to multisample
+  a.cv = derive_conventions(store->conventions, a.msaa);
+  a.cull = store->backface_culling ? store->cull : nullptr;
   const int ns = a.msaa ? kSamplesMsaa : 1;
   static const int rows_env = std::getenv("HP_RASTER_ROWS") ? std::atoi(std::getenv("HP_RASTER_ROWS")) : 0;
-  const int budget = a.msaa ? kBandKeysMsaa / kSamplesMsaa : kBandPixels;  // pixels of a band
-  HP_REQUIRE(w <= budget, "hp_rasterize: image too wide for one band");
-  a.band_rows = rows_env > 0 && !a.msaa && rows_env * w <= 2 * kBandPixels ? rows_env : budget / w;
-  if (a.band_rows > h) a.band_rows = h;
-  a.n_bands = (h + a.band_rows - 1) / a.band_rows;
+  BandPlan bp;
+  HP_REQUIRE(band_plan(h, w, a.msaa, rows_env, &bp), "hp_rasterize: image too wide for one band");
+  a.band_rows = bp.band_rows; a.n_bands = bp.n_bands;
   HP_REQUIRE(a.n_bands <= kMaxBands, "hp_rasterize: unsupported resolution (too many bands)");
-  const int npix_max = a.band_rows * w;
+  const int npix_max = bp.npix_max;
   HP_REQUIRE(npix_max < 65536, "hp_rasterize: band too large");
   HP_REQUIRE(!a.msaa || npix_max < 16384, "hp_rasterize: multisampled band too large");  // invocation entries: pixel | sample << 14
   a.w_magic = (unsigned)(0x100000000ull / (unsigned)w + 1);
   a.depth_max = kZNear / (1.0f - (1.0f - 1e-3f) * (kZFar - kZNear) / kZFar);
-  // Views are processed in chunks so that the per-(view, band) triangle lists stay within a fixed scratch budget.  The
-  // scratch is owned by the store and only ever grows (hp_mesh_store_reserve_raster pre-sizes it; predictors do that at
-  // construction for their largest batch); a growth bumps the store's scratch generation, which tells holders of
-  // captured hipGraphs that the pointers their launches carry are gone.  Callers sharing one store must be stream-ordered.
+  // the shading needs barycentrics (sector 2 of the records): normals, point lights, or an object without a texture
+  a.need_attr = (a.rec ? a.want_nrm != 0 : a.nrm != nullptr) || a.n_lights > 0 || store->any_untextured;
+  // Views are processed in chunks so that the scratch stays within a fixed budget.  The scratch is owned by the store and only
+  // ever grows (hp_mesh_store_reserve_raster pre-sizes it; predictors do that at construction for their largest batch); a
+  // growth bumps the store's scratch generation, which tells holders of captured hipGraphs that the pointers their launches
+  // carry are gone.  Callers sharing one store must be stream-ordered.
   hp::MeshStore* ms = const_cast<hp_mesh_store*>(store);
   a.max_faces = (int)store->max_faces;
   a.bin_cap = a.max_faces;
-  a.max_verts = (int)store->max_verts;
+  a.rec_slots = 2 * a.max_faces;
   int chunk = 0;
   {
     const int rc = raster_scratch(ms, n, a.n_bands, st, &chunk);
@@ -1479,17 +1431,19 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
   }
   a.bin_list = ms->bin_list;
   a.bin_count = ms->bin_count;
-  a.xverts = ms->xverts;
+  a.recs = ms->recs;
   const size_t lds = band_lds_bytes(npix_max, ns, a.band_rows, w, crop);
   HP_REQUIRE(lds <= 150 * 1024, "hp_rasterize: band does not fit the LDS");
   const bool half = (a.flags & HP_RASTER_OUT_F16) != 0, aniso = (a.flags & HP_RASTER_TEX_ANISO) != 0;
   typedef void (*BandKernel)(RasterArgs, int);
-  static const BandKernel kernels[8] = {
-      raster_kernel<1, false, false>, raster_kernel<1, false, true>, raster_kernel<1, true, false>, raster_kernel<1, true, true>,
-      raster_kernel<kSamplesMsaa, false, false>, raster_kernel<kSamplesMsaa, false, true>, raster_kernel<kSamplesMsaa, true, false>,
-      raster_kernel<kSamplesMsaa, true, true>};
-  const int ki = 4 * a.msaa + 2 * (half ? 1 : 0) + (aniso ? 1 : 0);
-  static size_t opted[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static const BandKernel kernels[12] = {
+      raster_kernel<1, false, false, false>, raster_kernel<1, false, true, false>, raster_kernel<1, true, false, false>, raster_kernel<1, true, true, false>,
+      raster_kernel<kSamplesMsaa, false, false, false>, raster_kernel<kSamplesMsaa, false, true, false>, raster_kernel<kSamplesMsaa, true, false, false>,
+      raster_kernel<kSamplesMsaa, true, true, false>,
+      raster_kernel<kSamplesMsaa, false, false, true>, raster_kernel<kSamplesMsaa, false, true, true>, raster_kernel<kSamplesMsaa, true, false, true>,
+      raster_kernel<kSamplesMsaa, true, true, true>};
+  const int ki = (bp.wide ? 8 : 4 * a.msaa) + 2 * (half ? 1 : 0) + (aniso ? 1 : 0);
+  static size_t opted[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (opted[ki] < lds) {
     HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[ki]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     opted[ki] = lds;
@@ -1498,10 +1452,9 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
     const int nv = n - v0 < chunk ? n - v0 : chunk;
     a.view0 = v0;
     a.n = nv;
-    hipLaunchKernelGGL(raster_xform_kernel, dim3((a.max_verts + 255) / 256, nv), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(raster_bin_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
+    hipLaunchKernelGGL(raster_setup_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
     const int total = nv * a.n_bands;
-    hipLaunchKernelGGL(kernels[ki], dim3(8 * ((total + 7) / 8)), dim3(band_threads(ns)), lds, st, a, npix_max);
+    hipLaunchKernelGGL(kernels[ki], dim3(8 * ((total + 7) / 8)), dim3(band_threads(ns, bp.wide)), lds, st, a, npix_max);
     static const bool chunk_sync = std::getenv("HP_RASTER_CHUNK_SYNC") != nullptr;  // diagnostics (see raster_scratch)
     if (chunk_sync && v0 + chunk < n) (void)hipStreamSynchronize(st);
   }
@@ -1509,35 +1462,35 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
 }
 }  // namespace hp
 
-extern "C" int hp_raster_set_conventions(const hp_raster_conventions* c) {
+extern "C" int hp_mesh_store_set_raster_conventions(hp_mesh_store* store, const hp_raster_conventions* c) {
   using namespace hp;
+  HP_REQUIRE(store != nullptr, "hp_mesh_store_set_raster_conventions: null mesh store");
   hp_raster_conventions v = c ? *c : kDefaultConventions;
   for (int k = 0; k < 4; ++k)
     HP_REQUIRE(v.msaa_x[k] > 0.0f && v.msaa_x[k] < 1.0f && v.msaa_y[k] > 0.0f && v.msaa_y[k] < 1.0f,
-               "hp_raster_set_conventions: sample positions must lie inside the pixel, in (0, 1)");
-  HP_REQUIRE(v.aniso_max >= 1 && v.aniso_max <= 16, "hp_raster_set_conventions: aniso_max must be in 1..16");
-  HP_REQUIRE(v.aniso_round >= 0 && v.aniso_round <= 2 && v.lod_from >= 0 && v.lod_from <= 2, "hp_raster_set_conventions: unknown rule");
-  HP_REQUIRE(std::isfinite(v.lod_bias) && std::isfinite(v.aniso_ratio_bias), "hp_raster_set_conventions: biases must be finite");
+               "hp_mesh_store_set_raster_conventions: sample positions must lie inside the pixel, in (0, 1)");
+  HP_REQUIRE(v.aniso_max >= 1 && v.aniso_max <= 16, "hp_mesh_store_set_raster_conventions: aniso_max must be in 1..16");
+  HP_REQUIRE(v.aniso_round >= 0 && v.aniso_round <= 2 && v.lod_from >= 0 && v.lod_from <= 2, "hp_mesh_store_set_raster_conventions: unknown rule");
+  HP_REQUIRE(std::isfinite(v.lod_bias) && std::isfinite(v.aniso_ratio_bias), "hp_mesh_store_set_raster_conventions: biases must be finite");
   for (int k = 0; k < 3; ++k)
     HP_REQUIRE(v.normal_axis[k] >= 0 && v.normal_axis[k] <= 2 && (v.normal_sign[k] == 1.0f || v.normal_sign[k] == -1.0f),
-               "hp_raster_set_conventions: normal_axis in 0..2, normal_sign +1 / -1");
-  std::lock_guard<std::mutex> lock(g_conventions_mutex);
-  g_conventions = v;
+               "hp_mesh_store_set_raster_conventions: normal_axis in 0..2, normal_sign +1 / -1");
+  store->conventions = v;
   return HP_OK;
 }
 
-extern "C" int hp_raster_set_backface_culling(int on) {
-  const int prev = raster_cull_enabled() ? 1 : 0;
-  g_cull.store(on ? 1 : 0, std::memory_order_relaxed);
-  return prev;
-}
-
-extern "C" int hp_raster_get_conventions(hp_raster_conventions* out) {
+extern "C" int hp_mesh_store_get_raster_conventions(const hp_mesh_store* store, hp_raster_conventions* out) {
   using namespace hp;
-  HP_REQUIRE(out != nullptr, "hp_raster_get_conventions: null argument");
-  std::lock_guard<std::mutex> lock(g_conventions_mutex);
-  *out = g_conventions;
+  HP_REQUIRE(store != nullptr && out != nullptr, "hp_mesh_store_get_raster_conventions: null argument");
+  *out = store->conventions;
   return HP_OK;
+}
+
+extern "C" int hp_mesh_store_set_backface_culling(hp_mesh_store* store, int on) {
+  if (!store) return -1;
+  const int prev = store->backface_culling ? 1 : 0;
+  store->backface_culling = on ? 1 : 0;
+  return prev;
 }
 
 extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
@@ -1562,7 +1515,7 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_rasterize: depth_norm_z missing");
   RasterArgs a{};
   a.verts4 = store->verts4; a.normals4 = store->normals4; a.uvs = store->uvs; a.colors = store->colors;
-  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj; a.cull = raster_cull_enabled() ? store->cull : nullptr; a.face_planes = store->face_planes;
+  a.faces4 = store->faces4; a.tex = store->tex; a.obj = store->obj;
   a.obj_ids = d_obj_ids; a.TCO = d_TCO; a.K = d_K; a.ambient = d_ambient;
   a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
   a.rgb = d_rgb; a.nrm = d_nrm; a.depth = d_depth; a.mask = d_mask;
@@ -1608,7 +1561,7 @@ extern "C" int hp_render_inputs(const hp_mesh_store* store, int n_items, int vie
   }
   RasterArgs a{};
   a.verts4 = store->verts4; a.normals4 = store->normals4; a.uvs = store->uvs; a.colors = store->colors;
-  a.faces = store->faces; a.tex = store->tex; a.obj = store->obj; a.cull = raster_cull_enabled() ? store->cull : nullptr; a.face_planes = store->face_planes;
+  a.faces4 = store->faces4; a.tex = store->tex; a.obj = store->obj;
   a.obj_ids = d_obj_ids; a.TCO = d_TCV_O; a.K = d_KV; a.ambient = d_ambient;
   a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
   a.n = n_items * views_per_item; a.views_per_item = views_per_item; a.n_lights = n_lights; a.h = h; a.w = w;
@@ -1634,10 +1587,3 @@ extern "C" int hp_render_inputs(const hp_mesh_store* store, int n_items, int vie
   return launch_raster(store, a, a.n, crop, (hipStream_t)stream);
 }
 
-#ifdef HP_RABL_COUNT
-extern "C" int hp_debug_raster_counters(unsigned long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hp::hp_dbg_cnt), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hp::hp_dbg_cnt), z, sizeof(z)) != hipSuccess) return -1; }
-  return 0;
-}
-#endif

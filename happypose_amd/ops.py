@@ -122,6 +122,42 @@ class MeshStore:
         captured under an older generation hold freed pointers."""
         return int(lib().hp_mesh_store_scratch_generation(self.handle))
 
+    def set_raster_conventions(self, conv: Optional[Dict] = None) -> None:
+        """``hp_mesh_store_set_raster_conventions``: the three renderer conventions nobody can pin without Panda3D --
+        multisample positions, the anisotropic filter's probe-count / level-of-detail rule, the axis / sign map of the eye-normal
+        code (``TB/renderer/panda3d_scene_renderer.py:68-71,221-230``, ``TB/renderer/utils.py:63-79``) -- of THIS store's renders
+        (two stores in one process may differ).  ``conv``: ``None`` = defaults, or a dict overriding any of
+        :data:`RASTER_CONVENTION_DEFAULTS`.  Read at launch time; captured graphs are dropped (``bump_graph_epoch``).
+        ``tools/calibrate_renderer.py`` fits the record to Panda3D renders."""
+        if conv is None:
+            check(lib().hp_mesh_store_set_raster_conventions(self.handle, None), "hp_mesh_store_set_raster_conventions")
+        else:
+            d = dict(RASTER_CONVENTION_DEFAULTS)
+            unknown = set(conv) - set(d)
+            if unknown:
+                raise KeyError(f"unknown raster convention(s): {sorted(unknown)}")
+            d.update(conv)
+            c = RasterConventions((C.c_float * 4)(*d["msaa_x"]), (C.c_float * 4)(*d["msaa_y"]), int(d["aniso_max"]), int(d["aniso_round"]),
+                                  int(d["lod_from"]), float(d["lod_bias"]), float(d["aniso_ratio_bias"]), (C.c_int * 3)(*d["normal_axis"]),
+                                  (C.c_float * 3)(*d["normal_sign"]))
+            check(lib().hp_mesh_store_set_raster_conventions(self.handle, C.byref(c)), "hp_mesh_store_set_raster_conventions")
+        bump_graph_epoch()
+
+    def get_raster_conventions(self) -> Dict:
+        c = RasterConventions()
+        check(lib().hp_mesh_store_get_raster_conventions(self.handle, C.byref(c)), "hp_mesh_store_get_raster_conventions")
+        return dict(msaa_x=tuple(c.msaa_x), msaa_y=tuple(c.msaa_y), aniso_max=c.aniso_max, aniso_round=c.aniso_round, lod_from=c.lod_from,
+                    lod_bias=c.lod_bias, aniso_ratio_bias=c.aniso_ratio_bias, normal_axis=tuple(c.normal_axis), normal_sign=tuple(c.normal_sign))
+
+    def set_backface_culling(self, on: bool = True) -> bool:
+        """``hp_mesh_store_set_backface_culling``: drop triangles whose inward side is turned to the camera when they belong to a
+        closed, consistently oriented connected component of the mesh seen from outside (they can never be seen; the renders stay
+        two-sided like the reference's for everything else).  Per store; returns the previous setting.  Default on;
+        ``HP_RASTER_NO_CULL=1`` creates stores with it off."""
+        prev = bool(lib().hp_mesh_store_set_backface_culling(self.handle, 1 if on else 0))
+        bump_graph_epoch()
+        return prev
+
     def point_ids(self, n_points: int) -> torch.Tensor:
         """ids of ``sample_points(n, deterministic=True)`` (TB/lib3d/mesh_ops.py:74-84)."""
         if n_points not in self._point_ids:
@@ -142,40 +178,6 @@ class RasterConventions(C.Structure):
 
 RASTER_CONVENTION_DEFAULTS = dict(msaa_x=(0.375, 0.875, 0.125, 0.625), msaa_y=(0.125, 0.375, 0.625, 0.875), aniso_max=16,
                                   aniso_round=0, lod_from=0, lod_bias=0.0, aniso_ratio_bias=0.0, normal_axis=(0, 1, 2), normal_sign=(1.0, -1.0, -1.0))
-
-
-def set_raster_conventions(conv: Optional[Dict] = None) -> None:
-    """``hp_raster_set_conventions``: the three renderer conventions nobody can pin without Panda3D -- multisample positions,
-    the anisotropic filter's probe-count / level-of-detail rule, the axis / sign map of the eye-normal code
-    (``TB/renderer/panda3d_scene_renderer.py:68-71,221-230``, ``TB/renderer/utils.py:63-79``).  ``conv``: ``None`` = defaults,
-    or a dict overriding any of :data:`RASTER_CONVENTION_DEFAULTS`.  Process-wide, read at launch time; captured graphs are
-    dropped (``bump_graph_epoch``).  ``tools/calibrate_renderer.py`` fits the record to Panda3D renders."""
-    if conv is None:
-        check(lib().hp_raster_set_conventions(None), "hp_raster_set_conventions")
-    else:
-        d = dict(RASTER_CONVENTION_DEFAULTS)
-        unknown = set(conv) - set(d)
-        if unknown:
-            raise KeyError(f"unknown raster convention(s): {sorted(unknown)}")
-        d.update(conv)
-        c = RasterConventions((C.c_float * 4)(*d["msaa_x"]), (C.c_float * 4)(*d["msaa_y"]), int(d["aniso_max"]), int(d["aniso_round"]),
-                              int(d["lod_from"]), float(d["lod_bias"]), float(d["aniso_ratio_bias"]), (C.c_int * 3)(*d["normal_axis"]), (C.c_float * 3)(*d["normal_sign"]))
-        check(lib().hp_raster_set_conventions(C.byref(c)), "hp_raster_set_conventions")
-    bump_graph_epoch()
-
-
-def set_backface_culling(on: bool = True) -> bool:
-    """``hp_raster_set_backface_culling``: drop triangles that face away from the camera when that cannot change the image
-    (closed objects seen from outside; the renders stay two-sided like the reference's for everything else).  Returns the
-    previous setting.  Default on; ``HP_RASTER_NO_CULL=1`` starts with it off."""
-    return bool(lib().hp_raster_set_backface_culling(1 if on else 0))
-
-
-def get_raster_conventions() -> Dict:
-    c = RasterConventions()
-    check(lib().hp_raster_get_conventions(C.byref(c)), "hp_raster_get_conventions")
-    return dict(msaa_x=tuple(c.msaa_x), msaa_y=tuple(c.msaa_y), aniso_max=c.aniso_max, aniso_round=c.aniso_round, lod_from=c.lod_from,
-                lod_bias=c.lod_bias, aniso_ratio_bias=c.aniso_ratio_bias, normal_axis=tuple(c.normal_axis), normal_sign=tuple(c.normal_sign))
 
 
 def rasterize(store: MeshStore, obj_ids: torch.Tensor, TCO: torch.Tensor, K: torch.Tensor,

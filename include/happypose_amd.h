@@ -120,8 +120,10 @@ typedef struct {
  * They are a RECORD, not compile-time constants, so that an owner of a Panda3D installation can fit them:
  * tools/calibrate_renderer.py scores candidate records against Panda3D renders of the reference's own test scene
  * (tests/test_batch_renderer_panda3d.py:43-69); oracle/csrc/oracle.c mirrors the record (hp_oracle_set_raster_conventions).
- * hp_raster_set_conventions(NULL) restores the defaults below; the record is process-wide and read at launch time (launches
- * already enqueued keep the values they were launched with; captured hipGraphs must be re-captured after a change). */
+ * The record belongs to a MESH STORE (hp_mesh_store_set_raster_conventions; NULL restores the defaults below) and is read at
+ * launch time: two stores -- two renderers -- in one process may differ; launches already enqueued keep the values they were
+ * launched with; captured hipGraphs must be re-captured after a change.  Sample positions are used on a 1/256-pixel grid
+ * (rounded to nearest; hardware keeps them on such a grid -- D3D: 1/16 --, and so does the oracle). */
 typedef struct {
   float msaa_x[4], msaa_y[4];  /* sample positions inside the pixel, each in (0, 1).  Default: the standard 4x pattern
                                   (0.375, 0.125) (0.875, 0.375) (0.125, 0.625) (0.625, 0.875) */
@@ -136,14 +138,17 @@ typedef struct {
   float normal_sign[3];        /* ... times normal_sign[c] (+1 / -1).  Default axes {0, 1, 2}, signs {+1, -1, -1}: GL eye space
                                   (x right, y up, z backward) as R, G, B */
 } hp_raster_conventions;
-int hp_raster_set_conventions(const hp_raster_conventions* conventions /* NULL = defaults */);
-int hp_raster_get_conventions(hp_raster_conventions* out);
-/* Back-face culling in the binning pass (process-wide, read at launch time; default on, HP_RASTER_NO_CULL=1 starts with it off).
- * The reference renders two-sided (TB/renderer/panda3d_scene_renderer.py:102).  A triangle facing away from the camera is
- * dropped only when that cannot change the image: the object is a closed, consistently oriented surface (checked at
- * hp_mesh_store_create on position-welded vertices), the camera is outside its bounding sphere and the sphere lies beyond
- * the near plane.  Returns the previous setting. */
-int hp_raster_set_backface_culling(int on);
+int hp_mesh_store_set_raster_conventions(hp_mesh_store* store, const hp_raster_conventions* conventions /* NULL = defaults */);
+int hp_mesh_store_get_raster_conventions(const hp_mesh_store* store, hp_raster_conventions* out);
+/* Back-face culling in the set-up pass of this store's renders (read at launch time; default on, HP_RASTER_NO_CULL=1 creates
+ * stores with it off).  The reference renders two-sided (TB/renderer/panda3d_scene_renderer.py:102).  A triangle whose
+ * inward side is turned to the camera is dropped only when it cannot be seen: it belongs to a CONNECTED COMPONENT of the
+ * (position-welded) mesh that is a closed, consistently oriented surface with a non-zero signed volume -- decided per
+ * component at hp_mesh_store_create, so nested shells, parts with flipped winding and open sheets each get their own
+ * answer --, the camera is outside the object's bounding sphere and the sphere lies beyond the near plane.  The facing test
+ * is the exact sign of the triangle's area on the 1/256-px vertex grid.  Pixels may differ from the two-sided render only
+ * where a sample lies exactly on a silhouette edge.  Returns the previous setting (-1: null store). */
+int hp_mesh_store_set_backface_culling(hp_mesh_store* store, int on);
 
 int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
                  const int32_t* d_obj_ids /* [n / views_per_item] */,

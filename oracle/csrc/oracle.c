@@ -149,17 +149,6 @@ typedef struct {
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-/* cross product of homogeneous screen vertices with a canonical operand order (lower
- * vertex id first) so the edge function of a shared edge is bit-identical (up to sign) in
- * both triangles: no cracks between neighbours. */
-static inline void edge_fn(const float* A, int ia, const float* B, int ib, float* e) {
-  const float* P = A; const float* Q = B; float sgn = 1.0f;
-  if (ib < ia) { P = B; Q = A; sgn = -1.0f; }
-  e[0] = sgn * fmaf(P[1], Q[2], -(P[2] * Q[1]));
-  e[1] = sgn * fmaf(P[2], Q[0], -(P[0] * Q[2]));
-  e[2] = sgn * fmaf(P[0], Q[1], -(P[1] * Q[0]));
-}
-
 static inline float quant8(float c, int on) {
   c = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
   if (!on) return c;
@@ -241,49 +230,169 @@ static inline void tex_fetch_aniso(const uint8_t* tex, int tw, int th, int nlev,
 }
 
 /*
+ * ---- the rasteriser's geometry, round 5: the way OpenGL hardware defines it ----------------------------------------------
+ * (replaces the homogeneous fp32 edge functions of rounds 1-4: their sample tests were order-dependent at round-off level,
+ * could not be evaluated incrementally and needed an IEEE division per covered sample.)
+ *
+ *  1. Vertices: camera coordinates by the fmaf chains below, w = 1 / z, window coordinates (Xh w, Yh w) SNAPPED to a
+ *     1/256-pixel grid (rintf, clamped to a guard band of +-16384 px): int32 (x, y).  Two vertices at the same position snap
+ *     to the same point whatever their index: texture seams are watertight.
+ *  2. Near plane: a triangle with a corner in front of z = 0.1 m is CLIPPED against that plane (1 or 2 sub-triangles; the new
+ *     corners are interpolated from the inside corner to the outside one, so both triangles of a shared edge compute the same
+ *     point); corners carry their barycentric coordinates with respect to the original triangle.  Far plane and the image
+ *     borders need no clipping: the depth test rejects beyond-range samples and only image pixels are visited.
+ *  3. Coverage: EXACT integer edge functions E_k(X, Y) = (x_b - x_a)(Y - y_a) - (y_b - y_a)(X - x_a) on the snapped corners
+ *     (triangle orientation normalised so that the interior is the positive side), sample positions on the same 1/256 grid,
+ *     top-left fill rule: a sample ON an edge belongs to the triangle iff the edge vector (ex, ey) has ey > 0 or (ey == 0
+ *     and ex < 0) -- every point of a shared edge belongs to exactly one of the two triangles, whatever their winding.
+ *  4. Depth: w = 1 / z is AFFINE in window coordinates (that is what a hardware depth buffer interpolates); the plane
+ *     W(x, y) through the three corners is evaluated per sample, the depth test keeps the largest W in [1 / far, 1 / near]
+ *     (64-bit key {~bits(W) : sub-triangle id}: ties go to the lower id, independent of submission order), and the metric
+ *     depth of a pixel is 1 / W at its centre (TB/renderer/utils.py:46-60 decodes the same quantity from the depth buffer).
+ *  5. Attributes: perspective-correct interpolation as planes as well -- for an attribute q the plane N_q through
+ *     (corner, q_k w_k); q = N_q / W.  u, v (texture coordinates) and the barycentric coordinates b1, b2 (for normals and
+ *     vertex colours) are interpolated this way; du/dx = (N_u,x - u W_x) / W etc. for the anisotropic footprint.
+ *
  * obj_ids [n]; TCO [n][16]; K [n][9]; ambient [n][3]; n_lights point lights per view:
  * light_pos [n][n_lights][3] (object frame, metres), light_col [n][n_lights][3].
  * Outputs are addressed as base + view*sv + chan*sc + row*sr + col*sp (element strides), so
  * NCHW (sc=h*w, sr=w, sp=1) and NHWC slices are both expressible.  Any output pointer may
- * be NULL.  mask is uint8 with the same (sv, sr, sp) strides divided by... its own strides.
+ * be NULL.
  */
-/* One fragment-shader invocation: colour and normal code of triangle f at the CENTRE of pixel (i, j) -- albedo (texture or
- * vertex colours) x (ambient + Lambert point lights), eye-space normal code; perspective-correct barycentrics from the
- * edge functions (extrapolated when the centre lies outside the triangle: multisampled edge pixels). */
-static void shade_centre(const hp_oracle_meshes* M, const float* sv3, const float* T, const float* Kv, const float* amb,
-                         int n_lights, const float* light_pos, const float* light_col, int view, int64_t voff, int64_t foff,
-                         int64_t toff, int tw, int th, int nlev, int aniso, int64_t f, int i, int j, int q8, float* o_rgb,
+#define SUBPIX 256
+#define GUARD_SUB 4194304.0f /* 2^22 sub-pixel units = 16384 px */
+
+typedef struct { float c[3]; float b[3]; } clipv;             /* camera-space corner + barycentrics w.r.t. the original triangle */
+typedef struct { float q0, qx, qy; } plane;                   /* q(fx, fy) = q0 + qx fx + qy fy, (fx, fy) = pixels from the origin pixel's corner */
+typedef struct {
+  int64_t id;                                                 /* f, or n_faces + f for the second half of a clipped quad */
+  int32_t v[3];                                               /* the original triangle's vertex ids (object-local) */
+  int64_t rx[3], ry[3];                                       /* snapped corners relative to (256 ox, 256 oy), orientation normalised */
+  int ox, oy;                                                 /* origin pixel of the planes / relative coordinates */
+  int j0, i0, j1, i1;                                         /* candidate pixels: columns j0..j1, rows i0..i1 (inside the image) */
+  plane W, NU, NV, NB1, NB2;
+} subtri;
+
+static inline int32_t snap_sub(float s) {
+  float r = s * (float)SUBPIX;
+  if (!(r >= -GUARD_SUB)) r = -GUARD_SUB; /* NaN lands here */
+  if (!(r <= GUARD_SUB)) r = GUARD_SUB;
+  return (int32_t)rintf(r);
+}
+static inline int64_t floor_div(int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return -floor_div(-a, b); }
+static inline float plane_at(const plane* p, float fx, float fy) { return fmaf(p->qy, fy, fmaf(p->qx, fx, p->q0)); }
+
+/* plane through the corners' values q[0..2]; (px, py) = corners in pixels from the origin, inv = 1 / (2 area) */
+static inline plane make_plane(const float* q, const float* px, const float* py, float inv) {
+  const float dx1 = px[1] - px[0], dy1 = py[1] - py[0], dx2 = px[2] - px[0], dy2 = py[2] - py[0];
+  const float dq1 = q[1] - q[0], dq2 = q[2] - q[0];
+  plane p;
+  p.qx = fmaf(dq1, dy2, -(dq2 * dy1)) * inv;
+  p.qy = fmaf(dq2, dx1, -(dq1 * dx2)) * inv;
+  p.q0 = fmaf(-p.qy, py[0], fmaf(-p.qx, px[0], q[0]));
+  return p;
+}
+
+/* Set-up of one sub-triangle from three camera-space corners (all with z >= near).  Returns 0 when nothing can be covered. */
+static int setup_subtri(const clipv* cv3, const float* Kv, const float* uv3 /* [3][2] of the ORIGINAL vertices */, int h, int w,
+                        int lo_x, int hi_x, int lo_y, int hi_y, subtri* s) {
+  int64_t x[3], y[3];
+  float wk[3], bb[3][3];
+  for (int k = 0; k < 3; ++k) {
+    const float cx = cv3[k].c[0], cy = cv3[k].c[1], cz = cv3[k].c[2];
+    const float Xh = fmaf(Kv[0], cx, fmaf(Kv[1], cy, Kv[2] * cz));
+    const float Yh = fmaf(Kv[4], cy, Kv[5] * cz);
+    wk[k] = 1.0f / cz;
+    x[k] = snap_sub(Xh * wk[k]);
+    y[k] = snap_sub(Yh * wk[k]);
+    for (int c = 0; c < 3; ++c) bb[k][c] = cv3[k].b[c];
+  }
+  int64_t area2 = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+  if (area2 == 0) return 0;
+  if (area2 < 0) { /* normalise the orientation: swap corners 1 and 2 */
+    int64_t t = x[1]; x[1] = x[2]; x[2] = t; t = y[1]; y[1] = y[2]; y[2] = t;
+    float tf = wk[1]; wk[1] = wk[2]; wk[2] = tf;
+    for (int c = 0; c < 3; ++c) { tf = bb[1][c]; bb[1][c] = bb[2][c]; bb[2][c] = tf; }
+    area2 = -area2;
+  }
+  int64_t xmin = x[0], xmax = x[0], ymin = y[0], ymax = y[0];
+  for (int k = 1; k < 3; ++k) {
+    if (x[k] < xmin) xmin = x[k];
+    if (x[k] > xmax) xmax = x[k];
+    if (y[k] < ymin) ymin = y[k];
+    if (y[k] > ymax) ymax = y[k];
+  }
+  /* origin pixel of the sub-triangle's planes and relative coordinates: the pixel that holds the bounding box's minimum,
+   * clamped into the image -- independent of the sample pattern, so single-sample and multisampled renders see the same
+   * planes (and the same centre depths) */
+  int64_t j0 = floor_div(xmin, SUBPIX), i0 = floor_div(ymin, SUBPIX);
+  if (j0 < 0) j0 = 0;
+  if (j0 > w - 1) j0 = w - 1;
+  if (i0 < 0) i0 = 0;
+  if (i0 > h - 1) i0 = h - 1;
+  /* candidate pixels: pixel j has a sample with xmin <= 256 j + s <= xmax for some sample offset s in [lo, hi] */
+  int64_t ja = ceil_div(xmin - hi_x, SUBPIX), j1 = floor_div(xmax - lo_x, SUBPIX);
+  int64_t ia = ceil_div(ymin - hi_y, SUBPIX), i1 = floor_div(ymax - lo_y, SUBPIX);
+  if (ja < j0) ja = j0;
+  if (j1 > w - 1) j1 = w - 1;
+  if (ia < i0) ia = i0;
+  if (i1 > h - 1) i1 = h - 1;
+  if (ja > j1 || ia > i1) return 0;
+  s->ox = (int)j0; s->oy = (int)i0; s->j0 = (int)ja; s->i0 = (int)ia; s->j1 = (int)j1; s->i1 = (int)i1;
+  float px[3], py[3];
+  for (int k = 0; k < 3; ++k) {
+    s->rx[k] = x[k] - (int64_t)SUBPIX * j0;
+    s->ry[k] = y[k] - (int64_t)SUBPIX * i0;
+    px[k] = (float)s->rx[k] * (1.0f / (float)SUBPIX);   /* exact: |rx| < 2^24 */
+    py[k] = (float)s->ry[k] * (1.0f / (float)SUBPIX);
+  }
+  const float det = (float)area2 * (1.0f / (float)(SUBPIX * SUBPIX)); /* (float)area2: correctly rounded */
+  const float inv = 1.0f / det;
+  float q[3];
+  s->W = make_plane(wk, px, py, inv);
+  for (int k = 0; k < 3; ++k) q[k] = fmaf(bb[k][0], uv3[0], fmaf(bb[k][1], uv3[2], bb[k][2] * uv3[4])) * wk[k];
+  s->NU = make_plane(q, px, py, inv);
+  for (int k = 0; k < 3; ++k) q[k] = fmaf(bb[k][0], uv3[1], fmaf(bb[k][1], uv3[3], bb[k][2] * uv3[5])) * wk[k];
+  s->NV = make_plane(q, px, py, inv);
+  for (int k = 0; k < 3; ++k) q[k] = bb[k][1] * wk[k];
+  s->NB1 = make_plane(q, px, py, inv);
+  for (int k = 0; k < 3; ++k) q[k] = bb[k][2] * wk[k];
+  s->NB2 = make_plane(q, px, py, inv);
+  return 1;
+}
+
+/* sample (X, Y) (sub-pixel units from the origin) inside the sub-triangle: exact integers + top-left rule */
+static inline int sample_inside(const subtri* s, int64_t X, int64_t Y) {
+  for (int k = 0; k < 3; ++k) {
+    const int a = (k + 1) % 3, b = (k + 2) % 3;
+    const int64_t ex = s->rx[b] - s->rx[a], ey = s->ry[b] - s->ry[a];
+    const int64_t E = ex * (Y - s->ry[a]) - ey * (X - s->rx[a]);
+    const int owns = ey > 0 || (ey == 0 && ex < 0);
+    if (E < 0 || (E == 0 && !owns)) return 0;
+  }
+  return 1;
+}
+
+/* One fragment-shader invocation: colour and normal code of sub-triangle s at the CENTRE of pixel (i, j) -- albedo (texture or
+ * vertex colours) x (ambient + Lambert point lights), eye-space normal code; attributes from the planes (extrapolated when
+ * the centre lies outside the triangle: multisampled edge pixels). */
+static void shade_centre(const hp_oracle_meshes* M, const subtri* s, const float* T, const float* Kv, const float* amb,
+                         int n_lights, const float* light_pos, const float* light_col, int view, int64_t voff,
+                         int64_t toff, int tw, int th, int nlev, int aniso, int i, int j, int q8, float* o_rgb,
                          float* o_n) {
-  const int32_t* tri = M->faces + 3 * (foff + f);
-  const float* V0 = sv3 + 3 * tri[0];
-  const float* V1 = sv3 + 3 * tri[1];
-  const float* V2 = sv3 + 3 * tri[2];
-  float e0[3], e1[3], e2[3];
-  edge_fn(V1, tri[1], V2, tri[2], e0);
-  edge_fn(V2, tri[2], V0, tri[0], e1);
-  edge_fn(V0, tri[0], V1, tri[1], e2);
-  const float pu = (float)j + 0.5f, pv = (float)i + 0.5f;
-  float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
-  float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
-  float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
-  float s = l0 + l1 + l2;
-  float b0 = l0 / s, b1 = l1 / s, b2 = l2 / s; /* perspective-correct barycentrics */
-  const float Z = fmaf(l0, V0[2], fmaf(l1, V1[2], l2 * V2[2])) / s; /* the depth the coverage pass stored for a covered centre */
-  const int64_t g0 = voff + tri[0], g1 = voff + tri[1], g2 = voff + tri[2];
-  /* albedo */
+  const float fx = (float)(j - s->ox) + 0.5f, fy = (float)(i - s->oy) + 0.5f;
+  const float Wc = plane_at(&s->W, fx, fy);
+  const float iw = 1.0f / Wc;
+  const float b1 = plane_at(&s->NB1, fx, fy) * iw, b2 = plane_at(&s->NB2, fx, fy) * iw;
+  const float b0 = (1.0f - b1) - b2;
+  const int64_t g0 = voff + s->v[0], g1 = voff + s->v[1], g2 = voff + s->v[2];
   float alb[3];
   if (toff >= 0) {
-    float tu = fmaf(b0, M->uvs[2 * g0], fmaf(b1, M->uvs[2 * g1], b2 * M->uvs[2 * g2]));
-    float tv = fmaf(b0, M->uvs[2 * g0 + 1], fmaf(b1, M->uvs[2 * g1 + 1], b2 * M->uvs[2 * g2 + 1]));
+    const float tu = plane_at(&s->NU, fx, fy) * iw, tv = plane_at(&s->NV, fx, fy) * iw;
     if (aniso && nlev > 1) {
-      /* screen-space derivatives of the perspective-correct barycentrics: b_i = l_i / s, l_i affine in (x, y) */
-      const float sx = e0[0] + e1[0] + e2[0], sy = e0[1] + e1[1] + e2[1];
-      const float bx[3] = {(e0[0] - b0 * sx) / s, (e1[0] - b1 * sx) / s, (e2[0] - b2 * sx) / s};
-      const float by[3] = {(e0[1] - b0 * sy) / s, (e1[1] - b1 * sy) / s, (e2[1] - b2 * sy) / s};
-      const float ux = fmaf(bx[0], M->uvs[2 * g0], fmaf(bx[1], M->uvs[2 * g1], bx[2] * M->uvs[2 * g2]));
-      const float vx = fmaf(bx[0], M->uvs[2 * g0 + 1], fmaf(bx[1], M->uvs[2 * g1 + 1], bx[2] * M->uvs[2 * g2 + 1]));
-      const float uy = fmaf(by[0], M->uvs[2 * g0], fmaf(by[1], M->uvs[2 * g1], by[2] * M->uvs[2 * g2]));
-      const float vy = fmaf(by[0], M->uvs[2 * g0 + 1], fmaf(by[1], M->uvs[2 * g1 + 1], by[2] * M->uvs[2 * g2 + 1]));
+      const float ux = fmaf(-tu, s->W.qx, s->NU.qx) * iw, vx = fmaf(-tv, s->W.qx, s->NV.qx) * iw;
+      const float uy = fmaf(-tu, s->W.qy, s->NU.qy) * iw, vy = fmaf(-tv, s->W.qy, s->NV.qy) * iw;
       tex_fetch_aniso(M->tex + toff, tw, th, nlev, tu, tv, ux, vx, uy, vy, alb);
     } else {
       tex_fetch(M->tex + toff, tw, th, tu, tv, alb);
@@ -306,6 +415,7 @@ static void shade_centre(const hp_oracle_meshes* M, const float* sv3, const floa
   float lit[3] = {amb[0], amb[1], amb[2]};
   if (n_lights > 0) {
     /* camera-space position of the surface point */
+    const float pu = (float)j + 0.5f, pv = (float)i + 0.5f, Z = iw;
     float py = (pv - Kv[5]) * Z / Kv[4];
     float px = ((pu - Kv[2]) * Z - Kv[1] * py) / Kv[0];
     for (int l = 0; l < n_lights; ++l) {
@@ -324,6 +434,9 @@ static void shade_centre(const hp_oracle_meshes* M, const float* sv3, const floa
   for (int c = 0; c < 3; ++c) o_n[c] = quant8(normal_code(g_conv.normal_sign[c] * nc[g_conv.normal_axis[c]]), q8);
 }
 
+/* sample offsets of the conventions record on the 1/256 grid (hardware keeps them on such a grid; D3D: 1/16) */
+static inline int sample_sub(float s) { return (int)rintf(s * (float)SUBPIX); }
+
 void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_ids,
                          const float* TCO, const float* K, const float* ambient,
                          int n_lights, const float* light_pos, const float* light_col,
@@ -332,18 +445,25 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
                          int64_t sv, int64_t sc, int64_t sr, int64_t sp,
                          int64_t dsv, int64_t dsr, int64_t dsp) {
   const float depth_max = Z_NEAR / (1.0f - (1.0f - 1e-3f) * (Z_FAR - Z_NEAR) / Z_FAR);
+  const float W_NEAR = 1.0f / Z_NEAR, W_FAR = 1.0f / Z_FAR;
 #pragma omp parallel
   {
     const int msaa = (flags & HP_R_MSAA4) && (rgb || nrm);
     const int ns = msaa ? 5 : 1;                 /* keys per pixel: 4 colour samples + the centre, or the centre alone */
-    float SX[5], SY[5], lo_x = 1.0f, hi_x = 0.0f, lo_y = 1.0f, hi_y = 0.0f;  /* the four colour samples + the centre */
+    int SX[5], SY[5], lo_x = SUBPIX / 2, hi_x = SUBPIX / 2, lo_y = SUBPIX / 2, hi_y = SUBPIX / 2;
     for (int k = 0; k < 4; ++k) {
-      SX[k] = g_conv.msaa_x[k]; SY[k] = g_conv.msaa_y[k];
-      lo_x = fminf(lo_x, SX[k]); hi_x = fmaxf(hi_x, SX[k]); lo_y = fminf(lo_y, SY[k]); hi_y = fmaxf(hi_y, SY[k]);
+      SX[k] = sample_sub(g_conv.msaa_x[k]); SY[k] = sample_sub(g_conv.msaa_y[k]);
+      if (msaa) {
+        if (SX[k] < lo_x) lo_x = SX[k];
+        if (SX[k] > hi_x) hi_x = SX[k];
+        if (SY[k] < lo_y) lo_y = SY[k];
+        if (SY[k] > hi_y) hi_y = SY[k];
+      }
     }
-    SX[4] = SY[4] = 0.5f;
+    SX[4] = SY[4] = SUBPIX / 2;
     uint64_t* zbuf = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)h * w * ns);
-    float* sv3 = NULL; size_t sv_cap = 0;
+    float* cam = NULL; size_t cam_cap = 0;
+    subtri* st = NULL; size_t st_cap = 0;
 #pragma omp for schedule(dynamic, 1)
     for (int view = 0; view < n; ++view) {
       const float* T = TCO + 16 * view;
@@ -356,74 +476,94 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
       const int tw = (int)ob[5], th = (int)ob[6], nlev = (int)ob[7] > 0 ? (int)ob[7] : 1;
       const int aniso = (flags & HP_R_TEX_ANISO) != 0;
       for (size_t p = 0; p < (size_t)h * w * ns; ++p) zbuf[p] = KEY_EMPTY;
-      if ((size_t)nv * 3 > sv_cap) { sv_cap = (size_t)nv * 3; sv3 = (float*)realloc(sv3, sv_cap * 4); }
+      if ((size_t)nv * 3 > cam_cap) { cam_cap = (size_t)nv * 3; cam = (float*)realloc(cam, cam_cap * 4); }
+      if ((size_t)nf * 2 > st_cap) { st_cap = (size_t)nf * 2; st = (subtri*)realloc(st, st_cap * sizeof(subtri)); }
+      /* slot of a sub-triangle = its id: f, or nf + f (second half of a clipped quad); 0 in `used` = no such sub-triangle */
+      unsigned char* used = (unsigned char*)calloc((size_t)nf * 2, 1);
 
       if (finite) {
-        /* vertex stage: homogeneous pixel coordinates (Xh, Yh, W) = K * (R p + t) */
+        /* vertex stage: camera coordinates */
         for (int64_t i = 0; i < nv; ++i) {
           const float* p = M->verts + 3 * (voff + i);
-          float cx = fmaf(T[0], p[0], fmaf(T[1], p[1], fmaf(T[2], p[2], T[3])));
-          float cy = fmaf(T[4], p[0], fmaf(T[5], p[1], fmaf(T[6], p[2], T[7])));
-          float cz = fmaf(T[8], p[0], fmaf(T[9], p[1], fmaf(T[10], p[2], T[11])));
-          sv3[3 * i + 0] = fmaf(Kv[0], cx, fmaf(Kv[1], cy, Kv[2] * cz));
-          sv3[3 * i + 1] = fmaf(Kv[4], cy, Kv[5] * cz);
-          sv3[3 * i + 2] = cz;
+          cam[3 * i + 0] = fmaf(T[0], p[0], fmaf(T[1], p[1], fmaf(T[2], p[2], T[3])));
+          cam[3 * i + 1] = fmaf(T[4], p[0], fmaf(T[5], p[1], fmaf(T[6], p[2], T[7])));
+          cam[3 * i + 2] = fmaf(T[8], p[0], fmaf(T[9], p[1], fmaf(T[10], p[2], T[11])));
         }
-        /* coverage + depth: 2-D homogeneous rasterisation (no explicit clipping) */
+        /* set-up (+ near-plane clipping), then coverage + depth */
         for (int64_t f = 0; f < nf; ++f) {
           const int32_t* tri = M->faces + 3 * (foff + f);
-          const float* V0 = sv3 + 3 * tri[0];
-          const float* V1 = sv3 + 3 * tri[1];
-          const float* V2 = sv3 + 3 * tri[2];
-          float zmin = fminf(V0[2], fminf(V1[2], V2[2])), zmax = fmaxf(V0[2], fmaxf(V1[2], V2[2]));
+          const float* C0 = cam + 3 * tri[0];
+          const float* C1 = cam + 3 * tri[1];
+          const float* C2 = cam + 3 * tri[2];
+          const float zmin = fminf(C0[2], fminf(C1[2], C2[2])), zmax = fmaxf(C0[2], fmaxf(C1[2], C2[2]));
           if (!(zmax >= Z_NEAR) || !(zmin <= Z_FAR)) continue;
-          float e0[3], e1[3], e2[3];
-          edge_fn(V1, tri[1], V2, tri[2], e0);
-          edge_fn(V2, tri[2], V0, tri[0], e1);
-          edge_fn(V0, tri[0], V1, tri[1], e2);
-          float det = fmaf(V0[0], e0[0], fmaf(V0[1], e0[1], V0[2] * e0[2]));
-          if (!(det != 0.0f) || !isfinite(det)) continue;
-          int x0 = 0, x1 = w - 1, y0 = 0, y1 = h - 1;
-          if (zmin > 1e-6f) { /* all in front: tight screen bbox */
-            float u0 = V0[0] / V0[2], u1 = V1[0] / V1[2], u2 = V2[0] / V2[2];
-            float v0 = V0[1] / V0[2], v1 = V1[1] / V1[2], v2 = V2[1] / V2[2];
-            float umin = fminf(u0, fminf(u1, u2)), umax = fmaxf(u0, fmaxf(u1, u2));
-            float vmin = fminf(v0, fminf(v1, v2)), vmax = fmaxf(v0, fmaxf(v1, v2));
-            if (!(umax >= 0.0f) || !(umin <= (float)w) || !(vmax >= 0.0f) || !(vmin <= (float)h)) continue;
-            /* pixel centre j+0.5 in [umin, umax]  <=>  j in [ceil(umin-0.5), floor(umax-0.5)] */
-            float a = ceilf(umin - 0.5f), b = floorf(umax - 0.5f);
-            float c = ceilf(vmin - 0.5f), d = floorf(vmax - 0.5f);
-            if (msaa) { /* some sample of pixel j inside [umin, umax]: the offsets run from lo to hi (default 0.125 to 0.875) */
-              a = ceilf(umin - hi_x); b = floorf(umax - lo_x); c = ceilf(vmin - hi_y); d = floorf(vmax - lo_y);
+          const float uv3[6] = {M->uvs[2 * (voff + tri[0])], M->uvs[2 * (voff + tri[0]) + 1], M->uvs[2 * (voff + tri[1])],
+                                M->uvs[2 * (voff + tri[1]) + 1], M->uvs[2 * (voff + tri[2])], M->uvs[2 * (voff + tri[2]) + 1]};
+          clipv poly[4];
+          int np = 0;
+          const float* Cc[3] = {C0, C1, C2};
+          if (zmin >= Z_NEAR) {
+            for (int k = 0; k < 3; ++k)
+              for (int c = 0; c < 3; ++c) { poly[k].c[c] = Cc[k][c]; poly[k].b[c] = c == k ? 1.0f : 0.0f; }
+            np = 3;
+          } else {
+            /* clip against z = near.  The corners are first rotated (cyclically: the winding stays) so that corner 0 is
+             * inside and corner 2 outside -- r = the inside corner when there is one, the corner after the outside one when
+             * there are two -- then the polygon is [V0, I(0->1), I(0->2)] or [V0, V1, I(1->2), I(0->2)], I(i->o) = the point
+             * of the edge on the plane, interpolated FROM the inside corner TO the outside one (both triangles of a shared
+             * edge compute the same point).  Barycentrics refer to the ORIGINAL corner order. */
+            const int in0 = C0[2] >= Z_NEAR, in1 = C1[2] >= Z_NEAR, in2 = C2[2] >= Z_NEAR;
+            const int n_in = in0 + in1 + in2;
+            int r;
+            if (n_in == 1) r = in0 ? 0 : in1 ? 1 : 2;
+            else r = !in0 ? 1 : !in1 ? 2 : 0;
+            clipv V[3];
+            for (int k = 0; k < 3; ++k) {
+              const int o = (k + r) % 3;
+              for (int c = 0; c < 3; ++c) { V[k].c[c] = Cc[o][c]; V[k].b[c] = c == o ? 1.0f : 0.0f; }
             }
-            x0 = a < 0.0f ? 0 : (int)a; x1 = b > (float)(w - 1) ? w - 1 : (int)b;
-            y0 = c < 0.0f ? 0 : (int)c; y1 = d > (float)(h - 1) ? h - 1 : (int)d;
+#define ISECT(dst, I, O)                                                           \
+            do {                                                                   \
+              const float t_ = ((I).c[2] - Z_NEAR) / ((I).c[2] - (O).c[2]);        \
+              (dst).c[0] = fmaf(t_, (O).c[0] - (I).c[0], (I).c[0]);                \
+              (dst).c[1] = fmaf(t_, (O).c[1] - (I).c[1], (I).c[1]);                \
+              (dst).c[2] = Z_NEAR;                                                 \
+              for (int c_ = 0; c_ < 3; ++c_) (dst).b[c_] = fmaf(t_, (O).b[c_] - (I).b[c_], (I).b[c_]); \
+            } while (0)
+            poly[0] = V[0];
+            if (n_in == 1) {
+              ISECT(poly[1], V[0], V[1]);
+              ISECT(poly[2], V[0], V[2]);
+              np = 3;
+            } else {
+              poly[1] = V[1];
+              ISECT(poly[2], V[1], V[2]);
+              ISECT(poly[3], V[0], V[2]);
+              np = 4;
+            }
+#undef ISECT
           }
-          for (int i = y0; i <= y1; ++i) {
-            for (int j = x0; j <= x1; ++j) {
-              for (int sm = 0; sm < ns; ++sm) {
-                const int slot = msaa ? sm : 4;  /* single-sample mode: the centre only */
-                const float pv = (float)i + SY[slot], pu = (float)j + SX[slot];
-                float l0 = fmaf(e0[0], pu, fmaf(e0[1], pv, e0[2]));
-                float l1 = fmaf(e1[0], pu, fmaf(e1[1], pv, e1[2]));
-                float l2 = fmaf(e2[0], pu, fmaf(e2[1], pv, e2[2]));
-                float s = l0 + l1 + l2;
-                int in_pos = (l0 >= 0.0f) & (l1 >= 0.0f) & (l2 >= 0.0f) & (s > 0.0f);
-                int in_neg = (l0 <= 0.0f) & (l1 <= 0.0f) & (l2 <= 0.0f) & (s < 0.0f);
-                if (!(in_pos | in_neg)) continue;
-                /* camera-space depth: affine over the 3-D triangle, i.e. linear in the perspective-correct barycentrics
-                 * l_i / s.  (Z = det / s is the same number algebraically, but det -- a 3x3 determinant of homogeneous
-                 * pixel coordinates ~1e2 whose value is ~area * z^3 ~ 0.1 -- cancels to ~5e-4 relative in fp32 on
-                 * pixel-sized triangles: 0.1 mm of depth noise at 0.4 m.  Interpolating the vertex depths is accurate to
-                 * ~1e-7 m, the precision class of the 24-bit depth buffer the reference reads back,
-                 * TB/renderer/utils.py:46-60.) */
-                float Z = fmaf(l0, V0[2], fmaf(l1, V1[2], l2 * V2[2])) / s;
-                if (!(Z >= Z_NEAR) || !(Z <= Z_FAR)) continue;
-                uint64_t key = ((uint64_t)f2u(Z) << 32) | (uint32_t)f;
-                uint64_t* zp = zbuf + ((size_t)i * w + j) * ns + sm;
-                if (key < *zp) *zp = key;
-              }
-            }
+          for (int part = 0; part + 2 < np; ++part) {
+            const clipv cv3[3] = {poly[0], poly[part + 1], poly[part + 2]};
+            subtri* s = st + (part == 0 ? f : nf + f);
+            if (!setup_subtri(cv3, Kv, uv3, h, w, lo_x, hi_x, lo_y, hi_y, s)) continue;
+            s->id = part == 0 ? f : nf + f;
+            s->v[0] = tri[0]; s->v[1] = tri[1]; s->v[2] = tri[2];
+            used[s->id] = 1;
+            for (int i = s->i0; i <= s->i1; ++i)
+              for (int j = s->j0; j <= s->j1; ++j)
+                for (int sm = 0; sm < ns; ++sm) {
+                  const int slot = msaa ? sm : 4;  /* single-sample mode: the centre only */
+                  const int64_t X = (int64_t)SUBPIX * (j - s->ox) + SX[slot], Y = (int64_t)SUBPIX * (i - s->oy) + SY[slot];
+                  if (!sample_inside(s, X, Y)) continue;
+                  const float fx = (float)(j - s->ox) + (float)SX[slot] * (1.0f / (float)SUBPIX);
+                  const float fy = (float)(i - s->oy) + (float)SY[slot] * (1.0f / (float)SUBPIX);
+                  const float Ws = plane_at(&s->W, fx, fy);
+                  if (!(Ws <= W_NEAR) || !(Ws >= W_FAR)) continue;
+                  const uint64_t key = ((uint64_t)(~f2u(Ws)) << 32) | (uint32_t)s->id;
+                  uint64_t* zp = zbuf + ((size_t)i * w + j) * ns + sm;
+                  if (key < *zp) *zp = key;
+                }
           }
         }
       }
@@ -438,13 +578,13 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
           const uint64_t ckey = keys[ns - 1]; /* the pixel centre */
           float o_rgb[3] = {0, 0, 0}, o_n[3] = {0, 0, 0}, o_d = 0.0f;
           if (ckey != KEY_EMPTY) {
-            const float Z = u2f((uint32_t)(ckey >> 32));
+            const float Z = 1.0f / u2f(~(uint32_t)(ckey >> 32));
             o_d = Z > depth_max ? 0.0f : Z;
           }
           if (!msaa) {
             if (ckey != KEY_EMPTY)
-              shade_centre(M, sv3, T, Kv, amb, n_lights, light_pos, light_col, view, voff, foff, toff, tw, th, nlev, aniso,
-                           (int64_t)(ckey & 0xFFFFFFFFull), i, j, q8, o_rgb, o_n);
+              shade_centre(M, st + (ckey & 0xFFFFFFFFull), T, Kv, amb, n_lights, light_pos, light_col, view, voff, toff, tw, th, nlev,
+                           aniso, i, j, q8, o_rgb, o_n);
           } else {
             int64_t cf[4]; float crgb[4][3], cn[4][3]; int ncached = 0;
             float a_rgb[3] = {0, 0, 0}, a_n[3] = {0, 0, 0};
@@ -456,8 +596,8 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
               while (k < ncached && cf[k] != f) ++k;
               if (k == ncached) { /* one fragment-shader invocation per pixel and primitive */
                 cf[k] = f;
-                shade_centre(M, sv3, T, Kv, amb, n_lights, light_pos, light_col, view, voff, foff, toff, tw, th, nlev, aniso, f, i,
-                             j, q8, crgb[k], cn[k]);
+                shade_centre(M, st + f, T, Kv, amb, n_lights, light_pos, light_col, view, voff, toff, tw, th, nlev, aniso, i, j, q8,
+                             crgb[k], cn[k]);
                 ++ncached;
               }
               for (int c = 0; c < 3; ++c) {
@@ -480,8 +620,10 @@ void hp_oracle_rasterize(const hp_oracle_meshes* M, int n, const int32_t* obj_id
           if (depth && (flags & HP_R_DEPTH)) depth[dbase] = o_d;
           if (mask && (flags & HP_R_MASK)) mask[(size_t)view * h * w + (size_t)i * w + j] = o_d > 0.0f;
         }
+      free(used);
     }
     free(zbuf);
-    free(sv3);
+    free(cam);
+    free(st);
   }
 }

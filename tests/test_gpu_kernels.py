@@ -186,20 +186,20 @@ def _render_both(scene_store, n=9, seed=7):
 
 def test_rasterizer_conventions_record(dev, scene_store):
     """The calibration path of a-6: multisample positions, the anisotropic footprint rule and the eye-normal axis map are a
-    RECORD (``hp_raster_set_conventions``, mirrored by ``hp_oracle_set_raster_conventions``), not compile-time constants.
+    RECORD (``hp_mesh_store_set_raster_conventions``, mirrored by ``hp_oracle_set_raster_conventions``), not compile-time constants.
     Every flipped convention keeps HIP == oracle to the tolerances of the fixed-convention tests AND changes the render; back
     on the defaults the render is bit-identical to the one made before any flip (so golden G10, generated with the
     constants, still holds: tests/test_gpu_pipeline.py::test_*_vs_reference_golden_g10 run on the defaults)."""
     from happypose_amd import ops
     from oracle import native
 
-    assert ops.get_raster_conventions() == ops.RASTER_CONVENTION_DEFAULTS
+    assert scene_store.get_raster_conventions() == ops.RASTER_CONVENTION_DEFAULTS
     base_gpu, base_ref = _render_both(scene_store)
     try:
         for flip in CONVENTION_FLIPS:
-            ops.set_raster_conventions(flip)
+            scene_store.set_raster_conventions(flip)
             native.set_raster_conventions(flip)
-            assert ops.get_raster_conventions() == dict(ops.RASTER_CONVENTION_DEFAULTS, **flip)
+            assert scene_store.get_raster_conventions() == dict(ops.RASTER_CONVENTION_DEFAULTS, **flip)
             gpu, ref = _render_both(scene_store)
             assert torch.equal(gpu[2], base_gpu[2]), flip                       # depth stays centre-sampled, whatever the record
             for k, (got, want, base) in enumerate(((gpu[0], ref["rgbs"], base_gpu[0]), (gpu[1], ref["normals"], base_gpu[1]))):
@@ -210,16 +210,16 @@ def test_rasterizer_conventions_record(dev, scene_store):
             assert (not torch.equal(gpu[0], base_gpu[0])) == touches_rgb, flip
             assert (not torch.equal(gpu[1], base_gpu[1])) == touches_nrm, flip
     finally:
-        ops.set_raster_conventions(None)
+        scene_store.set_raster_conventions(None)
         native.set_raster_conventions(None)
     again_gpu, again_ref = _render_both(scene_store)
     for a, b in zip(again_gpu[:3], base_gpu[:3]):
         assert torch.equal(a, b)
     assert np.array_equal(again_ref["rgbs"], base_ref["rgbs"]) and np.array_equal(again_ref["normals"], base_ref["normals"])
     with pytest.raises(AssertionError):
-        ops.set_raster_conventions(dict(msaa_x=(0.0, 0.5, 0.5, 0.5)))         # a sample on the pixel border
+        scene_store.set_raster_conventions(dict(msaa_x=(0.0, 0.5, 0.5, 0.5)))         # a sample on the pixel border
     with pytest.raises(KeyError):
-        ops.set_raster_conventions(dict(samples=4))
+        scene_store.set_raster_conventions(dict(samples=4))
 
 
 def test_rasterizer_outliers_are_boundary_pixels(dev, scene_store):
@@ -231,11 +231,11 @@ def test_rasterizer_outliers_are_boundary_pixels(dev, scene_store):
     from happypose_amd import ops
     from oracle import native
 
-    prev = ops.set_backface_culling(False)  # this test is about the conventions: the two-sided render (culling: the next test)
+    prev = scene_store.set_backface_culling(False)  # this test is about the conventions: the two-sided render (culling: the next test)
     try:
         gpu, ref = _render_both(scene_store, n=12, seed=5)
     finally:
-        ops.set_backface_culling(prev)
+        scene_store.set_backface_culling(prev)
     rgb, nrm = gpu[0].cpu().numpy(), gpu[1].cpu().numpy()
     e = 3e-5
     d0 = ops.RASTER_CONVENTION_DEFAULTS
@@ -267,40 +267,124 @@ def test_rasterizer_outliers_are_boundary_pixels(dev, scene_store):
     assert sens_rgb.mean() < 0.05  # the perturbations are round-off sized: they must not touch ordinary pixels
 
 
-def test_rasterizer_backface_culling_keeps_the_image(dev, scene_store):
-    """``hp_raster_set_backface_culling`` (default on): the binning pass drops triangles that face away from the camera when the
-    object is a closed, consistently oriented surface seen from outside -- the reference renders two-sided
-    (TB/renderer/panda3d_scene_renderer.py:102), and of a closed surface only front faces are ever visible.  Culled and two-sided
-    renders of the test scene (reference render state, 12 views, three objects, 0.3 - 1.6 m) are identical except for hairline
-    cracks along texture seams (duplicated vertices: the canonical edge functions are keyed by vertex index, not position),
-    through which the two-sided render shows the inside of the far wall and the culled one the background: < 2e-5 of the
-    pixels, depth / mask included.  An OPEN surface (the same mesh without a strip of faces) is never culled: bit-identical."""
+def _render_cull_pair(store, obj, T, K, res=(240, 320)):
     from happypose_amd import ops
 
-    T = _poses(12, 5, zlo=0.3, zhi=1.6)
-    K = np.tile(np.array([[900.0, 0, 160], [0, 900.0, 120], [0, 0, 1]], np.float32), (12, 1, 1))
-    obj = (np.arange(12) % 3).astype(np.int32)
-
-    def render(store, cull):
-        prev = ops.set_backface_culling(cull)
+    outs = []
+    for cull in (True, False):
+        prev = store.set_backface_culling(cull)
         try:
-            out = ops.rasterize(store, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), (240, 320), render_normals=True,
+            out = ops.rasterize(store, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), res, render_normals=True,
                                 render_depth=True, msaa=True, aniso=True)
         finally:
-            ops.set_backface_culling(prev)
-        return [o.cpu().numpy() for o in out[:3]]
-
-    a, b = render(scene_store, True), render(scene_store, False)
+            store.set_backface_culling(prev)
+        outs.append([o.cpu().numpy() for o in out[:3]])
+    a, b = outs
     diff = np.zeros(a[0].shape[:1] + a[0].shape[2:], bool)
     for x, y in zip(a, b):
         diff |= (x != y).reshape(x.shape[0], -1, *x.shape[-2:]).any(1)
-    assert diff.mean() < 2e-5, diff.mean()
+    return a, b, diff
+
+
+def test_rasterizer_backface_culling_keeps_the_image(dev, scene_store):
+    """``hp_mesh_store_set_backface_culling`` (default on): the set-up pass drops triangles whose inward side is turned to the
+    camera when they belong to a closed, consistently oriented CONNECTED COMPONENT seen from outside -- the reference renders
+    two-sided (TB/renderer/panda3d_scene_renderer.py:102), and of a closed surface only outward faces are ever visible.  The
+    facing test is the exact sign of the snapped area, vertices at the same position snap to the same point (texture seams are
+    watertight), so culled and two-sided renders may differ only where a sample lies exactly on a silhouette edge: < 1e-5 of
+    the pixels, depth / mask included.  An OPEN surface (the same mesh without a strip of faces) is never culled."""
+    T = _poses(12, 5, zlo=0.3, zhi=1.6)
+    K = np.tile(np.array([[900.0, 0, 160], [0, 900.0, 120], [0, 0, 1]], np.float32), (12, 1, 1))
+    obj = (np.arange(12) % 3).astype(np.int32)
+    a, b, diff = _render_cull_pair(scene_store, obj, T, K)
+    assert diff.mean() < 1e-5, diff.mean()
     assert (a[2] > 0).mean() > 0.02  # the objects are in view
     # an open surface: remove a strip of faces from every object and rebuild the store
     open_store = _open_copy(dev)
-    c, d = render(open_store, True), render(open_store, False)
-    for x, y in zip(c, d):
-        assert np.array_equal(x, y)
+    c, d, diff_open = _render_cull_pair(open_store, obj, T, K)
+    assert not diff_open.any()
+
+
+def _shell(radius, centre=(0.0, 0.0, 0.0), flip=False, n_lat=24, n_lon=36, seed=0):
+    """A closed UV-sphere-like shell as MeshData (outward winding; ``flip``: every face reversed)."""
+    import dataclasses
+
+    from happypose_amd.synthetic import make_mesh
+
+    m = make_mesh(seed, n_lat=n_lat, n_lon=n_lon, diameter=2 * radius, tex_size=64)
+    verts = m.vertices + np.asarray(centre, np.float32)
+    faces = m.faces[:, ::-1].copy() if flip else m.faces
+    normals = -m.normals if flip else m.normals
+    return dataclasses.replace(m, vertices=verts.astype(np.float32), faces=np.ascontiguousarray(faces), normals=normals.astype(np.float32))
+
+
+def _merge(meshes):
+    import dataclasses
+
+    off, vs, ns, uvs, cols, fs = 0, [], [], [], [], []
+    for m in meshes:
+        vs.append(m.vertices); ns.append(m.normals); uvs.append(m.uvs); fs.append(m.faces + off)
+        if m.colors is not None:
+            cols.append(m.colors)
+        off += len(m.vertices)
+    return dataclasses.replace(meshes[0], vertices=np.concatenate(vs), normals=np.concatenate(ns), uvs=np.concatenate(uvs),
+                               faces=np.concatenate(fs).astype(np.int32), colors=np.concatenate(cols) if cols else None)
+
+
+def test_backface_culling_is_decided_per_connected_component(dev, golden_dir):
+    """Orientation per connected component of the welded mesh (``api.cpp: mesh_cull_flags``): a part with flipped winding or a
+    nested, inverted shell must not vanish (a single sign for the whole object -- round 4 -- culled the VISIBLE faces of the
+    minority part).  (i) two nested shells, the inner one inverted (invisible either way: the outer shell hides it, and its own
+    flag is -1); (ii) two disjoint shells with opposite winding, both fully visible; (iii) a closed shell next to an open sheet;
+    (iv) the reference's own test asset ``obj_000001``.  Culled == two-sided up to samples exactly on silhouette edges."""
+    from happypose_amd.mesh_store import RigidObject, RigidObjectDataset
+    from happypose_amd.ops import MeshStore
+
+    sheet = _shell(0.04, centre=(0.0, 0.09, 0.0))
+    import dataclasses
+    sheet = dataclasses.replace(sheet, faces=np.ascontiguousarray(sheet.faces[: len(sheet.faces) // 2]))  # half a shell: open
+    objs = [
+        RigidObject("nested", _merge([_shell(0.06), _shell(0.03, flip=True, seed=1)]), mesh_units="m"),
+        RigidObject("disjoint", _merge([_shell(0.04, centre=(-0.05, 0, 0)), _shell(0.04, centre=(0.05, 0, 0), flip=True, seed=2)]), mesh_units="m"),
+        RigidObject("mixed", _merge([_shell(0.04, centre=(0.0, -0.03, 0.0)), sheet]), mesh_units="m"),
+        RigidObject("asset", golden_dir / "obj_000001.npz", mesh_units="mm"),
+    ]
+    store = MeshStore(RigidObjectDataset(objs), dev)
+    n = 16
+    T = _poses(n, 21, zlo=0.35, zhi=0.7)
+    K = np.tile(np.array([[700.0, 0, 160], [0, 700.0, 120], [0, 0, 1]], np.float32), (n, 1, 1))
+    obj = (np.arange(n) % 4).astype(np.int32)
+    a, b, diff = _render_cull_pair(store, obj, T, K)
+    assert diff.mean() < 1e-5, [diff[obj == k].mean() for k in range(4)]
+    for k in range(4):
+        assert (b[2][obj == k] > 0).mean() > 0.01, k  # every object is in view
+    # the flipped shell of "disjoint" is really there in the culled render: both halves of the image hold object pixels
+    for v in np.nonzero(obj == 1)[0]:
+        cov_c, cov_t = a[2][v, 0] > 0, b[2][v, 0] > 0
+        assert abs(int(cov_c.sum()) - int(cov_t.sum())) <= 2 and cov_t.sum() > 500
+
+
+def test_two_stores_hold_their_own_renderer_state(dev, scene_store):
+    """No process-wide renderer state: conventions and the culling switch live on the mesh store.  Two stores of the
+    same objects in one process, one with a flipped normal map and ordered-grid samples, render differently; the first
+    store's output does not move."""
+    from happypose_amd import ops
+    from happypose_amd.synthetic import make_object_dataset
+
+    other = ops.MeshStore(make_object_dataset(3, seed=1, tex_size=256), dev)
+    base, _ = _render_both(scene_store)
+    other.set_raster_conventions(dict(normal_sign=(1.0, 1.0, 1.0), msaa_x=(0.25, 0.75, 0.25, 0.75), msaa_y=(0.25, 0.25, 0.75, 0.75)))
+    other.set_backface_culling(False)
+    assert scene_store.get_raster_conventions() == ops.RASTER_CONVENTION_DEFAULTS
+    T = _poses(9, 7, zlo=0.3, zhi=1.6)
+    K = np.tile(np.array([[900.0, 0, 160], [0, 900.0, 120], [0, 0, 1]], np.float32), (9, 1, 1))
+    obj = (np.arange(9) % 3).astype(np.int32)
+    o = ops.rasterize(other, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), (240, 320), render_normals=True,
+                      render_depth=True, msaa=True, aniso=True)
+    again, _ = _render_both(scene_store)
+    assert not torch.equal(o[1], base[1]) and not torch.equal(o[0], base[0])
+    for x, y in zip(again[:3], base[:3]):
+        assert torch.equal(x, y)
 
 
 def test_rasterizer_chunked_launch_is_bit_identical(dev, scene_store, tmp_path):

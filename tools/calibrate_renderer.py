@@ -3,7 +3,7 @@
 Nothing in this repository's containers can run Panda3D, so three conventions of the reference-state rasteriser (a-6) rest
 on a reading of OpenGL: the four multisample positions, the anisotropic filter's probe-count / level-of-detail rule and the
 axis / sign map of the eye-normal code (``TB/renderer/panda3d_scene_renderer.py:68-71,221-230``,
-``TB/renderer/utils.py:63-79``).  They are a run-time record on both sides (``hp_raster_set_conventions`` for the HIP
+``TB/renderer/utils.py:63-79``).  They are a run-time record on both sides (``hp_mesh_store_set_raster_conventions`` for the HIP
 rasteriser, ``hp_oracle_set_raster_conventions`` for the CPU oracle), and this tool is how an owner of a Panda3D
 installation pins them:
 
@@ -14,7 +14,7 @@ installation pins them:
 It renders the same views with the oracle (``--hip``: with the HIP rasteriser) under every candidate record, scores each
 against the Panda3D pixels in 8-bit units on the pixels the convention can move (normal map: covered interior; sample
 pattern: the silhouette band; texture rule: covered, textured interior), prints the ranking of every group and writes the
-best record as JSON -- ``happypose_amd.ops.set_raster_conventions(json.load(open(...)))`` applies it; to make it the
+best record as JSON -- ``store.set_raster_conventions(json.load(open(...)))`` (``happypose_amd.ops.MeshStore``) applies it; to make it the
 default change ``kDefaultConventions`` (csrc/raster.hip) and ``HP_ORACLE_CONV_DEFAULT`` (oracle.c) and regenerate G10.
 
 ``--self-test`` needs no Panda3D: it makes the "Panda3D" views with the oracle under a hidden non-default record and checks
@@ -94,10 +94,10 @@ class Renderer:
         rec = dict(DEFAULTS, **conv)
         if self.hip:
             t = self.torch
-            self.ops.set_raster_conventions(rec)
+            self.store.set_raster_conventions(rec)
             rgb, nrm, dep, _ = self.ops.rasterize(self.store, t.as_tensor(self.obj), t.as_tensor(self.TCO), t.as_tensor(self.K), self.res,
                                                   render_normals=True, render_depth=True, msaa=True, aniso=True)
-            self.ops.set_raster_conventions(None)
+            self.store.set_raster_conventions(None)
             r = dict(rgbs=rgb.cpu().numpy(), normals=nrm.cpu().numpy(), depths=dep.cpu().numpy())
         else:
             from oracle import native
