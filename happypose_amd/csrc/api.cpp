@@ -128,6 +128,29 @@ void mesh_cull_flags(const float* v, int64_t nv, const int32_t* f, int64_t nf, f
   out8[4] = any ? 1.f : 0.f;
 }
 
+// Row-pair copy of one power-of-two texture (level 0 + its mip chain) for the anisotropic filter -- see MeshStore::tex_quads.
+// Returns the bytes appended.
+size_t build_tex_quads(const uint8_t* tex, int64_t w, int64_t h, int64_t nlev, std::vector<uint8_t>& out) {
+  const size_t start = out.size();
+  for (int64_t k = 0; k < nlev; ++k) {
+    const size_t base = out.size();
+    out.resize(base + (size_t)8 * (size_t)(w + 1) * (size_t)h);
+    uint8_t* dst = out.data() + base;
+    for (int64_t y = 0; y < h; ++y) {
+      const uint8_t* r0 = tex + 4 * y * w;
+      const uint8_t* r1 = tex + 4 * ((y + 1) % h) * w;
+      for (int64_t x = 0; x <= w; ++x) {
+        const int64_t xs = x == w ? 0 : x;
+        std::memcpy(dst + 8 * (y * (w + 1) + x), r0 + 4 * xs, 4);
+        std::memcpy(dst + 8 * (y * (w + 1) + x) + 4, r1 + 4 * xs, 4);
+      }
+    }
+    tex += 4 * w * h;
+    w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1;
+  }
+  return out.size() - start;
+}
+
 }  // namespace
 
 extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float* h_normals,
@@ -187,6 +210,19 @@ extern "C" hp_mesh_store* hp_mesh_store_create(const float* h_verts, const float
   rc |= upload(&s->tex, h_tex, (size_t)(tex_bytes > 0 ? tex_bytes : 0));
   rc |= upload(&s->obj, h_obj, (size_t)n_obj * 8);
   {
+    std::vector<uint8_t> quads;
+    std::vector<int64_t> qoff((size_t)n_obj, -1);
+    for (int o = 0; o < n_obj; ++o) {
+      const int64_t* r = h_obj + 8 * o;
+      if (r[4] < 0 || (r[5] & (r[5] - 1)) != 0 || (r[6] & (r[6] - 1)) != 0) continue;
+      qoff[o] = (int64_t)quads.size();
+      build_tex_quads(h_tex + r[4], r[5], r[6], r[7] > 0 ? r[7] : 1, quads);
+    }
+    quads.resize(quads.size() + 16);  // the last entry's 16-B load stays inside the allocation
+    rc |= upload(&s->tex_quads, quads.data(), quads.size());
+    rc |= upload(&s->tex_quads_off, qoff.data(), qoff.size());
+  }
+  {
     std::vector<float> cull((size_t)n_obj * 8);
     std::vector<int32_t> flags((size_t)n_faces_total);
     std::vector<int4> f4((size_t)n_faces_total);
@@ -209,7 +245,8 @@ extern "C" void hp_mesh_store_destroy(hp_mesh_store* s) {
   if (!s) return;
   (void)hipFree(s->verts); (void)hipFree(s->normals); (void)hipFree(s->uvs); (void)hipFree(s->colors);
   (void)hipFree(s->faces4); (void)hipFree(s->tex); (void)hipFree(s->obj); (void)hipFree(s->points); (void)hipFree(s->cull);
-  (void)hipFree(s->bin_list); (void)hipFree(s->bin_count); (void)hipFree(s->recs);
+  (void)hipFree(s->bin_list); (void)hipFree(s->bin_count); (void)hipFree(s->recs); (void)hipFree(s->xverts);
+  (void)hipFree(s->tex_quads); (void)hipFree(s->tex_quads_off);
   (void)hipFree(s->verts4); (void)hipFree(s->normals4);
   delete s;
 }

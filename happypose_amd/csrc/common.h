@@ -46,6 +46,11 @@ struct MeshStore {
   float* uvs = nullptr;
   uint8_t* colors = nullptr;
   uint8_t* tex = nullptr;
+  // the power-of-two textures once more in ROW-PAIR layout for the anisotropic filter (api.cpp: build_tex_quads): per level,
+  // for every row y an array of w + 1 entries {T(x, y), T(x, (y + 1) % h)} (8 B; entry w repeats entry 0) -- the 2 x 2 footprint of a
+  // bilinear tap at (x0, y0) is the 16 contiguous bytes at entry x0 of row-pair y0: ONE load instead of four gathers
+  uint8_t* tex_quads = nullptr;
+  int64_t* tex_quads_off = nullptr;  // [n_obj] byte offset of the object's level 0 in tex_quads, -1: none (no texture / not power-of-two)
   int64_t* obj = nullptr;  // [n_obj][8]
   float* points = nullptr; // [n_obj][n_pad][3]
   // [n_obj][8] view-level back-face culling record of the rasteriser's set-up pass: bounding sphere (cx, cy, cz, r) in the vertices'
@@ -61,6 +66,8 @@ struct MeshStore {
   size_t bin_list_bytes = 0;
   int32_t* bin_count = nullptr;
   size_t bin_count_bytes = 0;
+  int4* xverts = nullptr;     // [view][max_verts] {x, y (snapped, 1/256 px), bits(1 / z), bits(z)} of the vertex pre-pass
+  size_t xverts_bytes = 0;
   uint4* recs = nullptr;      // [view][2 * max_faces][8]: 128-B set-up record of every sub-triangle (raster.hip: FaceRec)
   size_t recs_bytes = 0;
   int64_t scratch_generation = 0;  // bumped whenever the scratch above is reallocated (captured graphs hold the old pointers)

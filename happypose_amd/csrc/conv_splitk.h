@@ -41,7 +41,12 @@ __device__ __forceinline__ bool splitk_reduce(const ConvArgs& a, sk_floatx16 (&a
   if (ticket_s != a.sk_S - 1) return false;  // not the last slice of this tile
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    a.sk_counters[tail_tile] = 0;  // every slice has taken its ticket: re-arm for the next launch
+    // every slice has taken its ticket: re-arm for the next launch.  An AGENT-scope atomic store like the tickets themselves:
+    // the slices' atomics run at the memory side, a plain store sits in THIS XCD's L2 until something writes it back -- between
+    // two launches replayed from a hipGraph nothing did, the next launch's tickets then started from sk_S, no slice saw
+    // sk_S - 1, the tile's epilogue never ran and its rows kept the previous forward's values (round 5: the co-scheduling
+    // "non-determinism" of two-lane graph replays, tools/probes/two_lane_repro.py)
+    __hip_atomic_store(a.sk_counters + tail_tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
 #pragma unroll
@@ -92,7 +97,7 @@ __device__ __forceinline__ bool splitk_reduce_sc1(const ConvArgs& a, sk_floatx16
   if (tid == 0) ticket_s1 = __hip_atomic_fetch_add(a.sk_counters + tail_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (ticket_s1 != a.sk_S - 1) return false;  // not the last slice of this tile
-  if (tid == 0) a.sk_counters[tail_tile] = 0;  // every slice has taken its ticket: re-arm for the next launch
+  if (tid == 0) __hip_atomic_store(a.sk_counters + tail_tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm (an atomic: see splitk_reduce)
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll

@@ -69,7 +69,8 @@ struct RasterConv {
   int n_axis[3]; float n_sign[3];
 };
 // probe count and level of detail of the anisotropic filter from the footprint (pmax >= pmin, texel units)
-__device__ __forceinline__ void aniso_footprint(const RasterConv& cv, float pmax, float pmin, int nlev, float& nf, float& lod) {
+template <class CV>
+__device__ __forceinline__ void aniso_footprint(const CV& cv, float pmax, float pmin, int nlev, float& nf, float& lod) {
   const float r = pmax / pmin + cv.ratio_bias;
   nf = pmin > 0.0f ? (cv.aniso_round == 0 ? ceilf(r) : cv.aniso_round == 1 ? rintf(r) : floorf(r)) : cv.aniso_max;
   if (!(nf >= 1.0f)) nf = 1.0f;
@@ -81,12 +82,13 @@ __device__ __forceinline__ void aniso_footprint(const RasterConv& cv, float pmax
 }
 constexpr int kBigQueue = 512;
 constexpr int kBigArea = 128;  // candidate pixels above which a triangle is walked cooperatively
+constexpr int kSmallArea = 6;  // ... up to which a record goes to the front of its band's list (raster_setup_kernel)
 #ifndef HP_RASTER_THREADS_MSAA
 #define HP_RASTER_THREADS_MSAA 256
 #endif
 // NS: keys per pixel (1 / 5); WIDE: the multisampled instantiation for renders wider than 640 px (512 threads, 6400 keys)
 constexpr __host__ __device__ int band_threads(int ns, bool wide = false) { return ns == 1 ? HP_RASTER_THREADS : wide ? 512 : HP_RASTER_THREADS_MSAA; }
-constexpr int kBinThreads = 1024;  // set-up kernel
+constexpr int kBinThreads = 256;   // set-up kernel: small workgroups (six per CU) -- a 1024-thread workgroup left one per CU waiting at its barriers (66 us per 128 views instead of ~25)
 constexpr int kMaxBands = 512;  // 480 one-row multisampled bands of a 640-wide render
 
 struct RasterArgs {
@@ -96,6 +98,7 @@ struct RasterArgs {
   const uint8_t* colors;
   const int4* faces4;     // {i0, i1, i2, cull flag} (MeshStore::faces4)
   const uint8_t* tex;
+  const uint8_t* tex_quads; const int64_t* tex_quads_off;  // MeshStore::tex_quads
   const int64_t* obj;
   const float* cull;      // MeshStore::cull ([n_obj][8]) or null: back faces of closed components are not set up
   const int32_t* obj_ids;
@@ -115,9 +118,10 @@ struct RasterArgs {
   int msaa;             // 1: five keys per pixel (HP_RASTER_MSAA4 and a colour / normal output), 0: the centre only
   float depth_max;
   // per-(view, band) lists of sub-triangle ids built by raster_setup_kernel
-  int32_t* bin_count;   // [chunk views][n_bands]; zero between launches (the band kernel clears what it consumed)
+  int32_t* bin_count;   // [chunk views][n_bands][2] (small boxes from the front of the list, the others from the back); zero between launches
   int32_t* bin_list;    // [chunk views][n_bands][bin_cap]
-  int bin_cap, view0, max_faces;
+  int bin_cap, view0, max_faces, max_verts;
+  int4* xverts;         // [chunk views][max_verts] {x, y, bits(1 / z), bits(z)} written by raster_xform_kernel
   // set-up records of the chunk's views: [view][rec_slots = 2 * max_faces] x 128 B (FaceRec)
   uint4* recs;
   int rec_slots;
@@ -197,7 +201,8 @@ __device__ __forceinline__ void tex_fetch_level(const uint8_t* tex, int tw, int 
 }
 
 // trilinear + anisotropic fetch (HP_RASTER_TEX_ANISO; oracle.c tex_fetch_aniso, same operations in the same order)
-__device__ __forceinline__ void tex_fetch_aniso(const RasterConv& cv, const uint8_t* tex, int tw, int th, int nlev, float u, float v, float ux,
+template <class CV>
+__device__ __forceinline__ void tex_fetch_aniso(const CV& cv, const uint8_t* tex, int tw, int th, int nlev, float u, float v, float ux,
                                                 float vx, float uy, float vy, float* rgb) {
   const float px = sqrtf(fmaf(ux * (float)tw, ux * (float)tw, vx * (float)th * (vx * (float)th)));
   const float py = sqrtf(fmaf(uy * (float)tw, uy * (float)tw, vy * (float)th * (vy * (float)th)));
@@ -232,34 +237,36 @@ __device__ __forceinline__ void tex_fetch_aniso(const RasterConv& cv, const uint
 // loads of two trilinear probes are in flight together (the rolled loop pays one L2 round trip per probe).
 struct MipTable {
   int off[16], w[16], h[16];
-  int sh[16];        // log2(w) + 2 when the texture's sizes are powers of two (row pitch in bytes as a shift)
-  int p2;            // both sizes of level 0 are powers of two (then every level's are)
+  int qoff[16];      // power-of-two textures: byte offset of the level in the ROW-PAIR copy (MeshStore::tex_quads), entries per row = w + 1
+  int p2;            // the object has a row-pair copy (both sizes of level 0 are powers of two; then every level's are)
   float tt[16][16];  // probe position t = i / (N + 1) - 0.5 at [N - 1][i - 1]: one IEEE division per entry and workgroup, not per probe
 };
 
 struct BiTexels { uchar4 a, b, c, d; };
 
-// The same filter for power-of-two textures (every level a power of two): wraps are masks, row pitches shifts, texel
-// addresses 32-bit offsets from the view's texture (a scalar base), probe positions from the workgroup's table.  Identical
-// values: the integer identities hold for every operand, the table entries are the quotients the loop used to recompute.
-struct BiTapP2 { uint32_t o00, o01, o10, o11; float fx, fy; };
-__device__ __forceinline__ BiTapP2 bi_setup_p2(int off, int w, int h, int sh, float u, float v) {
+// The same filter for power-of-two textures (every level a power of two): wraps are masks, the 2 x 2 footprint of a bilinear
+// tap is ONE 16-B load from the row-pair copy of the texture (MeshStore::tex_quads; round 5: the four 4-B gathers per tap
+// made the shading phase bound by the texture-address path), addresses are 32-bit offsets from the object's copy (a scalar
+// base), probe positions come from the workgroup's table.  Identical values: the integer identities hold for every operand,
+// the table entries are the quotients the loop used to recompute.
+struct BiTapP2 { uint32_t o; float fx, fy; };
+__device__ __forceinline__ BiTapP2 bi_setup_p2(int qoff, int w, int h, float u, float v) {
   const float x = fmaf(u, (float)w, -0.5f);
   const float y = fmaf(1.0f - v, (float)h, -0.5f);
   const float xf = floorf(x), yf = floorf(y);
   BiTapP2 t;
   t.fx = x - xf; t.fy = y - yf;
   const int x0 = (int)xf & (w - 1), y0 = (int)yf & (h - 1);
-  const int x1 = (x0 + 1) & (w - 1), y1 = (y0 + 1) & (h - 1);
-  const uint32_t r0 = (uint32_t)off + ((uint32_t)y0 << sh), r1 = (uint32_t)off + ((uint32_t)y1 << sh);
-  t.o00 = r0 + 4u * (uint32_t)x0; t.o01 = r0 + 4u * (uint32_t)x1;
-  t.o10 = r1 + 4u * (uint32_t)x0; t.o11 = r1 + 4u * (uint32_t)x1;
+  // entry x0 of row-pair y0: {T(x0, y0), T(x0, y1)}, the next entry {T(x1, y0), T(x1, y1)} (entry w repeats entry 0)
+  t.o = (uint32_t)qoff + 8u * (uint32_t)(y0 * (w + 1) + x0);
   return t;
 }
-__device__ __forceinline__ BiTexels bi_load_p2(const uint8_t* tex, const BiTapP2& t) {
+typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ BiTexels bi_load_p2(const uint8_t* texq, const BiTapP2& t) {
+  const u32x4_a8 q = *reinterpret_cast<const u32x4_a8*>(texq + t.o);  // the whole 2 x 2 footprint: one 16-B load, 8-B aligned
   BiTexels r;
-  r.a = *reinterpret_cast<const uchar4*>(tex + t.o00); r.b = *reinterpret_cast<const uchar4*>(tex + t.o01);
-  r.c = *reinterpret_cast<const uchar4*>(tex + t.o10); r.d = *reinterpret_cast<const uchar4*>(tex + t.o11);
+  auto px = [](uint32_t v) { return make_uchar4((unsigned char)(v & 255u), (unsigned char)((v >> 8) & 255u), (unsigned char)((v >> 16) & 255u), (unsigned char)(v >> 24)); };
+  r.a = px(q.x); r.c = px(q.y); r.b = px(q.z); r.d = px(q.w);
   return r;
 }
 __device__ __forceinline__ void bi_finish_p2(float fx, float fy, const BiTexels& q, float* rgb) {
@@ -275,7 +282,8 @@ __device__ __forceinline__ void bi_finish_p2(float fx, float fy, const BiTexels&
   }
 }
 
-__device__ __forceinline__ void tex_fetch_aniso_p2(const RasterConv& cv, const uint8_t* tex, const MipTable& mt, int tw, int th, int nlev, float u, float v,
+template <class CV>
+__device__ __forceinline__ void tex_fetch_aniso_p2(const CV& cv, const uint8_t* tex, const MipTable& mt, int tw, int th, int nlev, float u, float v,
                                                    float ux, float vx, float uy, float vy, float* rgb) {
   const float px = sqrtf(fmaf(ux * (float)tw, ux * (float)tw, vx * (float)th * (vx * (float)th)));
   const float py = sqrtf(fmaf(uy * (float)tw, uy * (float)tw, vy * (float)th * (vy * (float)th)));
@@ -289,8 +297,8 @@ __device__ __forceinline__ void tex_fetch_aniso_p2(const RasterConv& cv, const u
   const float du = along_x ? ux : uy, dv = along_x ? vx : vy;
   const bool two = fl > 0.0f && l0 + 1 < nlev;
   const int l1 = two ? l0 + 1 : l0;
-  const int off0 = mt.off[l0], w0 = mt.w[l0], h0 = mt.h[l0], s0 = mt.sh[l0];
-  const int off1 = mt.off[l1], w1 = mt.w[l1], h1 = mt.h[l1], s1 = mt.sh[l1];
+  const int off0 = mt.qoff[l0], w0 = mt.w[l0], h0 = mt.h[l0];
+  const int off1 = mt.qoff[l1], w1 = mt.w[l1], h1 = mt.h[l1];
   const float* const tt = mt.tt[N - 1];
   float acc[3] = {0.0f, 0.0f, 0.0f};
   for (int i = 1; i <= N; i += 2) {
@@ -298,8 +306,8 @@ __device__ __forceinline__ void tex_fetch_aniso_p2(const RasterConv& cv, const u
     const float ta = tt[i - 1];
     const float tb = tt[second ? i : i - 1];
     const float sua = fmaf(ta, du, u), sva = fmaf(ta, dv, v), sub = fmaf(tb, du, u), svb = fmaf(tb, dv, v);
-    const BiTapP2 a0 = bi_setup_p2(off0, w0, h0, s0, sua, sva), a1 = bi_setup_p2(off1, w1, h1, s1, sua, sva);
-    const BiTapP2 b0 = bi_setup_p2(off0, w0, h0, s0, sub, svb), b1 = bi_setup_p2(off1, w1, h1, s1, sub, svb);
+    const BiTapP2 a0 = bi_setup_p2(off0, w0, h0, sua, sva), a1 = bi_setup_p2(off1, w1, h1, sua, sva);
+    const BiTapP2 b0 = bi_setup_p2(off0, w0, h0, sub, svb), b1 = bi_setup_p2(off1, w1, h1, sub, svb);
     const BiTexels qa0 = bi_load_p2(tex, a0), qa1 = bi_load_p2(tex, a1), qb0 = bi_load_p2(tex, b0), qb1 = bi_load_p2(tex, b1);
     float ca[3], cb[3], c1[3];
     bi_finish_p2(a0.fx, a0.fy, qa0, ca);
@@ -328,7 +336,7 @@ __device__ __forceinline__ void tex_fetch_aniso_p2(const RasterConv& cv, const u
 // ---- set-up records ---------------------------------------------------------------------------------------------------
 // One 128-B record (8 x uint4, one cache line) per sub-triangle and view, written by raster_setup_kernel at
 // recs[(view * rec_slots + id) * 8], id = f, or n_faces + f for the second half of a near-clipped quad:
-//   q0 = {ox | oy << 16, flags (bit 0: big), rx0 | ry0 << 16, rx1 | ry1 << 16}     coverage: origin pixel, corners relative to
+//   q0 = {ox | oy << 16, flags (bit 0: big, bit 1: probe-count class), rx0 | ry0 << 16, rx1 | ry1 << 16}     coverage: origin pixel, corners relative to
 //   q1 = {rx2 | ry2 << 16, W.q0, W.qx, W.qy}                                         (256 ox, 256 oy) as int16 pairs, 1 / z plane
 //   q2 = {NU.q0, NU.qx, NU.qy, NV.q0}                                               shading: numerator planes of u and v,
 //   q3 = {NV.qx, NV.qy, v0, v1}                                                      original vertex ids (object-local)
@@ -357,25 +365,27 @@ __device__ __forceinline__ PlaneQ make_plane(float qa, float qb, float qc, const
   return p;
 }
 
-// Set-up of one sub-triangle (oracle.c setup_subtri: same operations in the same order).  Writes its record and returns the
+// Set-up of one sub-triangle from its projected, snapped corners (oracle.c setup_subtri: same operations in the same order;
+// project_corner = its first loop, run per VERTEX by raster_xform_kernel for unclipped triangles).  Writes its record and returns the
 // rows [row_lo, row_hi] its candidate pixels span; false when nothing can be covered (or the face is culled).
 // cull_flag: 0, or the face's orientation flag (+1 / -1) when this view may cull: a closed component's face whose inward
 // side is turned to the camera.  The camera looks along +z with x right and y down, so a face whose winding normal
 // (b - a) x (c - a) points at the camera has NEGATIVE snapped area.
-__device__ __forceinline__ bool setup_subtri(const RasterArgs& a, const float (&Kv)[9], const Corner& c0, const Corner& c1, const Corner& c2,
-                                             const float2 (&uv)[3], const int4 tri, int cull_flag, uint4* rec, int& row_lo, int& row_hi) {
-  int x[3], y[3];
-  float wk[3];
-  const Corner* const cs[3] = {&c0, &c1, &c2};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float cx = cs[k]->c[0], cy = cs[k]->c[1], cz = cs[k]->c[2];
-    const float Xh = fmaf(Kv[0], cx, fmaf(Kv[1], cy, Kv[2] * cz));
-    const float Yh = fmaf(Kv[4], cy, Kv[5] * cz);
-    wk[k] = 1.0f / cz;
-    x[k] = snap_sub(Xh * wk[k]);
-    y[k] = snap_sub(Yh * wk[k]);
-  }
+struct SnapCorner { int x, y; float w; float b[3]; };  // snapped window position (1/256 px), 1 / z, barycentrics w.r.t. the original triangle
+__device__ __forceinline__ SnapCorner project_corner(const float (&Kv)[9], const Corner& c) {
+  const float Xh = fmaf(Kv[0], c.c[0], fmaf(Kv[1], c.c[1], Kv[2] * c.c[2]));
+  const float Yh = fmaf(Kv[4], c.c[1], Kv[5] * c.c[2]);
+  SnapCorner r;
+  r.w = 1.0f / c.c[2];
+  r.x = snap_sub(Xh * r.w);
+  r.y = snap_sub(Yh * r.w);
+  r.b[0] = c.b[0]; r.b[1] = c.b[1]; r.b[2] = c.b[2];
+  return r;
+}
+__device__ __forceinline__ bool setup_subtri(const RasterArgs& a, const SnapCorner& c0, const SnapCorner& c1, const SnapCorner& c2,
+                                             const float2 (&uv)[3], const int4 tri, int cull_flag, int tw, int th, uint4* rec, int& row_lo, int& row_hi, int& cols) {
+  int x[3] = {c0.x, c1.x, c2.x}, y[3] = {c0.y, c1.y, c2.y};
+  float wk[3] = {c0.w, c1.w, c2.w};
   long long area2 = (long long)(x[1] - x[0]) * (long long)(y[2] - y[0]) - (long long)(x[2] - x[0]) * (long long)(y[1] - y[0]);
   if (area2 == 0) return false;
   if (cull_flag != 0 && ((area2 > 0) == (cull_flag > 0))) return false;
@@ -419,7 +429,26 @@ __device__ __forceinline__ bool setup_subtri(const RasterArgs& a, const float (&
   const PlaneQ NV = make_plane(q[0], q[1], q[2], px, py, inv);
   auto pk = [](int lo, int hi) { return (uint32_t)(lo & 0xFFFF) | ((uint32_t)hi << 16); };
   auto fb = [](float f) { return __float_as_uint(f); };
-  rec[0] = make_uint4(pk(j0, i0), big ? 1u : 0u, pk(rx[0], ry[0]), pk(rx[1], ry[1]));
+  // probe-count class of the anisotropic filter at the triangle's centroid (tw > 0: a mip-mapped texture is filtered): 0: at
+  // most 4 probes, 1: more.  A HINT for the band kernel (it groups shading invocations by it); it changes no pixel.
+  uint32_t cls = 0;
+  if (tw > 0) {
+    const float fx = (px[0] + px[1] + px[2]) * (1.0f / 3.0f), fy = (py[0] + py[1] + py[2]) * (1.0f / 3.0f);
+    const float iw = __frcp_rn(plane_at(W, fx, fy));
+    const float tu = plane_at(NU, fx, fy) * iw, tv = plane_at(NV, fx, fy) * iw;
+    const float ux = (NU.qx - tu * W.qx) * iw * (float)tw, vx = (NV.qx - tv * W.qx) * iw * (float)th;
+    const float uy = (NU.qy - tu * W.qy) * iw * (float)tw, vy = (NV.qy - tv * W.qy) * iw * (float)th;
+    const float p2x = ux * ux + vx * vx, p2y = uy * uy + vy * vy;
+    const float hi2 = fmaxf(p2x, p2y), lo2 = fminf(p2x, p2y);
+#ifndef HP_CLS_RATIO2
+#define HP_CLS_RATIO2 16.0f
+#endif
+    cls = (hi2 > HP_CLS_RATIO2 * lo2) ? 1u : 0u;  // Pmax / Pmin > 4: more than four probes = more than two rounds of the probe-pair loop
+  }
+#ifdef HP_SABL_NOREC
+  if (a.w > 0 && fb(W.q0 + NU.q0 + NV.q0) != 0x12345u) { row_lo = ia; row_hi = i1; cols = j1 - ja + 1; return true; }
+#endif
+  rec[0] = make_uint4(pk(j0, i0), (big ? 1u : 0u) | (cls << 1), pk(rx[0], ry[0]), pk(rx[1], ry[1]));
   rec[1] = make_uint4(pk(rx[2], ry[2]), fb(W.q0), fb(W.qx), fb(W.qy));
   rec[2] = make_uint4(fb(NU.q0), fb(NU.qx), fb(NU.qy), fb(NV.q0));
   rec[3] = make_uint4(fb(NV.qx), fb(NV.qy), (uint32_t)tri.x, (uint32_t)tri.y);
@@ -437,7 +466,7 @@ __device__ __forceinline__ bool setup_subtri(const RasterArgs& a, const float (&
     rec[6] = make_uint4((uint32_t)rx[0], (uint32_t)ry[0], (uint32_t)rx[1], (uint32_t)ry[1]);
     rec[7] = make_uint4((uint32_t)rx[2], (uint32_t)ry[2], 0u, 0u);
   }
-  row_lo = ia; row_hi = i1;
+  row_lo = ia; row_hi = i1; cols = j1 - ja + 1;
   return true;
 }
 
@@ -472,7 +501,30 @@ __device__ __forceinline__ Corner isect_near(const Corner& I, const Corner& O) {
   return r;
 }
 
-// Pass 1: one lane per (view, triangle): camera transform, near-plane clipping, snapping, culling, plane set-up -> the
+// Pass 0: one lane per (view, vertex): camera + intrinsics transform, perspective division and snapping, once instead of once
+// per triangle corner (a vertex is shared by six triangles).  Record: {x, y (1/256 px), bits(1 / z), bits(z)}.
+__global__ __launch_bounds__(256) void raster_xform_kernel(RasterArgs a) {
+  const int lv = blockIdx.y, view = a.view0 + lv;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int item = view / a.views_per_item;
+  const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
+  if (v >= (int)ob[1]) return;
+  float T[12], Kv[9];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = a.TCO[16 * (int64_t)view + k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Kv[k] = a.K[9 * (int64_t)view + k];
+  const float4 p = a.verts4[ob[0] + v];
+  Corner c;
+  c.c[0] = fmaf(T[0], p.x, fmaf(T[1], p.y, fmaf(T[2], p.z, T[3])));
+  c.c[1] = fmaf(T[4], p.x, fmaf(T[5], p.y, fmaf(T[6], p.z, T[7])));
+  c.c[2] = fmaf(T[8], p.x, fmaf(T[9], p.y, fmaf(T[10], p.z, T[11])));
+  c.b[0] = c.b[1] = c.b[2] = 0.f;
+  const SnapCorner sc = project_corner(Kv, c);
+  a.xverts[(int64_t)lv * a.max_verts + v] = make_int4(sc.x, sc.y, (int)__float_as_uint(sc.w), (int)__float_as_uint(c.c[2]));
+}
+
+// Pass 1: one lane per (view, triangle): near-plane clipping (rare), culling, plane set-up -> the
 // sub-triangle's record, and its id appended to the list of every band its candidate rows touch (appends are aggregated
 // per workgroup: one returning LDS atomic per touched band and lane, one global atomic per band and workgroup).  A view
 // with a non-finite pose or intrinsics sets nothing up: zero images (panda3d_batch_renderer.py:81-111).
@@ -497,86 +549,100 @@ __global__ __launch_bounds__(kBinThreads) void raster_setup_kernel(RasterArgs a)
   }
   int b0 = 1, b1 = 0;  // band range of the (first) sub-triangle: empty
   int c0 = 1, c1 = 0;  // ... of the second half of a near-clipped quad (rare)
+  int lo = 0, hi = -1, cols = 0, lo2 = 0, hi2 = -1, cols2 = 0;  // candidate rows / columns of the two
+  // a mip-mapped texture will be filtered anisotropically: the set-up classifies the triangles' probe counts
+  const int ftw = (a.flags & HP_RASTER_TEX_ANISO) && ob[4] >= 0 && ob[7] > 1 ? (int)ob[5] : 0, fth = (int)ob[6];
   uint4* const recs = a.recs + (int64_t)lv * a.rec_slots * 8;
   if (f < nf) {
     const int4 tri = a.faces4[ob[2] + f];
     const int64_t voff = ob[0];
-    const float4 p0 = a.verts4[voff + tri.x], p1 = a.verts4[voff + tri.y], p2 = a.verts4[voff + tri.z];
-    const float2 uv[3] = {*reinterpret_cast<const float2*>(a.uvs + 2 * (voff + tri.x)), *reinterpret_cast<const float2*>(a.uvs + 2 * (voff + tri.y)),
-                          *reinterpret_cast<const float2*>(a.uvs + 2 * (voff + tri.z))};
-    const float4 pp[3] = {p0, p1, p2};
-    Corner V[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      V[k].c[0] = fmaf(x.T[0], pp[k].x, fmaf(x.T[1], pp[k].y, fmaf(x.T[2], pp[k].z, x.T[3])));
-      V[k].c[1] = fmaf(x.T[4], pp[k].x, fmaf(x.T[5], pp[k].y, fmaf(x.T[6], pp[k].z, x.T[7])));
-      V[k].c[2] = fmaf(x.T[8], pp[k].x, fmaf(x.T[9], pp[k].y, fmaf(x.T[10], pp[k].z, x.T[11])));
-#pragma unroll
-      for (int c = 0; c < 3; ++c) V[k].b[c] = c == k ? 1.0f : 0.0f;
-    }
-    const float zmin = fminf(V[0].c[2], fminf(V[1].c[2], V[2].c[2])), zmax = fmaxf(V[0].c[2], fmaxf(V[1].c[2], V[2].c[2]));
+    const int4* const xv = a.xverts + (int64_t)lv * a.max_verts;
+    const int4 v0 = xv[tri.x], v1 = xv[tri.y], v2 = xv[tri.z];
+    const float z0 = __uint_as_float((uint32_t)v0.w), z1 = __uint_as_float((uint32_t)v1.w), z2 = __uint_as_float((uint32_t)v2.w);
+    const float zmin = fminf(z0, fminf(z1, z2)), zmax = fmaxf(z0, fmaxf(z1, z2));
     if ((zmax >= kZNear) && (zmin <= kZFar)) {
-      int lo, hi;
+      const float2 uv[3] = {*reinterpret_cast<const float2*>(a.uvs + 2 * (voff + tri.x)), *reinterpret_cast<const float2*>(a.uvs + 2 * (voff + tri.y)),
+                            *reinterpret_cast<const float2*>(a.uvs + 2 * (voff + tri.z))};
       if (zmin >= kZNear) {
-        if (setup_subtri(a, x.Kv, V[0], V[1], V[2], uv, tri, view_cull ? tri.w : 0, recs + (int64_t)f * 8, lo, hi)) {
+        const SnapCorner s0{v0.x, v0.y, __uint_as_float((uint32_t)v0.z), {1.f, 0.f, 0.f}};
+        const SnapCorner s1{v1.x, v1.y, __uint_as_float((uint32_t)v1.z), {0.f, 1.f, 0.f}};
+        const SnapCorner s2{v2.x, v2.y, __uint_as_float((uint32_t)v2.z), {0.f, 0.f, 1.f}};
+        if (setup_subtri(a, s0, s1, s2, uv, tri, view_cull ? tri.w : 0, ftw, fth, recs + (int64_t)f * 8, lo, hi, cols)) {
           b0 = lo / a.band_rows; b1 = hi / a.band_rows;
         }
       } else {
-        // near-plane clipping (oracle.c): rotate the corners cyclically so that corner 0 is inside and corner 2 outside, then
-        // the polygon is [V0, I(0->1), I(0->2)] or [V0, V1, I(1->2), I(0->2)]
+        // near-plane clipping (oracle.c): camera-space corners again (the pre-pass keeps window coordinates only), rotated
+        // cyclically so that corner 0 is inside and corner 2 outside; then the polygon is [V0, I(0->1), I(0->2)] or
+        // [V0, V1, I(1->2), I(0->2)]
+        const float4 pp[3] = {a.verts4[voff + tri.x], a.verts4[voff + tri.y], a.verts4[voff + tri.z]};
+        Corner V[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          V[k].c[0] = fmaf(x.T[0], pp[k].x, fmaf(x.T[1], pp[k].y, fmaf(x.T[2], pp[k].z, x.T[3])));
+          V[k].c[1] = fmaf(x.T[4], pp[k].x, fmaf(x.T[5], pp[k].y, fmaf(x.T[6], pp[k].z, x.T[7])));
+          V[k].c[2] = fmaf(x.T[8], pp[k].x, fmaf(x.T[9], pp[k].y, fmaf(x.T[10], pp[k].z, x.T[11])));
+#pragma unroll
+          for (int c = 0; c < 3; ++c) V[k].b[c] = c == k ? 1.0f : 0.0f;
+        }
         const bool in0 = V[0].c[2] >= kZNear, in1 = V[1].c[2] >= kZNear, in2 = V[2].c[2] >= kZNear;
         const int n_in = (int)in0 + (int)in1 + (int)in2;
         const int r = n_in == 1 ? (in0 ? 0 : in1 ? 1 : 2) : (!in0 ? 1 : !in1 ? 2 : 0);
         const Corner R0 = r == 0 ? V[0] : r == 1 ? V[1] : V[2];
         const Corner R1 = r == 0 ? V[1] : r == 1 ? V[2] : V[0];
         const Corner R2 = r == 0 ? V[2] : r == 1 ? V[0] : V[1];
+        const SnapCorner S0 = project_corner(x.Kv, R0);
         if (n_in == 1) {
-          const Corner P1 = isect_near(R0, R1), P2 = isect_near(R0, R2);
-          if (setup_subtri(a, x.Kv, R0, P1, P2, uv, tri, 0, recs + (int64_t)f * 8, lo, hi)) { b0 = lo / a.band_rows; b1 = hi / a.band_rows; }
+          const SnapCorner P1 = project_corner(x.Kv, isect_near(R0, R1)), P2 = project_corner(x.Kv, isect_near(R0, R2));
+          if (setup_subtri(a, S0, P1, P2, uv, tri, 0, ftw, fth, recs + (int64_t)f * 8, lo, hi, cols)) { b0 = lo / a.band_rows; b1 = hi / a.band_rows; }
         } else {
-          const Corner P2 = isect_near(R1, R2), P3 = isect_near(R0, R2);
-          if (setup_subtri(a, x.Kv, R0, R1, P2, uv, tri, 0, recs + (int64_t)f * 8, lo, hi)) { b0 = lo / a.band_rows; b1 = hi / a.band_rows; }
-          if (setup_subtri(a, x.Kv, R0, P2, P3, uv, tri, 0, recs + (int64_t)(nf + f) * 8, lo, hi)) { c0 = lo / a.band_rows; c1 = hi / a.band_rows; }
+          const SnapCorner S1 = project_corner(x.Kv, R1);
+          const SnapCorner P2 = project_corner(x.Kv, isect_near(R1, R2)), P3 = project_corner(x.Kv, isect_near(R0, R2));
+          if (setup_subtri(a, S0, S1, P2, uv, tri, 0, ftw, fth, recs + (int64_t)f * 8, lo, hi, cols)) { b0 = lo / a.band_rows; b1 = hi / a.band_rows; }
+          if (setup_subtri(a, S0, P2, P3, uv, tri, 0, ftw, fth, recs + (int64_t)(nf + f) * 8, lo2, hi2, cols2)) { c0 = lo2 / a.band_rows; c1 = hi2 / a.band_rows; }
         }
       }
     }
   }
-  // Appends.  The order of a list is arbitrary; the z-buffer minimum {depth : id} does not depend on it.
-  __shared__ int wg_cnt[kMaxBands], wg_base[kMaxBands];
+  // Appends.  The order of a list is arbitrary (the z-buffer minimum {depth : id} does not depend on it) -- but the band kernel
+  // walks the candidate pixels of 64 listed records per wave in lockstep, to the LARGEST box of the 64.  So a band's list is
+  // filled from both ends: records with at most kSmallArea candidate pixels in that band from the front, the others from the
+  // back (counters [band][0] and [band][1]): waves see boxes of similar size (round 5: 1.7x fewer walk steps).
+  __shared__ int wg_cnt[2 * kMaxBands], wg_base[2 * kMaxBands];
   const int tid = threadIdx.x;
-  for (int b = tid; b < a.n_bands; b += kBinThreads) wg_cnt[b] = 0;
+  for (int b = tid; b < 2 * a.n_bands; b += kBinThreads) wg_cnt[b] = 0;
   __syncthreads();
-  int slot0 = 0, slot1 = 0;  // local slots in the first two bands
-  if (b0 <= b1) {
-    slot0 = atomicAdd(&wg_cnt[b0], 1);
-    if (b1 > b0) slot1 = atomicAdd(&wg_cnt[b0 + 1], 1);
-  }
-  int extra[6];  // bands b0 + 2 .. b0 + 7 of a triangle taller than two bands
+  auto band_class = [&](int b, int rlo, int rhi, int ncols) {  // 1: more than kSmallArea candidate pixels inside band b
+    const int r0 = max(rlo, b * a.band_rows), r1 = min(rhi, (b + 1) * a.band_rows - 1);
+    return (r1 - r0 + 1) * ncols > kSmallArea ? 1 : 0;
+  };
+  int32_t* const cnt_v = a.bin_count + (int64_t)lv * a.n_bands * 2;
+  int32_t* const list_v = a.bin_list + (int64_t)lv * a.n_bands * a.bin_cap;
+  auto put_direct = [&](int b, int cls, int id) {  // one global atomic per append (rare paths)
+    const int slot = atomicAdd(&cnt_v[2 * b + cls], 1);
+    if (slot + cnt_v[2 * b + 1 - cls] < a.bin_cap) list_v[(int64_t)b * a.bin_cap + (cls ? a.bin_cap - 1 - slot : slot)] = id;
+  };
+  int slot[8], kls[8];  // local slots / classes in the bands b0 .. b0 + 7
 #pragma unroll
-  for (int k = 0; k < 6; ++k) extra[k] = (b0 <= b1 && b0 + 2 + k <= b1) ? atomicAdd(&wg_cnt[b0 + 2 + k], 1) : 0;
-  for (int b = b0 + 8; b <= b1; ++b) {  // rare: beyond eight bands a triangle appends itself with a global atomic per band
-    const int slot = atomicAdd(&a.bin_count[lv * a.n_bands + b], 1);
-    if (slot < a.bin_cap) a.bin_list[((int64_t)lv * a.n_bands + b) * a.bin_cap + slot] = f;
+  for (int k = 0; k < 8; ++k) {
+    slot[k] = 0; kls[k] = 0;
+    if (b0 <= b1 && b0 + k <= b1) {
+      kls[k] = band_class(b0 + k, lo, hi, cols);
+      slot[k] = atomicAdd(&wg_cnt[2 * (b0 + k) + kls[k]], 1);
+    }
   }
-  for (int b = c0; b <= c1; ++b) {      // rarer: the second half of a near-clipped quad
-    const int slot = atomicAdd(&a.bin_count[lv * a.n_bands + b], 1);
-    if (slot < a.bin_cap) a.bin_list[((int64_t)lv * a.n_bands + b) * a.bin_cap + slot] = nf + f;
-  }
+  for (int b = b0 + 8; b <= b1; ++b) put_direct(b, band_class(b, lo, hi, cols), f);  // rare: a triangle taller than eight bands
+  for (int b = c0; b <= c1; ++b) put_direct(b, band_class(b, lo2, hi2, cols2), nf + f);  // rarer: the second half of a near-clipped quad
   __syncthreads();
-  for (int b = tid; b < a.n_bands; b += kBinThreads)
-    if (wg_cnt[b] > 0) wg_base[b] = atomicAdd(&a.bin_count[lv * a.n_bands + b], wg_cnt[b]);
+  for (int b = tid; b < 2 * a.n_bands; b += kBinThreads)
+    if (wg_cnt[b] > 0) wg_base[b] = atomicAdd(&cnt_v[b], wg_cnt[b]);
   __syncthreads();
-  if (b0 <= b1) {
-    auto put = [&](int b, int local) {
-      const int slot = wg_base[b] + local;
-      if (slot < a.bin_cap) a.bin_list[((int64_t)lv * a.n_bands + b) * a.bin_cap + slot] = f;
-    };
-    put(b0, slot0);
-    if (b1 > b0) put(b0 + 1, slot1);
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
-      if (b0 + 2 + k <= b1) put(b0 + 2 + k, extra[k]);
-  }
+  for (int k = 0; k < 8; ++k)
+    if (b0 <= b1 && b0 + k <= b1) {
+      const int b = b0 + k, sl = wg_base[2 * b + kls[k]] + slot[k];
+      // (a face appends at most once per band and bin_cap = the largest face count: the two ends cannot meet)
+      if (sl < a.bin_cap) list_v[(int64_t)b * a.bin_cap + (kls[k] ? a.bin_cap - 1 - sl : sl)] = f;
+    }
 }
 
 // One fragment-shader invocation: colour and normal code of sub-triangle `id` at the CENTRE of pixel (i, j) (attributes
@@ -585,14 +651,15 @@ struct ShadeCtx {
   const float* T; const float* Kv; const float* amb; const uint4* recs;
   int64_t voff, toff; int tw, th, view, q8, nlev, aniso;
   const MipTable* mips;  // per-workgroup table of the object's mip levels (LDS)
+  const uint8_t* texq;   // the object's row-pair texture copy (mips->p2)
   bool need_normal;      // the view renders normals or has point lights: otherwise the normal is never looked at
 };
-template <bool ANISO>
-__device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx& cx, int id, int i, int j, float* o_rgb, float* o_n) {
+template <bool ANISO, class A>
+__device__ __forceinline__ void shade_centre(const A& a, const ShadeCtx& cx, int id, int i, int j, float* o_rgb, float* o_n) {
   const float* T = cx.T; const float* Kv = cx.Kv; const float* amb = cx.amb;
   const int64_t voff = cx.voff, toff = cx.toff;
   const int tw = cx.tw, th = cx.th, view = cx.view, q8 = cx.q8;
-  const uint4* const r = cx.recs + (int64_t)id * 8;
+  const uint4* const r = cx.recs + (int64_t)(id & 0x3FFFFFFF) * 8;  // (bit 30 of a key's low word: the probe-count class)
   const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
   const int ox = (int)(short)(r0.x & 0xFFFFu), oy = (int)r0.x >> 16;
   const PlaneQ W{__uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w)};
@@ -619,7 +686,7 @@ __device__ __forceinline__ void shade_centre(const RasterArgs& a, const ShadeCtx
       // screen-space derivatives of the perspective-correct coordinates: u = N_u / W, both affine in (x, y)
       const float ux = fmaf(-tu, W.qx, NU.qx) * iw, vx = fmaf(-tv, W.qx, NV.qx) * iw;
       const float uy = fmaf(-tu, W.qy, NU.qy) * iw, vy = fmaf(-tv, W.qy, NV.qy) * iw;
-      if (cx.mips->p2) tex_fetch_aniso_p2(a.cv, a.tex + toff, *cx.mips, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
+      if (cx.mips->p2) tex_fetch_aniso_p2(a.cv, cx.texq, *cx.mips, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
       else tex_fetch_aniso(a.cv, a.tex + toff, tw, th, cx.nlev, tu, tv, ux, vx, uy, vy, alb);
     } else {
       tex_fetch(a.tex + toff, tw, th, tu, tv, alb);
@@ -764,6 +831,22 @@ __device__ __forceinline__ void crop_taps(const float* __restrict__ img, int HW,
   }
 }
 
+#ifdef HP_RASTER_STAMPS
+// -DHP_RASTER_STAMPS (tools/raster_stamps.py): shader cycles between the phases of the band kernel, summed over the workgroups
+// (thread 0's clock), [phase] and workgroup count in [15]
+__device__ unsigned long long hp_rstamp[16];
+#define HP_STAMP(k)                                                                         \
+  do {                                                                                      \
+    if (threadIdx.x == 0) {                                                                 \
+      const unsigned long long now_ = __builtin_readcyclecounter();                          \
+      atomicAdd(&hp_rstamp[k], now_ - stamp_t_);                                            \
+      stamp_t_ = now_;                                                                      \
+    }                                                                                       \
+  } while (0)
+#else
+#define HP_STAMP(k) do { } while (0)
+#endif
+
 // ---- coverage ---------------------------------------------------------------------------------------------------------
 // The three edge functions of a record in the form E_k(X, Y) = A_k X + B_k Y + C_k on sub-pixel coordinates relative to the
 // origin, the top-left rule folded into C_k (- 1 on the edges that do not own their points): inside <=> all E_k >= 0.
@@ -781,7 +864,8 @@ __device__ __forceinline__ void edge_setup(const int (&rx)[3], const int (&ry)[3
 }
 
 // candidate pixels of a record inside the band: columns [jlo, jhi], rows [ilo, ihi] relative to the origin pixel
-__device__ __forceinline__ bool candidate_range(const RasterArgs& a, const int (&rx)[3], const int (&ry)[3], int ox, int oy, int row0, int row1,
+template <class A>
+__device__ __forceinline__ bool candidate_range(const A& a, const int (&rx)[3], const int (&ry)[3], int ox, int oy, int row0, int row1,
                                                 int& jlo, int& jhi, int& ilo, int& ihi) {
   const int xmin = min(rx[0], min(rx[1], rx[2])), xmax = max(rx[0], max(rx[1], rx[2]));
   const int ymin = min(ry[0], min(ry[1], ry[2])), ymax = max(ry[0], max(ry[1], ry[2]));
@@ -793,33 +877,42 @@ __device__ __forceinline__ bool candidate_range(const RasterArgs& a, const int (
 // HALF: fp16 destinations (the input of an fp16 network plan) -- its own instantiation so that the fp32 path's register
 // budget does not carry the 16-half record assembly
 template <int NS, bool HALF, bool ANISO, bool WIDE>
-__global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO) ? 6 : 4) void raster_kernel(RasterArgs a, int npix_max) {
+__global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO) ? 6 : 4) void raster_kernel(RasterArgs a_in, int npix_max) {
   constexpr int kThreads = band_threads(NS, WIDE);
+#ifdef HP_RASTER_STAMPS
+  unsigned long long stamp_t_ = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) atomicAdd(&hp_rstamp[15], 1ull);
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int big_q[kBigQueue];
-  __shared__ int big_n, n_cov, span_max[2];
+  __shared__ int big_n, n_cov, n_cov_hi, span_max[2];  // n_cov / n_cov_hi: list entries of the two probe-count classes (front / back)
   __shared__ MipTable mips;
 
-  // XCD-aware renumbering: dispatch order b -> XCD b % 8; give each XCD a contiguous range.
+  // XCD-aware renumbering: dispatch order b -> XCD b % 8; give each XCD a contiguous range.  (One workgroup per (view, band):
+  // a persistent grid pulling items from per-XCD queues was built in round 5 and LOST -- 1110 us per 128 views with the queue
+  // atomics on the workgroup's critical path, 531 us with static striding, against 446 us: the hardware dispatcher balances
+  // the uneven bands better, and four resident workgroups per CU already hide each other's start-up.)
+  const RasterArgs& a = a_in;
   const int total = a.n * a.n_bands;  // a.n = views of this chunk
   const int per_xcd = (total + 7) / 8;
   const int lin = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (lin >= total) return;
+  const int tid = threadIdx.x;
   const int lv = lin / a.n_bands;
   const int view = a.view0 + lv;
   const int band = lin % a.n_bands;
   const int row0 = band * a.band_rows;
   const int row1 = min(a.h, row0 + a.band_rows) - 1;
   const int npix = (row1 - row0 + 1) * a.w;
-  const int tid = threadIdx.x;
   const BandLds L = carve_lds(smem, npix_max, NS, a.band_rows);
   unsigned long long* const zb = L.zb;
 
   // the band's list: the first entry's loads are issued before anything else (a non-finite view set nothing up: cnt = 0)
-  const int cnt = min(a.bin_count[lin], a.bin_cap);
+  const int cnt_s = min(a.bin_count[2 * lin], a.bin_cap), cnt = cnt_s + min(a.bin_count[2 * lin + 1], a.bin_cap - cnt_s);
   const int32_t* const list = a.bin_list + (int64_t)lin * a.bin_cap;
   const uint4* const recs = a.recs + (int64_t)lv * a.rec_slots * 8;
-  int id_n = tid < cnt ? list[tid] : 0;
+  auto entry = [&](int k) { return k < cnt_s ? list[k] : list[a.bin_cap - 1 - (k - cnt_s)]; };  // small boxes first, the others from the back
+  int id_n = tid < cnt ? entry(tid) : 0;
   uint4 q0_n = recs[(int64_t)id_n * 8], q1_n = recs[(int64_t)id_n * 8 + 1];
 
   const int item = view / a.views_per_item, vi = view % a.views_per_item;
@@ -853,27 +946,15 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
     }
   }
 
-  if (tid == 0) {  // level k of the texture: max(1, tw >> k) x max(1, th >> k), stored behind the levels before it
-    int off = 0, lw = tw, lh = th;
-    for (int k = 0; k < 16; ++k) {
-      mips.off[k] = off; mips.w[k] = lw; mips.h[k] = lh;
-      mips.sh[k] = 33 - __clz(lw);  // log2(lw) + 2 for a power of two
-      off += 4 * lw * lh; lw = lw > 1 ? lw >> 1 : 1; lh = lh > 1 ? lh >> 1 : 1;
-    }
-    mips.p2 = tw > 0 && th > 0 && (tw & (tw - 1)) == 0 && (th & (th - 1)) == 0;
-  }
-  if (ANISO && tid < 256) {
-    const int N = (tid >> 4) + 1, i = (tid & 15) + 1;
-    mips.tt[N - 1][i - 1] = (float)i / (float)(N + 1) - 0.5f;
-  }
   // a band no triangle touches skips the z-buffer passes altogether: the output pass streams the background (and the crop)
   const bool band_empty = cnt == 0;
   if (!band_empty) {
     for (int p = tid; p < npix * NS; p += kThreads) zb[p] = kKeyEmpty;
-    if (tid == 0) { big_n = 0; n_cov = 0; }
+    if (tid == 0) { big_n = 0; n_cov = 0; n_cov_hi = 0; }
   }
   __syncthreads();
-  if (!band_empty && tid == 0) a.bin_count[lin] = 0;  // consumed (every thread has read it by now): zero for the next launch
+  HP_STAMP(0);  // head: list / record loads in flight, z-buffer initialised
+  if (!band_empty && tid == 0) { a.bin_count[2 * lin] = 0; a.bin_count[2 * lin + 1] = 0; }  // consumed (every thread has read them by now): zero for the next launch
 #ifdef HP_RABL_NO_COVER
   const int cnt_loop = 0;
 #else
@@ -885,10 +966,11 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
     const int id = id_n;
     const uint4 q0 = q0_n, q1 = q1_n;
     if (k + kThreads < cnt_loop) {
-      id_n = list[k + kThreads];
+      id_n = entry(k + kThreads);
       q0_n = recs[(int64_t)id_n * 8]; q1_n = recs[(int64_t)id_n * 8 + 1];
     }
     const int ox = (int)(short)(q0.x & 0xFFFFu), oy = (int)q0.x >> 16;
+    const uint32_t key_lo = (uint32_t)id | ((q0.y & 2u) << 29);  // bit 30: the probe-count class (shading groups invocations by it)
     if (q0.y & 1u) {  // big: corners beyond the 32-bit range of the edge functions -> cooperative walk in 64 bits
       const int q = atomicAdd(&big_n, 1);
       if (q < kBigQueue) big_q[q] = id;
@@ -913,27 +995,34 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
 #pragma unroll
       for (int c = 0; c < 3; ++c) off[c][s] = __mul24(e.A[c], a.cv.sxi[sl]) + __mul24(e.B[c], a.cv.syi[sl]);
     }
-    for (int di = ilo; di <= ihi; ++di) {
-      const float dif = (float)di;
-      unsigned long long* const zrow = zb + (size_t)((oy + di - row0) * a.w + ox) * NS;
-      const int Y0 = di << 8;
-      const int r0 = __mul24(e.B[0], Y0) + e.C[0], r1 = __mul24(e.B[1], Y0) + e.C[1], r2 = __mul24(e.B[2], Y0) + e.C[2];
-      for (int dj = jlo; dj <= jhi; ++dj) {
-        const int X0 = dj << 8;
-        const int e0 = __mul24(e.A[0], X0) + r0, e1 = __mul24(e.A[1], X0) + r1, e2 = __mul24(e.A[2], X0) + r2;
-        const float djf = (float)dj;
+    // one candidate pixel per step, row-major over the box (a nested row / column loop runs, per wave, the largest column
+    // count of every row step: 2.5x the steps)
+    const int bw = jhi - jlo + 1;
+    int di = ilo, dj = jlo;
+    for (int left = bw * (ihi - ilo + 1); left > 0; --left) {
+      const int X0 = dj << 8, Y0 = di << 8;
+      const int e0 = __mul24(e.A[0], X0) + __mul24(e.B[0], Y0) + e.C[0];
+      const int e1 = __mul24(e.A[1], X0) + __mul24(e.B[1], Y0) + e.C[1];
+      const int e2 = __mul24(e.A[2], X0) + __mul24(e.B[2], Y0) + e.C[2];
+      unsigned in = 0;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) in |= (((e0 + off[0][s]) | (e1 + off[1][s]) | (e2 + off[2][s])) >= 0 ? 1u : 0u) << s;
+      if (in) {
+        const float dif = (float)di, djf = (float)dj;
+        unsigned long long* const zpix = zb + (size_t)((oy + di - row0) * a.w + ox + dj) * NS;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           const int sl = NS == 1 ? 4 : s;
-          if (((e0 + off[0][s]) | (e1 + off[1][s]) | (e2 + off[2][s])) < 0) continue;
           const float Ws = fmaf(Wy, dif + a.cv.syf[sl], fmaf(Wx, djf + a.cv.sxf[sl], W0));
-          if (!(Ws <= w_near) || !(Ws >= w_far)) continue;
-          atomicMin(&zrow[dj * NS + s], ((unsigned long long)(~__float_as_uint(Ws)) << 32) | (uint32_t)id);
+          if (((in >> s) & 1u) && (Ws <= w_near) && (Ws >= w_far))
+            atomicMin(&zpix[s], ((unsigned long long)(~__float_as_uint(Ws)) << 32) | key_lo);
         }
       }
+      if (++dj > jhi) { dj = jlo; ++di; }
     }
   }
   if (!band_empty) __syncthreads();
+  HP_STAMP(1);  // coverage walk
   // ---- large footprints and far-reaching corners: the whole workgroup walks the candidate pixels, edge functions in
   // double precision (exact: |A X| < 2^43) ----
   const int nbig = band_empty ? 0 : min(big_n, kBigQueue);
@@ -942,6 +1031,7 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
     const uint4* const r = recs + (int64_t)id * 8;
     const uint4 q0 = r[0], q1 = r[1];
     const int ox = (int)(short)(q0.x & 0xFFFFu), oy = (int)q0.x >> 16;
+    const uint32_t key_lo = (uint32_t)id | ((q0.y & 2u) << 29);
     int rx[3], ry[3];
     if (q0.y & 1u) {
       const uint4 q6 = r[6], q7 = r[7];
@@ -976,21 +1066,36 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
         if (e0 < 0.0 || e1 < 0.0 || e2 < 0.0) continue;
         const float Ws = fmaf(Wy, (float)di + a.cv.syf[sl], fmaf(Wx, (float)dj + a.cv.sxf[sl], W0));
         if (!(Ws <= w_near) || !(Ws >= w_far)) continue;
-        atomicMin(&zpix[s], ((unsigned long long)(~__float_as_uint(Ws)) << 32) | (uint32_t)id);
+        atomicMin(&zpix[s], ((unsigned long long)(~__float_as_uint(Ws)) << 32) | key_lo);
       }
     }
   }
   if (!band_empty) __syncthreads();
+  HP_STAMP(2);  // cooperative walk of large footprints
 
+  // ---- the object's mip table (LDS), filled while the coverage results settle: its inputs hang on a chain of dependent scalar
+  // loads (obj_ids -> obj row) that used to sit in front of the kernel's first barrier ----
+  const int64_t qbase = a.tex_quads_off ? a.tex_quads_off[a.obj_ids[item]] : -1;
+  if (tid < 16) {  // level k of the texture: max(1, tw >> k) x max(1, th >> k), stored behind the levels before it
+    int off = 0, qo = 0, lw = tw, lh = th;
+    for (int k = 0; k < tid; ++k) { off += 4 * lw * lh; qo += 8 * (lw + 1) * lh; lw = lw > 1 ? lw >> 1 : 1; lh = lh > 1 ? lh >> 1 : 1; }
+    mips.off[tid] = off; mips.w[tid] = lw; mips.h[tid] = lh; mips.qoff[tid] = qo;
+    if (tid == 0) mips.p2 = qbase >= 0;
+  }
+  if (ANISO && tid < 256) {
+    const int N = (tid >> 4) + 1, i = (tid & 15) + 1;
+    mips.tt[N - 1][i - 1] = (float)i / (float)(N + 1) - 0.5f;
+  }
   // ---- shading of the compacted covered pixels (8-bit colour codes back into the z-buffer slots) ----
   const int q8 = 1;  // colours are 8-bit quantised like the reference's uint8 read-back (HP_RASTER_QUANT8 is implied)
   float amb[3] = {1.0f, 1.0f, 1.0f};
   if (a.ambient) { amb[0] = a.ambient[3 * view]; amb[1] = a.ambient[3 * view + 1]; amb[2] = a.ambient[3 * view + 2]; }
   const bool need_normal = (a.rec ? a.want_nrm != 0 : a.nrm != nullptr) || a.n_lights > 0;
   const ShadeCtx cx{a.TCO + 16 * (int64_t)view, a.K + 9 * (int64_t)view, amb, recs, voff, toff, tw, th, view, q8, (int)ob[7] > 0 ? (int)ob[7] : 1,
-                    (a.flags & HP_RASTER_TEX_ANISO) != 0, &mips, need_normal};
+                    (a.flags & HP_RASTER_TEX_ANISO) != 0, &mips, a.tex_quads + (qbase >= 0 ? qbase : 0), need_normal};
   const bool want_colour = a.rec ? true : (a.rgb != nullptr || a.nrm != nullptr);
   const bool coded = !band_empty;  // colours travel as 8-bit codes through LDS
+  const int list_cap = npix_max * band_list_per_pixel(NS);  // entries of L.plist
   if (coded && NS == 1) {
     const int lane = tid & 63;
     for (int p0 = 0; p0 < npix; p0 += kThreads) {
@@ -1003,21 +1108,30 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
           L.ex[p] = 0;
         }
       }
-      const unsigned long long m = __ballot(cov);
-      int base = 0;
+      // two lists in one array: invocations of triangles with at most two anisotropic probes from the front, the others from
+      // the back -- the probe loop of a wave runs to its largest probe count (the class is bit 30 of the key's low word)
+      const bool hi = ANISO && cov && ((uint32_t)zb[p < npix ? p : 0] >> 30) != 0;
+      const unsigned long long m = __ballot(cov && !hi), mh = ANISO ? __ballot(hi) : 0ull;
+      int base = 0, base_h = 0;
       if (lane == 0 && m != 0) base = atomicAdd(&n_cov, __popcll(m));
+      if (ANISO && lane == 0 && mh != 0) base_h = atomicAdd(&n_cov_hi, __popcll(mh));
       base = __shfl(base, 0);
-      if (cov) L.plist[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+      if (cov && !hi) L.plist[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+      if (ANISO) {
+        base_h = __shfl(base_h, 0);
+        if (hi) L.plist[list_cap - 1 - (base_h + __popcll(mh & ((1ull << lane) - 1ull)))] = (unsigned short)p;
+      }
     }
     __syncthreads();
-    const int ncov = n_cov;
+    HP_STAMP(3);  // compaction (single sample)
+    const int ncov_lo = n_cov, ncov = ncov_lo + (ANISO ? n_cov_hi : 0);
 #ifdef HP_RABL_NO_SHADE
     const int ncov_loop = a.w < 0 ? ncov : 0;
 #else
     const int ncov_loop = ncov;
 #endif
     for (int q = tid; q < ncov_loop; q += kThreads) {
-      const int p = L.plist[q];
+      const int p = L.plist[q < ncov_lo ? q : list_cap - 1 - (q - ncov_lo)];
       const int pr = (int)(((unsigned long long)p * a.w_magic) >> 32);
       const int i = row0 + pr, j = p - pr * a.w;
       unsigned cr[3], cn[3];
@@ -1040,52 +1154,75 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
     const int lane = tid & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t* const zlo = reinterpret_cast<uint32_t*>(zb);  // little endian: word 2 k = low half of key k
-    for (int p0 = 0; p0 < npix; p0 += kThreads) {
-      const int p = p0 + tid;
-      unsigned inv = 0;  // bit sm: sample sm starts an invocation
-      if (p < npix) {
-        uint32_t kf[4];
-        bool kc[4];
+    // three pixels per thread and round: ONE prefix sum / list reservation per wave for the lot (a round per pixel spent most of
+    // its time in the returning LDS atomics and ballots: 9.5 k of 93 k cycles per workgroup)
+    constexpr int kG = 3;
+    for (int p0 = 0; p0 < npix; p0 += kG * kThreads) {
+      unsigned inv_lo[kG], inv_hi[kG];  // bit sm: sample sm starts an invocation (of a triangle with at most / more than two anisotropic probes)
+      int cnt = 0, cnt_h = 0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { const unsigned long long kt = zb[p * NS + t]; kc[t] = kt != kKeyEmpty; kf[t] = (uint32_t)kt; }
-        const bool cov = (kc[0] | kc[1] | kc[2] | kc[3]) && want_colour;
-        zb[p * NS + (NS - 1)] &= 0xFFFFFFFF00000000ull;  // colour sums / codes 0, the depth bits stay
-        L.nsum[p] = 0;
-        L.ex[p] = 0;
-        if (cov) {
+      for (int g = 0; g < kG; ++g) {
+        const int p = p0 + g * kThreads + tid;
+        unsigned inv = 0, ihi = 0;
+        if (p < npix) {
+          uint32_t kf[4];
+          bool kc[4];
 #pragma unroll
-          for (int sm = 0; sm < 4; ++sm) {
-            bool first = kc[sm];
+          for (int t = 0; t < 4; ++t) { const unsigned long long kt = zb[p * NS + t]; kc[t] = kt != kKeyEmpty; kf[t] = (uint32_t)kt; }
+          const bool cov = (kc[0] | kc[1] | kc[2] | kc[3]) && want_colour;
+          zb[p * NS + (NS - 1)] &= 0xFFFFFFFF00000000ull;  // colour sums 0, the depth bits stay
+          L.nsum[p] = 0;
+          if (cov) {
 #pragma unroll
-            for (int t = 0; t < sm; ++t) first &= !(kc[t] && kf[t] == kf[sm]);
-            inv |= first ? (1u << sm) : 0u;
+            for (int sm = 0; sm < 4; ++sm) {
+              bool first = kc[sm];
+#pragma unroll
+              for (int t = 0; t < sm; ++t) first &= !(kc[t] && kf[t] == kf[sm]);
+              inv |= first ? (1u << sm) : 0u;
+              if (ANISO) ihi |= (first && (kf[sm] >> 30)) ? (1u << sm) : 0u;
+            }
           }
         }
+        inv_hi[g] = ihi; inv_lo[g] = inv & ~ihi;
+        cnt += __popc(inv_lo[g]); cnt_h += __popc(ihi);
       }
-      const int cnt = __popc(inv);
-      int pre = 0, tot = 0;
+      int pre = 0, tot = 0, pre_h = 0, tot_h = 0;
 #pragma unroll
-      for (int b = 0; b < 3; ++b) {
+      for (int b = 0; b < 4; ++b) {  // counts <= 12
         const unsigned long long m = __ballot((cnt >> b) & 1);
         pre += __popcll(m & lt_mask) << b;
         tot += __popcll(m) << b;
+        if (ANISO) {
+          const unsigned long long mh = __ballot((cnt_h >> b) & 1);
+          pre_h += __popcll(mh & lt_mask) << b;
+          tot_h += __popcll(mh) << b;
+        }
       }
-      int base = 0;
+      int base = 0, base_h = 0;
       if (lane == 0 && tot != 0) base = atomicAdd(&n_cov, tot);
+      if (ANISO && lane == 0 && tot_h != 0) base_h = atomicAdd(&n_cov_hi, tot_h);
       base = __shfl(base, 0) + pre;
+      base_h = list_cap - 1 - (__shfl(base_h, 0) + pre_h);
 #pragma unroll
-      for (int sm = 0; sm < 4; ++sm)
-        if (inv & (1u << sm)) L.plist[base++] = (unsigned short)(p | (sm << 14));
+      for (int g = 0; g < kG; ++g) {
+        const int p = p0 + g * kThreads + tid;
+#pragma unroll
+        for (int sm = 0; sm < 4; ++sm) {
+          if (inv_lo[g] & (1u << sm)) L.plist[base++] = (unsigned short)(p | (sm << 14));
+          if (ANISO && (inv_hi[g] & (1u << sm))) L.plist[base_h--] = (unsigned short)(p | (sm << 14));
+        }
+      }
     }
     __syncthreads();
-    const int ninv = n_cov;
+    HP_STAMP(3);  // compaction of the invocations
+    const int ninv_lo = n_cov, ninv = ninv_lo + (ANISO ? n_cov_hi : 0);
 #ifdef HP_RABL_NO_SHADE
     const int ninv_loop = a.w < 0 ? ninv : 0;
 #else
     const int ninv_loop = ninv;
 #endif
     for (int q = tid; q < ninv_loop; q += kThreads) {
-      const unsigned e = L.plist[q];
+      const unsigned e = L.plist[q < ninv_lo ? q : list_cap - 1 - (q - ninv_lo)];
       const int p = (int)(e & 0x3FFFu), sm = (int)(e >> 14);
       const int pr = (int)(((unsigned long long)p * a.w_magic) >> 32);
       const int i = row0 + pr, j = p - pr * a.w;
@@ -1100,18 +1237,9 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
       atomicAdd(&zlo[2 * (p * NS + (NS - 1))], mult * (code8(r3[0]) | (code8(r3[1]) << 10) | (code8(r3[2]) << 20)));
       if (cx.need_normal) atomicAdd(&L.nsum[p], mult * (code8(n3[0]) | (code8(n3[1]) << 10) | (code8(n3[2]) << 20)));
     }
-    __syncthreads();
-    for (int p = tid; p < npix; p += kThreads) {
-      const uint32_t sr = zlo[2 * (p * NS + (NS - 1))], sn = L.nsum[p];
-      if ((sr | sn) == 0) continue;  // nothing shaded: the codes are 0 already
-      unsigned cr[3], cn[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { cr[c] = (((sr >> (10 * c)) & 1023u) + 2u) >> 2; cn[c] = (((sn >> (10 * c)) & 1023u) + 2u) >> 2; }
-      zlo[2 * (p * NS + (NS - 1))] = cr[0] | (cr[1] << 8) | (cr[2] << 16) | (cn[0] << 24);
-      L.ex[p] = (unsigned short)(cn[1] | (cn[2] << 8));
-    }
   }
   __syncthreads();
+  HP_STAMP(4);  // shading
 
   // ---- output pass: pixel-parallel; crop taps + the view's run(s) of the pixel record, or the strided planes ----
   const float zn = a.depth_norm_z ? a.depth_norm_z[item] : 1.0f;
@@ -1176,11 +1304,19 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
         const float Z = 1.0f / __uint_as_float(~zbits);  // the key holds ~bits(1 / z)
         o_d = Z > a.depth_max ? 0.0f : Z;
       }
-      if (coded) {
+      if (coded && NS == 1) {
         const uint32_t lo = (uint32_t)slot;
         const uint32_t ex = L.ex[p];
-        o_rgb[0] = (float)(lo & 255u) / 255.0f; o_rgb[1] = (float)((lo >> 8) & 255u) / 255.0f; o_rgb[2] = (float)((lo >> 16) & 255u) / 255.0f;
-        o_n[0] = (float)(lo >> 24) / 255.0f; o_n[1] = (float)(ex & 255u) / 255.0f; o_n[2] = (float)(ex >> 8) / 255.0f;
+        o_rgb[0] = div255((float)(lo & 255u)); o_rgb[1] = div255((float)((lo >> 8) & 255u)); o_rgb[2] = div255((float)((lo >> 16) & 255u));  // = the IEEE quotient (div255)
+        o_n[0] = div255((float)(lo >> 24)); o_n[1] = div255((float)(ex & 255u)); o_n[2] = div255((float)(ex >> 8));
+      } else if (coded) {
+        // the resolve of the 8-bit multisampled buffers: the mean of the four samples' codes, rounded half up (the sums: 3 x 10 bits)
+        const uint32_t sr = (uint32_t)slot, sn = L.nsum[p];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          o_rgb[c] = div255((float)((((sr >> (10 * c)) & 1023u) + 2u) >> 2));
+          o_n[c] = div255((float)((((sn >> (10 * c)) & 1023u) + 2u) >> 2));
+        }
       }
     }
     float d_out = o_d;
@@ -1289,6 +1425,7 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
       else a.depth[dof] = d_out;
     }
   }
+  HP_STAMP(6);  // output pass issued
 }
 
 }  // namespace hp
@@ -1298,7 +1435,8 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
 // captured launch would keep the pointer that is freed here) -- run the call once eagerly, or reserve.
 static int raster_scratch(hp::MeshStore* ms, int n, int n_bands, hipStream_t st, int* chunk_out) {
   const size_t rec_view = (size_t)2 * (size_t)ms->max_faces * 128;
-  const size_t per_view = (size_t)n_bands * (size_t)ms->max_faces * sizeof(int32_t) + rec_view;
+  const size_t xv_view = (size_t)ms->max_verts * sizeof(int4);
+  const size_t per_view = (size_t)n_bands * (size_t)ms->max_faces * sizeof(int32_t) + rec_view + xv_view;
   // Scratch budget: min(8 GB, 1/16 of the device's free memory at the first call); what is allocated is what the largest call
   // needs (a multisampled 240 x 320 view of a 16 k-face object: 7.7 MB of list address space + 4 MB of records).  A call that
   // exceeds it renders in chunks of views.  HP_RASTER_LIST_BUDGET_MB overrides; HP_RASTER_CHUNK_VIEWS=<n> forces chunks (the
@@ -1316,9 +1454,9 @@ static int raster_scratch(hp::MeshStore* ms, int n, int n_bands, hipStream_t st,
   if (chunk < 1) chunk = 1;
   if (chunk > n) chunk = n;
   *chunk_out = chunk;
-  const size_t need_list = (size_t)chunk * n_bands * (size_t)ms->max_faces * sizeof(int32_t), need_cnt = (size_t)chunk * n_bands * sizeof(int32_t);
-  const size_t need_rec = (size_t)chunk * rec_view;
-  if (ms->bin_list_bytes >= need_list && ms->bin_count_bytes >= need_cnt && ms->recs_bytes >= need_rec) return HP_OK;
+  const size_t need_list = (size_t)chunk * n_bands * (size_t)ms->max_faces * sizeof(int32_t), need_cnt = (size_t)chunk * n_bands * 2 * sizeof(int32_t);
+  const size_t need_rec = (size_t)chunk * rec_view, need_xv = (size_t)chunk * xv_view;
+  if (ms->bin_list_bytes >= need_list && ms->bin_count_bytes >= need_cnt && ms->recs_bytes >= need_rec && ms->xverts_bytes >= need_xv) return HP_OK;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (st) (void)hipStreamIsCapturing(st, &cap);
   HP_REQUIRE(cap == hipStreamCaptureStatusNone,
@@ -1335,6 +1473,7 @@ static int raster_scratch(hp::MeshStore* ms, int n, int n_bands, hipStream_t st,
   int rc = grow((void**)&ms->bin_list, &ms->bin_list_bytes, need_list, false);
   if (!rc) rc = grow((void**)&ms->bin_count, &ms->bin_count_bytes, need_cnt, true);  // the kernels keep the counters at zero between launches
   if (!rc) rc = grow((void**)&ms->recs, &ms->recs_bytes, need_rec, false);
+  if (!rc) rc = grow((void**)&ms->xverts, &ms->xverts_bytes, need_xv, false);
   ms->scratch_generation += 1;
   return rc;
 }
@@ -1432,6 +1571,8 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
   a.bin_list = ms->bin_list;
   a.bin_count = ms->bin_count;
   a.recs = ms->recs;
+  a.xverts = ms->xverts;
+  a.max_verts = (int)store->max_verts;
   const size_t lds = band_lds_bytes(npix_max, ns, a.band_rows, w, crop);
   HP_REQUIRE(lds <= 150 * 1024, "hp_rasterize: band does not fit the LDS");
   const bool half = (a.flags & HP_RASTER_OUT_F16) != 0, aniso = (a.flags & HP_RASTER_TEX_ANISO) != 0;
@@ -1452,6 +1593,7 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
     const int nv = n - v0 < chunk ? n - v0 : chunk;
     a.view0 = v0;
     a.n = nv;
+    hipLaunchKernelGGL(raster_xform_kernel, dim3((a.max_verts + 255) / 256, nv), dim3(256), 0, st, a);
     hipLaunchKernelGGL(raster_setup_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
     const int total = nv * a.n_bands;
     hipLaunchKernelGGL(kernels[ki], dim3(8 * ((total + 7) / 8)), dim3(band_threads(ns, bp.wide)), lds, st, a, npix_max);
@@ -1515,7 +1657,7 @@ extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_ite
   HP_REQUIRE(depth_norm_mode == 0 || d_depth_norm_z, "hp_rasterize: depth_norm_z missing");
   RasterArgs a{};
   a.verts4 = store->verts4; a.normals4 = store->normals4; a.uvs = store->uvs; a.colors = store->colors;
-  a.faces4 = store->faces4; a.tex = store->tex; a.obj = store->obj;
+  a.faces4 = store->faces4; a.tex = store->tex; a.tex_quads = store->tex_quads; a.tex_quads_off = store->tex_quads_off; a.obj = store->obj;
   a.obj_ids = d_obj_ids; a.TCO = d_TCO; a.K = d_K; a.ambient = d_ambient;
   a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
   a.rgb = d_rgb; a.nrm = d_nrm; a.depth = d_depth; a.mask = d_mask;
@@ -1561,7 +1703,7 @@ extern "C" int hp_render_inputs(const hp_mesh_store* store, int n_items, int vie
   }
   RasterArgs a{};
   a.verts4 = store->verts4; a.normals4 = store->normals4; a.uvs = store->uvs; a.colors = store->colors;
-  a.faces4 = store->faces4; a.tex = store->tex; a.obj = store->obj;
+  a.faces4 = store->faces4; a.tex = store->tex; a.tex_quads = store->tex_quads; a.tex_quads_off = store->tex_quads_off; a.obj = store->obj;
   a.obj_ids = d_obj_ids; a.TCO = d_TCV_O; a.K = d_KV; a.ambient = d_ambient;
   a.light_pos = d_light_pos; a.light_col = d_light_col; a.depth_norm_z = d_depth_norm_z;
   a.n = n_items * views_per_item; a.views_per_item = views_per_item; a.n_lights = n_lights; a.h = h; a.w = w;
@@ -1587,3 +1729,10 @@ extern "C" int hp_render_inputs(const hp_mesh_store* store, int n_items, int vie
   return launch_raster(store, a, a.n, crop, (hipStream_t)stream);
 }
 
+#ifdef HP_RASTER_STAMPS
+extern "C" int hp_debug_raster_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hp::hp_rstamp), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hp::hp_rstamp), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
