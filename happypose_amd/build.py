@@ -19,7 +19,12 @@ LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libhappypose_amd.so"
 OBJ_DIR = PKG / "build_obj"
 SOURCES = ["api.cpp", "net.cpp", "raster.hip", "geometry.hip", "crop.hip", "conv.hip", "conv_patch.hip", "conv_wino.hip", "conv_wino2.hip", "conv_split.hip", "conv_pp.hip", "conv_igemm_split.hip", "conv_stem_split.hip", "conv_stem7.hip", "conv_f16.hip", "pool_head.hip", "icp.hip", "mbconv.hip", "mbconv_front.hip", "probe.hip", "detect.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
+# -fno-slp-vectorize: the SLP vectoriser turns adjacent scalar fp32 operations into packed-fp32 instructions (v_pk_fma_f32 /
+# v_pk_mul_f32 / v_pk_add_f32 with op_sel operand swizzles).  On gfx950 / ROCm 7.2 those intermittently returned WRONG
+# values when the SIMD co-executed another queue's MFMA stream (two-lane steps: the rasteriser's set-up planes beside the
+# other lane's conv kernels; 100 - 160 of 1200 steps differed, 0 of 2400 with this flag -- DESIGN.md "the co-scheduling
+# non-determinism", tools/probes/two_lane_repro.py).  Explicit vector types (float4 epilogues) are not affected by the flag.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-slp-vectorize",
          "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 
 

@@ -830,7 +830,14 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
     return HP_OK;
   };
   // the guard of an EARLIER forward fired (read without synchronising): from now on exact-fp32 kernels only
-  if (net->h_status && *(volatile unsigned*)net->h_status) net->exact_only = true;
+  // (not while `stream` is capturing: the exact set may still have to be BUILT -- ensure_wino_weights allocates -- and a
+  // capture must record the kernels of the signature it was started for; the flag is adopted by the next eager forward or
+  // by hp_net_status, which the predictors call after every step and which drops the captured graphs)
+  if (net->h_status && *(volatile unsigned*)net->h_status) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+    if (cap == hipStreamCaptureStatusNone) net->exact_only = true;
+  }
   const int net_algo = net->exact_only ? HP_CONV_ALGO_WINOGRAD : (net->algo >= 0 ? net->algo : conv_algo());
   if (!f16 && (rc = ensure_wino_weights(net, net_algo, stream))) return rc;
   static const bool no_act_scale = std::getenv("HP_CONV_NO_ACT_SCALE") != nullptr;  // A/B: the round-2 arithmetic (no activation scale)

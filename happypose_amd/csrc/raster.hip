@@ -263,7 +263,17 @@ __device__ __forceinline__ BiTapP2 bi_setup_p2(int qoff, int w, int h, float u, 
 }
 typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 __device__ __forceinline__ BiTexels bi_load_p2(const uint8_t* texq, const BiTapP2& t) {
+#if defined(HP_TEXQ_4X4)
+  const uint32_t* const qp = reinterpret_cast<const uint32_t*>(texq + t.o);
+  struct { uint32_t x, y, z, w; } q{qp[0], qp[1], qp[2], qp[3]};
+  asm volatile("" ::: "memory");
+#elif defined(HP_TEXQ_2X8)
+  typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+  const u32x2_a8 qa = *reinterpret_cast<const u32x2_a8*>(texq + t.o), qb = *reinterpret_cast<const u32x2_a8*>(texq + t.o + 8);
+  struct { uint32_t x, y, z, w; } q{qa.x, qa.y, qb.x, qb.y};
+#else
   const u32x4_a8 q = *reinterpret_cast<const u32x4_a8*>(texq + t.o);  // the whole 2 x 2 footprint: one 16-B load, 8-B aligned
+#endif
   BiTexels r;
   auto px = [](uint32_t v) { return make_uchar4((unsigned char)(v & 255u), (unsigned char)((v >> 8) & 255u), (unsigned char)((v >> 16) & 255u), (unsigned char)(v >> 24)); };
   r.a = px(q.x); r.c = px(q.y); r.b = px(q.z); r.d = px(q.w);
@@ -297,9 +307,36 @@ __device__ __forceinline__ void tex_fetch_aniso_p2(const CV& cv, const uint8_t* 
   const float du = along_x ? ux : uy, dv = along_x ? vx : vy;
   const bool two = fl > 0.0f && l0 + 1 < nlev;
   const int l1 = two ? l0 + 1 : l0;
+#ifdef HP_TEX_NO_TABLE  // diagnostics: the level geometry / probe positions recomputed per fetch instead of read from the LDS table
+  int off0 = 0, w0 = tw, h0 = th;
+  for (int k = 0; k < l0; ++k) { off0 += 8 * (w0 + 1) * h0; w0 = w0 > 1 ? w0 >> 1 : 1; h0 = h0 > 1 ? h0 >> 1 : 1; }
+  int off1 = off0, w1 = w0, h1 = h0;
+  if (l1 != l0) { off1 += 8 * (w0 + 1) * h0; w1 = w0 > 1 ? w0 >> 1 : 1; h1 = h0 > 1 ? h0 >> 1 : 1; }
+  float tt[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tt[k] = (float)(k + 1) / (float)(N + 1) - 0.5f;
+#else
   const int off0 = mt.qoff[l0], w0 = mt.w[l0], h0 = mt.h[l0];
   const int off1 = mt.qoff[l1], w1 = mt.w[l1], h1 = mt.h[l1];
   const float* const tt = mt.tt[N - 1];
+#endif
+#ifdef HP_TEX_DEBUG_MATH  // diagnostics: colour = a hash of everything the fetch addresses are computed from; no texel is read
+  {
+#if HP_TEX_DEBUG_MATH == 1   // the interpolated coordinates and their derivatives (the records' planes)
+    uint32_t hsh = __float_as_uint(u) * 31u ^ __float_as_uint(v) * 131u ^ __float_as_uint(ux) * 7u ^ __float_as_uint(vx) * 13u ^ __float_as_uint(uy) * 3u ^ __float_as_uint(vy) * 5u;
+#elif HP_TEX_DEBUG_MATH == 2  // the footprint arithmetic on them (sqrt, division, ceil, log2)
+    uint32_t hsh = (uint32_t)N * 2654435761u ^ (uint32_t)l0 * 40503u ^ __float_as_uint(fl);
+#elif HP_TEX_DEBUG_MATH == 3  // the level table
+    uint32_t hsh = (uint32_t)off0 ^ (uint32_t)w0 * 17u ^ (uint32_t)h0 * 257u ^ (uint32_t)off1 * 3u ^ __float_as_uint(tt[0]);
+#else
+    uint32_t hsh = (uint32_t)N * 2654435761u ^ (uint32_t)l0 * 40503u ^ __float_as_uint(fl) ^ __float_as_uint(u) * 31u ^ __float_as_uint(v) * 131u ^
+                   __float_as_uint(du) * 7u ^ __float_as_uint(dv) * 13u ^ (uint32_t)off0 ^ (uint32_t)w0 * 17u;
+#endif
+    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+    rgb[0] = (float)(hsh & 255u) / 255.0f; rgb[1] = (float)((hsh >> 8) & 255u) / 255.0f; rgb[2] = (float)((hsh >> 16) & 255u) / 255.0f;
+    return;
+  }
+#endif
   float acc[3] = {0.0f, 0.0f, 0.0f};
   for (int i = 1; i <= N; i += 2) {
     const bool second = i + 1 <= N;
@@ -660,7 +697,16 @@ __device__ __forceinline__ void shade_centre(const A& a, const ShadeCtx& cx, int
   const int64_t voff = cx.voff, toff = cx.toff;
   const int tw = cx.tw, th = cx.th, view = cx.view, q8 = cx.q8;
   const uint4* const r = cx.recs + (int64_t)(id & 0x3FFFFFFF) * 8;  // (bit 30 of a key's low word: the probe-count class)
+#ifdef HP_REC_SCOPE  // diagnostics: the record read word by word with scoped atomic loads (1: agent = L2-served, 2: system = memory-served)
+  auto ldw = [&](int k) {
+    const uint32_t* wp = reinterpret_cast<const uint32_t*>(r) + k;
+    return HP_REC_SCOPE == 2 ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  const uint4 r0 = make_uint4(ldw(0), ldw(1), ldw(2), ldw(3)), r1 = make_uint4(ldw(4), ldw(5), ldw(6), ldw(7));
+  const uint4 r2 = make_uint4(ldw(8), ldw(9), ldw(10), ldw(11)), r3 = make_uint4(ldw(12), ldw(13), ldw(14), ldw(15));
+#else
   const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+#endif
   const int ox = (int)(short)(r0.x & 0xFFFFu), oy = (int)r0.x >> 16;
   const PlaneQ W{__uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w)};
   const float fx = (float)(j - ox) + 0.5f, fy = (float)(i - oy) + 0.5f;
@@ -1080,7 +1126,11 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
     int off = 0, qo = 0, lw = tw, lh = th;
     for (int k = 0; k < tid; ++k) { off += 4 * lw * lh; qo += 8 * (lw + 1) * lh; lw = lw > 1 ? lw >> 1 : 1; lh = lh > 1 ? lh >> 1 : 1; }
     mips.off[tid] = off; mips.w[tid] = lw; mips.h[tid] = lh; mips.qoff[tid] = qo;
+#ifdef HP_TEX_NO_QUADS
+    if (tid == 0) mips.p2 = 0;
+#else
     if (tid == 0) mips.p2 = qbase >= 0;
+#endif
   }
   if (ANISO && tid < 256) {
     const int N = (tid >> 4) + 1, i = (tid & 15) + 1;

@@ -78,7 +78,9 @@ def test_icp_matches_cpu_restatement_and_recovers_pose(dev, scene):
     K = scene["K"][0].cpu().numpy()
     # (rot_atol, t_atol): the rotation of these blob-like meshes is weakly constrained, so round-off
     # in the normal equations shows up there first; the translation stays tight
-    for iters, (rot_atol, t_atol) in ((1, (2e-5, 2e-5)), (3, (3e-3, 5e-5))):
+    # (1 iteration: 5e-5 since round 5 -- the library is built without the SLP vectoriser, which moved a few FMA contractions in
+    # the normal equations; the CPU restatement's rotation entries then differ by up to 2.6e-5)
+    for iters, (rot_atol, t_atol) in ((1, (5e-5, 2e-5)), (3, (3e-3, 5e-5))):
         short = ICPRefiner(scene["store"].mesh_db, scene["renderer"], n_iterations=iters)
         o, ex = short.refine_poses(preds, depth=scene["measured"], K=scene["K"])
         for n in range(3):

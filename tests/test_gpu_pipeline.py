@@ -777,6 +777,53 @@ def test_index_guards(dev, world):
     assert np.isfinite(init[0]).all() and np.isnan(init[1]).all()
 
 
+def test_two_lane_steps_are_bit_reproducible(dev, world):
+    """The co-scheduling non-determinism of rounds 2-4, root-caused in round 5: packed-fp32 instructions the SLP
+    vectoriser formed (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel swizzles -- in the rasteriser's plane set-up, in
+    round 4 its facing test, in round 2 pose_prep) intermittently returned wrong values while the SIMD co-executed the OTHER
+    lane's MFMA stream: 100 - 160 of 1200 two-lane MegaPose steps differed from the first (texture coordinates of whole views:
+    thousands of colour values), 0 of 2400 when the library is built with -fno-slp-vectorize (happypose_amd/build.py).  The
+    stress: 150 eager two-lane steps of 3 iterations (4 views, normals + depth; > 4000 rasteriser-stage launches beside the
+    other lane's conv launches), EVERY field of every iteration -- the rendered pixels included -- equal to the first step's,
+    bit for bit.  tools/probes/two_lane_repro.py is the stand-alone reproducer (per-process statistics, graph replays)."""
+    from happypose_amd.models import create_model_pose
+    from happypose_amd.synthetic import make_scene
+
+    renderer = world["renderer"]
+    w = _weights("vanilla_resnet34", 32, seed=4)
+    cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+               render_depth=True, input_depth=True, predict_pose_update=True, depth_augmentation=False,
+               depth_normalization_type="tCR_scale_clamp_center")
+    model = create_model_pose(cfg, renderer, state_dict=w, max_batch=48, n_lanes=2)
+    for lane in model.lanes:
+        lane.keep_pixels = True
+    sc = make_scene(n_detections=6, n_hypotheses=8, n_objects=len(renderer.store.labels), seed=9, with_depth=True)
+    labels = [renderer.store.labels[j] for j in sc["hyp_obj_ids"]]
+    args = (torch.as_tensor(sc["images"][:, :4].copy(), device=dev), torch.as_tensor(sc["K"], device=dev), labels,
+            torch.as_tensor(sc["TCO_hyp"], device=dev))
+    im_ids = torch.zeros(len(labels), dtype=torch.int32)
+    fields = ("TCO_input", "TCV_O_input", "boxes_crop", "K_crop", "KV_crop", "images_crop", "renders", "TCO_output")
+
+    def step():
+        out = model.forward(*args, n_iterations=3, im_ids=im_ids)
+        snap = {}
+        for n in (1, 2, 3):
+            o = out[f"iteration={n}"]
+            for f in fields:
+                t = getattr(o, f, None)
+                if t is not None:
+                    snap[(n, f)] = t.clone()
+            snap[(n, "pose")] = o.network_outputs["pose"].clone()
+        return snap
+
+    ref = step()
+    assert ("renders" in {k[1] for k in ref}) and ref[(1, "renders")].abs().sum() > 0
+    for r in range(150):
+        cur = step()
+        for key in ref:
+            assert torch.equal(ref[key], cur[key]), (r, key, int((ref[key] != cur[key]).sum()))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # hipGraph replay of forward() (happypose_amd.graphs): the captured step must reproduce the eager one bit for bit
 # (same kernels, same order, same buffers), on new inputs, with results that survive the next replay.

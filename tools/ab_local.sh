@@ -10,7 +10,7 @@ mkdir -p happypose_amd/lib/abl
 objs=$(python3 -c "from happypose_amd.build import SOURCES; print(' '.join('happypose_amd/build_obj/' + s.replace('.', '_') + '.o' for s in SOURCES if s != '$src'))")
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc $flags -x hip -c happypose_amd/csrc/$src -o /tmp/ab_$name.o 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -fno-gpu-rdc $flags -x hip -c happypose_amd/csrc/$src -o /tmp/ab_$name.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o happypose_amd/lib/abl/$name.so $objs /tmp/ab_$name.o
   echo built $name
 done

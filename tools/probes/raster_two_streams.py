@@ -55,8 +55,17 @@ def co_step():
         torch.matmul(ma, mb)
 
 
+full = bool(int(os.environ.get("HP_PROBE_FULL", "0")))  # rgb + normals + depth (the MegaPose render), else rgb into the 8-float record
+if full:
+    x = torch.zeros((nv, 240, 320, 8), device=dev)
+    zn = prep["tCR"][:, 2].contiguous()
+
+
 def render():
-    ops.rasterize_into(store, x, 3, obj, prep["TCV_O"], prep["K_crop"], False, False, None, 0, msaa=msaa, aniso=aniso)
+    if full:
+        ops.rasterize_into(store, x, 0, obj, prep["TCV_O"], prep["K_crop"], True, True, zn, 2, msaa=msaa, aniso=aniso)
+    else:
+        ops.rasterize_into(store, x, 3, obj, prep["TCV_O"], prep["K_crop"], False, False, None, 0, msaa=msaa, aniso=aniso)
 
 
 torch.cuda.synchronize()

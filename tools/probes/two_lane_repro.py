@@ -75,6 +75,11 @@ for r in range(runs):
                               max_abs=float((ref[key].float() - cur[key].float()).abs().max()))
                 if key[1] in ("renders", "images_crop"):
                     detail["channels"] = [int(c) for c in d.any(0).reshape(d.shape[1], -1).any(1).nonzero().flatten()]
+                    where = d.nonzero()[:2000]
+                    detail["samples"] = [dict(at=[int(v) for v in w], ref=round(float(ref[key][tuple(w)]) * 255, 2), cur=round(float(cur[key][tuple(w)]) * 255, 2))
+                                         for w in where[:: max(1, len(where) // 24)][:24]]
+                    per_row = d.reshape(d.shape[0], -1).sum(1)
+                    detail["per_row"] = {int(r): int(per_row[r]) for r in per_row.nonzero().flatten()}
                 if key[1].startswith("x_lane"):  # [rows, h, w, record]
                     detail["channels"] = [int(c) for c in d.reshape(-1, d.shape[-1]).any(0).nonzero().flatten()]
                     detail["pixels"] = int(d.any(-1).sum())
