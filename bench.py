@@ -174,8 +174,57 @@ def e2e_run(device, rank, world, lanes, coarse_precision, steps, warmup, run_det
     if detector is not None:
         stage_ms["detection"] = 1e3 * det_s[0] / steps
     stage_ms["host_and_bookkeeping"] = 1e3 * elapsed / steps - sum(stage_ms.values())
+    cp = extra["coarse"]["preds"]
+    product = dict(coarse_logit=cp.infos.coarse_logit.values.astype(np.float64), final_hyp=final.infos.hypothesis_id.tolist(),
+                   final_labels=final.infos.label.tolist(), final_poses=final.poses.cpu().numpy(),
+                   filtered_hyp=extra["coarse_filter"]["preds"].infos.hypothesis_id.tolist())
     return {"elapsed": elapsed, "steps": steps, "prof": prof, "conv_union_ms": conv_union_ms, "stage_ms_per_frame": stage_ms,
-            "timing_str": extra["timing_str"]}
+            "timing_str": extra["timing_str"], "product": product,
+            "job_inputs": dict(images=scene["images"][:, :3], K=scene["K"], labels=[store.labels[i] for i in scene["det_obj_ids"]], boxes=boxes,
+                               wc=wc, wr=wr, packed=store.packed, points=store.mesh_db.points, store_labels=list(store.labels),
+                               render_kw=dict(msaa=renderer.msaa, aniso=renderer.aniso))}
+
+
+def e2e_oracle(job, cores=None):
+    """The SAME end-to-end job (8 detections x 576 coarse poses, top-5, 5 refiner iterations x 40 hypotheses x 4 views, re-scoring,
+    top-1) through the CPU oracle's estimator (oracle/estimator.py: the checker, fp32 throughout), once, on every host core --
+    about a minute.  Returns its result dict and the seconds it took."""
+    from oracle import native as oracle_native
+    from oracle.estimator import OracleEstimator
+    from oracle.pipeline import OraclePredictor
+
+    cores = cores or effective_cpu_count()
+    oracle_native.set_threads(cores)
+    torch.set_num_threads(cores)
+    rk = job["render_kw"]
+    oc = OraclePredictor(job["wc"], job["packed"], job["points"], arch="vanilla_resnet34", render_normals=True, **rk)
+    orf = OraclePredictor(job["wr"], job["packed"], job["points"], arch="vanilla_resnet34", n_views=4, multiview_type="TCO+front_3views",
+                          render_normals=True, **rk)
+    t0 = time.time()
+    ref = OracleEstimator(orf, oc, job["store_labels"], SO3_grid_size=576, bsz_objects=8, bsz_images=576).run_inference_pipeline(
+        job["images"], job["K"], job["labels"], job["boxes"], n_refiner_iterations=N_ITERS, n_pose_hypotheses=5,
+        instance_id=np.arange(len(job["labels"])))
+    return ref, time.time() - t0
+
+
+def e2e_parity(product, ref, logit_tol):
+    """Final-pose parity of an end-to-end run against the oracle estimator's run of the same job: coarse logits of all 4608 poses,
+    the top-5 selection, and -- for the detections where both sides picked the same hypothesis in the end -- the final poses."""
+    cl = ref["coarse_df"]["coarse_logit"].values.astype(np.float64)
+    same_top = sorted(product["filtered_hyp"]) == sorted(ref["filtered_df"]["hypothesis_id"].tolist())
+    rl = dict(zip(ref["final_df"]["label"].tolist(), zip(ref["final_df"]["hypothesis_id"].tolist(), range(len(ref["final_df"])))))
+    match, dts, drs = 0, [], []
+    for k, (lab, hyp) in enumerate(zip(product["final_labels"], product["final_hyp"])):
+        if lab in rl and rl[lab][0] == hyp:
+            match += 1
+            pp = pose_parity(product["final_poses"][k:k + 1], ref["final_TCO"][rl[lab][1]:rl[lab][1] + 1])
+            dts.append(pp["max_dt_m"]); drs.append(pp["max_dR_rad"])
+    return {"coarse_logit_max_abs_diff": float(np.abs(product["coarse_logit"] - cl).max()), "coarse_logit_tol": logit_tol,
+            "top5_sets_equal": bool(same_top), "detections": len(product["final_hyp"]), "final_hypothesis_agrees": match,
+            "max_dt_m": max(dts) if dts else None, "max_dR_rad": max(drs) if drs else None, "tol": {"dt_m": T_TOL, "dR_rad": R_TOL},
+            "ok": bool(np.abs(product["coarse_logit"] - cl).max() <= logit_tol and (not dts or (max(dts) <= T_TOL and max(drs) <= R_TOL))),
+            "note": "a detection whose two best hypotheses score within the logit tolerance of each other may legitimately end on the other one: "
+                    "poses are compared where the final hypothesis ids agree"}
 
 
 def bench_e2e(args, device, rank, world):
@@ -498,6 +547,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the 3-step C3 / C5 runs appended to the C2 line")
     ap.add_argument("--no-cpu-1thread", action="store_true")
+    ap.add_argument("--no-e2e-parity", action="store_true", help="skip the oracle estimator's run of the end-to-end job (about a minute of CPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -750,6 +800,7 @@ def main():
         if estimator is not None:
             line["estimator_ms_per_step"] = estimator["ms_per_step"]
             line["estimator"] = dict(estimator, overhead_vs_predictor=estimator["ms_per_step"] / line["ms_per_step"] - 1.0)
+        line["arithmetic"] = ("3xf16-split products (22 significant bits), fp32 accumulate" if precision == "f32" else "fp16 products, fp32 accumulate")
         if precision == "f32":
             line["dtype_note"] = ("fp32 tensors and fp32 accumulation everywhere; the convolutions multiply fp16 hi/lo halves of the fp32 "
                                   "operands (three fp16 MFMAs per product, 22 significant bits: per-layer error vs fp64 as the exact-fp32 "
@@ -793,6 +844,7 @@ def main():
                     import gc
 
                     gc.collect()
+                    e2e_products = {}
                     for key, cprec in (("e2e", "f32"), ("e2e_f16_coarse", "f16")):
                         # the second one: the coarse / scoring model on the fp16 plan (BASELINE.json config 5 names fp16 for that
                         # stage), the refiner in fp32 as always
@@ -803,7 +855,13 @@ def main():
                                      "job": "PoseEstimator.run_inference_pipeline: Mask-RCNN detector (random weights, timed, its detections "
                                             "discarded) + 8 detections x 576-pose coarse grid, top-5, 5 refiner iterations x 40 hypotheses x 4 "
                                             "views, re-scoring, top-1; pandas bookkeeping included"}
+                        e2e_products[key] = (r["product"], r["job_inputs"])
                         gc.collect()
+                    if not args.no_cpu_baseline and not args.no_e2e_parity and world == 1:
+                        # final-pose parity of BOTH end-to-end runs against ONE run of the oracle estimator on the same job
+                        ref, secs = e2e_oracle(e2e_products["e2e"][1])
+                        for key, tol in (("e2e", 5e-3), ("e2e_f16_coarse", 5e-2)):  # logits: fp32 as in the tests; the fp16 plan's stated 5e-2
+                            line[key]["parity"] = dict(e2e_parity(e2e_products[key][0], ref, tol), oracle_seconds=round(secs, 1))
                 except Exception as e:
                     line.setdefault("e2e", {"error": f"{type(e).__name__}: {e}"})
                     line.setdefault("e2e_f16_coarse", {"error": f"{type(e).__name__}: {e}"})

@@ -89,7 +89,7 @@ constexpr int kSmallArea = 6;  // ... up to which a record goes to the front of 
 // NS: keys per pixel (1 / 5); WIDE: the multisampled instantiation for renders wider than 640 px (512 threads, 6400 keys)
 constexpr __host__ __device__ int band_threads(int ns, bool wide = false) { return ns == 1 ? HP_RASTER_THREADS : wide ? 512 : HP_RASTER_THREADS_MSAA; }
 constexpr int kBinThreads = 256;   // set-up kernel: small workgroups (six per CU) -- a 1024-thread workgroup left one per CU waiting at its barriers (66 us per 128 views instead of ~25)
-constexpr int kMaxBands = 512;  // 480 one-row multisampled bands of a 640-wide render
+constexpr int kMaxBands = 768;  // 720 one-row multisampled bands of a 1280 x 720 render
 
 struct RasterArgs {
   const float4* verts4;   // xyz + pad

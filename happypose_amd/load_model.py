@@ -115,13 +115,16 @@ def load_pose_models(coarse_run_id: Optional[str], refiner_run_id: Optional[str]
 
 
 def load_named_model(model_name: str, object_dataset: RigidObjectDataset, n_workers: int = 4, bsz_images: int = 128,
-                     models_root: Optional[Path] = None, device="cuda") -> PoseEstimator:
-    """``TB/utils/load_model.py:52-88``."""
+                     models_root: Optional[Path] = None, device="cuda", coarse_precision: str = "f32") -> PoseEstimator:
+    """``TB/utils/load_model.py:52-88``.  ``coarse_precision`` (beyond the reference's signature): ``"f16"`` plans the coarse /
+    scoring network in fp16 (BASELINE.json config 5: 576 views per object are SCORED, not regressed -- the stated tolerance is
+    5e-2 on a logit, tests/test_gpu_pipeline.py); the refiner always runs in fp32.  Measured on the end-to-end frame:
+    ``bench.py`` keys ``e2e`` / ``e2e_f16_coarse``, each with its parity against the oracle estimator."""
     model = NAMED_MODELS[model_name]
     coarse_model, refiner_model, mesh_db = load_pose_models(
         coarse_run_id=model["coarse_run_id"], refiner_run_id=model["refiner_run_id"], object_dataset=object_dataset,
         force_panda3d_renderer=True, renderer_kwargs={"preload_cache": False, "split_objects": False, "n_workers": n_workers},
-        models_root=models_root, device=device, max_batch=bsz_images)
+        models_root=models_root, device=device, max_batch=bsz_images, coarse_precision=coarse_precision)
     depth_refiner = None
     if model.get("depth_refiner") == "ICP":
         from .icp_refiner import ICPRefiner

@@ -159,6 +159,29 @@ def test_rasterizer_texture_filter_vs_oracle(dev, scene_store, msaa, tex_size):
     assert gx(rgb) < gx(plain[0].cpu().numpy())                                        # ... namely smooth the minified texture
 
 
+def test_rasterizer_msaa_wider_than_640(dev, scene_store):
+    """Multisampled renders wider than 640 px (720 x 540 T-LESS frames, 1280 x 720 visualisation renders) take the 512-thread /
+    6400-key instantiation of the band kernel (the 256-thread / 3200-key one holds 640 five-key pixels per row): same
+    definition, against the oracle; a 1281-wide multisampled render is refused with a message."""
+    from happypose_amd import ops
+    from oracle import native
+
+    n = 2
+    T = _poses(n, 13, zlo=0.4, zhi=0.6)
+    K = np.tile(np.array([[1100.0, 0, 360], [0, 1100.0, 270], [0, 0, 1]], np.float32), (n, 1, 1))
+    obj = np.array([0, 2], np.int32)
+    gpu = ops.rasterize(scene_store, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), (540, 720), render_normals=True,
+                        render_depth=True, msaa=True, aniso=True)
+    ref = native.rasterize(scene_store.packed, obj, T, K, (540, 720), True, True, False, msaa=True, aniso=True)
+    assert (ref["depths"] > 0).mean() > 0.05
+    assert np.array_equal(gpu[2].cpu().numpy(), ref["depths"])                   # coverage and depth: exact integer / same-order fp32 arithmetic
+    for got, want in ((gpu[0].cpu().numpy(), ref["rgbs"]), (gpu[1].cpu().numpy(), ref["normals"])):
+        d = np.abs(got - want).max(1)
+        assert (d > 1.5 / 255).mean() < 2e-3 and d.max() <= 0.5 + 1e-6
+    with pytest.raises(Exception, match="too wide"):
+        ops.rasterize(scene_store, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), (64, 1281), msaa=True)
+
+
 CONVENTION_FLIPS = [
     dict(msaa_x=(0.25, 0.75, 0.25, 0.75), msaa_y=(0.25, 0.25, 0.75, 0.75)),            # ordered-grid samples
     dict(msaa_x=(0.625, 0.125, 0.875, 0.375), msaa_y=(0.125, 0.375, 0.625, 0.875)),    # the mirrored rotated grid

@@ -22,7 +22,7 @@ def main():
     out, specs = sys.argv[1], sys.argv[2:]
     res = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one pass per counter AND per workload over tools/stage_workload.py "
                      "(HP_STAGE_ONLY=raster, reference render state); FETCH_SIZE x 2 (gfx950 wide-read correction), 1024-B units; "
-                     "bytes per call = sum over the raster_xform / raster_bin / raster_kernel dispatches of the timed calls / calls",
+                     "bytes per call = sum over the raster_xform / raster_setup / raster_kernel dispatches of the timed calls / calls",
            "workloads": {}}
     for spec in specs:
         wl, fd, wd, sj = spec.split(":")
@@ -43,13 +43,13 @@ def main():
                 tot_f += fb; tot_w += wb
         # xform / bin dispatches of the one depth-only pass are in the totals: (calls + 1) passes launched them
         scale = calls / (calls + 1.0)
-        xb = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in per_kernel.items() if k.startswith(("raster_xform", "raster_bin")))
+        xb = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in per_kernel.items() if k.startswith(("raster_xform", "raster_bin", "raster_setup")))
         band = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in per_kernel.items() if k.startswith("raster_kernel<5"))
         counter_per_call = (band + xb * scale) / calls
         alg = stage["raster"]["algorithmic_MB"] * 1e6
         res["workloads"][wl] = {"views": stage["views"], "calls": calls, "us_per_call": stage["raster"]["us"], "algorithmic_bytes_per_call": alg,
                                 "counter_bytes_per_call": counter_per_call, "fetch_bytes_per_call": (tot_f - (1 - scale) * sum(
-                                    v["fetch_bytes"] for k, v in per_kernel.items() if k.startswith(("raster_xform", "raster_bin")))) / calls,
+                                    v["fetch_bytes"] for k, v in per_kernel.items() if k.startswith(("raster_xform", "raster_bin", "raster_setup")))) / calls,
                                 "counter_over_algorithmic": counter_per_call / alg, "per_kernel": per_kernel}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_kernel"} for k, v in res["workloads"].items()}, indent=1))
