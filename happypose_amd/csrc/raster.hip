@@ -124,7 +124,8 @@ struct RasterArgs {
   int4* xverts;         // [chunk views][max_verts] {x, y, bits(1 / z), bits(z)} written by raster_xform_kernel
   // set-up records of the chunk's views: [view][rec_slots = 2 * max_faces] x 128 B (FaceRec)
   uint4* recs;
-  int rec_slots;
+  uint4* recs_wide;     // [view][rec_slots][2]: the corners of a BIG sub-triangle as int32 (rare: the lines are only touched then)
+  int rec_slots, rec_q;  // rec_q: uint4s per record -- 4 (64 B: coverage + texture planes) or 8 (128 B: + barycentric planes, need_attr)
   int need_attr;        // the shading needs barycentrics (normals, point lights or vertex colours): sector 2 of the records
   // ---- record mode (rec != nullptr): the network input [item][row][col][rec_col elements], fp32 or fp16.  View v of an
   // item writes its render channels (rgb, normals, depth as requested) at element v_c0[v] of the pixel record and, when
@@ -420,7 +421,7 @@ __device__ __forceinline__ SnapCorner project_corner(const float (&Kv)[9], const
   return r;
 }
 __device__ __forceinline__ bool setup_subtri(const RasterArgs& a, const SnapCorner& c0, const SnapCorner& c1, const SnapCorner& c2,
-                                             const float2 (&uv)[3], const int4 tri, int cull_flag, int tw, int th, uint4* rec, int& row_lo, int& row_hi, int& cols) {
+                                             const float2 (&uv)[3], const int4 tri, int cull_flag, int tw, int th, uint4* rec, uint4* wrec, int& row_lo, int& row_hi, int& cols) {
   int x[3] = {c0.x, c1.x, c2.x}, y[3] = {c0.y, c1.y, c2.y};
   float wk[3] = {c0.w, c1.w, c2.w};
   long long area2 = (long long)(x[1] - x[0]) * (long long)(y[2] - y[0]) - (long long)(x[2] - x[0]) * (long long)(y[1] - y[0]);
@@ -500,8 +501,8 @@ __device__ __forceinline__ bool setup_subtri(const RasterArgs& a, const SnapCorn
     rec[5] = make_uint4(fb(NB2.qx), fb(NB2.qy), (uint32_t)tri.z, 0u);
   }
   if (big) {
-    rec[6] = make_uint4((uint32_t)rx[0], (uint32_t)ry[0], (uint32_t)rx[1], (uint32_t)ry[1]);
-    rec[7] = make_uint4((uint32_t)rx[2], (uint32_t)ry[2], 0u, 0u);
+    wrec[0] = make_uint4((uint32_t)rx[0], (uint32_t)ry[0], (uint32_t)rx[1], (uint32_t)ry[1]);
+    wrec[1] = make_uint4((uint32_t)rx[2], (uint32_t)ry[2], 0u, 0u);
   }
   row_lo = ia; row_hi = i1; cols = j1 - ja + 1;
   return true;
@@ -589,7 +590,8 @@ __global__ __launch_bounds__(kBinThreads) void raster_setup_kernel(RasterArgs a)
   int lo = 0, hi = -1, cols = 0, lo2 = 0, hi2 = -1, cols2 = 0;  // candidate rows / columns of the two
   // a mip-mapped texture will be filtered anisotropically: the set-up classifies the triangles' probe counts
   const int ftw = (a.flags & HP_RASTER_TEX_ANISO) && ob[4] >= 0 && ob[7] > 1 ? (int)ob[5] : 0, fth = (int)ob[6];
-  uint4* const recs = a.recs + (int64_t)lv * a.rec_slots * 8;
+  uint4* const recs = a.recs + (int64_t)lv * a.rec_slots * a.rec_q;
+  uint4* const wide = a.recs_wide + (int64_t)lv * a.rec_slots * 2;
   if (f < nf) {
     const int4 tri = a.faces4[ob[2] + f];
     const int64_t voff = ob[0];
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(kBinThreads) void raster_setup_kernel(RasterArgs a)
         const SnapCorner s0{v0.x, v0.y, __uint_as_float((uint32_t)v0.z), {1.f, 0.f, 0.f}};
         const SnapCorner s1{v1.x, v1.y, __uint_as_float((uint32_t)v1.z), {0.f, 1.f, 0.f}};
         const SnapCorner s2{v2.x, v2.y, __uint_as_float((uint32_t)v2.z), {0.f, 0.f, 1.f}};
-        if (setup_subtri(a, s0, s1, s2, uv, tri, view_cull ? tri.w : 0, ftw, fth, recs + (int64_t)f * 8, lo, hi, cols)) {
+        if (setup_subtri(a, s0, s1, s2, uv, tri, view_cull ? tri.w : 0, ftw, fth, recs + (int64_t)f * a.rec_q, wide + (int64_t)f * 2, lo, hi, cols)) {
           b0 = lo / a.band_rows; b1 = hi / a.band_rows;
         }
       } else {
@@ -630,12 +632,12 @@ __global__ __launch_bounds__(kBinThreads) void raster_setup_kernel(RasterArgs a)
         const SnapCorner S0 = project_corner(x.Kv, R0);
         if (n_in == 1) {
           const SnapCorner P1 = project_corner(x.Kv, isect_near(R0, R1)), P2 = project_corner(x.Kv, isect_near(R0, R2));
-          if (setup_subtri(a, S0, P1, P2, uv, tri, 0, ftw, fth, recs + (int64_t)f * 8, lo, hi, cols)) { b0 = lo / a.band_rows; b1 = hi / a.band_rows; }
+          if (setup_subtri(a, S0, P1, P2, uv, tri, 0, ftw, fth, recs + (int64_t)f * a.rec_q, wide + (int64_t)f * 2, lo, hi, cols)) { b0 = lo / a.band_rows; b1 = hi / a.band_rows; }
         } else {
           const SnapCorner S1 = project_corner(x.Kv, R1);
           const SnapCorner P2 = project_corner(x.Kv, isect_near(R1, R2)), P3 = project_corner(x.Kv, isect_near(R0, R2));
-          if (setup_subtri(a, S0, S1, P2, uv, tri, 0, ftw, fth, recs + (int64_t)f * 8, lo, hi, cols)) { b0 = lo / a.band_rows; b1 = hi / a.band_rows; }
-          if (setup_subtri(a, S0, P2, P3, uv, tri, 0, ftw, fth, recs + (int64_t)(nf + f) * 8, lo2, hi2, cols2)) { c0 = lo2 / a.band_rows; c1 = hi2 / a.band_rows; }
+          if (setup_subtri(a, S0, S1, P2, uv, tri, 0, ftw, fth, recs + (int64_t)f * a.rec_q, wide + (int64_t)f * 2, lo, hi, cols)) { b0 = lo / a.band_rows; b1 = hi / a.band_rows; }
+          if (setup_subtri(a, S0, P2, P3, uv, tri, 0, ftw, fth, recs + (int64_t)(nf + f) * a.rec_q, wide + (int64_t)(nf + f) * 2, lo2, hi2, cols2)) { c0 = lo2 / a.band_rows; c1 = hi2 / a.band_rows; }
         }
       }
     }
@@ -696,7 +698,7 @@ __device__ __forceinline__ void shade_centre(const A& a, const ShadeCtx& cx, int
   const float* T = cx.T; const float* Kv = cx.Kv; const float* amb = cx.amb;
   const int64_t voff = cx.voff, toff = cx.toff;
   const int tw = cx.tw, th = cx.th, view = cx.view, q8 = cx.q8;
-  const uint4* const r = cx.recs + (int64_t)(id & 0x3FFFFFFF) * 8;  // (bit 30 of a key's low word: the probe-count class)
+  const uint4* const r = cx.recs + (int64_t)(id & 0x3FFFFFFF) * a.rec_q;  // (bit 30 of a key's low word: the probe-count class)
 #ifdef HP_REC_SCOPE  // diagnostics: the record read word by word with scoped atomic loads (1: agent = L2-served, 2: system = memory-served)
   auto ldw = [&](int k) {
     const uint32_t* wp = reinterpret_cast<const uint32_t*>(r) + k;
@@ -956,10 +958,10 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
   // the band's list: the first entry's loads are issued before anything else (a non-finite view set nothing up: cnt = 0)
   const int cnt_s = min(a.bin_count[2 * lin], a.bin_cap), cnt = cnt_s + min(a.bin_count[2 * lin + 1], a.bin_cap - cnt_s);
   const int32_t* const list = a.bin_list + (int64_t)lin * a.bin_cap;
-  const uint4* const recs = a.recs + (int64_t)lv * a.rec_slots * 8;
+  const uint4* const recs = a.recs + (int64_t)lv * a.rec_slots * a.rec_q;
   auto entry = [&](int k) { return k < cnt_s ? list[k] : list[a.bin_cap - 1 - (k - cnt_s)]; };  // small boxes first, the others from the back
   int id_n = tid < cnt ? entry(tid) : 0;
-  uint4 q0_n = recs[(int64_t)id_n * 8], q1_n = recs[(int64_t)id_n * 8 + 1];
+  uint4 q0_n = recs[(int64_t)id_n * a.rec_q], q1_n = recs[(int64_t)id_n * a.rec_q + 1];
 
   const int item = view / a.views_per_item, vi = view % a.views_per_item;
   const int64_t* ob = a.obj + 8 * (int64_t)a.obj_ids[item];
@@ -1013,7 +1015,7 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
     const uint4 q0 = q0_n, q1 = q1_n;
     if (k + kThreads < cnt_loop) {
       id_n = entry(k + kThreads);
-      q0_n = recs[(int64_t)id_n * 8]; q1_n = recs[(int64_t)id_n * 8 + 1];
+      q0_n = recs[(int64_t)id_n * a.rec_q]; q1_n = recs[(int64_t)id_n * a.rec_q + 1];
     }
     const int ox = (int)(short)(q0.x & 0xFFFFu), oy = (int)q0.x >> 16;
     const uint32_t key_lo = (uint32_t)id | ((q0.y & 2u) << 29);  // bit 30: the probe-count class (shading groups invocations by it)
@@ -1074,13 +1076,14 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
   const int nbig = band_empty ? 0 : min(big_n, kBigQueue);
   for (int q = 0; q < nbig; ++q) {
     const int id = big_q[q];
-    const uint4* const r = recs + (int64_t)id * 8;
+    const uint4* const r = recs + (int64_t)id * a.rec_q;
     const uint4 q0 = r[0], q1 = r[1];
     const int ox = (int)(short)(q0.x & 0xFFFFu), oy = (int)q0.x >> 16;
     const uint32_t key_lo = (uint32_t)id | ((q0.y & 2u) << 29);
     int rx[3], ry[3];
     if (q0.y & 1u) {
-      const uint4 q6 = r[6], q7 = r[7];
+      const uint4* const wr = a.recs_wide + ((int64_t)lv * a.rec_slots + id) * 2;
+      const uint4 q6 = wr[0], q7 = wr[1];
       rx[0] = (int)q6.x; ry[0] = (int)q6.y; rx[1] = (int)q6.z; ry[1] = (int)q6.w; rx[2] = (int)q7.x; ry[2] = (int)q7.y;
     } else {
       rx[0] = (int)(short)(q0.z & 0xFFFFu); rx[1] = (int)(short)(q0.w & 0xFFFFu); rx[2] = (int)(short)(q1.x & 0xFFFFu);
@@ -1484,7 +1487,7 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
 // counters and the per-(view, sub-triangle) set-up records.  Grows, never shrinks; refuses to grow under stream capture (a
 // captured launch would keep the pointer that is freed here) -- run the call once eagerly, or reserve.
 static int raster_scratch(hp::MeshStore* ms, int n, int n_bands, hipStream_t st, int* chunk_out) {
-  const size_t rec_view = (size_t)2 * (size_t)ms->max_faces * 128;
+  const size_t rec_view = (size_t)2 * (size_t)ms->max_faces * (128 + 32);  // records (up to 128 B) + the wide corners (32 B) per slot
   const size_t xv_view = (size_t)ms->max_verts * sizeof(int4);
   const size_t per_view = (size_t)n_bands * (size_t)ms->max_faces * sizeof(int32_t) + rec_view + xv_view;
   // Scratch budget: min(8 GB, 1/16 of the device's free memory at the first call); what is allocated is what the largest call
@@ -1621,6 +1624,8 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
   a.bin_list = ms->bin_list;
   a.bin_count = ms->bin_count;
   a.recs = ms->recs;
+  a.rec_q = a.need_attr ? 8 : 4;
+  a.recs_wide = ms->recs + (size_t)chunk * a.rec_slots * 8;  // behind the chunk's (up to 128-B) records
   a.xverts = ms->xverts;
   a.max_verts = (int)store->max_verts;
   const size_t lds = band_lds_bytes(npix_max, ns, a.band_rows, w, crop);
