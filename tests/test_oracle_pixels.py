@@ -218,3 +218,71 @@ def test_raster_conventions_record_and_calibration_self_test():
     assert report["eye-normal axis map"]["margin"] > 10 and report["anisotropic filter rule"]["score"] < 1e-3
     assert report["multisample positions"]["score"] < 1e-3 and report["multisample positions"]["margin"] > 0.3
     assert best["normal_axis"] == (0, 2, 1) and best["aniso_max"] == 8 and best["aniso_round"] == 1 and best["lod_bias"] == 0.5
+
+
+def _jittered_sheet(rs, n=9, flip=None, rot=None):
+    """A planar n x n grid of jittered vertices, each cell split along a random diagonal; white vertex colours.
+    ``flip`` / ``rot``: per-face winding flips and cyclic rotations of the index triple (the same surface)."""
+    g = np.linspace(-0.5, 0.5, n)
+    xx, yy = np.meshgrid(g, g)
+    v = np.stack([xx, yy, np.zeros_like(xx)], -1).reshape(-1, 3)
+    inner = ((np.abs(v[:, 0]) < 0.49) & (np.abs(v[:, 1]) < 0.49))
+    v[inner, :2] += rs.uniform(-0.4, 0.4, (inner.sum(), 2)) / (n - 1)
+    faces = []
+    for i in range(n - 1):
+        for j in range(n - 1):
+            a, b, c, d = i * n + j, i * n + j + 1, (i + 1) * n + j + 1, (i + 1) * n + j
+            faces += [[a, b, c], [a, c, d]] if rs.rand() < 0.5 else [[a, b, d], [b, c, d]]
+    f = np.array(faces, np.int32)
+    if flip is not None:
+        f[flip] = f[flip][:, ::-1]
+    if rot is not None:
+        f = np.stack([np.roll(t, r) for t, r in zip(f, rot)])
+    nrm = np.tile([0, 0, -1.0], (len(v), 1)).astype(np.float32)
+    col = np.full((len(v), 4), 255, np.uint8)
+    return PackedMeshes(RigidObjectDataset([RigidObject("sheet", MeshData(v, f, nrm, None, col))]))
+
+
+def test_rasteriser_coverage_rules_are_watertight_and_order_independent():
+    """The fixed-point coverage definition (oracle.c, rasteriser header): vertices snapped to 1/256 px, exact integer edge
+    functions, top-left rule.  What follows from it and from nothing weaker: a shared edge leaves no sample uncovered
+    (every interior pixel of a white sheet resolves to exactly 1.0 under 4x multisampling), and winding or the order
+    of a face's index triple changes neither coverage nor -- beyond the plane's fp32 set-up -- depth."""
+    K = np.array([[260, 0, 160.3], [0, 255, 119.6], [0, 0, 1]], np.float32)
+    ang = np.deg2rad([35.0, -20.0, 10.0])
+    Rx = np.array([[1, 0, 0], [0, np.cos(ang[0]), -np.sin(ang[0])], [0, np.sin(ang[0]), np.cos(ang[0])]])
+    Ry = np.array([[np.cos(ang[1]), 0, np.sin(ang[1])], [0, 1, 0], [-np.sin(ang[1]), 0, np.cos(ang[1])]])
+    Rz = np.array([[np.cos(ang[2]), -np.sin(ang[2]), 0], [np.sin(ang[2]), np.cos(ang[2]), 0], [0, 0, 1]])
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = (0.01, -0.02, 1.1)
+    nf = 2 * 8 * 8
+    base = _jittered_sheet(np.random.RandomState(3))
+    rs = np.random.RandomState(4)
+    other = _jittered_sheet(np.random.RandomState(3), flip=rs.rand(nf) < 0.5, rot=rs.randint(0, 3, nf))
+    for msaa in (False, True):
+        a = native.rasterize(base, [0], T[None], K[None], (240, 320), render_depth=True, render_binary_mask=True, quant8=False, msaa=msaa)
+        b = native.rasterize(other, [0], T[None], K[None], (240, 320), render_depth=True, render_binary_mask=True, quant8=False, msaa=msaa)
+        m = a["binary_masks"][0, 0]
+        assert 20000 < m.sum() < 60000
+        assert np.array_equal(m, b["binary_masks"][0, 0])
+        np.testing.assert_allclose(a["rgbs"], b["rgbs"], atol=3e-7)  # interpolated from fp32 attribute planes
+        np.testing.assert_allclose(a["depths"], b["depths"], atol=2e-6)
+        # interior = covered pixels whose 8 neighbours are covered: no seam may show there
+        inner = m.copy()
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                inner &= np.roll(np.roll(m, dy, 0), dx, 1)
+        assert inner.sum() > 0.9 * m.sum()
+        assert (np.abs(a["rgbs"][0][:, inner] - 1.0) < 3e-7).all()  # an uncovered sample would cost 0.25
+        # the sheet is one plane: depth is that plane at the pixel centre, whichever triangle owns the pixel
+        n_cam = T[:3, :3] @ np.array([0, 0, 1.0])
+        d0 = float(n_cam @ T[:3, 3])
+        jj, ii = np.meshgrid(np.arange(320) + 0.5, np.arange(240) + 0.5)
+        ray = np.stack([(jj - K[0, 2]) / K[0, 0], (ii - K[1, 2]) / K[1, 1], np.ones_like(jj)], -1)
+        z = d0 / (ray @ n_cam)
+        np.testing.assert_allclose(a["depths"][0, 0][inner], z[inner], rtol=2e-5)
+    # the mask does not depend on the sample pattern: depth is resolved at the pixel centre in both states
+    c1 = native.rasterize(base, [0], T[None], K[None], (240, 320), render_depth=True, quant8=False, msaa=False)
+    c4 = native.rasterize(base, [0], T[None], K[None], (240, 320), render_depth=True, quant8=False, msaa=True)
+    np.testing.assert_array_equal(c1["depths"], c4["depths"])
