@@ -17,6 +17,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libhappypose_amd.so"
+TORCH_LIB = LIB_DIR / "libhappypose_amd_torch.so"
 OBJ_DIR = PKG / "build_obj"
 SOURCES = ["api.cpp", "net.cpp", "raster.hip", "geometry.hip", "crop.hip", "conv.hip", "conv_patch.hip", "conv_wino.hip", "conv_wino2.hip", "conv_split.hip", "conv_pp.hip", "conv_igemm_split.hip", "conv_stem_split.hip", "conv_stem7.hip", "conv_f16.hip", "pool_head.hip", "icp.hip", "mbconv.hip", "mbconv_front.hip", "probe.hip", "detect.hip"]
 # -fno-slp-vectorize: the SLP vectoriser turns adjacent scalar fp32 operations into packed-fp32 instructions (v_pk_fma_f32 /
@@ -62,7 +63,27 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     objs = [str(OBJ_DIR / (s.replace(".", "_") + ".o")) for s in SOURCES]
     if force or jobs or not LIB.exists():
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs])
+    build_torch_library(force=force, run=run)
     return LIB
+
+
+def build_torch_library(force: bool = False, run=subprocess.check_call) -> Path:
+    """``csrc/torch_library.cpp`` -> ``lib/libhappypose_amd_torch.so``: the compiled TORCH_LIBRARY over the C ABI (host code
+    only; g++ against the installed torch's headers, linked to libhappypose_amd.so through ``$ORIGIN``)."""
+    src = CSRC / "torch_library.cpp"
+    if not (force or _stale(TORCH_LIB, [src, PKG.parent / "include" / "happypose_amd.h", LIB])):
+        return TORCH_LIB
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    tlib = Path(torch.__file__).resolve().parent / "lib"
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           *[f"-isystem{p}" for p in ce.include_paths("cuda")], str(src), "-o", str(TORCH_LIB),
+           f"-L{LIB_DIR}", "-lhappypose_amd", f"-L{tlib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch",
+           "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    run(cmd)
+    return TORCH_LIB
 
 
 if __name__ == "__main__":

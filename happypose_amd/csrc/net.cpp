@@ -696,6 +696,14 @@ extern "C" int hp_net_set_precision(hp_net* net, int precision) {
 
 extern "C" int hp_net_precision(const hp_net* net) { return net ? net->precision : HP_ERR_ARG; }
 
+extern "C" int hp_net_output_dims(const hp_net* net, int* pose_dim, int* n_logits, int* n_features) {
+  HP_REQUIRE(net && net->finalized, "hp_net_output_dims: network not finalized");
+  if (pose_dim) *pose_dim = net->pose_dim;
+  if (n_logits) *n_logits = net->n_logits;
+  if (n_features) *n_features = net->n_features;
+  return HP_OK;
+}
+
 extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   HP_REQUIRE(net && max_batch >= 1, "hp_net_finalize: bad argument");
   int rc = conv_setup_once();

@@ -348,6 +348,9 @@ int hp_net_set_param(hp_net* net, const char* name, const float* h_data, int64_t
 int hp_net_set_precision(hp_net* net, int precision);
 int hp_net_precision(const hp_net* net);
 int hp_net_finalize(hp_net* net, int max_batch);
+/* Widths of the three outputs of a finalized network: pose_dim / n_logits are 0 when the checkpoint has no such head (what
+ * PosePredictor.net_forward returns, MP/models/pose_rigid.py:352-374); the compiled operator library sizes its outputs with it. */
+int hp_net_output_dims(const hp_net* net, int* pose_dim, int* n_logits, int* n_features);
 int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d_pose, float* d_logits,
                    float* d_features, void* stream);
 /* Feature-pyramid networks (HP_ARCH_RESNET50_FPN): number of output maps ('0', '1', '2', '3', 'pool' of torchvision's

@@ -1024,7 +1024,8 @@ def test_efficientnet_b3_backbone_golden_g9(dev, golden_dir):
 
 # ------------------------------------------------------------------- dispatcher registration
 def test_torch_ops_match_ctypes_path(dev, scene_store):
-    """``torch.ops.happypose_amd.*`` are the same C-ABI calls behind dispatcher schemas: bit-identical results."""
+    """``torch.ops.happypose_amd.*`` (the compiled TORCH_LIBRARY, ``csrc/torch_library.cpp``) are the same C-ABI calls behind
+    dispatcher schemas: bit-identical results."""
     from happypose_amd import ops, torch_ops
     from happypose_amd.synthetic import predictor_weights
     from oracle import backbones as ob
@@ -1044,7 +1045,10 @@ def test_torch_ops_match_ctypes_path(dev, scene_store):
     ref = ops.rasterize(scene_store, obj, T, K, (120, 160), render_normals=True, render_depth=True)
     assert len(got) == 3 and all(torch.equal(a, b) for a, b in zip(got, ref[:3]))
 
-    prep = o.pose_prep(st, T, K, torch.arange(3, dtype=torch.int32, device=dev), obj, 120, 160, 60, 80, "TCO+front_3views", True)
+    prep = torch_ops.pose_prep(scene_store, T, K, torch.arange(3, dtype=torch.int32, device=dev), obj, (120, 160), (60, 80), "TCO+front_3views", True)
+    direct = o.pose_prep(st, T, K, torch.arange(3, dtype=torch.int32, device=dev), obj, scene_store.point_ids(2000), scene_store.point_ids(200),
+                         120, 160, 60, 80, "TCO+front_3views", True)
+    assert all(torch.equal(a, b) for a, b in zip(prep, direct))
     ref = ops.pose_prep(scene_store, T, K, torch.arange(3, dtype=torch.int32), obj, (120, 160), (60, 80), "TCO+front_3views", True)
     for a, k in zip(prep, ("TCO", "tCR", "TCV_O", "boxes_rend", "boxes_crop", "K_crop")):
         assert torch.equal(a, ref[k]), k
@@ -1062,6 +1066,18 @@ def test_torch_ops_match_ctypes_path(dev, scene_store):
     x = torch.as_tensor(rs.randn(2, 12, 16, 32).astype(np.float32), device=dev)
     wt = torch.as_tensor(rs.randn(64, 3, 3, 32).astype(np.float32) * 0.05, device=dev)
     assert torch.equal(o.conv2d_nhwc(x, wt, 1, 1, act=1), ops.conv2d_nhwc(x, wt, 1, 1, relu=True))
+    got = o.rasterize(st, obj, T, K, 120, 160, False, True, True, True)  # the reference renderer's state
+    ref = ops.rasterize(scene_store, obj, T, K, (120, 160), render_depth=True, msaa=True, aniso=True)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[2])
+    # the ops run on torch's CURRENT stream
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        y_side = o.conv2d_nhwc(x, wt, 1, 1, act=1)
+    side.synchronize()
+    assert torch.equal(y_side, ops.conv2d_nhwc(x, wt, 1, 1, relu=True))
+    del net
+    import gc
+    gc.collect()
     with pytest.raises(ValueError):
         o.net_forward(10 ** 9, xin)  # not a live ticket
     with pytest.raises(NotImplementedError):

@@ -327,10 +327,12 @@ def test_detector_oracle_shapes():
 
 
 def test_torch_ops_registered_with_shape_functions():
-    """``torch.ops.happypose_amd.*`` exist, their Meta kernels give the output shapes, and there is no CPU kernel."""
+    """``torch.ops.happypose_amd.*`` come from the compiled operator library (``csrc/torch_library.cpp``), their Meta kernels
+    give the output shapes, and there is no CPU kernel."""
     from happypose_amd import torch_ops
 
     o = torch.ops.happypose_amd
+    assert torch_ops.LIBRARY.name == "libhappypose_amd_torch.so" and str(torch_ops.LIBRARY) in torch.ops.loaded_libraries
     for name in torch_ops.OPS:
         assert hasattr(o, name), name
     m = lambda *s, **k: torch.empty(*s, device="meta", **k)
@@ -338,9 +340,11 @@ def test_torch_ops_registered_with_shape_functions():
     assert o.crop_roi_align(m(2, 3, 48, 64), m(5, 4), m(5, **i32), 24, 32).shape == (5, 3, 24, 32)
     assert o.pose_update(m(5, 4, 4), m(5, 3, 3), m(5, 9)).shape == (5, 4, 4)
     assert [t.shape[1] for t in o.rasterize(0, m(5, **i32), m(5, 4, 4), m(5, 3, 3), 24, 32, True, True)] == [3, 3, 1]
-    prep = o.pose_prep(0, m(5, 4, 4), m(2, 3, 3), m(5, **i32), m(5, **i32), 48, 64, 24, 32, "TCO+front_3views")
+    prep = o.pose_prep(0, m(5, 4, 4), m(2, 3, 3), m(5, **i32), m(5, **i32), m(2000, **i32), m(200, **i32), 48, 64, 24, 32, "TCO+front_3views")
     assert prep[2].shape == (5, 4, 4, 4) and prep[5].shape == (5, 4, 3, 3)
     assert o.conv2d_nhwc(m(2, 8, 8, 16), m(32, 3, 3, 16), 2, 1).shape == (2, 4, 4, 32)
+    with pytest.raises(ValueError):
+        o.net_forward(12345, m(1, 240, 320, 8))  # an integer nobody announced is not dereferenced
     with pytest.raises(NotImplementedError):
         o.pose_update(torch.eye(4)[None], torch.eye(3)[None], torch.zeros(1, 9))
 
