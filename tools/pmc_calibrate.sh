@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 hipcc --offload-arch=gfx950 -O3 -o /tmp/pmc_calibrate $GRAFT_REPO_ROOT/tools/probes/pmc_calibrate.hip || exit 1
 /tmp/pmc_calibrate > $OUT/cal_bytes.txt
-for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_EA0_RD_UNCACHED_32B_sum TCC_EA0_WR_UNCACHED_32B_sum"; do
+for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_EA0_RDREQ_DRAM_32B" "TCC_EA0_WRREQ_WRITE_DRAM_32B" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum"; do
   N=$(echo $C | tr ' ' '_')
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/cal_$N -o p --output-format csv -- /tmp/pmc_calibrate > $OUT/cal_$N.log 2>&1
 done
