@@ -749,6 +749,57 @@ def test_split_fp16_overflow_guard(dev):
     np.testing.assert_allclose(p2.cpu().numpy(), p3.cpu().numpy(), rtol=1e-3, atol=1e-4)
 
 
+def test_guard_fires_inside_a_chunked_graph_run(dev, world):
+    """The numerical guard in the first chunk of a multi-chunk ``forward_refiner`` whose chunks replay / capture hipGraphs
+    (advisor r4): the chunks are enqueued back to back, so the guard word of chunk 1 turns non-zero while a later chunk of the
+    same signature may be CAPTURING -- the exact-fp32 weight sets are built lazily with hipMalloc, which a capture
+    forbids, so the asynchronous flip must not be adopted there (net.cpp: hipStreamIsCapturing).  The stage must end without
+    an exception, the estimator must see the flag and repeat it, and the repeated stage -- exact-fp32 kernels -- must give
+    the finite poses an all-exact model computes."""
+    import pandas as pd
+
+    from happypose_amd import ops
+    from happypose_amd.models import create_pose_model_cosypose
+    from happypose_amd.pose_estimator import CosyPoseEstimator, ObservationTensor
+    from happypose_amd.synthetic import make_scene
+    from happypose_amd.tensor_collection import PandasTensorCollection
+
+    renderer = world["renderer"]
+    sc = make_scene(n_detections=6, n_hypotheses=4, n_objects=len(renderer.store.labels), seed=21, with_depth=True)
+    w = _weights("resnet18", 6, seed=3, scale=0.05)
+    labels = [renderer.store.labels[j] for j in sc["hyp_obj_ids"]]
+    B = len(labels)
+    K = torch.as_tensor(sc["K"], device=dev)
+    T0 = torch.as_tensor(sc["TCO_hyp"], device=dev)
+    infos = pd.DataFrame({"label": labels, "batch_im_id": np.zeros(B, dtype=np.int64), "instance_id": np.arange(B) // 4,
+                          "hypothesis_id": np.arange(B) % 4})
+    clean = sc["images"][:, :3].copy()
+    hot = clean.copy()
+    hot[:, :, 150:330, 200:440] = 7.0e4  # a saturated patch under every crop: fp16 overflow inside the split kernels
+
+    def run(model, images, bsz=8):
+        est = CosyPoseEstimator(refiner_model=model, coarse_model=model, bsz_objects=bsz)
+        obs = ObservationTensor(torch.as_tensor(images, device=dev), K)
+        preds, extra = est.forward_refiner(obs, PandasTensorCollection(infos=infos.copy(), poses=T0.clone()), n_iterations=2)
+        return preds["iteration=2"].poses
+
+    graphed = create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=w, max_batch=8, graphs=True)
+    for _ in range(2):  # three chunks of 8 per stage: call 1 of the signature is eager, later ones capture / replay
+        p_clean = run(graphed, clean)
+    assert graphed.numerics_status() == 0 and torch.isfinite(p_clean).all()
+    p_hot = run(graphed, hot)  # the guard fires in chunk 1 while chunks 2, 3 replay; the estimator repeats the stage
+    assert torch.isfinite(p_hot).all()
+    assert graphed.numerics_status() == ops.STATUS_EXACT_ONLY  # switched, nothing pending
+    exact = create_pose_model_cosypose(dict(backbone_str="resnet18"), renderer, state_dict=w, max_batch=8)
+    exact.backbone.force_exact(True)
+    p_ref = run(exact, hot)
+    assert torch.isfinite(p_ref).all()
+    np.testing.assert_allclose(p_hot.cpu().numpy(), p_ref.cpu().numpy(), rtol=0, atol=1e-6)
+    # and the model keeps working (exact kernels, graphs re-captured under the new epoch)
+    p_again = run(graphed, clean)
+    np.testing.assert_allclose(p_again.cpu().numpy(), p_clean.cpu().numpy(), rtol=0, atol=2e-4)
+
+
 def test_index_guards(dev, world):
     """Ids that index frames / intrinsics / objects: host-resident ids raise like the reference's indexing, device-resident
     ids are guarded by the kernels (NaN poses, zero crops) -- never an out-of-bounds read."""
