@@ -182,6 +182,67 @@ def test_rasterizer_msaa_wider_than_640(dev, scene_store):
         ops.rasterize(scene_store, torch.as_tensor(obj), torch.as_tensor(T), torch.as_tensor(K), (64, 1281), msaa=True)
 
 
+def test_rasterizer_is_watertight_at_frame_size(dev):
+    """Size-independent property of the fixed-point coverage rules at the full 480 x 640 frame (the oracle's twin:
+    tests/test_oracle_pixels.py::test_rasteriser_coverage_rules_are_watertight_and_order_independent): a finely tessellated
+    white sheet (8192 jittered triangles, random diagonals) under a tilted camera leaves no sample uncovered -- every interior
+    pixel is exactly 1.0 after the 8-bit multisample resolve -- and flipping windings / rotating index triples changes no
+    pixel of mask, depth or colour; culling off (an open sheet) and on (it cannot engage: the sheet is not closed)."""
+    from happypose_amd import ops
+    from happypose_amd.mesh_io import MeshData
+    from happypose_amd.mesh_store import RigidObject, RigidObjectDataset
+
+    def sheet(rs, n, flip=None, rot=None):
+        g = np.linspace(-0.5, 0.5, n)
+        xx, yy = np.meshgrid(g, g)
+        v = np.stack([xx, yy, np.zeros_like(xx)], -1).reshape(-1, 3)
+        inner = (np.abs(v[:, 0]) < 0.499) & (np.abs(v[:, 1]) < 0.499)
+        v[inner, :2] += rs.uniform(-0.4, 0.4, (int(inner.sum()), 2)) / (n - 1)
+        faces = []
+        for i in range(n - 1):
+            for j in range(n - 1):
+                a, b, c, d = i * n + j, i * n + j + 1, (i + 1) * n + j + 1, (i + 1) * n + j
+                faces += [[a, b, c], [a, c, d]] if rs.rand() < 0.5 else [[a, b, d], [b, c, d]]
+        f = np.array(faces, np.int32)
+        if flip is not None:
+            f[flip] = f[flip][:, ::-1]
+        if rot is not None:
+            f = np.stack([np.roll(t, r) for t, r in zip(f, rot)])
+        nrm = np.tile([0, 0, -1.0], (len(v), 1)).astype(np.float32)
+        return MeshData(v, f, nrm, None, np.full((len(v), 4), 255, np.uint8))
+
+    n = 65
+    nf = 2 * (n - 1) ** 2
+    rs = np.random.RandomState(4)
+    ds = RigidObjectDataset([RigidObject("sheet", sheet(np.random.RandomState(3), n)),
+                             RigidObject("sheet_shuffled", sheet(np.random.RandomState(3), n, flip=rs.rand(nf) < 0.5, rot=rs.randint(0, 3, nf)))])
+    store = ops.MeshStore(ds, device=dev)
+    T = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
+    ax, ay = np.deg2rad(38.0), np.deg2rad(-21.0)
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    T[:, :3, :3] = (Ry @ Rx).astype(np.float32)
+    T[:, :3, 3] = (0.013, -0.021, 1.05)
+    K = np.tile(np.array([[560.0, 0, 320.3], [0, 555.0, 239.6], [0, 0, 1]], np.float32), (2, 1, 1))
+    obj = torch.as_tensor(np.array([0, 1], np.int32))
+    for msaa in (False, True):
+        for cull in (True, False):
+            store.set_backface_culling(cull)
+            rgb, _, dep, msk = ops.rasterize(store, obj, torch.as_tensor(T), torch.as_tensor(K), (480, 640), render_depth=True,
+                                             render_binary_mask=True, msaa=msaa, aniso=msaa)
+            rgb, dep, m = rgb.cpu().numpy(), dep.cpu().numpy(), msk.cpu().numpy()[:, 0]
+            assert np.array_equal(m[0], m[1]) and 0.25 < m[0].mean() < 0.8
+            assert np.array_equal(rgb[0], rgb[1])
+            np.testing.assert_allclose(dep[0], dep[1], rtol=0, atol=2e-6)  # the 1/z plane is set up from the first listed corner
+            inner = m[0].copy()
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    inner &= np.roll(np.roll(m[0], dy, 0), dx, 1)
+            assert inner.sum() > 0.95 * m[0].sum()
+            assert (rgb[0][:, inner] == 1.0).all()  # one uncovered sample would resolve to 191 / 255
+    store.set_backface_culling(True)
+
+
 CONVENTION_FLIPS = [
     dict(msaa_x=(0.25, 0.75, 0.25, 0.75), msaa_y=(0.25, 0.25, 0.75, 0.75)),            # ordered-grid samples
     dict(msaa_x=(0.625, 0.125, 0.875, 0.375), msaa_y=(0.125, 0.375, 0.625, 0.875)),    # the mirrored rotated grid
