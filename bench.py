@@ -37,7 +37,7 @@ N_DET, N_HYP, N_ITERS = 8, 16, 5
 
 
 WORKLOADS = ("C2", "C3", "C5", "E2E")
-DEFAULT_LANES = {"C2": 2, "C3": 3, "C5": 2, "E2E": 2}  # --lanes
+DEFAULT_LANES = {"C2": 2, "C3": 3, "C5": 2, "E2E": 3}  # --lanes (E2E: the refiner's bsz_objects chunks run one per lane; f16 coarse 7.99 / 8.53 / 8.28 frames/s at 2 / 3 / 4)
 
 
 def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32", n_lanes=1, update_scale=0.002, renderer_kw=None):
@@ -848,8 +848,9 @@ def main():
                     for key, cprec in (("e2e", "f32"), ("e2e_f16_coarse", "f16")):
                         # the second one: the coarse / scoring model on the fp16 plan (BASELINE.json config 5 names fp16 for that
                         # stage), the refiner in fp32 as always
-                        r = e2e_run(device, 0, 1, n_lanes, cprec, steps=3, warmup=2, run_detector=True)
+                        r = e2e_run(device, 0, 1, args.lanes or DEFAULT_LANES["E2E"], cprec, steps=3, warmup=2, run_detector=True)
                         line[key] = {"value": r["steps"] / r["elapsed"], "unit": "frames/s", "ms_per_frame": 1e3 * r["elapsed"] / r["steps"],
+                                     "lanes": args.lanes or DEFAULT_LANES["E2E"],
                                      "steps": r["steps"], "stage_ms_per_frame": r["stage_ms_per_frame"],
                                      "conv_time_share": r["conv_union_ms"] * 1e-3 / r["elapsed"], "coarse_precision": cprec,
                                      "job": "PoseEstimator.run_inference_pipeline: Mask-RCNN detector (random weights, timed, its detections "

@@ -259,15 +259,19 @@ class _EstimatorBase:
         labels_all = infos["label"].tolist()
         im_all_host = np.ascontiguousarray(infos["batch_im_id"].values)
         poses_all = data_TCO_input.poses
-        for a in range(s, e, bsz):
-            b = min(e, a + bsz)
-            # slices of the table's columns: the launches of a chunk are on their way before any pandas work happens
-            # (the frames below are built while the GPU runs; `data_TCO_input[ids]` cost a gather + a frame per chunk)
-            im_ids = torch.as_tensor(im_all_host[a:b], device=self.device)
-            t0 = time.time()
-            outputs_ = model(images=observation.images, K=observation.K, TCO=poses_all[a:b],
-                             n_iterations=n_iterations, labels=labels_all[a:b], im_ids=im_ids, **kw)
-            model_time += time.time() - t0
+        # slices of the table's columns: the launches of a chunk are on their way before any pandas work happens
+        # (the frames below are built while the GPU runs; `data_TCO_input[ids]` cost a gather + a frame per chunk)
+        bounds = [(a, min(e, a + bsz)) for a in range(s, e, bsz)]
+        chunks = [(labels_all[a:b], poses_all[a:b], torch.as_tensor(im_all_host[a:b], device=self.device)) for a, b in bounds]
+        t0 = time.time()
+        if len(chunks) > 1 and bsz < getattr(model, "MIN_BATCH", 0) and hasattr(model, "forward_chunks"):
+            # chunks too small to be split over the model's lanes run side by side, one whole chunk per lane
+            chunk_outputs = model.forward_chunks(observation.images, observation.K, chunks, n_iterations=n_iterations, **kw)
+        else:
+            chunk_outputs = [model(images=observation.images, K=observation.K, TCO=T, n_iterations=n_iterations, labels=lab,
+                                   im_ids=ids, **kw) for lab, T, ids in chunks]
+        model_time += time.time() - t0
+        for outputs_ in chunk_outputs:
             if keep_all_outputs:
                 all_outputs.append(outputs_)
             for n in range(1, n_iterations + 1):

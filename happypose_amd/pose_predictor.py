@@ -684,6 +684,31 @@ class TwoLanePredictor:
     __call__ = forward
 
     @torch.no_grad()
+    def forward_chunks(self, images, K, chunks, n_iterations: int = 1, **kw):
+        """Independent SMALL batches (each below ``MIN_BATCH``: the ``bsz_objects`` chunks of an estimator stage, reference
+        default 8, ``MP/inference/pose_estimator.py:74``) as concurrent chains: chunk ``c`` runs whole -- all its iterations --
+        on lane ``c % n_lanes`` on that lane's stream.  ``forward`` sends such a batch to lane 0, and an estimator that calls
+        it chunk after chunk leaves the other lanes (and, at batch 8, half of the CUs) idle: the refiner stage of the E2E
+        frame, 5 chunks of 8 hypotheses, took 35 ms of 133.  Same launches per chunk as lane 0 would make (every lane holds the
+        same plan and weights): the results do not depend on which lane ran a chunk.
+        ``chunks``: ``[(labels, TCO, im_ids), ...]``; returns the chunks' outputs in order."""
+        n = len(self.lanes)
+        cur = torch.cuda.current_stream(self.device)
+        used = self.streams[:min(n, len(chunks))]
+        for stream in used:
+            stream.wait_stream(cur)
+        outs = []
+        for c, (labels, TCO, im_ids) in enumerate(chunks):
+            assert len(labels) < self.MIN_BATCH, "forward_chunks is for batches that forward() would not split"
+            lane = self.lanes[c % n]
+            lane.use_graphs = self.use_graphs
+            with torch.cuda.stream(self.streams[c % n]):
+                outs.append(lane.forward(images, K, labels, TCO, n_iterations=n_iterations, im_ids=im_ids, **kw))
+        for stream in used:
+            cur.wait_stream(stream)
+        return outs
+
+    @torch.no_grad()
     def forward_coarse(self, images, K, labels, TCO_input, cuda_timer: bool = False, return_debug_data: bool = False,
                        im_ids=None):
         """Coarse scoring with the two halves of the views on the two lanes (``MP/models/pose_rigid.py:708-788``)."""

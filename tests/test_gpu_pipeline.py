@@ -749,6 +749,51 @@ def test_split_fp16_overflow_guard(dev):
     np.testing.assert_allclose(p2.cpu().numpy(), p3.cpu().numpy(), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_small_estimator_chunks_run_side_by_side(dev, world, lanes):
+    """``bsz_objects`` chunks below the lanes' split threshold (the reference's default of 8) run as whole chains on different
+    lanes at the same time (``forward_chunks``) instead of one after the other on lane 0: same launches per chunk, so the
+    stage's table is bit-identical to the single-lane estimator's, whichever lane ran which chunk; a ragged last chunk and
+    more chunks than lanes included."""
+    import pandas as pd
+
+    from happypose_amd.models import create_model_pose
+    from happypose_amd.pose_estimator import ObservationTensor, PoseEstimator
+    from happypose_amd.synthetic import make_scene
+    from happypose_amd.tensor_collection import PandasTensorCollection
+
+    renderer = world["renderer"]
+    sc = make_scene(n_detections=7, n_hypotheses=5, n_objects=len(renderer.store.labels), seed=31, with_depth=True)
+    w = _weights("vanilla_resnet34", 32, seed=4)
+    cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+               render_depth=True, input_depth=True, predict_pose_update=True, depth_augmentation=False,
+               depth_normalization_type="tCR_scale_clamp_center")
+    labels = [renderer.store.labels[j] for j in sc["hyp_obj_ids"]]
+    B = len(labels)  # 35 hypotheses: chunks of 8, 8, 8, 8, 3
+    infos = pd.DataFrame({"label": labels, "batch_im_id": np.zeros(B, dtype=np.int64), "instance_id": np.arange(B) // 5,
+                          "hypothesis_id": np.arange(B) % 5})
+    obs = ObservationTensor(torch.as_tensor(sc["images"].copy(), device=dev), torch.as_tensor(sc["K"], device=dev))
+    T0 = torch.as_tensor(sc["TCO_hyp"], device=dev)
+
+    def run(model):
+        est = PoseEstimator(refiner_model=model, coarse_model=model, bsz_objects=8)
+        preds, extra = est.forward_refiner(obs, PandasTensorCollection(infos=infos.copy(), poses=T0.clone()), n_iterations=3)
+        return preds
+
+    single = create_model_pose(cfg, renderer, state_dict=w, max_batch=32)
+    multi = create_model_pose(cfg, renderer, state_dict=w, max_batch=32 * lanes, n_lanes=lanes)
+    calls = []
+    for lane in multi.lanes:
+        lane.forward = (lambda f, lane=lane: lambda *a, **k: (calls.append(multi.lanes.index(lane)), f(*a, **k))[1])(lane.forward)
+    ref, got = run(single), run(multi)
+    assert calls == [c % lanes for c in range(5)]
+    for k in ref:
+        for name in ("poses", "poses_input", "K_crop", "boxes_rend", "boxes_crop"):
+            assert torch.equal(getattr(ref[k], name), getattr(got[k], name)), (k, name)
+        assert ref[k].infos.equals(got[k].infos)
+    assert torch.isfinite(got["iteration=3"].poses).all() and not torch.equal(got["iteration=3"].poses, T0)
+
+
 def test_guard_fires_inside_a_chunked_graph_run(dev, world):
     """The numerical guard in the first chunk of a multi-chunk ``forward_refiner`` whose chunks replay / capture hipGraphs
     (advisor r4): the chunks are enqueued back to back, so the guard word of chunk 1 turns non-zero while a later chunk of the
