@@ -792,6 +792,14 @@ def test_small_estimator_chunks_run_side_by_side(dev, world, lanes):
             assert torch.equal(getattr(ref[k], name), getattr(got[k], name)), (k, name)
         assert ref[k].infos.equals(got[k].infos)
     assert torch.isfinite(got["iteration=3"].poses).all() and not torch.equal(got["iteration=3"].poses, T0)
+    # ... and with hipGraph replay per lane: the first stage runs eagerly, the second captures (two signatures per lane: the
+    # full chunk and the ragged one), the third replays -- each lane's capture happens on ITS stream while the others hold work
+    graphed = create_model_pose(cfg, renderer, state_dict=w, max_batch=32 * lanes, n_lanes=lanes, graphs=True)
+    for _ in range(3):
+        rep = run(graphed)
+        for k in ref:
+            assert torch.equal(ref[k].poses, rep[k].poses), k
+    assert any(l._graphs is not None and l._graphs.replays > 0 for l in graphed.lanes)
 
 
 def test_guard_fires_inside_a_chunked_graph_run(dev, world):
