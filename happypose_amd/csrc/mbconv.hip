@@ -63,28 +63,49 @@ __global__ __launch_bounds__(256) void dwconv_swish_nhwc(DwArgs a) {
 // per output is the same (dy, dx ascending), so the conv result is bit-identical.  The lanes also sum what they store:
 // the per-(image, strip, channel) sums are the squeeze-excitation pooling partials (se_pool_kernel re-read the whole
 // tensor for them); lanes of one channel quad meet in LDS in a fixed order (reproducible).
-// output rows per strip: 8 on the maps with >= 30 rows (input rows re-read by neighbouring strips: (R-1)S+K for R outputs), 4 on
-// the small maps, where strips are what fills the GPU
-// (5x5 / stride 2 stays at 4: 11 + 4 input rows x 5 quads beside 25 taps spill at 8)
-__host__ __device__ constexpr int dw_rows(int Ho, int k, int stride) { return Ho >= 30 && !(k == 5 && stride == 2) ? 8 : 4; }
+// output rows per strip: 3 x 3: 8 on the maps with >= 30 rows (input rows re-read by neighbouring strips: (R-1)S+K for R
+// outputs), 4 on the small maps, where strips are what fills the GPU; 5 x 5 (taps in LDS, see WLDS): 4 everywhere (round 5,
+// one forward of 64: all 5 x 5 launches 860 us at 4 rows, 897 at 8 rows on the 30-row maps, 972 at 8 rows everywhere)
+__host__ __device__ constexpr int dw_rows(int Ho, int k, int stride) { return Ho >= 30 && k == 3 ? 8 : 4; }
 
-template <int K, int S, int R>
+__host__ __device__ inline int dw_quads_per_block(int C4) {
+  const int nb = (C4 + 63) / 64;
+  return (C4 + nb - 1) / nb;
+}
+
+// WLDS (the 5 x 5 kernels): the taps live in LDS ([tap][quad], read at use) instead of 100 registers per lane -- with them in
+// registers the 5 x 5 instantiations need all 256 VGPRs: ONE wave per SIMD, every tap load of a column exposed (66 us for a
+// 126-MB layer).  Same FMA order, bit-identical outputs.
+template <int K, int S, int R, bool WLDS>
 __global__ __launch_bounds__(256) void dwconv_strip_kernel(DwArgs a) {
   constexpr int NR = (R - 1) * S + K;
   __shared__ floatx4 red[256];
+  __shared__ floatx4 wl[WLDS ? K * K * 64 : 1];
   const int C4 = a.C >> 2;
-  const int cq0 = blockIdx.x * 256;
-  const int nq = C4 - cq0 < 256 ? C4 - cq0 : 256;
+  // channel quads per workgroup: even shares of at most 64 (dw_quads_per_block) -- 256 per workgroup left 112 of 256 lanes idle
+  // at C = 576 and made ONE 4-wave workgroup per (image, strip): 256 workgroups on the 15 x 20 maps, nothing to hide the tap loads
+  const int qb = dw_quads_per_block(C4);
+  const int cq0 = blockIdx.x * qb;
+  const int nq = C4 - cq0 < qb ? C4 - cq0 : qb;
   const int nph = 256 / nq;
   const int tid = threadIdx.x;
   const int ph = tid / nq, q = tid - ph * nq;
   const int img = blockIdx.z, strip = blockIdx.y, oh0 = strip * R;
   const int c = 4 * (cq0 + q);
   floatx4 psum = {0.f, 0.f, 0.f, 0.f};
+  if (WLDS) {
+    for (int i = tid; i < K * K * nq; i += 256) {
+      const int t = i / nq, qq = i - t * nq;
+      wl[t * 64 + qq] = *reinterpret_cast<const floatx4*>(a.w + t * a.C + 4 * (cq0 + qq));
+    }
+    __syncthreads();
+  }
   if (ph < nph) {
-    floatx4 w[K * K];
+    floatx4 w[WLDS ? 1 : K * K];
+    if (!WLDS) {
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) w[t] = *reinterpret_cast<const floatx4*>(a.w + t * a.C + c);
+      for (int t = 0; t < K * K; ++t) w[t] = *reinterpret_cast<const floatx4*>(a.w + t * a.C + c);
+    }
     const floatx4 bias = *reinterpret_cast<const floatx4*>(a.bias + c);
     const int ih0 = oh0 * S - a.pad_t;
     const float* const ximg = a.x + (int64_t)img * a.H * a.W * a.C + c;
@@ -94,6 +115,34 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(DwArgs a) {
 #pragma unroll
       for (int o = 0; o < R; ++o) acc[o] = bias;
       const int iw0 = ow * S - a.pad_l;
+      if constexpr (WLDS) {
+        // rolled over the input rows (tap row dy = r - o S is a wave-uniform run-time value: a scalar branch, the taps indexed in
+        // LDS): five loads in flight per wave instead of (R - 1) S + K rows of them, ~70 registers, eight waves per SIMD
+#pragma unroll 4
+        for (int r = 0; r < NR; ++r) {
+          const int ih = ih0 + r;
+          const bool rok = (unsigned)ih < (unsigned)a.H;
+          floatx4 xv[K];
+#pragma unroll
+          for (int dx = 0; dx < K; ++dx) {
+            const int iw = iw0 + dx;
+            const bool ok = rok && (unsigned)iw < (unsigned)a.W;
+            xv[dx] = ok ? *reinterpret_cast<const floatx4*>(ximg + ((int64_t)ih * a.W + iw) * a.C) : floatx4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int o = 0; o < R; ++o) {
+            const int dy = r - o * S;
+            if (dy >= 0 && dy < K) {
+#pragma unroll
+              for (int dx = 0; dx < K; ++dx) {
+                const floatx4 wv = wl[(dy * K + dx) * 64 + q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(xv[dx][e], wv[e], acc[o][e]);
+              }
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const int ih = ih0 + r;
@@ -110,9 +159,11 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(DwArgs a) {
           const int dy = r - o * S;  // compile-time after unrolling
           if (dy >= 0 && dy < K) {
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx)
+            for (int dx = 0; dx < K; ++dx) {
+              const floatx4 wv = w[WLDS ? 0 : dy * K + dx];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(xv[dx][e], w[dy * K + dx][e], acc[o][e]);
+              for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(xv[dx][e], wv[e], acc[o][e]);
+            }
           }
         }
       }
@@ -162,13 +213,19 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const float* y, float* par
 //   se_mean_kernel:   pooled[n][c]  = sum of the strip partials / HW            (fixed order)
 //   se_reduce_kernel: sq[n][j]      = swish(W1[j] . pooled[n] + b1[j])          one wave per (n, j)
 //   se_expand_kernel: gate[n][c]    = sigmoid(W2t[.][c] . sq[n] + b2[c])        W2 transposed: coalesced
+// 64 (image, channel) pairs x 4 interleaved groups of partials per workgroup, combined in LDS in a fixed order (the 150 tile
+// partials of the first fused block were a 150-deep dependent chain per lane: 63 us)
 __global__ __launch_bounds__(256) void se_mean_kernel(const float* partial, float* pooled, int HW, int C, int total, int n_partials) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int img = idx / C, c = idx - img * C;
+  __shared__ float red[4][64];
+  const int idx = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
   float s = 0.f;
-  for (int st = 0; st < n_partials; ++st) s += partial[((int64_t)img * n_partials + st) * C + c];
-  pooled[idx] = s / (float)HW;
+  if (idx < total) {
+    const int img = idx / C, c = idx - img * C;
+    for (int st = g; st < n_partials; st += 4) s += partial[((int64_t)img * n_partials + st) * C + c];
+  }
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && idx < total) pooled[idx] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) / (float)HW;
 }
 
 __global__ __launch_bounds__(256) void se_reduce_kernel(const float* pooled, const float* w1, const float* b1, float* sq, int C,
@@ -204,11 +261,12 @@ int dwconv_pool_strips(int Ho, int k, int stride) { return (Ho + dw_rows(Ho, k, 
 int launch_dwconv(const DwArgs& a, hipStream_t stream) {
   static const bool old_kernel = std::getenv("HP_DW_OLD") != nullptr;
   if (!old_kernel && (a.stride == 1 || a.stride == 2) && (a.k == 3 || a.k == 5) && a.n < 65536) {
-    const dim3 grid((unsigned)((a.C / 4 + 255) / 256), (unsigned)dwconv_pool_strips(a.Ho, a.k, a.stride), (unsigned)a.n);
+    const int qb = dw_quads_per_block(a.C / 4);
+    const dim3 grid((unsigned)((a.C / 4 + qb - 1) / qb), (unsigned)dwconv_pool_strips(a.Ho, a.k, a.stride), (unsigned)a.n);
 #define HP_DW(K_, S_)                                                                                                        \
   if (a.k == K_ && a.stride == S_) {                                                                                        \
-    if (dw_rows(a.Ho, K_, S_) == 8) hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 8>), grid, dim3(256), 0, stream, a);            \
-    else hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 4>), grid, dim3(256), 0, stream, a);                               \
+    if (dw_rows(a.Ho, K_, S_) == 8) hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 8, K_ == 5>), grid, dim3(256), 0, stream, a);   \
+    else hipLaunchKernelGGL((dwconv_strip_kernel<K_, S_, 4, K_ == 5>), grid, dim3(256), 0, stream, a);                      \
   }
     HP_DW(3, 1) HP_DW(3, 2) HP_DW(5, 1) HP_DW(5, 2)
 #undef HP_DW
@@ -241,7 +299,7 @@ int launch_se(const float* y, float* partial, float* pooled, float* sq, float* g
     if ((rc = check_launch("se_pool_kernel"))) return rc;
     n_partials = kSeStrips;
   }
-  hipLaunchKernelGGL(se_mean_kernel, dim3((n * C + 255) / 256), dim3(256), 0, stream, partial, pooled, HW, C, n * C, n_partials);
+  hipLaunchKernelGGL(se_mean_kernel, dim3((n * C + 63) / 64), dim3(256), 0, stream, partial, pooled, HW, C, n * C, n_partials);
   if ((rc = check_launch("se_mean_kernel"))) return rc;
   hipLaunchKernelGGL(se_reduce_kernel, dim3((Cse + 3) / 4, n), dim3(256), 0, stream, pooled, w1, b1, sq, C, Cse);
   if ((rc = check_launch("se_reduce_kernel"))) return rc;
