@@ -78,7 +78,10 @@ constexpr int kPoolRows = 3, kPoolCols = 8, kPoolCW = 2 * kPoolCols + 1, kPoolCH
 // VGPRs for the 128-wide tile's cousins that fit, but THREE per CU (168 VGPRs) for the 64-wide tile: at 128 it spilled
 // 36-220 B per lane to scratch (EfficientNet's narrow 1x1 layers, the detector), and a launch that uses scratch also keeps
 // hipGraph replay off for the whole network.
-template <int BN, int PRE, int NBUF, bool POOL>
+// LIN: a 1x1 / stride-1 / pad-0 layer (EfficientNet's expansions and projections): K-tile t, chunk kc IS channel 32 t + 4 kc of
+// the row's own pixel -- no look-up table.  The table entry is a global load that every activation load of a K-tile depends
+// on: in program order the wave waits for it (and with it for everything issued before) at the head of every K-tile.
+template <int BN, int PRE, int NBUF, bool POOL, bool LIN = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF == 2 ? 2 : 3, NBUF == 2 ? 2 : 4))) void conv_igemm_split_f32(ConvArgs a) {
   constexpr int MT = 2, NT = BN / 64;  // 4 waves 2 x 2, wave tile 64 x BN/2
   constexpr int NA = 4, NB = BN / 32;  // staged 16-B pieces per thread and K-tile
@@ -161,7 +164,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF =
   // t+1 is written to LDS (these launches are latency-bound: a dozen MFMAs per K-tile and wave)
   struct Stage { floatx4 ra[NA]; halfx8 rbw[NB]; floatx4 ps, pb; floatx4 g[PRE == 2 ? NA : 1]; unsigned ok; };
   auto issue = [&](int t, Stage& st) {
-    const int4 e = a.lut[t * 8 + kc];  // {offset, kh, kw, channel}; kh < 0 marks K padding
+    int4 e;  // {offset, kh, kw, channel}; kh < 0 marks K padding
+    if (LIN) { const int c = 32 * t + 4 * kc; e = make_int4(c, c < a.Cin ? 0 : -1, 0, c); }
+    else e = a.lut[t * 8 + kc];
     st.ok = 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -335,13 +340,20 @@ int launch_igs_pool(ConvArgs args, hipStream_t stream) {
   return check_launch("conv_igemm_split_f32<pool>");
 }
 
-template <int BN, int PRE, int NBUF>
+template <int BN, int PRE, int NBUF, bool LIN = false>
 int launch_igs(ConvArgs args, hipStream_t stream) {
   static bool opted = false, spills = false;
+  if (!LIN) {
+    // a 1x1 / stride-1 / pad-0 layer (same map size without padding, K = the channels): the table-free instantiation
+    static const bool no_lin = std::getenv("HP_IGS_NO_LIN") != nullptr;
+    if (!no_lin && args.pad == 0 && args.stride == 1 && args.Ho == args.H && args.Wo == args.W && args.Kpad == (args.Cin + 31) / 32 * 32 &&
+        args.Cin % 4 == 0)
+      return launch_igs<BN, PRE, NBUF, true>(args, stream);
+  }
   if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false>),
+    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false, LIN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)igs_lds_bytes<BN, NBUF>()));
-    spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false>));
+    spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false, LIN>));
     opted = true;
   }
   if (spills) count_scratch_launch();
@@ -356,7 +368,7 @@ int launch_igs(ConvArgs args, hipStream_t stream) {
   if (rc) return rc;
   const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
   const size_t lds = igs_lds_bytes<BN, NBUF>();
-  hipLaunchKernelGGL((conv_igemm_split_f32<BN, PRE, NBUF, false>), dim3(8 * per_xcd), dim3(kThreads), lds, stream, args);
+  hipLaunchKernelGGL((conv_igemm_split_f32<BN, PRE, NBUF, false, LIN>), dim3(8 * per_xcd), dim3(kThreads), lds, stream, args);
   return check_launch("conv_igemm_split_f32");
 }
 
