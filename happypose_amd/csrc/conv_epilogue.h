@@ -77,7 +77,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* lds, epi
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
       } else if (a.relu == HP_ACT_SWISH) {  // x * sigmoid(x)  (MemoryEfficientSwish, CP/models/efficientnet_utils.py)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + __expf(-v[q]));
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.f + __expf(-v[q]));  // v_rcp_f32 (1 ulp), as mbconv_front.hip:
+        // the IEEE division was ~10 of the ~15 VALU instructions per stored element, and EfficientNet's wide expansions are
+        // bound by exactly those (SQ counters, round 5: VALU active 0.24 of the wave cycles at 3 - 4 waves per SIMD)
       }
 #ifndef HP_EABL_NO_AMAX_VALU
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));

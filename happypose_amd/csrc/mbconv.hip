@@ -21,7 +21,7 @@ namespace {
 
 __device__ __forceinline__ floatx4 swish4(floatx4 v) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + __expf(-v[q]));
+  for (int q = 0; q < 4; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.f + __expf(-v[q]));  // v_rcp_f32: 1 ulp (mbconv_front.hip)
   return v;
 }
 
