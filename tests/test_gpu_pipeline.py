@@ -443,6 +443,38 @@ def test_c2_full_size_two_lanes_vs_oracle(dev):
     assert _pose_err(out["iteration=5"].TCO_output.cpu().numpy(), scene["TCO_hyp"])[1] > 10 * R_TOL
 
 
+def test_c2_full_size_efficientnet_vs_oracle(dev):
+    """The benchmark job with the backbone of the released CosyPose checkpoints (``bench.py --arch efficientnet-b3``; the
+    ``c2_efficientnet_b3`` block of the default line): 128 hypotheses, two lanes of 64 -- the depthwise strip kernels, the
+    fused MBConv fronts, the squeeze-excitation launches and the gated 1x1 projections at the sizes that are timed -- three
+    iterations against the CPU oracle, T_TOL / R_TOL at every iteration."""
+    from oracle.pipeline import OraclePredictor
+
+    bench = _bench()
+    ds, renderer, scene, weights, model = bench.build_world(dev, "efficientnet-b3", seed=0, workload="C2", n_lanes=2)
+    store = renderer.store
+    B = len(scene["TCO_hyp"])
+    assert B == 128
+    images, K = torch.as_tensor(scene["images"], device=dev), torch.as_tensor(scene["K"], device=dev)
+    labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
+    im_ids = torch.zeros(B, dtype=torch.int32, device=dev)
+    out = model.forward(images, K, labels, torch.as_tensor(scene["TCO_hyp"], device=dev), n_iterations=3, im_ids=im_ids)
+    assert model.numerics_status() == 0
+    from happypose_amd import ops as _ops
+
+    assert _ops.scratch_launches() == 0
+    torch.set_num_threads(bench.effective_cpu_count())
+    ora = OraclePredictor(weights, store.packed, store.mesh_db.points, arch="efficientnet-b3", cosypose=True)
+    ref = ora.forward(scene["images"][:, :3], scene["K"], np.zeros(B, np.int32), scene["hyp_obj_ids"], scene["TCO_hyp"], 3,
+                      bsz_objects=8)
+    for n in range(3):
+        got = out[f"iteration={n + 1}"].TCO_output.cpu().numpy()
+        dt, dr = _pose_err(got, ref[n]["TCO_output"])
+        assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
+        assert _pose_med(got, ref[n]["TCO_output"])[0] <= T_MED
+    assert _pose_err(out["iteration=3"].TCO_output.cpu().numpy(), scene["TCO_hyp"])[1] > 10 * R_TOL
+
+
 BATCH_DT, BATCH_DR = 5e-6, 2e-5  # the same hypothesis in different batches (stated in INTEGRATION.md, "Batch dependence")
 
 
