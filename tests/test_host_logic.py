@@ -379,3 +379,65 @@ def test_graph_cache_structure_helpers():
     assert torch.equal(back[0][0]["TCO"], torch.full((2, 4, 4), 2.0)) and torch.equal(back[0][0]["parts"][1], torch.arange(2) + 1)
     assert torch.equal(back[1][0]["TCO"], torch.eye(4) + 1)
     assert GraphCache.MAX_ENTRIES >= 2
+
+
+def test_estimator_hands_small_chunks_to_the_lanes():
+    """``_run_model_chunks_once``: a stage whose ``bsz_objects`` chunks are below the model's ``MIN_BATCH`` (and more than one)
+    goes to ``forward_chunks`` in ONE call -- chunk order, slices and keyword arguments as the sequential loop would pass them;
+    a model without lanes, a single chunk, or chunks at / above ``MIN_BATCH`` take the loop.  Same table either way."""
+    from types import SimpleNamespace
+
+    import pandas as pd
+
+    from happypose_amd.pose_estimator import CosyPoseEstimator, ObservationTensor
+    from happypose_amd.tensor_collection import PandasTensorCollection
+
+    class Model:
+        device = torch.device("cpu")
+        mesh_db = None
+        log: list = []
+
+        def __call__(self, images, K, TCO, n_iterations, labels, im_ids):
+            self.log.append(("call", len(labels)))
+            out, T = {}, TCO.clone().float()
+            for n in range(1, n_iterations + 1):
+                Tn = T * 0.5 + images[im_ids.long()].mean(dim=(1, 2, 3))[:, None, None] + torch.as_tensor([float(l[3:]) for l in labels])[:, None, None]
+                out[f"iteration={n}"] = SimpleNamespace(TCO_output=Tn, TCO_input=T, K_crop=K[im_ids.long()] * n, boxes_rend=Tn[:, 0, :4], boxes_crop=Tn[:, 1, :4])
+                T = Tn
+            return out
+
+        def numerics_status(self):
+            return 0
+
+    class LaneModel(Model):
+        MIN_BATCH = 32
+
+        def forward_chunks(self, images, K, chunks, n_iterations=1, **kw):
+            self.log.append(("chunks", [len(c[0]) for c in chunks]))
+            return [Model.__call__(self, images, K, T, n_iterations, lab, ids) for lab, T, ids in chunks]
+
+    rs = np.random.RandomState(0)
+    B = 21
+    infos = pd.DataFrame({"label": [f"obj{i % 4}" for i in range(B)], "batch_im_id": np.arange(B) % 2, "instance_id": np.arange(B)})
+    obs = ObservationTensor(torch.as_tensor(rs.rand(2, 3, 4, 5).astype(np.float32)), torch.eye(3)[None].repeat(2, 1, 1))
+    T0 = torch.as_tensor(rs.rand(B, 4, 4).astype(np.float32))
+
+    def run(model, bsz):
+        Model.log = []
+        est = CosyPoseEstimator(refiner_model=model, coarse_model=model, bsz_objects=bsz)
+        preds, _ = est.forward_refiner(obs, PandasTensorCollection(infos=infos.copy(), poses=T0.clone()), n_iterations=2)
+        return preds, [e for e in Model.log if e[0] in ("call", "chunks")]
+
+    ref, log = run(Model(), 8)
+    assert log == [("call", 8), ("call", 8), ("call", 5)]
+    got, log = run(LaneModel(), 8)
+    assert log[0] == ("chunks", [8, 8, 5]) and len([e for e in log if e[0] == "chunks"]) == 1
+    for k in ref:
+        assert torch.equal(ref[k].poses, got[k].poses) and torch.equal(ref[k].K_crop, got[k].K_crop) and ref[k].infos.equals(got[k].infos)
+    _, log = run(LaneModel(), 32)   # one chunk of 21: forward() decides by itself
+    assert log == [("call", 21)]
+    _, log = run(LaneModel(), 21)
+    assert log == [("call", 21)]
+    LaneModel.MIN_BATCH = 8          # chunks AT the threshold are forward()'s to split over the lanes
+    _, log = run(LaneModel(), 8)
+    assert log == [("call", 8), ("call", 8), ("call", 5)]
