@@ -111,8 +111,10 @@ def e2e_run(device, rank, world, lanes, coarse_precision, steps, warmup, run_det
 
         detector = Detector(synthetic_maskrcnn(device, n_classes=len(store.labels) + 1, seed=3),
                             {f"{l}": i + 1 for i, l in enumerate(store.labels)})
-    est = PoseEstimator(refiner_model=refiner, coarse_model=coarse, detector_model=detector, bsz_objects=8, bsz_images=576,
-                        SO3_grid_size=576)
+    # chunk sizes of the reference's InferenceConfig (TB/inference/types.py:97-98), which its prediction runner passes to
+    # run_inference_pipeline (MP/evaluation/prediction_runner.py:125-126): 16 refiner hypotheses, 576 coarse views per chunk
+    est = PoseEstimator(refiner_model=refiner, coarse_model=coarse, detector_model=detector, bsz_objects=int(os.environ.get("HP_E2E_BSZ_OBJECTS", "16")),
+                        bsz_images=576, SO3_grid_size=576)
 
     # detections = bounding boxes of the projected objects (what a detector would hand over)
     pts = store.mesh_db.points[scene["det_obj_ids"]].astype(np.float64)
@@ -855,7 +857,7 @@ def main():
                                      "conv_time_share": r["conv_union_ms"] * 1e-3 / r["elapsed"], "coarse_precision": cprec,
                                      "job": "PoseEstimator.run_inference_pipeline: Mask-RCNN detector (random weights, timed, its detections "
                                             "discarded) + 8 detections x 576-pose coarse grid, top-5, 5 refiner iterations x 40 hypotheses x 4 "
-                                            "views, re-scoring, top-1; pandas bookkeeping included"}
+                                            "views, re-scoring, top-1; chunks of bsz_objects = 16 / bsz_images = 576 (the reference's InferenceConfig); pandas bookkeeping included"}
                         e2e_products[key] = (r["product"], r["job_inputs"])
                         gc.collect()
                     if not args.no_cpu_baseline and not args.no_e2e_parity and world == 1:
