@@ -72,6 +72,92 @@ __global__ __launch_bounds__(256) void split_weights_generic_kernel(const float*
 // written or re-read.  Conv pixels outside the map do not take part in the max (PyTorch pads with -inf).
 constexpr int kPoolRows = 3, kPoolCols = 8, kPoolCW = 2 * kPoolCols + 1, kPoolCH = 2 * kPoolRows + 1;
 
+// Direct epilogue (round 5; conv_pp.hip's, for this kernel's tiles).  The MFMAs run TRANSPOSED -- weights as the A operand
+// (rows read in the order sigma(i) = 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3)), pixels as B -- so a lane holds ONE pixel (l & 31)
+// and 16 CONSECUTIVE output channels per 32 x 32 tile: acc[mt][nt][r] = (pixel m0 + wm + 32 mt + (l & 31), channel n0 + wn + 32 nt +
+// 16 (l >> 5) + r).  A 4 x 4 transpose inside each lane quad gives lane j piece j (4 channels) of the quad's four pixels: store k
+// writes pixel k of every quad, 4 lanes x 16 B = 64 contiguous bytes, the two half-waves complete the 128-B line.  No LDS
+// transpose, no barrier: the shared epilogue (conv_epilogue.h: 32 ds_write_b32 + 8 ds_read_b128 per lane between two barriers,
+// then 8 stores) was HALF of these launches -- compiled without loads and MFMAs the 120 x 160 / 24-channel projection still took
+// 69 of its 141 us, the 7 x 10 / 1392-channel expansion 13.6 of 28.  Same dot products in the same order: bit-identical outputs.
+__device__ __forceinline__ void igs_quad_transpose4(int qj, float& r0, float& r1, float& r2, float& r3) {
+  {
+    const bool b = qj & 1;
+    const float s01 = b ? r0 : r1, s23 = b ? r2 : r3;
+    const float g01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+    const float g23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+    if (b) { r0 = g01; r2 = g23; } else { r1 = g01; r3 = g23; }
+  }
+  {
+    const bool b = qj & 2;
+    const float s02 = b ? r0 : r2, s13 = b ? r1 : r3;
+    const float g02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+    const float g13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+    if (b) { r0 = g02; r1 = g13; } else { r2 = g02; r3 = g13; }
+  }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void igs_epilogue_direct(const ConvArgs& a, floatx16 (&acc)[MT][NT], const float* unscale, float act_inv, int64_t m0,
+                                                    int n0, int wm, int wn, int lane) {
+  const int px = lane & 31, h16 = 16 * (lane >> 5), qj = lane & 3, qp = px & ~3;
+  float chk = 0.f, amax = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + wn + nt * 32 + h16 + 4 * qj;  // this lane's four channels after the transpose
+    const bool n_ok = n < a.Cout;                    // the last tile of a layer whose Cout is not a multiple of the tile width
+    const floatx4 sc = *reinterpret_cast<const floatx4*>(unscale + n) * act_inv;  // rows / bias padded to whole tiles by the planner
+    floatx4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias = *reinterpret_cast<const floatx4*>(a.bias + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      floatx4 res[4];
+      if (a.residual) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int64_t m = m0 + wm + mt * 32 + qp + k;
+          res[k] = *reinterpret_cast<const floatx4*>(a.residual + (m < a.M && n_ok ? m * a.Cout + n : 0));
+        }
+      }
+      floatx4 t[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) t[g] = floatx4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float r0 = t[0][c], r1 = t[1][c], r2 = t[2][c], r3 = t[3][c];
+        igs_quad_transpose4(qj, r0, r1, r2, r3);
+        t[0][c] = r0; t[1][c] = r1; t[2][c] = r2; t[3][c] = r3;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // t[k] = channels [n, n + 4) of pixel row m0 + wm + 32 mt + qp + k
+        const int64_t m = m0 + wm + mt * 32 + qp + k;
+        floatx4 v = t[k] * sc + bias;
+        if (a.residual) v += res[k];
+        if (m < a.M && n_ok) {
+          chk += (v[0] + v[1]) + (v[2] + v[3]);
+          if (a.relu == HP_ACT_RELU) v = __builtin_elementwise_max(v, floatx4{0.f, 0.f, 0.f, 0.f});
+          else if (a.relu == HP_ACT_SWISH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.f + __expf(-v[q]));
+          }
+          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+          *reinterpret_cast<floatx4*>(a.y + m * a.Cout + n) = v;
+        }
+      }
+    }
+  }
+  conv_report_nonfinite(a, chk);
+  if (a.amax_out) {  // as conv_epilogue.h: wave maximum, look before the atomic, words spread over L2 channels
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0 && amax > 0.f) {
+      const unsigned mine = __float_as_uint(amax);
+      unsigned* const slot = a.amax_out + (blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride;
+      if (mine > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mine);
+    }
+  }
+}
+
 // PRE: 0 none, 1 BN + ReLU on the input (pre_scale / pre_shift [Cin]), 2 squeeze-excitation gate (pre_scale [n][Cin],
 // EfficientNet projections: the gated input is formed in fp32 and then split, as the exact kernels form it)
 // Register budget: double-buffered (NBUF 2) two workgroups per CU = 256 VGPRs; single-buffered (NBUF 1) four per CU = 128
@@ -158,7 +244,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF =
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
   const int frow = lane & 31, fk = 8 * (lane >> 5);
   const _Float16* const Afr = As + (wm + frow) * LDH + fk;
-  const _Float16* const Bfr = Bs + (wn + frow) * LDH + fk;
+  // MFMA row i of a 32-channel block multiplies weight row sigma(i): the lane's 16 accumulator rows are 16 consecutive channels
+  const int srow = 16 * ((frow >> 2) & 1) + 4 * (frow >> 3) + (frow & 3);
+  const _Float16* const Bfr = Bs + (wn + srow) * LDH + fk;
 
   // staged K-tile in registers; two sets, so that the loads of K-tile t+2 are in flight while t is multiplied and
   // t+1 is written to LDS (these launches are latency-bound: a dozen MFMAs per K-tile and wave)
@@ -224,9 +312,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF =
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ni], ah[mi], acc[mi][ni], 0, 0, 0);  // D[channel][pixel]
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ni], ah[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ni], al[mi], acc[mi][ni], 0, 0, 0);
         }
     }
   };
@@ -239,6 +327,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF =
   store(0, s0);
   __syncthreads();
   // one K-tile: `cur` was written to LDS buffer `buf` (from the OTHER set), `nxt` holds t + 1 and takes t + 2 after it is stored
+  // (a third register stage -- the loads of t + 3 in flight -- was measured on the 1x1 layers: no change, round 5)
   auto ktile = [&](int t, int buf, Stage& stored, Stage& nxt) {
     if (t + 2 < t_end) issue(t + 2, stored);  // its registers are free: tile t went to LDS before the last barrier
     compute(buf);
@@ -253,21 +342,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF =
 
   if (split && !splitk_reduce<BM, BN, MT, NT, kThreads>(a, acc, lin - a.sk_regular, slice)) return;
 
-  // scale back (a lane holds one output channel per N tile), then the shared fp32 epilogue
+  // scale back + bias + residual + activation + store, straight from the accumulators
   const int rows_pad = a.tiles_n * BN;
   const float* const unscale = reinterpret_cast<const float*>(wsplit + (size_t)rows_pad * a.Kpad * 2);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const float s = unscale[n0 + wn + nt * 32 + (lane & 31)] * act_inv;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= s;
-  }
   if (!POOL) {
-    conv_epilogue<BM, BN, MT, NT, kThreads>(a, reinterpret_cast<float*>(lds_raw), acc, m0, n0, wm, wn);
+    igs_epilogue_direct<MT, NT>(a, acc, unscale, act_inv, m0, n0, wm, wn, lane);
     return;
   }
+  // pooled stem: scale back (a lane holds 16 consecutive channels of one conv pixel per tile)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const floatx4 s4 = *reinterpret_cast<const floatx4*>(unscale + n0 + wn + nt * 32 + 16 * (lane >> 5) + 4 * g) * act_inv;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[mt][nt][4 * g + q] *= s4[q];
+    }
   // ---- pooled epilogue: conv tile -> LDS [row][BN + 4], then max over the 3 x 3 windows (bias and ReLU commute with max)
   float* const cl = reinterpret_cast<float*>(lds_raw);
   constexpr int LDC = BN + 4;
@@ -277,10 +369,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF =
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        cl[row * LDC + wn + nt * 32 + (lane & 31)] = acc[mt][nt][r];
-      }
+      for (int g = 0; g < 4; ++g)  // row = the lane's conv pixel, 16 consecutive channels as four 16-B pieces
+        *reinterpret_cast<floatx4*>(cl + (wm + mt * 32 + (lane & 31)) * LDC + wn + nt * 32 + 16 * (lane >> 5) + 4 * g) =
+            floatx4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
   __syncthreads();
   constexpr int C4 = BN / 4;
   const int Hp = (a.Ho - 1) / 2 + 1, Wp = (a.Wo - 1) / 2 + 1;
@@ -346,8 +437,9 @@ int launch_igs(ConvArgs args, hipStream_t stream) {
   if (!LIN) {
     // a 1x1 / stride-1 / pad-0 layer (same map size without padding, K = the channels): the table-free instantiation
     static const bool no_lin = std::getenv("HP_IGS_NO_LIN") != nullptr;
-    if (!no_lin && args.pad == 0 && args.stride == 1 && args.Ho == args.H && args.Wo == args.W && args.Kpad == (args.Cin + 31) / 32 * 32 &&
-        args.Cin % 4 == 0)
+    // (not the single-buffered tile with a BN + ReLU prologue: its table-free instantiation spills 28 B per lane at 168 VGPRs)
+    if (!no_lin && !(PRE == 1 && NBUF == 1) && args.pad == 0 && args.stride == 1 && args.Ho == args.H && args.Wo == args.W &&
+        args.Kpad == (args.Cin + 31) / 32 * 32 && args.Cin % 4 == 0)
       return launch_igs<BN, PRE, NBUF, true>(args, stream);
   }
   if (!opted) {
