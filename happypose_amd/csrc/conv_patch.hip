@@ -265,12 +265,18 @@ int conv_plan_split(ConvArgs& a, int T, size_t lds_bytes, int k_units, int ktile
   int regular = (T / slots) * slots, tail = T - regular, S = 1;
   regular -= regular % 8;  // the kernel deals regular tiles to the 8 XCDs evenly
   tail = T - regular;
-  if (tail > 0 && ncc > 1 && !no_split && !a.no_tail_split) {
-    double best = rounds_cost((double)tail / slots);
+  // while two lanes share the GPU (no_tail_split) a launch is still sliced when it and its twin on the other lane together
+  // cannot fill the GPU: it then plans against half of the slots (the rule of plan_tail_split in conv_split.hip; EfficientNet's
+  // projections on the 7 x 10 maps are 70 - 105 workgroups x 44 - 72 K-tiles per lane)
+  static const bool lane_slices = !(std::getenv("HP_LANE_SLICES") && std::atoi(std::getenv("HP_LANE_SLICES")) == 0);
+  const bool shared = a.no_tail_split != 0;
+  const int fill = shared ? slots / 2 : slots;
+  if (tail > 0 && ncc > 1 && !no_split && (!shared || (lane_slices && regular == 0 && tail <= fill))) {
+    double best = rounds_cost((double)tail / fill);
     // a slice must stay long (>= 12 K-tiles of 32): parking and re-reading a 64-KB slab costs about
     // as much as 2-3 K-tiles, so splitting short tiles loses (measured on the 64->128 stride-2 layer)
     for (int s = 2; s <= ncc && s <= 16 && (ncc * ktiles_per_unit) / s >= 12; ++s) {
-      const double c = rounds_cost((double)tail * s / slots) / s + 0.015 * s;  // + slab traffic / item start-up
+      const double c = rounds_cost((double)tail * s / fill) / s + 0.015 * s;  // + slab traffic / item start-up
       if (c < 0.9 * best) { best = c; S = s; }
     }
   }
