@@ -105,15 +105,18 @@ __global__ __launch_bounds__(256, 2) void mbconv_front_kernel(FrontArgs a) {
   constexpr int NPASS = S == 2 ? 1 : 4 / RT;         // S == 1: a lane owns 4 of the 8 rows of its column
   constexpr int NR = (RT - 1) * S + K;  // E rows a lane walks
   float chk = 0.f;
-  // in-image flags of the 2 x 16 pixels whose expansion this lane activates (bit 16 i + r)
+  // The expansion's MFMAs run TRANSPOSED (weights as the A operand, rows in the order sigma(i) = 16 ((i >> 2) & 1) + 4 (i >> 3) +
+  // (i & 3): conv_pp.hip): a lane holds ONE staged pixel per row tile and 16 CONSECUTIVE expanded channels, so the activated
+  // tile goes to LDS as four 16-B stores per row tile (round 5; one channel of 16 pixels per lane meant 16 ds_write_b32 with
+  // an address each).  In-image flag of this lane's pixel in row tile wave + 4 i: bit i.
+  const int srow = 16 * ((frow >> 2) & 1) + 4 * (frow >> 3) + (frow & 3);
+  const int h16 = 16 * (lane >> 5);
   unsigned live = 0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int p = (wave + 4 * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (p < T::P && inimg[p]) live |= 1u << (16 * i + r);
-    }
+  for (int i = 0; i < 2; ++i) {
+    const int p = (wave + 4 * i) * 32 + frow;
+    if (p < T::P && inimg[p]) live |= 1u << i;
+  }
 
   const int n_chunks = (a.Cexp + kCC - 1) / kCC;
   // the pass's weights are fetched one pass ahead (L2 latency is ~1 us: unhidden it was a third of a pass): B fragments of
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_front_kernel(FrontArgs a) {
   constexpr int kWdQuads = (K * K + 1) * (kCC / 4);
   static_assert(kWdQuads <= 256, "one depthwise weight quad per lane");
   auto fetch = [&](int n0) {
-    const _Float16* const wrow = wsplit + (size_t)(n0 + frow) * KP * 2 + fk;
+    const _Float16* const wrow = wsplit + (size_t)(n0 + srow) * KP * 2 + fk;
 #pragma unroll
     for (int kk = 0; kk < KP / 16; ++kk) {
       const int ko = (kk >> 1) * 64 + (kk & 1) * 16;
@@ -157,30 +160,31 @@ __global__ __launch_bounds__(256, 2) void mbconv_front_kernel(FrontArgs a) {
           const _Float16* ap = As + (rt * 32 + frow) * LDA + ko + fk;
           const halfx8 ah = *reinterpret_cast<const halfx8*>(ap);
           const halfx8 al = *reinterpret_cast<const halfx8*>(ap + 32);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[i], 0, 0, 0);  // D[channel][pixel]
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[i], 0, 0, 0);
         }
       }
     }
-    // ---- BN shift + swish -> E (a lane holds channel n0 + frow of 16 pixels per row tile)
-    {
-      const int n = n0 + frow;
-      const float us = unscale[n];
-      const float be = n < a.Cexp ? a.bias_e[n] : 0.f;
+    // ---- BN shift + swish -> E (a lane holds channels n0 + h16 .. + 15 of pixel frow of each of its row tiles)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + h16 + 4 * g;
+      const floatx4 us = *reinterpret_cast<const floatx4*>(unscale + n);  // rows padded to whole passes by the planner
+      floatx4 be = {0.f, 0.f, 0.f, 0.f};
+      if (n < a.Cexp) be = *reinterpret_cast<const floatx4*>(a.bias_e + n);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int rt = wave + 4 * i;
-        if (rt < n_rt) {
+        const int pp = (wave + 4 * i) * 32 + frow;
+        if (wave + 4 * i < n_rt && pp < T::P) {
+          floatx4 v;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int p = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (p < T::P) {
-              const float pre = fmaf(acc[i][r], us, be);
-              chk += pre;
-              Es[p * kLDE + frow] = (live >> (16 * i + r)) & 1u ? swish1(pre) : 0.f;
-            }
+          for (int q = 0; q < 4; ++q) {
+            const float pre = fmaf(acc[i][4 * g + q], us[q], be[q]);
+            chk += pre;
+            v[q] = (live >> i) & 1u ? swish1(pre) : 0.f;
           }
+          *reinterpret_cast<floatx4*>(Es + pp * kLDE + h16 + 4 * g) = v;
         }
       }
     }
