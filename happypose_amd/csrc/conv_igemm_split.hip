@@ -223,6 +223,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF =
       ih0[i] = -(1 << 28); iw0[i] = 0; xrow[i] = a.x;
     }
   }
+  // LIN: the staged pixel of GEMM row m IS input pixel m: 32-bit byte offsets into a buffer resource over x, one per staged row;
+  // rows beyond M and channels beyond Cin read out of bounds = zeros -- no bounds arithmetic, no 64-bit addresses, no masks
+  constexpr unsigned kOob = 0xFFFFFFF0u;
+  unsigned voff[NA];
+  unsigned live_mask = 0;
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, LIN ? (int)(unsigned)(a.M * a.Cin * 4) : 0, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int64_t m = m0 + r0 + 32 * i;
+    voff[i] = LIN && m < a.M ? (unsigned)((m * a.Cin + 4 * kc) * 4) : kOob;
+    live_mask |= (m < a.M ? 1u : 0u) << i;
+  }
   const _Float16* const wsplit = reinterpret_cast<const _Float16*>(a.w);
   float act_sx, act_inv;  // ConvArgs::amax_in: power-of-two scale of the staged activations and its inverse
   conv_act_scale(a, act_sx, act_inv);
@@ -256,12 +268,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF =
     if (LIN) { const int c = 32 * t + 4 * kc; e = make_int4(c, c < a.Cin ? 0 : -1, 0, c); }
     else e = a.lut[t * 8 + kc];
     st.ok = 0;
+    if constexpr (LIN) {
+      const bool cok = e.y >= 0;
+      st.ok = cok ? live_mask : 0u;  // (only the BN + ReLU prologue needs it: relu(0 * s + b) is not zero)
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int ih = ih0[i] + e.y, iw = iw0[i] + e.z;
-      const bool in = (e.y >= 0) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-      st.ra[i] = *reinterpret_cast<const floatx4*>(in ? xrow[i] + e.x : a.x);
-      st.ok |= (in ? 1u : 0u) << i;
+      for (int i = 0; i < NA; ++i)
+        st.ra[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(cok ? voff[i] : kOob), t * 128, 0));
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int ih = ih0[i] + e.y, iw = iw0[i] + e.z;
+        const bool in = (e.y >= 0) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+        st.ra[i] = *reinterpret_cast<const floatx4*>(in ? xrow[i] + e.x : a.x);
+        st.ok |= (in ? 1u : 0u) << i;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) st.rbw[i] = *reinterpret_cast<const halfx8*>(wrow[i] + (size_t)t * 64);
@@ -283,7 +303,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF =
       if (PRE == 1) v = __builtin_elementwise_max(v * st.ps + st.pb, floatx4{0.f, 0.f, 0.f, 0.f});
       if (PRE == 2) v = v * st.g[PRE == 2 ? i : 0];
       v = v * act_sx;  // ConvArgs::amax_in: exact power of two (1 when the input's range is not tracked)
-      if (!((st.ok >> i) & 1u)) v = floatx4{0.f, 0.f, 0.f, 0.f};
+      if (!(LIN && PRE != 1) && !((st.ok >> i) & 1u)) v = floatx4{0.f, 0.f, 0.f, 0.f};  // (LIN: the load itself returned zeros)
       const halfx4 hi = __builtin_convertvector(v, halfx4);
       const halfx4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), halfx4);
       *reinterpret_cast<halfx4*>(Ast + buf * BM * LDH + 32 * i * LDH) = hi;
@@ -439,7 +459,7 @@ int launch_igs(ConvArgs args, hipStream_t stream) {
     static const bool no_lin = std::getenv("HP_IGS_NO_LIN") != nullptr;
     // (not the single-buffered tile with a BN + ReLU prologue: its table-free instantiation spills 28 B per lane at 168 VGPRs)
     if (!no_lin && !(PRE == 1 && NBUF == 1) && args.pad == 0 && args.stride == 1 && args.Ho == args.H && args.Wo == args.W &&
-        args.Kpad == (args.Cin + 31) / 32 * 32 && args.Cin % 4 == 0)
+        args.Kpad == (args.Cin + 31) / 32 * 32 && args.Cin % 4 == 0 && args.M * args.Cin * 4 < 0xFFFFFFF0ll)
       return launch_igs<BN, PRE, NBUF, true>(args, stream);
   }
   if (!opted) {
