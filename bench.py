@@ -37,6 +37,7 @@ N_DET, N_HYP, N_ITERS = 8, 16, 5
 
 
 WORKLOADS = ("C2", "C3", "C5", "E2E")
+EFFICIENTNET_LANES = 4  # C2 with the EfficientNet-b3 backbone: 153 small launches per forward; 3414 / 3455 / 3470 poses/s at 2 / 3 / 4 lanes
 DEFAULT_LANES = {"C2": 2, "C3": 3, "C5": 2, "E2E": 3}  # --lanes (E2E: the refiner's bsz_objects chunks run one per lane; f16 coarse 7.99 / 8.53 / 8.28 frames/s at 2 / 3 / 4)
 
 
@@ -579,7 +580,7 @@ def main():
         return
     precision = args.precision or ("f16" if args.workload == "C5" else "f32")
     peak = PEAK_F16_MFMA_TFLOPS if precision == "f16" else PEAK_F32_MFMA_TFLOPS
-    n_lanes = args.lanes or DEFAULT_LANES.get(args.workload, 2)
+    n_lanes = args.lanes or (EFFICIENTNET_LANES if args.arch == "efficientnet-b3" and args.workload == "C2" else DEFAULT_LANES.get(args.workload, 2))
     rkw = None if args.render_state == "reference" else dict(msaa=False, aniso=False)
     ds, renderer, scene, weights, model = build_world(device, args.arch, seed=rank, workload=args.workload,
                                                       precision=precision, n_lanes=n_lanes, renderer_kw=rkw)
@@ -838,7 +839,7 @@ def main():
             if args.arch == "resnet34" and precision == "f32":
                 # C2 on the backbone the released CosyPose checkpoints use (CP/models/efficientnet.py), 3 steps
                 try:
-                    line["c2_efficientnet_b3"] = quick_workload(device, "C2", "f32", n_lanes, steps=3, arch="efficientnet-b3")
+                    line["c2_efficientnet_b3"] = quick_workload(device, "C2", "f32", args.lanes or EFFICIENTNET_LANES, steps=3, arch="efficientnet-b3")
                 except Exception as e:
                     line["c2_efficientnet_b3"] = {"error": f"{type(e).__name__}: {e}"}
                 # the whole PoseEstimator.run_inference_pipeline on one frame (bench.py --workload E2E), detector included
