@@ -2,8 +2,8 @@
 // the backbone of the released CosyPose checkpoints -- SURVEY.md 8f-1): depthwise k x k
 // convolution + folded BatchNorm + swish, and squeeze-excitation (global mean -> 1x1 reduce ->
 // swish -> 1x1 expand -> sigmoid).  The 1x1 expansion / projection convolutions are GEMMs and
-// run on the generic MFMA kernel (conv.hip), which also applies the excitation gate while it
-// stages the projection's input, so the gated tensor never exists in memory.
+// run on the split-fp16 implicit-GEMM kernel (conv_igemm_split.hip; conv.hip when the exact-fp32 kernels are forced),
+// which also applies the excitation gate while it stages the projection's input, so the gated tensor never exists in memory.
 //
 // All tensors NHWC fp32 with C % 4 == 0 (every EfficientNet width is a multiple of 8).
 // "Same" padding follows Conv2dStaticSamePadding (efficientnet_utils.py:183-212): the pad
@@ -56,8 +56,9 @@ __global__ __launch_bounds__(256) void dwconv_swish_nhwc(DwArgs a) {
   *reinterpret_cast<floatx4*>(a.y + (((int64_t)img * a.Ho + oh) * a.Wo + ow) * a.C + c) = swish4(acc);
 }
 
-// Strip kernel: a workgroup owns R output rows of one image for up to 256 channel quads.  A lane keeps ONE channel quad
-// (its k*k weights stay in registers) and walks the columns of the strip; per column it streams the (R-1)*S+K input
+// Strip kernel: a workgroup owns R output rows of one image for an even share of at most 64 channel quads (dw_quads_per_block) and
+// as many column phases as fit 256 lanes.  A lane keeps ONE channel quad (3 x 3: its taps stay in registers; 5 x 5: in LDS, see WLDS)
+// and walks the columns of the strip; per column it streams the (R-1)*S+K input
 // rows once and feeds every output row they reach, so an output costs ((R-1)*S+K)*K/R quad loads instead of K*K
 // (k5: 10 vs 25 -- the one-output-per-lane kernel above is bound by the L1 request rate, not by HBM).  The FMA order
 // per output is the same (dy, dx ascending), so the conv result is bit-identical.  The lanes also sum what they store:
