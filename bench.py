@@ -38,6 +38,7 @@ N_DET, N_HYP, N_ITERS = 8, 16, 5
 
 WORKLOADS = ("C2", "C3", "C5", "E2E")
 EFFICIENTNET_LANES = 4  # C2 with the EfficientNet-b3 backbone: 153 small launches per forward; 3414 / 3455 / 3470 poses/s at 2 / 3 / 4 lanes
+COARSE_HEAD_SCALE = 1.0  # the coarse / scoring head of the C5 and E2E worlds: logits that discriminate between grid poses (std ~ O(1) over an object's 576 poses, as golden G10's `coarse` case); at the pose head's 0.002 their whole range was 4e-4 and every tolerance blind
 DEFAULT_LANES = {"C2": 2, "C3": 3, "C5": 2, "E2E": 3}  # --lanes (E2E: the refiner's bsz_objects chunks run one per lane; f16 coarse 7.99 / 8.53 / 8.28 frames/s at 2 / 3 / 4)
 
 
@@ -73,7 +74,7 @@ def build_world(device, arch="resnet34", seed=0, workload="C2", precision="f32",
         T[:, :3, :3] = np.tile(grid, (8, 1, 1))
         scene["TCO_hyp"] = T.astype(np.float32)
         scene["hyp_obj_ids"] = np.repeat(scene["det_obj_ids"], 576).astype(np.int32)
-        weights = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 9, pose_dim=0, n_views_logits=1), seed=0)
+        weights = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 9, pose_dim=0, n_views_logits=1), seed=0, update_scale=COARSE_HEAD_SCALE)
         cfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
                    predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
         model = create_model_pose(cfg, renderer, state_dict=weights, max_batch=576 * n_lanes, precision=precision, n_lanes=n_lanes)
@@ -102,7 +103,7 @@ def e2e_run(device, rank, world, lanes, coarse_precision, steps, warmup, run_det
                 predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
     rcfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
                 depth_augmentation=False)
-    wc = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 9, pose_dim=0, n_views_logits=1), seed=0)
+    wc = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 9, pose_dim=0, n_views_logits=1), seed=0, update_scale=COARSE_HEAD_SCALE)
     wr = predictor_weights(pose_model_param_shapes("vanilla_resnet34", 27), seed=1)
     coarse = create_model_pose(ccfg, renderer, state_dict=wc, max_batch=576, precision=coarse_precision, n_lanes=lanes)
     refiner = create_model_pose(rcfg, renderer, state_dict=wr, max_batch=64, precision="f32", n_lanes=lanes)
@@ -210,10 +211,26 @@ def e2e_oracle(job, cores=None):
     return ref, time.time() - t0
 
 
-def e2e_parity(product, ref, logit_tol):
-    """Final-pose parity of an end-to-end run against the oracle estimator's run of the same job: coarse logits of all 4608 poses,
-    the top-5 selection, and -- for the detections where both sides picked the same hypothesis in the end -- the final poses."""
+# coarse logits of an end-to-end run against the oracle estimator's, in units of the oracle's SPREAD over a detection's 576 grid
+# poses (std; the coarse head of the bench worlds has COARSE_HEAD_SCALE = 1.0): the measured error of the healthy path with
+# head-room, as tests/test_gpu_pipeline.py::test_c5_coarse_scoring_vs_oracle (tools/probes/c5_parity_probe.py; a network with
+# one conv layer off by 1 % is outside them)
+COARSE_LOGIT_REL = {"f32": 0.1, "f16": 0.3}
+
+
+def e2e_parity(product, ref, coarse_precision):
+    """Final-pose parity of an end-to-end run against the oracle estimator's run of the same job: coarse logits of all 4608 poses
+    RELATIVE to the oracle's own spread per detection, the top-5 selection, and -- for the detections where both sides picked the
+    same hypothesis in the end -- the final poses."""
     cl = ref["coarse_df"]["coarse_logit"].values.astype(np.float64)
+    det = ref["coarse_df"]["instance_id"].values if "instance_id" in ref["coarse_df"] else np.arange(len(cl)) // 576
+    diff = np.abs(product["coarse_logit"] - cl)
+    rel, spreads = [], []
+    for d in np.unique(det):
+        m = det == d
+        spreads.append(float(cl[m].std()))
+        rel.append(float(diff[m].max() / max(cl[m].std(), 1e-30)))
+    rel_tol = COARSE_LOGIT_REL[coarse_precision]
     same_top = sorted(product["filtered_hyp"]) == sorted(ref["filtered_df"]["hypothesis_id"].tolist())
     rl = dict(zip(ref["final_df"]["label"].tolist(), zip(ref["final_df"]["hypothesis_id"].tolist(), range(len(ref["final_df"])))))
     match, dts, drs = 0, [], []
@@ -222,12 +239,14 @@ def e2e_parity(product, ref, logit_tol):
             match += 1
             pp = pose_parity(product["final_poses"][k:k + 1], ref["final_TCO"][rl[lab][1]:rl[lab][1] + 1])
             dts.append(pp["max_dt_m"]); drs.append(pp["max_dR_rad"])
-    return {"coarse_logit_max_abs_diff": float(np.abs(product["coarse_logit"] - cl).max()), "coarse_logit_tol": logit_tol,
+    return {"coarse_logit_max_abs_diff": float(diff.max()), "coarse_logit_spread_per_detection": [round(x, 5) for x in spreads],
+            "coarse_logit_max_diff_over_spread": max(rel), "coarse_logit_rel_tol": rel_tol,
             "top5_sets_equal": bool(same_top), "detections": len(product["final_hyp"]), "final_hypothesis_agrees": match,
             "max_dt_m": max(dts) if dts else None, "max_dR_rad": max(drs) if drs else None, "tol": {"dt_m": T_TOL, "dR_rad": R_TOL},
-            "ok": bool(np.abs(product["coarse_logit"] - cl).max() <= logit_tol and (not dts or (max(dts) <= T_TOL and max(drs) <= R_TOL))),
-            "note": "a detection whose two best hypotheses score within the logit tolerance of each other may legitimately end on the other one: "
-                    "poses are compared where the final hypothesis ids agree"}
+            "ok": bool(max(rel) <= rel_tol and (not dts or (max(dts) <= T_TOL and max(drs) <= R_TOL))),
+            "note": "coarse logits are compared in units of the oracle's own standard deviation over a detection's 576 grid poses; a detection "
+                    "whose two best hypotheses score within the error of each other may legitimately end on the other one: poses are "
+                    "compared where the final hypothesis ids agree"}
 
 
 def bench_e2e(args, device, rank, world):
@@ -864,8 +883,8 @@ def main():
                     if not args.no_cpu_baseline and not args.no_e2e_parity and world == 1:
                         # final-pose parity of BOTH end-to-end runs against ONE run of the oracle estimator on the same job
                         ref, secs = e2e_oracle(e2e_products["e2e"][1])
-                        for key, tol in (("e2e", 5e-3), ("e2e_f16_coarse", 5e-2)):  # logits: fp32 as in the tests; the fp16 plan's stated 5e-2
-                            line[key]["parity"] = dict(e2e_parity(e2e_products[key][0], ref, tol), oracle_seconds=round(secs, 1))
+                        for key, cprec in (("e2e", "f32"), ("e2e_f16_coarse", "f16")):
+                            line[key]["parity"] = dict(e2e_parity(e2e_products[key][0], ref, cprec), oracle_seconds=round(secs, 1))
                 except Exception as e:
                     line.setdefault("e2e", {"error": f"{type(e).__name__}: {e}"})
                     line.setdefault("e2e_f16_coarse", {"error": f"{type(e).__name__}: {e}"})

@@ -81,6 +81,7 @@ _PROTOS = {
     "hp_net_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_net_precision": (C.c_int, [C.c_void_p]),
     "hp_net_output_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hp_net_input_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hp_net_finalize": (C.c_int, [C.c_void_p, C.c_int]),
     "hp_net_forward": (C.c_int, [C.c_void_p, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "hp_net_forward_f16in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),

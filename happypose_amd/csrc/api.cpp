@@ -1,6 +1,7 @@
 // C-ABI glue: error reporting, device queries and the device-resident mesh store.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>

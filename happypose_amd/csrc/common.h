@@ -5,9 +5,11 @@
 #include <stdint.h>
 
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 #include "../../include/happypose_amd.h"
+#include "debug.h"
 
 namespace hp {
 
@@ -36,6 +38,21 @@ inline int check_launch(const char* what) {
   if (e != hipSuccess) return fail(HP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
   return HP_OK;
 }
+
+// First-launch set-up of ONE kernel instantiation (dynamic-LDS opt-in, scratch query): `static FirstLaunch fl;` in its launcher,
+// `fl.once([&](FirstLaunch& s) { ...; return HP_OK; })` runs the set-up exactly once per process whichever host thread launches
+// first -- concurrent first launches on distinct streams wait for it instead of racing on a plain flag -- and
+// hands every caller its result code.
+struct FirstLaunch {
+  std::once_flag flag;
+  int rc = HP_OK;
+  bool spills = false;  // the kernel uses scratch (count_scratch_launch)
+  template <class F>
+  int once(F&& f) {
+    std::call_once(flag, [&] { rc = f(*this); });
+    return rc;
+  }
+};
 
 // device-resident object set (see include/happypose_amd.h)
 struct MeshStore {

@@ -151,16 +151,6 @@ bool conv_wino_launchable(const ConvArgs& a);  // per launch: batch-dependent li
 size_t conv_wino_weight_floats(int cout, int cin);
 int conv_wino_transform_weights(const float* d_w, float* d_U, int cout, int cin, int Kpad, hipStream_t stream);
 int launch_conv_wino(const ConvArgs& a, hipStream_t stream);
-// Winograd F(2x2,3x3) on the fp16 matrix path with the hi/lo split of conv_split.hip (conv_wino.hip, SPLIT instantiation)
-bool conv_wino_split_launchable(const ConvArgs& a);
-size_t conv_wino_split_weight_bytes(int cout, int cin);
-int conv_wino_split_transform_weights(const float* d_w, void* d_U, int cout, int cin, int Kpad, hipStream_t stream);
-int launch_conv_wino_split(const ConvArgs& a, hipStream_t stream);
-// the same arithmetic tiled for the fp16 matrix path: 64 tiles x 64 couts per item, v_mfma_f32_32x32x16_f16 (conv_wino2.hip)
-bool conv_wino2_launchable(const ConvArgs& a);
-size_t conv_wino2_weight_bytes(int cout, int cin);
-int conv_wino2_transform_weights(const float* d_w, void* d_U, int cout, int cin, int Kpad, hipStream_t stream);
-int launch_conv_wino2(const ConvArgs& a, hipStream_t stream);
 // 3x3 / pad 1, stride 1 (Cin % 32 == 0, Cout % 64 == 0) or stride 2 (Cin % 64 == 0, Cout % 128 == 0): fp32 operands split into fp16 halves, three fp16
 // MFMAs per product (conv_split.hip); a.w must point at weights split by conv_split_transform_weights
 bool conv_split_applicable(const ConvArgs& a, int kh, int kw);
@@ -200,30 +190,12 @@ int launch_conv_igemm_split_pool(const ConvArgs& a, hipStream_t stream);
 // plan-time choice between the split-fp16 kernel and the exact-fp32 ones for a 3x3 stride-1 layer
 inline bool conv_use_split(int algo, int H, int W, int cin, int cout) {
   (void)H; (void)W; (void)cin; (void)cout;  // measured faster than Winograd on every WideResNet / ResNet-34 layer shape
-  return algo == HP_CONV_ALGO_SPLIT || algo == HP_CONV_ALGO_AUTO || algo == HP_CONV_ALGO_WINO_SPLIT;
+  return algo == HP_CONV_ALGO_SPLIT || algo == HP_CONV_ALGO_AUTO;
 }
-// which 3x3 stride-1 layers run Winograd on the split operands instead of the direct split kernels: all eligible ones with
-// HP_CONV_ALGO_WINO_SPLIT; otherwise HP_WINO_SPLIT = a bit mask over the map widths {80, 40, 20, 10} -> bits {1, 2, 4, 8}
-// (WideResNet / ResNet-34 at 240 x 320), default 0: measured slower on every layer shape
-inline bool conv_use_wino_split(int algo, int W) {
-  if (algo == HP_CONV_ALGO_WINO_SPLIT) return true;
-  static const int mask = std::getenv("HP_WINO_SPLIT") ? std::atoi(std::getenv("HP_WINO_SPLIT")) : 0;
-  const int bit = W >= 80 ? 1 : W >= 40 ? 2 : W >= 20 ? 4 : 8;
-  return (mask & bit) != 0;
-}
-// conv_wino2.hip on a layer: always with HP_CONV_ALGO_WINO_SPLIT, else per HP_WINO2 = bit mask over the map widths
-// {80, 40, 20, 10} -> bits {1, 2, 4, 8}
-inline bool conv_use_wino2(int algo, int W) {
-  if (algo == HP_CONV_ALGO_WINO_SPLIT) return true;
-  static const int mask = std::getenv("HP_WINO2") ? std::atoi(std::getenv("HP_WINO2")) : 0;
-  const int bit = W >= 80 ? 1 : W >= 40 ? 2 : W >= 20 ? 4 : 8;
-  return (mask & bit) != 0;
-}
-// which generic-kernel layers move to conv_igemm_split.hip (HP_ISPLIT_MIN_KH: smallest filter size, default 1)
+// which generic-kernel layers move to conv_igemm_split.hip: all of them (1x1 included)
 inline bool conv_use_igemm_split(int kh, int Kpad) {
-  static const int min_kh = std::getenv("HP_ISPLIT_MIN_KH") ? std::atoi(std::getenv("HP_ISPLIT_MIN_KH")) : 1;
-  (void)Kpad;
-  return kh >= min_kh;
+  (void)kh; (void)Kpad;
+  return true;
 }
 // hipGraph safety (hp_scratch_launches): does kernel `fn` use scratch?  (asked once per instantiation, where it opts in to its
 // LDS size); every launch of such a kernel is counted
@@ -255,8 +227,9 @@ int launch_conv_f16(const ConvArgsH& a, hipStream_t stream);
 int launch_cast_pad_f16(const float* x, void* y, int64_t pixels, int c_in, int c_out, hipStream_t stream);
 int launch_maxpool_f16(const void* x, void* y, int n, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
 int conv_setup_once();
-// process-wide DEFAULT of the kernel-family choice (hp_conv_select_algo / HP_CONV_NO_WINOGRAD, HP_CONV_NO_PATCH); a
-// network overrides it with hp_net_set_conv_algo and hands its choice to the launchers in ConvArgs::algo
-int conv_algo();
+// kernel family of the SINGLE-LAYER entry points hp_conv2d_nhwc / hp_conv2d_nhwc_f16 (hp_conv_select_algo: parity tests and
+// tools/conv_fuzz.py walk the families with it).  Networks never read it: a network's choice is hp_net_set_conv_algo, default
+// AUTO, handed to the launchers in ConvArgs::algo.
+int conv_layer_algo();
 
 }  // namespace hp

@@ -369,38 +369,28 @@ static int opt_in_lds() {
 }
 
 int conv_setup_once() {
-  static bool done = false;
-  if (done) return HP_OK;
-  int rc;
-  if ((rc = opt_in_lds<128, 128, 0>())) return rc;
-  if ((rc = opt_in_lds<128, 128, 1>())) return rc;
-  if ((rc = opt_in_lds<128, 128, 2>())) return rc;
-  if ((rc = opt_in_lds<128, 64, 0>())) return rc;
-  if ((rc = opt_in_lds<128, 64, 1>())) return rc;
-  if ((rc = opt_in_lds<128, 64, 2>())) return rc;
-  done = true;
-  return HP_OK;
+  static FirstLaunch fl;
+  return fl.once([](FirstLaunch&) {
+    int rc;
+    if ((rc = opt_in_lds<128, 128, 0>())) return rc;
+    if ((rc = opt_in_lds<128, 128, 1>())) return rc;
+    if ((rc = opt_in_lds<128, 128, 2>())) return rc;
+    if ((rc = opt_in_lds<128, 64, 0>())) return rc;
+    if ((rc = opt_in_lds<128, 64, 1>())) return rc;
+    if ((rc = opt_in_lds<128, 64, 2>())) return rc;
+    return HP_OK;
+  });
 }
 
 }  // namespace hp
 
 // diagnostics: resident workgroups per CU the runtime grants a conv variant
-// ---- which kernel families the dispatchers may use (process-wide diagnostic switch) ----------
+// ---- kernel family of the single-layer entry points (hp_conv_select_algo; networks: hp_net_set_conv_algo) ----------
 namespace hp {
 namespace {
-int g_conv_algo = -1;  // -1: not initialised (environment), else HP_CONV_ALGO_*
+std::atomic<int> g_layer_algo{HP_CONV_ALGO_AUTO};
 }
-int conv_algo() {
-  if (g_conv_algo < 0) {
-    g_conv_algo = HP_CONV_ALGO_AUTO;
-    if (std::getenv("HP_CONV_NO_SPLIT")) g_conv_algo = HP_CONV_ALGO_WINOGRAD;
-    if (std::getenv("HP_CONV_SPLIT")) g_conv_algo = HP_CONV_ALGO_SPLIT;
-    if (std::getenv("HP_WINO_V1")) g_conv_algo = HP_CONV_ALGO_WINOGRAD_1WAVE;
-    if (std::getenv("HP_CONV_NO_WINOGRAD")) g_conv_algo = HP_CONV_ALGO_DIRECT;
-    if (std::getenv("HP_CONV_NO_WINOGRAD") && std::getenv("HP_CONV_NO_PATCH")) g_conv_algo = HP_CONV_ALGO_IGEMM;
-  }
-  return g_conv_algo;
-}
+int conv_layer_algo() { return g_layer_algo.load(std::memory_order_relaxed); }
 __global__ void zero_words_kernel(unsigned* p, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0u;
@@ -425,8 +415,8 @@ void count_scratch_launch() { g_scratch_launches.fetch_add(1); }
 extern "C" long long hp_scratch_launches(void) { return hp::g_scratch_launches.load(); }
 
 extern "C" int hp_conv_select_algo(int algo) {
-  HP_REQUIRE(algo >= HP_CONV_ALGO_AUTO && algo <= HP_CONV_ALGO_WINO_SPLIT, "hp_conv_select_algo: unknown algorithm");
-  hp::g_conv_algo = algo;
+  HP_REQUIRE(algo >= HP_CONV_ALGO_AUTO && algo <= HP_CONV_ALGO_SPLIT, "hp_conv_select_algo: unknown algorithm");
+  hp::g_layer_algo.store(algo, std::memory_order_relaxed);
   return HP_OK;
 }
 

@@ -472,14 +472,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 template <int BN, bool PRE, int NPC>
 int launch_patch_variant(ConvArgsH args, hipStream_t stream) {
-  static bool opted = false, spills = false;
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_f16<BN, PRE, NPC>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_patch_f16<BN, PRE, NPC>));
-    opted = true;
-  }
-  if (spills) count_scratch_launch();
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch& fl_) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_f16<BN, PRE, NPC>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        fl_.spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_patch_f16<BN, PRE, NPC>));
+        return HP_OK;
+      }))
+    return rc0;
+  if (fl.spills) count_scratch_launch();
   const int P = BM + 2 * args.W + 2;
   size_t lds = ((size_t)P * LDH + 2 * (size_t)BN * LDH) * 2;
   const size_t epi = (size_t)BM * (BN + 4) * 4;
@@ -497,8 +498,7 @@ int launch_patch_variant(ConvArgsH args, hipStream_t stream) {
 
 // instantiated patch sizes: BN = 64 (the 64-channel layers, 60x80 maps): NPC 10; BN = 128: NPC 5 / 6 / 7
 int patch_f16_npc(const ConvArgsH& a, int kh, int kw) {
-  static const bool off = std::getenv("HP_CONV_NO_PATCH") != nullptr;
-  if (off || kh != 3 || kw != 3 || a.stride != 1 || a.pad != 1 || a.Cin % BKH != 0 || a.Cout % 64 != 0) return 0;
+  if (kh != 3 || kw != 3 || a.stride != 1 || a.pad != 1 || a.Cin % BKH != 0 || a.Cout % 64 != 0) return 0;
   const int P = BM + 2 * a.W + 2;
   const int npc = (P * 8 + kThreads - 1) / kThreads;
   if (((size_t)P * LDH + 2 * 128 * LDH) * 2 > 80 * 1024) return 0;  // two workgroups per CU
@@ -516,14 +516,15 @@ int launch_patch(const ConvArgsH& a, int npc, hipStream_t stream) {
 
 template <int BN, bool PRE>
 int launch_variant(ConvArgsH args, hipStream_t stream) {
-  static bool opted = false, spills = false;
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16<BN, PRE>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_f16<BN>()));
-    spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_f16<BN, PRE>));
-    opted = true;
-  }
-  if (spills) count_scratch_launch();
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch& fl_) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f16<BN, PRE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_f16<BN>()));
+        fl_.spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_f16<BN, PRE>));
+        return HP_OK;
+      }))
+    return rc0;
+  if (fl.spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = args.Cout / BN;
   if (args.M >= (1ll << 31)) return fail(HP_ERR_ARG, "conv: more than 2^31 output pixels");

@@ -425,14 +425,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NBUF =
 
 template <int BN, int PRE, int NBUF>
 int launch_igs_pool(ConvArgs args, hipStream_t stream) {
-  static bool opted = false, spills = false;
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)igs_lds_bytes<BN, NBUF>()));
-    spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, true>));
-    opted = true;
-  }
-  if (spills) count_scratch_launch();
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch& fl_) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)igs_lds_bytes<BN, NBUF>()));
+        fl_.spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, true>));
+        return HP_OK;
+      }))
+    return rc0;
+  if (fl.spills) count_scratch_launch();
   const int Hp = (args.Ho - 1) / 2 + 1, Wp = (args.Wo - 1) / 2 + 1;
   const int tiles_y = (Hp + kPoolRows - 1) / kPoolRows, tiles_x = (Wp + kPoolCols - 1) / kPoolCols;
   const int n_img = (int)(args.M / ((int64_t)args.Ho * args.Wo));
@@ -453,22 +454,22 @@ int launch_igs_pool(ConvArgs args, hipStream_t stream) {
 
 template <int BN, int PRE, int NBUF, bool LIN = false>
 int launch_igs(ConvArgs args, hipStream_t stream) {
-  static bool opted = false, spills = false;
+  static FirstLaunch fl;
   if (!LIN) {
     // a 1x1 / stride-1 / pad-0 layer (same map size without padding, K = the channels): the table-free instantiation
-    static const bool no_lin = std::getenv("HP_IGS_NO_LIN") != nullptr;
     // (not the single-buffered tile with a BN + ReLU prologue: its table-free instantiation spills 28 B per lane at 168 VGPRs)
-    if (!no_lin && !(PRE == 1 && NBUF == 1) && args.pad == 0 && args.stride == 1 && args.Ho == args.H && args.Wo == args.W &&
+    if (!(PRE == 1 && NBUF == 1) && args.pad == 0 && args.stride == 1 && args.Ho == args.H && args.Wo == args.W &&
         args.Kpad == (args.Cin + 31) / 32 * 32 && args.Cin % 4 == 0 && args.M * args.Cin * 4 < 0xFFFFFFF0ll)
       return launch_igs<BN, PRE, NBUF, true>(args, stream);
   }
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false, LIN>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)igs_lds_bytes<BN, NBUF>()));
-    spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false, LIN>));
-    opted = true;
-  }
-  if (spills) count_scratch_launch();
+  if (const int rc0 = fl.once([](FirstLaunch& fl_) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false, LIN>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)igs_lds_bytes<BN, NBUF>()));
+        fl_.spills = note_kernel(reinterpret_cast<const void*>(&conv_igemm_split_f32<BN, PRE, NBUF, false, LIN>));
+        return HP_OK;
+      }))
+    return rc0;
+  if (fl.spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = (args.Cout + BN - 1) / BN;
   if (args.M >= (1ll << 31)) return fail(HP_ERR_ARG, "conv: more than 2^31 output pixels");
@@ -499,10 +500,8 @@ int conv_igemm_split_transform_weights(const float* d_w, void* d_ws, int rows_pa
 // a.w = weights split by conv_igemm_split_transform_weights over cout_pad rows (variant 0: cout_pad % 128 == 0 -> 128-wide
 // tiles, variant 1: 64-wide); a.pre_scale with a.pre_shift = BN + ReLU prologue, a.pre_scale alone = squeeze-excitation gate
 bool conv_igemm_split_launchable(const ConvArgs& a) {
-  static const bool off = std::getenv("HP_CONV_NO_SPLIT") != nullptr;
-  static const bool no_gate = std::getenv("HP_NO_SPLIT_GATE") != nullptr;
-  if (a.pre_scale && !a.pre_shift && (no_gate || a.Cin % 4)) return false;
-  return !off && a.Kpad % 32 == 0;
+  if (a.pre_scale && !a.pre_shift && a.Cin % 4) return false;
+  return a.Kpad % 32 == 0;
 }
 
 template <int BN, int NBUF>

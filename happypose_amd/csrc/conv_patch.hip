@@ -261,17 +261,16 @@ int conv_plan_split(ConvArgs& a, int T, size_t lds_bytes, int k_units, int ktile
   }
   const int slots = lds_bytes * 2 <= 160 * 1024 ? ws.slots : ws.slots / 2;
   const int ncc = k_units;
-  static const bool no_split = std::getenv("HP_CONV_NO_SPLITK") != nullptr;
+  const bool no_split = dbg(DBG_CONV_NO_SPLITK) != 0;
   int regular = (T / slots) * slots, tail = T - regular, S = 1;
   regular -= regular % 8;  // the kernel deals regular tiles to the 8 XCDs evenly
   tail = T - regular;
   // while two lanes share the GPU (no_tail_split) a launch is still sliced when it and its twin on the other lane together
   // cannot fill the GPU: it then plans against half of the slots (the rule of plan_tail_split in conv_split.hip; EfficientNet's
   // projections on the 7 x 10 maps are 70 - 105 workgroups x 44 - 72 K-tiles per lane)
-  static const bool lane_slices = !(std::getenv("HP_LANE_SLICES") && std::atoi(std::getenv("HP_LANE_SLICES")) == 0);
   const bool shared = a.no_tail_split != 0;
   const int fill = shared ? slots / 2 : slots;
-  if (tail > 0 && ncc > 1 && !no_split && (!shared || (lane_slices && regular == 0 && tail <= fill))) {
+  if (tail > 0 && ncc > 1 && !no_split && (!shared || (regular == 0 && tail <= fill))) {
     double best = rounds_cost((double)tail / fill);
     // a slice must stay long (>= 12 K-tiles of 32): parking and re-reading a 64-KB slab costs about
     // as much as 2-3 K-tiles, so splitting short tiles loses (measured on the 64->128 stride-2 layer)
@@ -314,17 +313,19 @@ int conv_plan_split(ConvArgs& a, int T, size_t lds_bytes, int k_units, int ktile
 namespace {
 
 template <int BN, bool PRE>
-int launch(ConvArgs args, hipStream_t stream, bool* opted) {
+int launch(ConvArgs args, hipStream_t stream) {
   const int P = BM + 2 * args.W + 2;
   const int npc = (P * 8 + kThreads - 1) / kThreads;
   size_t lds = ((size_t)P * LDK + 2 * BN * LDK) * sizeof(float);
   const size_t lds_epi = (size_t)epilogue_lds_floats<BM, BN>() * sizeof(float);
   if (lds < lds_epi) lds = lds_epi;
-  if (!*opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_f32<BN, PRE>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));  // + static ticket word
-    *opted = true;
-  }
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch&) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_f32<BN, PRE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));  // + static ticket word
+        return HP_OK;
+      }))
+    return rc0;
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = args.Cout / BN;
   if (args.M >= (1ll << 31)) return fail(HP_ERR_ARG, "conv: more than 2^31 output pixels");
@@ -350,10 +351,9 @@ bool conv_patch_applicable(const ConvArgs& a, int kh, int kw) {
 }
 
 int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream) {
-  static bool opted[4] = {false, false, false, false};
   const bool pre = a.pre_scale != nullptr;
-  if (variant == 0) return pre ? launch<128, true>(a, stream, &opted[0]) : launch<128, false>(a, stream, &opted[1]);
-  return pre ? launch<64, true>(a, stream, &opted[2]) : launch<64, false>(a, stream, &opted[3]);
+  if (variant == 0) return pre ? launch<128, true>(a, stream) : launch<128, false>(a, stream);
+  return pre ? launch<64, true>(a, stream) : launch<64, false>(a, stream);
 }
 
 }  // namespace hp

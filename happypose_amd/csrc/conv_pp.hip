@@ -959,14 +959,15 @@ template <int MODE, bool PRE, int NPC, int NT, bool WIDE = false>
 int launch_pp_variant(ConvArgs args, hipStream_t stream) {
   using T = PP<MODE, NT, WIDE>;
   constexpr int BN = T::BN, BM = T::BMT;  // shadows the 256-row constant in this launcher
-  static bool opted = false, spills = false;
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC, NT, WIDE>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));  // + the static ticket word
-    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC, NT, WIDE>));
-    opted = true;
-  }
-  if (spills) count_scratch_launch();
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch& s) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC, NT, WIDE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));  // + the static ticket word
+        s.spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_pp<MODE, PRE, NPC, NT, WIDE>));
+        return HP_OK;
+      }))
+    return rc0;
+  if (fl.spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = args.Cout / BN;
   args.fd_howo = make_fastdiv((unsigned)(args.H * args.W));
@@ -976,8 +977,8 @@ int launch_pp_variant(ConvArgs args, hipStream_t stream) {
   if (rc) return rc;
   const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
   // persistent grid: one workgroup per CU at most (the LDS admits no second one), a multiple of 8 so that a workgroup's
-  // virtual blocks stay on its XCD; HP_PP_GRID overrides the cap (experiments)
-  static const int cap = std::getenv("HP_PP_GRID") ? std::max(8, std::atoi(std::getenv("HP_PP_GRID")) / 8 * 8) : conv_num_cus() / 8 * 8;
+  // virtual blocks stay on its XCD; HP_PP_GRID (debug.h) overrides the cap: tools/conv_fuzz.py makes every workgroup walk many items
+  const int cap = dbg(DBG_PP_GRID) > 0 ? std::max(8, dbg(DBG_PP_GRID) / 8 * 8) : conv_num_cus() / 8 * 8;
   const int grid = std::min(8 * per_xcd, cap);
   hipLaunchKernelGGL((conv3x3_pp<MODE, PRE, NPC, NT, WIDE>), dim3(grid), dim3(kPPThreads), T::lds_bytes(args.W), stream, args,
                      T::P(args.W));
@@ -995,40 +996,28 @@ int launch_pp_nt(const ConvArgs& a, hipStream_t stream) {
 
 template <int MODE, int NT>
 bool pp_shape_ok(int W, int Cin, int Cout, int stride, int pad, int kh, int kw) {
-  static const bool off = std::getenv("HP_CONV_NO_PP") != nullptr;
   using T = PP<MODE, NT>;
-  return !off && kh == 3 && kw == 3 && stride == 1 && pad == 1 && Cout % T::BN == 0 && Cin % T::CKC == 0 && Cin <= 512 &&
+  return !dbg(DBG_CONV_NO_PP) && kh == 3 && kw == 3 && stride == 1 && pad == 1 && Cout % T::BN == 0 && Cin % T::CKC == 0 && Cin <= 512 &&
          T::npc(W) <= 6 && T::lds_bytes(W) <= 159 * 1024;
 }
-// 64-wide tiles (round 4, HP_PP_BN64=1): the 64-channel layers of the 60 x 80 maps on the ping-pong skeleton (fp32 / split
-// mode).  Built, parity-green and NOT the default: measured on the same box 169 / 204 us per layer at batch 128 against
-// 154 / 172 for conv3x3_split_f32's 256 x 64 tiles in two 4-wave workgroups per CU (85.6 vs 90.7 us at batch 64, the C2
-// step unchanged: 5255 vs 5257 poses/s) -- with 18 taps per tile these layers are bound by their 64-KB-per-tile output
-// stream, which two workgroups per CU overlap with one another's K loops and one workgroup per CU cannot.
-// 512 x 64 tiles (WIDE) for the 64-channel layers: HP_PP_WIDE64=0 switches them back to conv3x3_split_f32's two 4-wave workgroups
+// 512 x 64 tiles (WIDE) for the 64-channel layers (256 x 64 tiles on this skeleton, NT = 1, lost to them: CHANGELOG round 4)
 bool pp_wide64_ok(const ConvArgs& a, int kh, int kw) {
-  static const bool off = std::getenv("HP_CONV_NO_PP") != nullptr || (std::getenv("HP_PP_WIDE64") && std::atoi(std::getenv("HP_PP_WIDE64")) == 0);
   using T = PP<MODE_SPLIT, 2, true>;
-  return !off && kh == 3 && kw == 3 && a.stride == 1 && a.pad == 1 && a.Cout % 128 != 0 && a.Cout % 64 == 0 && a.Cin % T::CKC == 0 &&
+  return !dbg(DBG_CONV_NO_PP) && kh == 3 && kw == 3 && a.stride == 1 && a.pad == 1 && a.Cout % 128 != 0 && a.Cout % 64 == 0 && a.Cin % T::CKC == 0 &&
          a.Cin <= 512 && T::npc(a.W) <= 6 && T::lds_bytes(a.W) <= 159 * 1024;
 }
 
-bool pp_use_bn64(int Cout) {
-  static const bool on = std::getenv("HP_PP_BN64") != nullptr;
-  return on && Cout % 128 != 0;
-}
-
-
 template <bool PRE, int NPC>
 int launch_pp_s2_variant(ConvArgs args, hipStream_t stream) {
-  static bool opted = false, spills = false;
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_pp<PRE, NPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     159 * 1024));
-    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3s2_pp<PRE, NPC>));
-    opted = true;
-  }
-  if (spills) count_scratch_launch();
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch& s) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_pp<PRE, NPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         159 * 1024));
+        s.spills = note_kernel(reinterpret_cast<const void*>(&conv3x3s2_pp<PRE, NPC>));
+        return HP_OK;
+      }))
+    return rc0;
+  if (fl.spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + BM - 1) / BM);
   args.tiles_n = args.Cout / PPS2::BN;
   args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
@@ -1048,8 +1037,7 @@ int launch_pp_s2_variant(ConvArgs args, hipStream_t stream) {
 
 // stride-2 entry (fp32 / split mode): a.w = weights split by conv_split_transform_weights(..., stride 2)
 bool conv_pp_s2_applicable(const ConvArgs& a, int kh, int kw) {
-  static const bool off = std::getenv("HP_CONV_NO_PP") != nullptr || std::getenv("HP_CONV_NO_PP_S2") != nullptr;
-  return !off && kh == 3 && kw == 3 && a.stride == 2 && a.pad == 1 && a.Cin % 64 == 0 && a.Cin <= 512 && a.Cout % PPS2::BN == 0 &&
+  return !dbg(DBG_CONV_NO_PP) && !dbg(DBG_CONV_NO_PP_S2) && kh == 3 && kw == 3 && a.stride == 2 && a.pad == 1 && a.Cin % 64 == 0 && a.Cin <= 512 && a.Cout % PPS2::BN == 0 &&
          a.Ho == (a.H - 1) / 2 + 1 && a.Wo == (a.W - 1) / 2 + 1 && PPS2::npc(a.Wo) <= 3 && PPS2::lds_bytes(a.Wo) <= 159 * 1024;
 }
 
@@ -1057,36 +1045,24 @@ int launch_conv_pp_s2_split(const ConvArgs& a, hipStream_t stream) {
   return a.pre_scale ? launch_pp_s2_variant<true, 3>(a, stream) : launch_pp_s2_variant<false, 3>(a, stream);
 }
 
-namespace {
-}  // namespace
-
 // fp32 (split-fp16) entry: a.w = weights split by conv_split_transform_weights
 bool conv_pp_split_applicable(const ConvArgs& a, int kh, int kw) {
-  if (pp_use_bn64(a.Cout)) return pp_shape_ok<MODE_SPLIT, 1>(a.W, a.Cin, a.Cout, a.stride, a.pad, kh, kw);
   if (pp_wide64_ok(a, kh, kw)) return true;
   return pp_shape_ok<MODE_SPLIT, 2>(a.W, a.Cin, a.Cout, a.stride, a.pad, kh, kw);
 }
 
 int launch_conv_pp_split(const ConvArgs& a, hipStream_t stream) {
-  // HP_PP_SMALL64=<percent>: 256 x 64 tiles also for Cout % 128 == 0 layers whose 256 x 128 tiling has fewer tiles than that
-  // share of the CUs (the 15 x 20 and 8 x 10 layers at 64 samples per lane: 150 / 80 tiles on 256 CUs)
-  static const int small64 = std::getenv("HP_PP_SMALL64") ? std::atoi(std::getenv("HP_PP_SMALL64")) : 0;
-  const bool few = small64 > 0 && a.Cout % 128 == 0 &&
-                   (int64_t)((a.M + BM - 1) / BM) * (a.Cout / 128) * 100 < (int64_t)small64 * conv_num_cus() &&
-                   pp_shape_ok<MODE_SPLIT, 1>(a.W, a.Cin, a.Cout, a.stride, a.pad, 3, 3);
-  if (!pp_use_bn64(a.Cout) && pp_wide64_ok(a, 3, 3))
+  if (pp_wide64_ok(a, 3, 3))
     return a.pre_scale ? launch_pp_variant<MODE_SPLIT, true, 6, 2, true>(a, stream) : launch_pp_variant<MODE_SPLIT, false, 6, 2, true>(a, stream);
-  if (pp_use_bn64(a.Cout) || few) return a.pre_scale ? launch_pp_nt<MODE_SPLIT, true, 1>(a, stream) : launch_pp_nt<MODE_SPLIT, false, 1>(a, stream);
   return a.pre_scale ? launch_pp_nt<MODE_SPLIT, true, 2>(a, stream) : launch_pp_nt<MODE_SPLIT, false, 2>(a, stream);
 }
 
 // fp16 entry (the fp16 plan): packed weights [Cout][Kpad] with K = (tap, c)
 // fp16 plan, 64-channel layers with ONE 64-channel chunk (Cin == 64: the 60 x 80 layers of ResNet-34): the 512 x 64 tile needs
-// no chunk swap at all -- nine taps on one staged patch.  HP_PP_WIDE64=0 leaves them on conv3x3_patch_f16.
+// no chunk swap at all -- nine taps on one staged patch.
 static bool pp_f16_wide64_ok(const ConvArgsH& a) {
-  static const bool off = std::getenv("HP_CONV_NO_PP") != nullptr || (std::getenv("HP_PP_WIDE64") && std::atoi(std::getenv("HP_PP_WIDE64")) == 0);
   using T = PP<MODE_F16, 2, true>;
-  return !off && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Cout % 128 != 0 && a.Cout % 64 == 0 && a.Cin == 64 &&
+  return !dbg(DBG_CONV_NO_PP) && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Cout % 128 != 0 && a.Cout % 64 == 0 && a.Cin == 64 &&
          a.Ho == a.H && a.Wo == a.W && T::npc(a.W) <= 11 && T::lds_bytes(a.W) <= 159 * 1024;
 }
 

@@ -772,14 +772,14 @@ struct SplitTileS2 {
 template <int WAVES_M, int WAVES_N, bool PRE, int NPC>
 int launch_split_s2_variant(ConvArgs args, hipStream_t stream) {
   using T = SplitTileS2<WAVES_M, WAVES_N>;
-  static bool opted = false, spills = false;
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_split_f32<WAVES_M, WAVES_N, PRE, NPC>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3s2_split_f32<WAVES_M, WAVES_N, PRE, NPC>));
-    opted = true;
-  }
-  if (spills) count_scratch_launch();
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch& s) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_split_f32<WAVES_M, WAVES_N, PRE, NPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        s.spills = note_kernel(reinterpret_cast<const void*>(&conv3x3s2_split_f32<WAVES_M, WAVES_N, PRE, NPC>));
+        return HP_OK;
+      }))
+    return rc0;
+  if (fl.spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + T::BM - 1) / T::BM);
   args.tiles_n = args.Cout / T::BN;
   args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
@@ -809,17 +809,15 @@ int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_
     HP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     ws.slots = cus - cus % 8;
   }
-  static const bool no_split = std::getenv("HP_CONV_NO_SPLITK") != nullptr;
-  static const int force_s = std::getenv("HP_SPLIT_S") ? std::atoi(std::getenv("HP_SPLIT_S")) : 0;
+  const bool no_split = dbg(DBG_CONV_NO_SPLITK) != 0;
   const int slots = ws.slots * wg_per_cu;
   int regular = (T / slots) * slots, S = 1;
   int tail = T - regular;
   // while two lanes share the GPU (tail split off) a launch is still sliced when it and its twin on the other lane
-  // together cannot fill the GPU: it then plans against half of the CUs (HP_LANE_SLICES=0 disables this)
-  static const bool lane_slices = !(std::getenv("HP_LANE_SLICES") && std::atoi(std::getenv("HP_LANE_SLICES")) == 0);
+  // together cannot fill the GPU: it then plans against half of the CUs
   const bool shared = a.no_tail_split != 0;
   const int fill = shared ? slots / 2 : slots;
-  if (tail > 0 && ncc > 1 && !no_split && (!shared || (lane_slices && regular == 0 && tail <= fill))) {
+  if (tail > 0 && ncc > 1 && !no_split && (!shared || (regular == 0 && tail <= fill))) {
     // cost in units of a whole tile: rounds x longest slice + parking / re-reading the slabs (~1.3 us per 128 KB
     // against ~1 us per tap of the K loop)
     double best = 1.0;
@@ -827,7 +825,6 @@ int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_
       const double c = (double)((tail * s + fill - 1) / fill) * ((ncc + s - 1) / s) / ncc + 1.3 * (1 + s) / (9.0 * ncc);
       if (c < 0.92 * best) { best = c; S = s; }
     }
-    if (force_s > 0 && force_s <= ncc) S = force_s;
   }
   a.sk_regular = regular;
   a.sk_S = S;
@@ -863,14 +860,14 @@ int plan_tail_split(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg_per_
 template <int WAVES_M, int WAVES_N, bool PRE, int NPC>
 int launch_split_variant(ConvArgs args, hipStream_t stream) {
   using T = SplitTile<WAVES_M, WAVES_N>;
-  static bool opted = false, spills = false;
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_f32<WAVES_M, WAVES_N, PRE, NPC>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));  // + the static ticket word
-    spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_split_f32<WAVES_M, WAVES_N, PRE, NPC>));
-    opted = true;
-  }
-  if (spills) count_scratch_launch();
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch& s) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_f32<WAVES_M, WAVES_N, PRE, NPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024 /* + the static ticket word */));
+        s.spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_split_f32<WAVES_M, WAVES_N, PRE, NPC>));
+        return HP_OK;
+      }))
+    return rc0;
+  if (fl.spills) count_scratch_launch();
   args.tiles_m = (int)((args.M + T::BM - 1) / T::BM);
   args.tiles_n = args.Cout / T::BN;
   args.fd_howo = make_fastdiv((unsigned)(args.Ho * args.Wo));
@@ -900,8 +897,7 @@ int conv_split_plan_tail(ConvArgs& a, int T, int ncc, size_t tile_floats, int wg
 }
 
 bool conv_split_applicable(const ConvArgs& a, int kh, int kw) {
-  static const bool off = std::getenv("HP_CONV_NO_SPLIT") != nullptr;
-  if (off || kh != 3 || kw != 3 || a.pad != 1 || a.Cin % CK != 0 || a.Cout % 64 != 0) return false;
+  if (kh != 3 || kw != 3 || a.pad != 1 || a.Cin % CK != 0 || a.Cout % 64 != 0) return false;
   if (a.stride == 2)  // space-to-depth walk: an even number of 32-channel chunks, 256 x 128 tiles, <= 3 staging passes
     return a.Cin % (2 * CK) == 0 && a.Cout % 128 == 0 && SplitTileS2<4, 2>::npc(a.Wo) <= 3 &&
            a.Ho == (a.H - 1) / 2 + 1 && a.Wo == (a.W - 1) / 2 + 1;
@@ -931,17 +927,13 @@ int launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     if (conv_pp_s2_applicable(a, 3, 3)) return launch_conv_pp_s2_split(a, stream);  // ping-pong skeleton (conv_pp.hip)
     return pre ? launch_split_s2_variant<4, 2, true, 3>(a, stream) : launch_split_s2_variant<4, 2, false, 3>(a, stream);
   }
-  static const bool t128 = std::getenv("HP_SPLIT_128") != nullptr;  // experiment: 128 x 128 tiles, 4 waves, two workgroups per CU
-  if (t128 && a.Cout % 128 == 0 && SplitTile<2, 2>::npc(a.W) <= 7)
-    return pre ? launch_split_npc<2, 2, true>(a, stream) : launch_split_npc<2, 2, false>(a, stream);
   // >= 128 output channels: the ping-pong kernel (conv_pp.hip) wherever its double-buffered patch fits the LDS
   if (conv_pp_split_applicable(a, 3, 3)) return launch_conv_pp_split(a, stream);
   // (128 x 128 tiles in 4-wave workgroups, two per CU, measured 3-10 % slower than 256 x 128 on the >= 128-channel layers)
   if (a.Cout % 128 == 0) return pre ? launch_split_npc<4, 2, true>(a, stream) : launch_split_npc<4, 2, false>(a, stream);
   // 64-channel layers (60x80 maps, K = 18 taps): 256 x 64 tiles in 4-wave workgroups, TWO per CU -- with one 512 x 64
   // workgroup per CU nothing runs under its prologue, patch restaging and epilogue, a third of such a short tile
-  static const bool wide = std::getenv("HP_SPLIT_WIDE64") != nullptr;
-  if (!wide && SplitTile<4, 1>::npc(a.W) <= 7 && 2 * SplitTile<4, 1>::lds_bytes(a.W) + 1024 <= 160 * 1024)
+  if (SplitTile<4, 1>::npc(a.W) <= 7 && 2 * SplitTile<4, 1>::lds_bytes(a.W) + 1024 <= 160 * 1024)
     return pre ? launch_split_npc<4, 1, true>(a, stream) : launch_split_npc<4, 1, false>(a, stream);
   return pre ? launch_split_npc<8, 1, true>(a, stream) : launch_split_npc<8, 1, false>(a, stream);
 }

@@ -297,12 +297,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <int MODE, int SC>
 int launch_stem7(ConvArgs args, hipStream_t stream) {
   using S = Stem7<MODE, SC>;
-  static bool opted = false;
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7s2_pool<MODE, SC>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds));
-    opted = true;
-  }
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch&) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7s2_pool<MODE, SC>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::kLds));
+        return HP_OK;
+      }))
+    return rc0;
   const int Hp = (args.Ho - 1) / 2 + 1, Wp = (args.Wo - 1) / 2 + 1;
   const int tiles_y = (Hp + PR - 1) / PR, tiles_x = (Wp + PC - 1) / PC;
   const int n_img = (int)(args.M / ((int64_t)args.Ho * args.Wo));
@@ -599,12 +600,13 @@ __global__ __launch_bounds__(s7p::kT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 template <int DUMMY = 0>
 int launch_stem7_f16_pp(ConvArgs args, hipStream_t stream) {
-  static bool opted = false;
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7s2_pool_f16_pp),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)s7p::kLds));
-    opted = true;
-  }
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch&) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem7x7s2_pool_f16_pp),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)s7p::kLds));
+        return HP_OK;
+      }))
+    return rc0;
   const int Hp = (args.Ho - 1) / 2 + 1, Wp = (args.Wo - 1) / 2 + 1;
   const int tiles_y = (Hp + PR - 1) / PR, tiles_x = (Wp + PC - 1) / PC;
   const int n_img = (int)(args.M / ((int64_t)args.Ho * args.Wo));
@@ -621,8 +623,7 @@ int launch_stem7_f16_pp(ConvArgs args, hipStream_t stream) {
 
 // the persistent fp16 kernel takes the layers whose real channels fit its pixel layout (<= 9) (HP_STEM7_F16_OLD=1: the tile kernel)
 bool stem7_f16_pp(int cin_real) {
-  static const bool off = std::getenv("HP_STEM7_F16_OLD") != nullptr;
-  return !off && cin_real > 0 && cin_real <= s7p::CMAX;
+  return !dbg(DBG_STEM7_F16_OLD) && cin_real > 0 && cin_real <= s7p::CMAX;
 }
 
 int slab_of(int cin, int f16) { return f16 ? 16 : (cin % 8 == 0 ? 8 : 4); }
@@ -632,8 +633,7 @@ int slab_of(int cin, int f16) { return f16 ? 16 : (cin % 8 == 0 ? 8 : 4); }
 // the layers this kernel is written for: 7x7 / stride 2 / pad 3, 64 output channels, ReLU, followed by the 3x3 / s2 / p1
 // max-pool; fp32 input with Cin % 4 == 0 channels in memory, or the fp16 plan's 16-channel input
 bool conv_stem7_applicable(int kh, int kw, int stride, int pad, int cin_mem, int cout, int relu, int f16) {
-  static const bool off = std::getenv("HP_NO_STEM7_KERNEL") != nullptr;
-  return !off && kh == 7 && kw == 7 && stride == 2 && pad == 3 && cout == BN && relu == HP_ACT_RELU &&
+  return kh == 7 && kw == 7 && stride == 2 && pad == 3 && cout == BN && relu == HP_ACT_RELU &&
          (f16 ? cin_mem == 16 : (cin_mem % 4 == 0 && cin_mem <= 64));
 }
 

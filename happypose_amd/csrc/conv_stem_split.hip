@@ -490,12 +490,13 @@ bool conv_stem_split_applicable(const ConvArgs& a, int kh, int kw, int run_mode)
 
 // a.w = weights split by conv_igemm_split_transform_weights (64 rows), a.y = the POOLED map [n][Hp][Wp][64]
 int launch_conv_stem_split_pool(ConvArgs args, hipStream_t stream) {
-  static bool opted = false;
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem5x5s2_pool_split),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-    opted = true;
-  }
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch&) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem5x5s2_pool_split),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        return HP_OK;
+      }))
+    return rc0;
   const int Hp = (args.Ho - 1) / 2 + 1, Wp = (args.Wo - 1) / 2 + 1;
   const int tiles_y = (Hp + PR - 1) / PR, tiles_x = (Wp + PC - 1) / PC;
   const int n_img = (int)(args.M / ((int64_t)args.Ho * args.Wo));
@@ -504,14 +505,14 @@ int launch_conv_stem_split_pool(ConvArgs args, hipStream_t stream) {
   args.fd_wo = make_fastdiv((unsigned)tiles_x);
   args.sk_S2 = tiles_y * tiles_x;
   args.sk_S3 = tiles_x;
-  static const bool old_kernel = std::getenv("HP_STEM5_OLD") != nullptr;  // A/B: the tile kernel
-  if (!old_kernel) {
-    static bool opted2 = false;
-    if (!opted2) {
-      HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem5x5s2_pool_split_pp),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)s5p::kLds2));
-      opted2 = true;
-    }
+  if (!dbg(DBG_STEM5_OLD)) {  // (set: the tile kernel, for the A/B test)
+    static FirstLaunch fl2;
+    if (const int rc0 = fl2.once([](FirstLaunch&) {
+          HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem5x5s2_pool_split_pp),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)s5p::kLds2));
+          return HP_OK;
+        }))
+      return rc0;
     const int grid = std::min(8 * ((args.tiles_m + 7) / 8), conv_num_cus() / 8 * 8);
     hipLaunchKernelGGL(conv_stem5x5s2_pool_split_pp, dim3(grid), dim3(s5p::kT), s5p::kLds2, stream, args);
     return check_launch("conv_stem5x5s2_pool_split_pp");

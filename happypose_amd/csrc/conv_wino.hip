@@ -530,14 +530,7 @@ constexpr int X_BUF = 8 * 8 * 64 * 2;  // floats of the exchange buffer: [wave][
 // NT = cout tiles (of 16) per item: 2 = the whole 32-cout block; 1 = HALF items, used for the last,
 // partially filled round of a launch (see launch8): an item is then split into two 16-cout halves that
 // go to different blocks, and the partner waves split the finishing work by tile pairs instead.
-// SPLIT: the same kernel on the fp16 matrix path with fp32-level accuracy (the scheme of conv_split.hip): a float4 of
-// U (four input channels) is stored as {4 hi halves | 4 lo halves} in the same 16 bytes -- the LDS image and every copy
-// loop stay what they are --, the lane splits its V float4 the same way, and ONE v_mfma_f32_16x16x16_f16 does what the
-// four K = 4 fp32 MFMAs of a float4 did (lane l holds k = 4 (l / 16) .. + 3 of row / column l % 16 in both layouts):
-// three of them per product (hi hi + hi lo + lo hi) in 48 matrix-pipe cycles instead of 128.  U is scaled per output
-// channel by a power of two into fp16's upper range at plan time, the staged pixels by the activation scale of
-// ConvArgs::amax_in (one more factor 1/2: |V| <= 4 max|x|); both are undone on the float4 the epilogue stores.
-template <bool PRE, int NLD, int SETS, int NT, bool SPLIT>
+template <bool PRE, int NLD, int SETS, int NT>
 __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wino8_f32(
     ConvArgs a, int TH, int TW, int T, int tiles_n, int n_items, int Pmax, WinoDiv fd, int range_off, int range_len) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -575,15 +568,10 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
 #endif
   const int c4 = tid & 3, srow = tid >> 2;  // channel quad / first pixel row this thread stages
   if (tid < 16) rawl[((tid >> 2) * Pp + ZS) * 4 + (tid & 3)] = 0.f;
-  float act_sx = 1.f, act_inv = 1.f;  // SPLIT: power-of-two scale of the staged pixels (ConvArgs::amax_in) and its inverse
-  if constexpr (SPLIT) {
-    conv_act_scale(a, act_sx, act_inv);
-    if (a.amax_in) { act_sx *= 0.25f; act_inv *= 4.f; }  // |B^T d B| <= 4 max|d|
-  }
   if (PRE) {  // the prologue constants live in LDS: held in registers they would stay live across the epilogue
-    for (int i = tid; i < Cin; i += kThreads8) {  // (SPLIT: the activation scale rides on them: sx relu(x s + b) = relu(x s sx + b sx))
-      pl[i] = a.pre_scale[i] * act_sx;
-      pl[Cin + i] = a.pre_shift[i] * act_sx;
+    for (int i = tid; i < Cin; i += kThreads8) {
+      pl[i] = a.pre_scale[i];
+      pl[Cin + i] = a.pre_shift[i];
     }
   }
 
@@ -657,8 +645,6 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
       if (PRE) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(v[q], ps[q], pb[q]), 0.f);
-      } else if (SPLIT) {
-        v = v * act_sx;
       }
       *reinterpret_cast<floatx4*>(rdst + (srow + 128 * k) * 4) = v;  // rows past the item's range: never read
     }
@@ -824,26 +810,12 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
         if (q == 5) read_d(8, 12);    // E2
         if (q == 6) read_d(4, 8);     // E1
 #endif
-        if constexpr (SPLIT) {
-          const whalfx4 vh = __builtin_convertvector(V[q], whalfx4);
-          const whalfx4 vl = __builtin_convertvector(V[q] - __builtin_convertvector(vh, floatx4), whalfx4);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const floatx2 wpair_h = bf[q & 1][nt].xy, wpair_l = bf[q & 1][nt].zw;
-            const whalfx4 wh = __builtin_bit_cast(whalfx4, wpair_h), wl = __builtin_bit_cast(whalfx4, wpair_l);
-            floatx4 c = FIRST ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[q][nt];
-            c = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, vh, c, 0, 0, 0);  // D[cout][tile]
-            c = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, vl, c, 0, 0, 0);
-            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, vh, c, 0, 0, 0);
-          }
-        } else {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[q & 1][nt][j], V[q][j],  // D[cout][tile]
-                                                                FIRST && j == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[q][nt], 0, 0, 0);
-        }
+          for (int nt = 0; nt < NT; ++nt)
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[q & 1][nt][j], V[q][j],  // D[cout][tile]
+                                                              FIRST && j == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[q][nt], 0, 0, 0);
         if (q == 7) {  // V[0..3] of the next chunk (this chunk's were consumed by steps 0-3) and the rows of V[4..7]
           xform_first();
           xform_second_rows();
@@ -955,36 +927,18 @@ __global__ __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
     for (int k = 0; k < 2 * NPX; ++k)  // slot k = [cout pair k / NPX][pixel k % NPX]: the layout both sides wrote
       yk[k / NPX][k % NPX] = add2(yk[k / NPX][k % NPX], *reinterpret_cast<const floatx2*>(xl + (((wave ^ 4) * 8 + k) * 64 + lane) * 2));
-    floatx4 unsc = {1.f, 1.f, 1.f, 1.f};
-    float chk = 0.f, amax = 0.f;  // SPLIT: non-finite guard and range tracking, as the shared epilogue (conv_epilogue.h)
-    if constexpr (SPLIT) unsc = *reinterpret_cast<const floatx4*>(a.w + (size_t)16 * a.Cout * Cin + ncol) * act_inv;
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
       if (e_ok[i]) {
         floatx4 v = {yk[0][i].x, yk[0][i].y, yk[1][i].x, yk[1][i].y};
-        if constexpr (SPLIT) v = v * unsc;
         if (a.bias) v += *reinterpret_cast<const floatx4*>(a.bias + ncol);
         if (PRE) { if (a.residual) v += *reinterpret_cast<const floatx4*>(a.residual + e_off[i]); }
         else v += e_res[i];
-        if constexpr (SPLIT) chk += (v[0] + v[1]) + (v[2] + v[3]);
         if (a.relu) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
         }
-        if constexpr (SPLIT) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
         *reinterpret_cast<floatx4*>(a.y + e_off[i]) = v;
-      }
-    }
-    if constexpr (SPLIT) {
-      if (a.status && !(fabsf(chk) <= 3.0e38f)) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (a.amax_out) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-        if (lane == 0 && amax > 0.f) {
-          const unsigned mine = __float_as_uint(amax);
-          unsigned* const slot = a.amax_out + (blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride;
-          if (mine > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mine);
-        }
       }
     }
 #ifdef HP_WABL_TIMING
@@ -1022,65 +976,6 @@ __global__ void wino_weight_transform(const float* __restrict__ w, float* __rest
   }
 }
 
-// The same U for the SPLIT kernel: one block per output channel; pass 1 finds max|U| over (cin, position) and the power of
-// two that puts it into [2^13, 2^14), pass 2 writes every float4 (four consecutive input channels) as
-// {4 hi halves | 4 lo halves} of the scaled values into the SAME 16 bytes of the layout above; unscale[cout] behind it.
-__global__ __launch_bounds__(256) void wino_weight_transform_split(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Kpad) {
-  const int o = blockIdx.x;
-  __shared__ float red[256];
-  auto xform = [&](int ci, float (&u)[16]) {
-    float g[3][3];
-    for (int y = 0; y < 3; ++y)
-      for (int x = 0; x < 3; ++x) g[y][x] = w[(int64_t)o * Kpad + (y * 3 + x) * Cin + ci];
-    float tg[4][3];
-    for (int x = 0; x < 3; ++x) {
-      tg[0][x] = g[0][x];
-      tg[1][x] = 0.5f * (g[0][x] + g[1][x] + g[2][x]);
-      tg[2][x] = 0.5f * (g[0][x] - g[1][x] + g[2][x]);
-      tg[3][x] = g[2][x];
-    }
-    for (int i = 0; i < 4; ++i) {
-      u[4 * i + 0] = tg[i][0];
-      u[4 * i + 1] = 0.5f * (tg[i][0] + tg[i][1] + tg[i][2]);
-      u[4 * i + 2] = 0.5f * (tg[i][0] - tg[i][1] + tg[i][2]);
-      u[4 * i + 3] = tg[i][2];
-    }
-  };
-  float mx = 0.f;
-  for (int ci = threadIdx.x; ci < Cin; ci += 256) {
-    float u[16];
-    xform(ci, u);
-    for (int p = 0; p < 16; ++p) mx = fmaxf(mx, fabsf(u[p]));
-  }
-  red[threadIdx.x] = mx;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  mx = red[0];
-  int e = 0;
-  if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);  // mx = m 2^e, m in [0.5, 1)
-  const int sh = mx > 0.f ? 14 - e : 0;                 // mx 2^sh in [2^13, 2^14)
-  float* const unscale = U + (size_t)16 * Cout * Cin;
-  if (threadIdx.x == 0) unscale[o] = ldexpf(1.f, -sh);
-  _Float16* const Uh = reinterpret_cast<_Float16*>(U);
-  const int nb = o / BN, n = o % BN;
-  for (int ci = threadIdx.x; ci < Cin; ci += 256) {
-    float u[16];
-    xform(ci, u);
-    const int chunk = ci / CK, kgi = (ci % CK) / 4, j4 = ci % 4;
-    for (int p = 0; p < 16; ++p) {
-      const float v = ldexpf(u[p], sh);
-      const _Float16 hi = (_Float16)v;
-      const _Float16 lo = (_Float16)(v - (float)hi);
-      const int64_t e16 = (((((int64_t)chunk * 16 + p) * (Cout / BN) + nb) * 4 + kgi) * BN + n);  // 16-B element
-      Uh[e16 * 8 + j4] = hi;
-      Uh[e16 * 8 + 4 + j4] = lo;
-    }
-  }
-}
-
 struct WinoGeom { int TH, TW, T, Pmax; bool ok; };
 
 // tile counts and the largest staged pixel range of any item (the pattern of item starts
@@ -1109,16 +1004,14 @@ size_t wino_lds_bytes(int Pmax) { return ((size_t)4 * plane_len(Pmax) * 4 + 2 * 
 
 template <bool PRE, int NLD>
 int launch(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
-  static bool opted = false;
-  static int cus = 0;
-  if (!opted) {
-    int dev = 0;
-    HP_CHECK_HIP(hipGetDevice(&dev));
-    HP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<PRE, NLD>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    opted = true;
-  }
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch&) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32<PRE, NLD>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return HP_OK;
+      }))
+    return rc0;
+  const int cus = conv_num_cus();
   const int tiles_m = (g.T + TPB - 1) / TPB, tiles_n = a.Cout / BN;
   const int n_items = tiles_m * tiles_n;
   // one persistent block per CU, an equal number per XCD
@@ -1135,21 +1028,19 @@ size_t wino8_lds_bytes(int Pmax, int Cin = 512) {
   return ((size_t)4 * plane_len8(wino8_nld(Pmax)) * 4 + 2 * (size_t)U_BUF + (size_t)X_BUF + 2 * (size_t)Cin) * sizeof(float);
 }
 
-template <bool PRE, int NLD, bool SPLIT = false>
+template <bool PRE, int NLD>
 int launch8(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
   constexpr int SETS = NLD >= 6 ? 1 : 2;
-  static bool opted = false;
-  static int cus = 0;
-  if (!opted) {
-    int dev = 0;
-    HP_CHECK_HIP(hipGetDevice(&dev));
-    HP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32<PRE, NLD, SETS, 2, SPLIT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32<PRE, NLD, SETS, 1, SPLIT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    opted = true;
-  }
+  static FirstLaunch fl;
+  if (const int rc0 = fl.once([](FirstLaunch&) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32<PRE, NLD, SETS, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32<PRE, NLD, SETS, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return HP_OK;
+      }))
+    return rc0;
+  const int cus = conv_num_cus();
   const int tiles_m = (g.T + TPB - 1) / TPB, tiles_n = a.Cout / BN;
   const int n_items = tiles_m * tiles_n;
   const int ipx = (n_items + 7) / 8;  // items per XCD
@@ -1159,17 +1050,16 @@ int launch8(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
   // Rounds: every block of an XCD walks ipx / per_xcd items.  A last round that fills at most half of
   // the blocks (8x10 maps at batch 128: 2.5 rounds) would cost a whole round; its items are split into
   // two 16-cout halves instead and run as a second launch on twice as many blocks -- a half item costs
-  // ~0.6 of a whole one (half the MFMAs, the same staging).  HP_WINO_NO_TAIL_SPLIT disables it.
-  static const bool no_tail_split = std::getenv("HP_WINO_NO_TAIL_SPLIT") != nullptr;
+  // ~0.6 of a whole one (half the MFMAs, the same staging).
   const int full = (ipx / per_xcd) * per_xcd, tail = ipx - full;
-  if (!no_tail_split && full > 0 && tail > 0 && 2 * tail <= per_xcd) {
-    hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS, 2, SPLIT>), dim3(8 * per_xcd), dim3(kThreads8), lds, stream, a, g.TH, g.TW,
+  if (full > 0 && tail > 0 && 2 * tail <= per_xcd) {
+    hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS, 2>), dim3(8 * per_xcd), dim3(kThreads8), lds, stream, a, g.TH, g.TW,
                        g.T, tiles_n, n_items, g.Pmax, fd, 0, full);
-    hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS, 1, SPLIT>), dim3(8 * 2 * tail), dim3(kThreads8), lds, stream, a, g.TH, g.TW,
+    hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS, 1>), dim3(8 * 2 * tail), dim3(kThreads8), lds, stream, a, g.TH, g.TW,
                        g.T, tiles_n, n_items, g.Pmax, fd, full, tail);
   } else {
     const int slots = std::max(1, std::min(ipx, per_xcd));
-    hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS, 2, SPLIT>), dim3(8 * slots), dim3(kThreads8), lds, stream, a, g.TH, g.TW,
+    hipLaunchKernelGGL((conv3x3_wino8_f32<PRE, NLD, SETS, 2>), dim3(8 * slots), dim3(kThreads8), lds, stream, a, g.TH, g.TW,
                        g.T, tiles_n, n_items, g.Pmax, fd, 0, ipx);
   }
   return check_launch("conv3x3_wino8_f32");
@@ -1234,38 +1124,6 @@ bool conv_wino_launchable(const ConvArgs& a) {
   if (a.M * a.Cout >= (1ll << 31)) return false;                  // 32-bit output element offsets
   const WinoGeom& g = cached_geom(a.H, a.W, n_img);
   return g.ok && g.Pmax <= kMaxNld * 64 && wino_lds_bytes(g.Pmax) <= 160 * 1024;
-}
-
-// ---- SPLIT (fp16 matrix path, fp32-level accuracy): the two-waves-per-SIMD kernel only
-bool conv_wino_split_launchable(const ConvArgs& a) {
-  if (!conv_wino_launchable(a) || a.Cin < 4 * CK || a.Cin % (2 * CK) != 0 || a.relu == HP_ACT_SWISH || (a.pre_scale && !a.pre_shift)) return false;
-  const WinoGeom& g = cached_geom(a.H, a.W, a.M / ((int64_t)a.Ho * a.Wo));
-  return wino8_nld(g.Pmax) <= 6 && wino8_lds_bytes(g.Pmax, a.Cin) <= 160 * 1024;
-}
-
-size_t conv_wino_split_weight_bytes(int cout, int cin) { return (size_t)16 * cout * cin * 4 + (size_t)cout * 4; }
-
-int conv_wino_split_transform_weights(const float* d_w, void* d_U, int cout, int cin, int Kpad, hipStream_t stream) {
-  hipLaunchKernelGGL(wino_weight_transform_split, dim3(cout), dim3(256), 0, stream, d_w, reinterpret_cast<float*>(d_U), cout, cin, Kpad);
-  return check_launch("wino_weight_transform_split");
-}
-
-template <bool PRE>
-static int launch_split_nld(const ConvArgs& a, const WinoGeom& g, hipStream_t stream) {
-  const int nld8 = wino8_nld(g.Pmax);
-  if (nld8 <= 2) return launch8<PRE, 2, true>(a, g, stream);
-  if (nld8 <= 3) return launch8<PRE, 3, true>(a, g, stream);
-  if (nld8 <= 4) return launch8<PRE, 4, true>(a, g, stream);
-  if (nld8 <= 5) return launch8<PRE, 5, true>(a, g, stream);
-  return launch8<PRE, 6, true>(a, g, stream);
-}
-
-// a.w must point at the weights of conv_wino_split_transform_weights
-int launch_conv_wino_split(const ConvArgs& a, hipStream_t stream) {
-  if (!conv_wino_split_launchable(a))
-    return fail(HP_ERR_ARG, "conv3x3_wino8 (split): geometry not supported (check conv_wino_split_launchable)");
-  const WinoGeom& g = cached_geom(a.H, a.W, a.M / ((int64_t)a.Ho * a.Wo));
-  return a.pre_scale ? launch_split_nld<true>(a, g, stream) : launch_split_nld<false>(a, g, stream);
 }
 
 // a.w must point at the transformed weights U

@@ -34,122 +34,6 @@ struct CropArgs {
 };
 
 
-// One workgroup = a 16 x 16 tile of output pixels of one crop.  The sample placement depends only
-// on the output row (y axis) or column (x axis), so 32 lanes build the 16 + 16 folded weight sets
-// once and the tile shares them through LDS (building them per pixel made the kernel VALU bound:
-// ~250 of its ~330 vector instructions per pixel).
-__global__ __launch_bounds__(256) void crop_kernel(CropArgs a) {
-  __shared__ Fold folds[2][16];
-  const int r = blockIdx.z;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int ph = blockIdx.y * 16 + ty, pw = blockIdx.x * 16 + tx;
-  const float* box = a.boxes + 4 * (int64_t)r;
-  const float x1 = box[0], y1 = box[1];
-  float roi_w = box[2] - x1, roi_h = box[3] - y1;
-  roi_w = roi_w < 1.0f ? 1.0f : roi_w;  // aligned=False
-  roi_h = roi_h < 1.0f ? 1.0f : roi_h;
-  const float bin_h = roi_h / (float)a.oh, bin_w = roi_w / (float)a.ow;
-  const int g = a.sr;
-  const float count = (float)(g * g);
-  const int H = a.H, W = a.W;
-
-  if (threadIdx.x < 32) {  // lanes 0-15: the tile's rows, lanes 16-31: its columns
-    const bool is_x = threadIdx.x >= 16;
-    const int k = threadIdx.x & 15;
-    Axis t;
-    Fold f;
-    if (is_x) make_axis(x1, blockIdx.x * 16 + k, bin_w, g, W, t);
-    else make_axis(y1, blockIdx.y * 16 + k, bin_h, g, H, t);
-    fold_axis(t, g, f.first, f.span, f.w);
-    folds[is_x ? 1 : 0][k] = f;
-  }
-  __syncthreads();
-  if (ph >= a.oh || pw >= a.ow) return;
-  const Fold fy = folds[0][ty], fx = folds[1][tx];
-  const int r0 = fy.first, nr = fy.span, c0 = fx.first, nc = fx.span;
-  const float (&wy)[kSpan] = fy.w;
-  const float (&wx)[kSpan] = fx.w;
-  const bool separable = nr <= kSpan && nc <= kSpan;
-
-  // an image id outside the batch reads frame 0 and writes zeros (the reference's indexing would raise)
-  const int im_id = a.im_ids[r];
-  const bool bad_id = (unsigned)im_id >= (unsigned)a.Bi;
-  const float* img = a.images + (int64_t)(bad_id ? 0 : im_id) * a.C * H * W;
-  const int64_t obase = (int64_t)r * a.os.s_item + (int64_t)ph * a.os.s_row + (int64_t)pw * a.os.s_col;
-  const int HW = H * W;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  float vacc = 0.0f;
-  if (separable) {
-    // taps outermost, channels innermost: one 32-bit offset per tap serves every plane (the plane
-    // bases are wave-uniform), so a tap costs one load + one FMA per channel
-    const int off0 = r0 * W + c0;
-#pragma unroll
-    for (int i = 0; i < kSpan; ++i) {
-      if (i < nr) {
-        const int off = off0 + i * W;
-        float racc[4] = {0.f, 0.f, 0.f, 0.f};
-        float rv = 0.0f;
-#pragma unroll
-        for (int j = 0; j < kSpan; ++j) {
-          if (j < nc) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              if (c < a.NC) {
-                const float v = img[c * HW + off + j];
-                racc[c] += wx[j] * v;
-                if (c == 3) rv += wx[j] * (v > 0.0f ? 1.0f : 0.0f);
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] += wy[i] * racc[c];
-        vacc += wy[i] * rv;
-      }
-    }
-  } else {
-#pragma unroll 1
-    for (int c = 0; c < a.NC; ++c) {
-      float s = 0.0f, sv = 0.0f;
-      slow_pixel(img + (int64_t)c * HW, H, W, y1, x1, ph, pw, bin_h, bin_w, g, c == 3, s, sv);
-      acc[c] = s;
-      if (c == 3) vacc = sv;
-    }
-  }
-  float outv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (c >= a.NC) break;
-    float val = acc[c] / count;
-    if (c == 3) {
-      if (vacc / count < 0.99f) val = 0.0f;  // TB/lib3d/cropping.py:184-195
-      if (a.depth_norm_mode != 0) {
-        const float zn = a.depth_norm_z[r];
-        if (a.depth_norm_mode == 1) val = val / zn;
-        else if (a.depth_norm_mode == 2) val = fminf(fmaxf(val / zn, 0.0f), 2.0f) - 1.0f;
-        else val = fminf(fmaxf(val - zn, -2.0f), 2.0f);
-      }
-    }
-    outv[c] = bad_id ? 0.0f : val;
-  }
-  // channel-interleaved destination (NHWC slice of the network input): one 12-B store per pixel
-  typedef float float3v __attribute__((ext_vector_type(3)));
-  if (a.out_half) {  // strides count fp16 elements
-    _Float16* const o = reinterpret_cast<_Float16*>(a.out);
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < a.NC) o[obase + (int64_t)c * a.os.s_chan] = (_Float16)outv[c];
-  } else if (a.os.s_chan == 1 && a.NC == 3) {
-    *reinterpret_cast<float3v*>(reinterpret_cast<float*>(a.out) + obase) = float3v{outv[0], outv[1], outv[2]};
-  } else {
-    float* const o = reinterpret_cast<float*>(a.out);
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < a.NC) o[obase + (int64_t)c * a.os.s_chan] = outv[c];
-  }
-}
-
-
 // ---- second-generation kernel: one workgroup = a 32 x 64 tile of output pixels.  The 16 x 16 kernel above spent most of
 // its ~600 vector instructions per pixel on (a) building the folded axis weights -- 32 lanes work, 224 wait, once per 256
 // pixels -- and (b) a fully predicated 5 x 5 x 4 tap loop although a typical crop (bin <= 1 source pixel) folds into 2-3
@@ -198,7 +82,7 @@ __global__ __launch_bounds__(256) void crop_tile_kernel(CropArgs a) {
   const Fold fx = folds_x[tx];
   const int c0 = fx.first, nc = fx.span;
   const int im_id = a.im_ids[r];
-  const bool bad_id = (unsigned)im_id >= (unsigned)a.Bi;  // reads frame 0, writes zeros (see crop_kernel)
+  const bool bad_id = (unsigned)im_id >= (unsigned)a.Bi;  // reads frame 0, writes zeros (the reference's indexing would raise)
   const float* img = a.images + (int64_t)(bad_id ? 0 : im_id) * a.C * H * W;
   const int HW = H * W;
   const float zn = (NC == 4 && a.depth_norm_mode != 0) ? a.depth_norm_z[r] : 1.0f;
@@ -321,12 +205,6 @@ static int crop_launch(const float* d_images, int Bi, int C, int n_channels, int
   }
   CropArgs a{d_images, Bi, C, n_channels, H, W, d_boxes, d_im_ids, n, out_h, out_w, sampling_ratio,
              d_out, out_half, *out_strides, d_depth_norm_z, depth_norm_mode, full_record ? 1 : 0};
-  static const bool old_kernel = std::getenv("HP_CROP_OLD") != nullptr;  // A/B: the 16 x 16 tile kernel
-  if (old_kernel) {
-    dim3 grid((out_w + 15) / 16, (out_h + 15) / 16, n);
-    hipLaunchKernelGGL(crop_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-    return check_launch("crop_kernel");
-  }
   dim3 grid((out_w + kTC - 1) / kTC, (out_h + kTR - 1) / kTR, n);
   if (n_channels == 3) hipLaunchKernelGGL(crop_tile_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(crop_tile_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);

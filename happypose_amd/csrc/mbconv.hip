@@ -267,8 +267,7 @@ int dwconv_pool_strips(int Ho, int k, int stride) { return (Ho + dw_rows(Ho, k, 
 
 // a.pool_partial (or null) receives [n][dwconv_pool_strips(Ho)][C] sums of the outputs (strip kernel only)
 int launch_dwconv(const DwArgs& a, hipStream_t stream) {
-  static const bool old_kernel = std::getenv("HP_DW_OLD") != nullptr;
-  if (!old_kernel && (a.stride == 1 || a.stride == 2) && (a.k == 3 || a.k == 5) && a.n < 65536) {
+  if ((a.stride == 1 || a.stride == 2) && (a.k == 3 || a.k == 5) && a.n < 65536) {
     const int qb = dw_quads_per_block(a.C / 4);
     const dim3 grid((unsigned)((a.C / 4 + qb - 1) / qb), (unsigned)dwconv_pool_strips(a.Ho, a.k, a.stride), (unsigned)a.n);
 #define HP_DW(K_, S_)                                                                                                        \
@@ -290,8 +289,7 @@ int launch_dwconv(const DwArgs& a, hipStream_t stream) {
 }
 
 bool dwconv_pools(const DwArgs& a) {
-  static const bool old_kernel = std::getenv("HP_DW_OLD") != nullptr;
-  return !old_kernel && (a.stride == 1 || a.stride == 2) && (a.k == 3 || a.k == 5) && a.n < 65536;
+  return (a.stride == 1 || a.stride == 2) && (a.k == 3 || a.k == 5) && a.n < 65536;
 }
 
 int se_partial_floats(int n, int C) { return n * kSeStrips * C; }

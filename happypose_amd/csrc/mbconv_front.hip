@@ -250,16 +250,17 @@ __global__ __launch_bounds__(256, 2) void mbconv_front_kernel(FrontArgs a) {
 template <int K, int S, int KP>
 int launch_front_t(const FrontArgs& a, hipStream_t stream) {
   using T = FrontTile<K, S>;
-  static bool opted = false, spills = false;
+  static FirstLaunch fl;
   constexpr size_t lds = front_lds_bytes<K, S, KP>();
   static_assert(lds <= 160 * 1024, "LDS of a CU");
-  if (!opted) {
-    HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_front_kernel<K, S, KP>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    spills = note_kernel(reinterpret_cast<const void*>(&mbconv_front_kernel<K, S, KP>));
-    opted = true;
-  }
-  if (spills) count_scratch_launch();
+  if (const int rc0 = fl.once([](FirstLaunch& fl_) {
+        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_front_kernel<K, S, KP>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        fl_.spills = note_kernel(reinterpret_cast<const void*>(&mbconv_front_kernel<K, S, KP>));
+        return HP_OK;
+      }))
+    return rc0;
+  if (fl.spills) count_scratch_launch();
   const dim3 grid((unsigned)((a.Wo + T::TW - 1) / T::TW), (unsigned)((a.Ho + T::TH - 1) / T::TH), (unsigned)a.n);
   hipLaunchKernelGGL((mbconv_front_kernel<K, S, KP>), grid, dim3(256), lds, stream, a);
   return check_launch("mbconv_front_kernel");
@@ -268,12 +269,10 @@ int launch_front_t(const FrontArgs& a, hipStream_t stream) {
 }  // namespace
 
 bool mbconv_front_applicable(int cin, int kpad, int cexp, int k, int stride) {
-  static const bool off = std::getenv("HP_NO_MBCONV_FRONT") != nullptr;
-  // not the 5x5 / stride-1 blocks: 25 taps x 4 channels in registers beside a sliding window of E rows spills, and the
-  // launch (642 us) loses to expansion + strip kernel (~230 us); the template stays for HP_MBCONV_FRONT_ALL experiments
-  static const bool all = std::getenv("HP_MBCONV_FRONT_ALL") != nullptr;
-  if (k == 5 && stride == 1 && !all) return false;
-  return !off && (kpad == 32 || kpad == 64) && cin % 4 == 0 && cin <= kpad && cexp % 4 == 0 && (k == 3 || k == 5) &&
+  // not the 5x5 / stride-1 blocks: 25 taps x 4 channels in registers beside a sliding window of E rows spills (60 - 67 VGPRs, 100 -
+  // 160 B of scratch per lane), and the launch (642 us) loses to expansion + strip kernel (~230 us): not instantiated
+  if (k == 5 && stride == 1) return false;
+  return !dbg(DBG_NO_MBCONV_FRONT) && (kpad == 32 || kpad == 64) && cin % 4 == 0 && cin <= kpad && cexp % 4 == 0 && (k == 3 || k == 5) &&
          (stride == 1 || stride == 2);
 }
 
@@ -288,7 +287,7 @@ int launch_mbconv_front(const FrontArgs& a, hipStream_t stream) {
 #define HP_FRONT(K_, S_)                                                                    \
   if (a.k == K_ && a.stride == S_)                                                          \
     return a.Kpad == 32 ? launch_front_t<K_, S_, 32>(a, stream) : launch_front_t<K_, S_, 64>(a, stream);
-  HP_FRONT(3, 1) HP_FRONT(3, 2) HP_FRONT(5, 1) HP_FRONT(5, 2)
+  HP_FRONT(3, 1) HP_FRONT(3, 2) HP_FRONT(5, 2)
 #undef HP_FRONT
   return fail(HP_ERR_ARG, "mbconv_front: unsupported depthwise geometry");
 }

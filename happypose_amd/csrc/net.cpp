@@ -50,13 +50,11 @@ struct ConvLayer {
   int cout_real = 0;       // rows of the parameter tensor when cout was rounded up to 4 (zero rows; 0 = cout)
   int H, W, Ho, Wo, Kpad;
   int in_buf, out_buf, res_buf;  // arena slots; -1 = network input / none
-  DevBuf w_wsplit;         // Winograd-transformed weights as fp16 hi/lo halves (conv_wino.hip, SPLIT)
-  DevBuf w_w2;             // the same for conv_wino2.hip (64 x 64 items)
   DevBuf w_short;  // a 1x1 / stride-2 shortcut in the centre of a zero 3x3 filter, split like a stride-2 3x3 layer's weights: it runs as
                    // extra work items of the block's 3x3 / stride-2 launch (ConvArgs::sc_w)
   DevBuf w, w_wino, w_split, w_isplit, bias, lut, pre_scale, pre_shift;  // w_isplit: hi/lo halves for conv_igemm_split.hip  // w_wino: Winograd-transformed weights (3x3 s1 layers)
                                                                // w_split: fp16 hi/lo halves (conv_split.hip)
-  bool wino_ok = false, wsplit_ok = false, w2_ok = false;  // eligible for w_wino / w_wsplit / w_w2 (built on first use)
+  bool wino_ok = false;  // eligible for w_wino (built on first use)
   int cout_pad = 0;        // weight rows / bias padded to whole 64-wide tiles
   float pre_smax = 1.f, pre_bmax = 0.f;  // bound of the BN + ReLU prologue: |x_act| <= pre_smax max|x| + pre_bmax (ConvArgs::amax_a / amax_b)
   int se = 0;              // the input is gated by the squeeze-excitation vector of this block (1x1 projections)
@@ -94,6 +92,7 @@ struct Net {
   int precision = HP_PRECISION_F32;
   DevBuf x16;  // fp16 plan: the network input converted to fp16 NHWC [max_batch][h][w][cin16 of the stem]
   int max_batch = 0;
+  int device = -1;  // the HIP device that was current in hp_net_create: where the weights and the arena live
   std::map<std::string, std::vector<float>> params;
   std::vector<std::unique_ptr<ConvLayer>> convs;
   std::vector<std::unique_ptr<DwLayer>> dws;
@@ -451,19 +450,11 @@ int pack_conv(Net& n, ConvLayer& L) {
     ConvArgs probe{};
     probe.stride = L.stride; probe.pad = L.pad; probe.Cin = L.cin; probe.Cout = L.cout;
     probe.H = L.H; probe.W = L.W; probe.Ho = L.Ho; probe.Wo = L.Wo;
-    // The Winograd weight sets (exact-fp32 U = G g G^T, and the two split-fp16 forms) are LAZY: only eligibility is
-    // recorded here; ensure_wino_weights() transforms a set the first time a forward's algorithm can reach it (the
-    // guard's exact-fp32 fallback, hp_net_set_conv_algo, HP_WINO_SPLIT / HP_WINO2).  The default plan never touches
-    // them: hp_net_create used to spend 2 x 150 MB and 3 x 58 transform launches per WideResNet-34 on kernels that
-    // lost to the direct split kernels.
-    if (conv_wino_applicable(probe, L.kh, L.kw)) {
-      L.wino_ok = true;
-      static const bool no_wsplit = std::getenv("HP_CONV_NO_WINO_SPLIT") != nullptr;
-      if (!no_wsplit && L.cin >= 64 && L.cin % 32 == 0 && L.cout_pad == L.cout && L.relu != HP_ACT_SWISH && !L.se) {
-        L.wsplit_ok = true;
-        L.w2_ok = L.cout % 64 == 0;
-      }
-    }
+    // The Winograd weight set (exact-fp32 U = G g G^T) is LAZY: only eligibility is recorded here; ensure_wino_weights()
+    // transforms it the first time a forward's algorithm can reach it (the guard's exact-fp32 fallback,
+    // hp_net_set_conv_algo).  The default plan never touches it: hp_net_create used to spend 150 MB and 58 transform
+    // launches per WideResNet-34 on kernels that lost to the direct split kernels.
+    if (conv_wino_applicable(probe, L.kh, L.kw)) L.wino_ok = true;
     if (conv_split_applicable(probe, L.kh, L.kw) && L.cout_pad == L.cout && L.relu != HP_ACT_SWISH && !L.se) {
       if ((rc = L.w_split.alloc(conv_split_weight_bytes(L.cout, L.cin)))) return rc;
       if ((rc = conv_split_transform_weights((const float*)L.w.p, L.w_split.p, L.cout, L.cin, L.Kpad, L.stride, nullptr))) return rc;
@@ -633,6 +624,7 @@ extern "C" hp_net* hp_net_create(int arch, int n_inputs, int h, int w) {
   }
   hp_net* n = new hp_net();
   n->arch = arch; n->n_inputs = n_inputs; n->c_pad = (n_inputs + 3) / 4 * 4; n->h = h; n->w = w;
+  (void)hipGetDevice(&n->device);
   if (arch == HP_ARCH_CUSTOM) return n;  // the caller describes the graph: hp_net_add_conv / hp_net_add_output
   if ((arch == HP_ARCH_EFFICIENTNET_B3 ? build_graph_efficientnet(*n) : arch == HP_ARCH_RESNET50_FPN ? build_graph_r50fpn(*n)
                                                                                                     : build_graph(*n)) != HP_OK) {
@@ -704,6 +696,15 @@ extern "C" int hp_net_output_dims(const hp_net* net, int* pose_dim, int* n_logit
   return HP_OK;
 }
 
+extern "C" int hp_net_input_dims(const hp_net* net, int* h, int* w, int* c_pad, int* device) {
+  HP_REQUIRE(net, "hp_net_input_dims: null network");
+  if (h) *h = net->h;
+  if (w) *w = net->w;
+  if (c_pad) *c_pad = net->c_pad;
+  if (device) *device = net->device;
+  return HP_OK;
+}
+
 extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
   HP_REQUIRE(net && max_batch >= 1, "hp_net_finalize: bad argument");
   int rc = conv_setup_once();
@@ -771,7 +772,6 @@ extern "C" int hp_net_finalize(hp_net* net, int max_batch) {
 // captures (hipMalloc): the Python layer runs the first call after an algorithm switch eagerly (ops.bump_graph_epoch).
 static int ensure_wino_weights(hp_net* net, int algo, hipStream_t stream) {
   const bool exact = algo == HP_CONV_ALGO_WINOGRAD_1WAVE || algo == HP_CONV_ALGO_WINOGRAD;
-  const bool split = conv_use_split(algo, 0, 0, 0, 0);
   int rc;
   bool capturing_checked = false;
   auto can_build = [&]() -> int {
@@ -791,16 +791,6 @@ static int ensure_wino_weights(hp_net* net, int algo, hipStream_t stream) {
       if ((rc = L.w_wino.alloc(conv_wino_weight_floats(L.cout, L.cin) * 4))) return rc;
       if ((rc = conv_wino_transform_weights((const float*)L.w.p, (float*)L.w_wino.p, L.cout, L.cin, L.Kpad, stream))) return rc;
     }
-    if (split && L.w2_ok && !L.w_w2.p && conv_use_wino2(algo, L.W)) {
-      if ((rc = can_build())) return rc;
-      if ((rc = L.w_w2.alloc(conv_wino2_weight_bytes(L.cout, L.cin)))) return rc;
-      if ((rc = conv_wino2_transform_weights((const float*)L.w.p, L.w_w2.p, L.cout, L.cin, L.Kpad, stream))) return rc;
-    }
-    if (split && L.wsplit_ok && !L.w_wsplit.p && conv_use_wino_split(algo, L.W)) {
-      if ((rc = can_build())) return rc;
-      if ((rc = L.w_wsplit.alloc(conv_wino_split_weight_bytes(L.cout, L.cin)))) return rc;
-      if ((rc = conv_wino_split_transform_weights((const float*)L.w.p, L.w_wsplit.p, L.cout, L.cin, L.Kpad, stream))) return rc;
-    }
   }
   return HP_OK;
 }
@@ -815,8 +805,8 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       return rc;
     d_x16 = net->x16.p;
   }
-  static const bool sync_ops = std::getenv("HP_NET_SYNC") != nullptr;  // diagnostics: fault isolation
-  static const bool per_launch = std::getenv("HP_PROFILE_LAYERS") != nullptr;
+  const bool sync_ops = dbg(DBG_NET_SYNC) != 0;  // diagnostics: fault isolation
+  const bool per_launch = dbg(DBG_PROFILE_LAYERS) != 0;
   // profiling: events are recorded on the launch stream and only READ in hp_net_profile_collect
   EventPair run{};
   bool run_open = false;
@@ -846,21 +836,19 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
     (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
     if (cap == hipStreamCaptureStatusNone) net->exact_only = true;
   }
-  const int net_algo = net->exact_only ? HP_CONV_ALGO_WINOGRAD : (net->algo >= 0 ? net->algo : conv_algo());
+  const int net_algo = net->exact_only ? HP_CONV_ALGO_WINOGRAD : (net->algo >= 0 ? net->algo : HP_CONV_ALGO_AUTO);
   if (!f16 && (rc = ensure_wino_weights(net, net_algo, stream))) return rc;
-  static const bool no_act_scale = std::getenv("HP_CONV_NO_ACT_SCALE") != nullptr;  // A/B: the round-2 arithmetic (no activation scale)
-  unsigned* const amax_words = (f16 || no_act_scale || !net->act_scale) ? nullptr : (unsigned*)net->amax.p;
+  unsigned* const amax_words = (f16 || !net->act_scale) ? nullptr : (unsigned*)net->amax.p;
   if (amax_words && (rc = launch_zero_words(amax_words, ((int)net->ops.size() + 1) * kAmaxSlots * kAmaxStride, stream))) return rc;
   std::vector<int> buf_amax(net->bufs.size(), -1);  // arena slot -> op whose launch tracked max|y| of what it holds (-1: unknown)
   int op_index = 0;
   bool pool_fused = false;  // the stem wrote the pooled map itself: skip the max-pool op that follows it
   bool front_fused = false; // the expansion conv ran the depthwise conv after it too (mbconv_front.hip): skip that op
   int dw_partials = 0;      // > 0: the depthwise launch left this many pooling partials per image for the SE op after it
-  static const bool no_fuse = std::getenv("HP_NO_POOL_FUSION") != nullptr;
   // A down-sampling block's 1x1 / stride-2 shortcut runs as extra work items of the block's 3x3 / stride-2 launch (conv3x3s2_pp,
   // ConvArgs::sc_w): as a launch of its own it sits on a floor of 20 - 30 us whatever the kernel.  The plans put the shortcut
   // right behind the 3x3 op.  HP_NET_NO_SHORTCUT_FUSION=1 / per-layer profiling: separate launches.
-  static const bool no_sc_fusion = std::getenv("HP_NET_NO_SHORTCUT_FUSION") != nullptr;
+  const bool no_sc_fusion = dbg(DBG_NET_NO_SHORTCUT_FUSION) != 0;
   int sc_done = -1;       // op index of a shortcut the 3x3 op before it has already run
   auto sc_pair = [&](size_t o3, size_t o1) -> bool {  // may op o1 (shortcut) ride in the launch of op o3 (3x3 / stride 2)?
     if (no_sc_fusion || per_launch || sync_ops || f16 || o3 >= net->ops.size() || o1 >= net->ops.size()) return false;
@@ -902,7 +890,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       a.w_bytes = (int64_t)L.cout * L.Kpad16 * 2;
       if ((rc = prof_begin(op.conv))) return rc;
       const Op* next16 = op_index < (int)net->ops.size() ? &net->ops[op_index] : nullptr;
-      if (L.w_stem7.p && !no_fuse && next16 && next16->kind == OP_MAXPOOL && next16->in_buf == L.out_buf && next16->H == L.Ho &&
+      if (L.w_stem7.p && next16 && next16->kind == OP_MAXPOOL && next16->in_buf == L.out_buf && next16->H == L.Ho &&
           next16->W == L.Wo) {
         // stem + ReLU + max-pool in one launch (conv_stem7.hip): the conv map is never written
         ConvArgs s7{};
@@ -935,8 +923,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
       a.stride = L.stride; a.pad = L.pad; a.Kpad = L.Kpad; a.ktiles = L.Kpad / 32; a.relu = L.relu;
       a.algo = net_algo; a.no_tail_split = net->tail_split ? 0 : 1;
       if (amax_words) {
-        static const bool producers_only = std::getenv("HP_ACT_SCALE_PRODUCERS_ONLY") != nullptr;  // A/B
-        if (L.in_buf >= 0 && buf_amax[L.in_buf] >= 0 && !L.se && !producers_only) {
+        if (L.in_buf >= 0 && buf_amax[L.in_buf] >= 0 && !L.se) {
           a.amax_in = amax_words + (size_t)buf_amax[L.in_buf] * kAmaxSlots * kAmaxStride;
           a.amax_a = L.pre_scale.p ? L.pre_smax : 1.f; a.amax_b = L.pre_scale.p ? L.pre_bmax : 0.f;
         }
@@ -979,7 +966,7 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         const int rows = (((th - 1) * fdw->stride + fdw->k) * ((tw - 1) * fdw->stride + fdw->k) + 31) / 32 * 32;
         mfma_flops = 2.0 * (double)batch * dw_partials * rows * ((L.cout + 31) / 32 * 32) * L.Kpad * 3.0 / 16.0;
       } else
-      if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_stem7.p && !no_fuse && next7 && next7->kind == OP_MAXPOOL &&
+      if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_stem7.p && next7 && next7->kind == OP_MAXPOOL &&
           next7->in_buf == L.out_buf && next7->H == L.Ho && next7->W == L.Wo) {
         // MegaPose stem + ReLU + max-pool in one launch, the input region of a pooled tile staged once per channel slab
         a.w = (const float*)L.w_stem7.p;
@@ -989,19 +976,6 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
         pool_fused = true; tracks_amax = false;
         const int sc = L.cin % 8 == 0 ? 8 : 4, ks = (7 * sc + 15) / 16;
         mfma_flops = 3.0 / 16.0 * 2.0 * (double)a.M * (256.0 / 192.0) * L.cout * (L.cin / sc) * 7.0 * ks * 16.0;
-      } else if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_w2.p && conv_use_wino2(algo, L.W) && conv_wino2_launchable(a)) {
-        // Winograd F(2x2,3x3) on the split operands, 64 tiles x 64 couts per workgroup on 32x32x16 MFMAs
-        a.w = (const float*)L.w_w2.p;
-        a.status = net->d_status;
-        rc = launch_conv_wino2(a, stream);
-        mfma_flops = 3.0 * 2.0 * 16.0 * (double)((((int64_t)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2)) + 63) / 64 * 64) * L.cin * L.cout / 16.0;
-      } else if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_wsplit.p && conv_use_wino_split(algo, L.W) &&
-                 conv_wino_split_launchable(a)) {
-        // Winograd F(2x2,3x3) on the split operands: 2.25x fewer products, each three fp16 MFMAs (16x16x16)
-        a.w = (const float*)L.w_wsplit.p;
-        a.status = net->d_status;
-        rc = launch_conv_wino_split(a, stream);
-        mfma_flops = 3.0 * 2.0 * 16.0 * (double)batch * ((L.Ho + 1) / 2) * ((L.Wo + 1) / 2) * L.cin * L.cout / 16.0;
       } else if (conv_use_split(algo, L.H, L.W, L.cin, L.cout) && L.w_split.p && conv_split_launchable(a)) {
         a.w = (const float*)L.w_split.p;
         a.status = net->d_status;
@@ -1032,12 +1006,11 @@ static int forward_chunk(hp_net* net, const float* d_x, const void* d_x16, int b
             conv_use_igemm_split(L.kh, L.Kpad)) {
           a.w = (const float*)L.w_isplit.p;
           a.status = net->d_status;
-          if (!no_fuse && next && next->kind == OP_MAXPOOL && next->in_buf == L.out_buf && next->H == L.Ho && next->W == L.Wo &&
+          if (next && next->kind == OP_MAXPOOL && next->in_buf == L.out_buf && next->H == L.Ho && next->W == L.Wo &&
               conv_igemm_split_pool_launchable(a, L.cout_pad)) {
             // stem + ReLU + 3x3/s2 max-pool in one launch: the conv map is never written
             a.y = (float*)net->bufs[next->out_buf].p;
-            static const bool no_stem = std::getenv("HP_NO_STEM_KERNEL") != nullptr;
-            if (!no_stem && conv_stem_split_applicable(a, L.kh, L.kw, L.run_mode)) {
+            if (conv_stem_split_applicable(a, L.kh, L.kw, L.run_mode)) {
               rc = launch_conv_stem_split_pool(a, stream);
               mfma_flops *= 256.0 / 192.0;  // 256 GEMM rows per 6 x 32 conv pixels (7 x 33 computed, the rest padding)
             } else {
@@ -1220,7 +1193,7 @@ extern "C" int hp_net_profile_collect(hp_net* net, double* conv_ms, int64_t* n_l
                                       double* mfma_flops) {
   HP_REQUIRE(net, "hp_net_profile_collect: null net");
   double ms_total = 0.0, fl = 0.0, mfl = 0.0;
-  const bool verbose = std::getenv("HP_PROFILE_LAYERS") != nullptr;
+  const bool verbose = dbg(DBG_PROFILE_LAYERS) != 0;
   std::vector<double> lms(net->convs.size(), 0.0), lfl(net->convs.size(), 0.0);
   std::vector<int> lcnt(net->convs.size(), 0);
   for (auto& p : net->ev_pending) {
@@ -1283,7 +1256,7 @@ extern "C" int hp_net_profile_intervals(hp_net* net, double* t0_ms, double* t1_m
 
 extern "C" int hp_net_set_conv_algo(hp_net* net, int algo) {
   HP_REQUIRE(net, "hp_net_set_conv_algo: null net");
-  HP_REQUIRE(algo >= -1 && algo <= HP_CONV_ALGO_WINO_SPLIT, "hp_net_set_conv_algo: unknown algorithm");
+  HP_REQUIRE(algo >= -1 && algo <= HP_CONV_ALGO_SPLIT, "hp_net_set_conv_algo: unknown algorithm");
   net->algo = algo;
   return HP_OK;
 }
@@ -1391,9 +1364,9 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
   a.H = h; a.W = w; a.Cin = cin; a.Ho = (h + 2 * pad - kh) / stride + 1; a.Wo = (w + 2 * pad - kw) / stride + 1;
   a.Cout = cout; a.stride = stride; a.pad = pad; a.Kpad = Kpad; a.ktiles = Kpad / 32; a.relu = relu;
   a.M = (int64_t)n * a.Ho * a.Wo;
-  a.algo = conv_algo();
+  a.algo = conv_layer_algo();
   const bool classic = !padded && relu != HP_ACT_SWISH && (d_pre_shift || !d_pre_scale);  // what the 3x3 kernels support
-  const int algo = classic ? conv_algo() : HP_CONV_ALGO_IGEMM;
+  const int algo = classic ? conv_layer_algo() : HP_CONV_ALGO_IGEMM;
   if (conv_use_split(algo, h, w, cin, cout) && conv_split_applicable(a, kh, kw) && conv_split_launchable(a)) {
     // test entry: the weights are split on every call into a per-process scratch buffer
     static void* d_S = nullptr;
@@ -1424,7 +1397,7 @@ extern "C" int hp_conv2d_nhwc(const float* d_x, int n, int h, int w, int cin, co
     a.w = d_U;
     return launch_conv_wino(a, (hipStream_t)stream);
   }
-  if (conv_use_split(conv_algo(), h, w, cin, cout) && conv_igemm_split_launchable(a) && conv_use_igemm_split(kh, Kpad)) {
+  if (conv_use_split(conv_layer_algo(), h, w, cin, cout) && conv_igemm_split_launchable(a) && conv_use_igemm_split(kh, Kpad)) {
     // test entry: the weights are split on every call into a per-process scratch buffer
     static void* d_G = nullptr;
     static size_t G_bytes = 0;

@@ -679,7 +679,8 @@ __global__ __launch_bounds__(kBinThreads) void raster_setup_kernel(RasterArgs a)
   for (int k = 0; k < 8; ++k)
     if (b0 <= b1 && b0 + k <= b1) {
       const int b = b0 + k, sl = wg_base[2 * b + kls[k]] + slot[k];
-      // (a face appends at most once per band and bin_cap = the largest face count: the two ends cannot meet)
+      // (a record id appends at most once per band and bin_cap = rec_slots = all the ids there are -- f and nf + f, the two halves
+      // of a near-clipped quad, can both land in a band --: the two ends cannot meet, the bound checks are defensive only)
       if (sl < a.bin_cap) list_v[(int64_t)b * a.bin_cap + (kls[k] ? a.bin_cap - 1 - sl : sl)] = f;
     }
 }
@@ -1489,25 +1490,26 @@ __global__ __launch_bounds__(band_threads(NS, WIDE), (NS == 1 && !HALF && !ANISO
 static int raster_scratch(hp::MeshStore* ms, int n, int n_bands, hipStream_t st, int* chunk_out) {
   const size_t rec_view = (size_t)2 * (size_t)ms->max_faces * (128 + 32);  // records (up to 128 B) + the wide corners (32 B) per slot
   const size_t xv_view = (size_t)ms->max_verts * sizeof(int4);
-  const size_t per_view = (size_t)n_bands * (size_t)ms->max_faces * sizeof(int32_t) + rec_view + xv_view;
+  const size_t list_view = (size_t)n_bands * 2 * (size_t)ms->max_faces * sizeof(int32_t);  // bin_cap = rec_slots ids per band (launch_raster)
+  const size_t per_view = list_view + rec_view + xv_view;
   // Scratch budget: min(8 GB, 1/16 of the device's free memory at the first call); what is allocated is what the largest call
-  // needs (a multisampled 240 x 320 view of a 16 k-face object: 7.7 MB of list address space + 4 MB of records).  A call that
+  // needs (a multisampled 240 x 320 view of a 16 k-face object: 15 MB of list address space + 5 MB of records).  A call that
   // exceeds it renders in chunks of views.  HP_RASTER_LIST_BUDGET_MB overrides; HP_RASTER_CHUNK_VIEWS=<n> forces chunks (the
   // tests' way to run the chunked path), HP_RASTER_CHUNK_SYNC=1 synchronises the stream after every chunk (diagnostics).
   static const size_t budget = [] {
-    if (const char* e = std::getenv("HP_RASTER_LIST_BUDGET_MB")) return (size_t)std::atoll(e) << 20;
+    if (hp::dbg(hp::DBG_RASTER_LIST_BUDGET_MB) > 0) return (size_t)hp::dbg(hp::DBG_RASTER_LIST_BUDGET_MB) << 20;
     size_t free_b = 0, total_b = 0;
     size_t b = (size_t)8192 << 20;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 16 < b) b = free_b / 16;
     return b < ((size_t)64 << 20) ? ((size_t)64 << 20) : b;
   }();
   int chunk = (int)std::min<size_t>(budget / (per_view ? per_view : 1), 1u << 30);
-  static const int chunk_env = std::getenv("HP_RASTER_CHUNK_VIEWS") ? std::atoi(std::getenv("HP_RASTER_CHUNK_VIEWS")) : 0;
+  const int chunk_env = hp::dbg(hp::DBG_RASTER_CHUNK_VIEWS);
   if (chunk_env > 0 && chunk_env < chunk) chunk = chunk_env;
   if (chunk < 1) chunk = 1;
   if (chunk > n) chunk = n;
   *chunk_out = chunk;
-  const size_t need_list = (size_t)chunk * n_bands * (size_t)ms->max_faces * sizeof(int32_t), need_cnt = (size_t)chunk * n_bands * 2 * sizeof(int32_t);
+  const size_t need_list = (size_t)chunk * list_view, need_cnt = (size_t)chunk * n_bands * 2 * sizeof(int32_t);
   const size_t need_rec = (size_t)chunk * rec_view, need_xv = (size_t)chunk * xv_view;
   if (ms->bin_list_bytes >= need_list && ms->bin_count_bytes >= need_cnt && ms->recs_bytes >= need_rec && ms->xverts_bytes >= need_xv) return HP_OK;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1568,7 +1570,7 @@ static const hp_raster_conventions kDefaultConventions = {{0.375f, 0.875f, 0.125
 // state of a new store: the default record, culling on (HP_RASTER_NO_CULL=1: off)
 void raster_store_defaults(MeshStore* s) {
   s->conventions = kDefaultConventions;
-  s->backface_culling = std::getenv("HP_RASTER_NO_CULL") ? 0 : 1;
+  s->backface_culling = hp::dbg(hp::DBG_RASTER_NO_CULL) ? 0 : 1;
 }
 
 static RasterConv derive_conventions(const hp_raster_conventions& c, int msaa) {
@@ -1596,7 +1598,7 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
   a.cv = derive_conventions(store->conventions, a.msaa);
   a.cull = store->backface_culling ? store->cull : nullptr;
   const int ns = a.msaa ? kSamplesMsaa : 1;
-  static const int rows_env = std::getenv("HP_RASTER_ROWS") ? std::atoi(std::getenv("HP_RASTER_ROWS")) : 0;
+  const int rows_env = 0;  // band height: band_plan's choice
   BandPlan bp;
   HP_REQUIRE(band_plan(h, w, a.msaa, rows_env, &bp), "hp_rasterize: image too wide for one band");
   a.band_rows = bp.band_rows; a.n_bands = bp.n_bands;
@@ -1614,8 +1616,8 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
   // carry are gone.  Callers sharing one store must be stream-ordered.
   hp::MeshStore* ms = const_cast<hp_mesh_store*>(store);
   a.max_faces = (int)store->max_faces;
-  a.bin_cap = a.max_faces;
   a.rec_slots = 2 * a.max_faces;
+  a.bin_cap = a.rec_slots;  // every record id (f, or nf + f: the second half of a near-clipped quad) at most once per band
   int chunk = 0;
   {
     const int rc = raster_scratch(ms, n, a.n_bands, st, &chunk);
@@ -1652,7 +1654,7 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
     hipLaunchKernelGGL(raster_setup_kernel, dim3((a.max_faces + kBinThreads - 1) / kBinThreads, nv), dim3(kBinThreads), 0, st, a);
     const int total = nv * a.n_bands;
     hipLaunchKernelGGL(kernels[ki], dim3(8 * ((total + 7) / 8)), dim3(band_threads(ns, bp.wide)), lds, st, a, npix_max);
-    static const bool chunk_sync = std::getenv("HP_RASTER_CHUNK_SYNC") != nullptr;  // diagnostics (see raster_scratch)
+    const bool chunk_sync = hp::dbg(hp::DBG_RASTER_CHUNK_SYNC) != 0;  // diagnostics (see raster_scratch)
     if (chunk_sync && v0 + chunk < n) (void)hipStreamSynchronize(st);
   }
   return check_launch("raster_kernel");

@@ -184,11 +184,27 @@ std::vector<Tensor> pose_prep_meta(int64_t, const Tensor& TCO, const Tensor&, co
 }
 
 // ---- network --------------------------------------------------------------------------------------------------------
+// x against the planned input map: hp_net_forward strides by h * w * c_pad per sample, so a smaller H or W (a traced Meta shape, a
+// caller's mistake) would be an out-of-bounds read, not an error
+void check_net_input(const hp_net* n, const Tensor& x) {
+  int h = 0, w = 0, c_pad = 0, dev = -1;
+  check(hp_net_input_dims(n, &h, &w, &c_pad, &dev), "hp_net_input_dims");
+  TORCH_CHECK(!x.is_cuda() || x.device().index() == dev, "net_forward: x is on device ", (int)x.device().index(), ", the network was built on device ", dev);
+  TORCH_CHECK(x.dim() == 4 && x.size(1) == h && x.size(2) == w, "net_forward: x must be NHWC [b, ", h, ", ", w, ", c] for this network, got ", x.sizes());
+  if (x.scalar_type() == at::kHalf) {
+    TORCH_CHECK(hp_net_precision(n) == HP_PRECISION_F16 && x.size(3) == hp_net_input_channels_f16(n),
+                "net_forward: an fp16 input needs the fp16 plan and its record width");
+  } else {
+    TORCH_CHECK(x.scalar_type() == at::kFloat && x.size(3) == c_pad, "net_forward: x must be fp32 [b, h, w, ", c_pad, "]");
+  }
+}
+
 std::vector<Tensor> net_forward(int64_t net, const Tensor& x) {
   hp_net* n = resolve<hp_net>(net, kNet, "Net");
   int pose_dim = 0, n_logits = 0, n_features = 0;
   check(hp_net_output_dims(n, &pose_dim, &n_logits, &n_features), "hp_net_output_dims");
   TORCH_CHECK(x.is_cuda() && x.dim() == 4 && x.is_contiguous(), "net_forward: x must be a contiguous NHWC device tensor");
+  check_net_input(n, x);
   const DeviceGuard guard(x.device());
   const int64_t b = x.size(0);
   const auto o = x.options().dtype(at::kFloat);
@@ -198,10 +214,8 @@ std::vector<Tensor> net_forward(int64_t net, const Tensor& x) {
   float* const dp = pose_dim > 0 ? pose.data_ptr<float>() : nullptr;
   float* const dl = n_logits > 0 ? logits.data_ptr<float>() : nullptr;
   if (x.scalar_type() == at::kHalf) {
-    TORCH_CHECK(hp_net_precision(n) == HP_PRECISION_F16 && x.size(3) == hp_net_input_channels_f16(n), "net_forward: an fp16 input needs the fp16 plan and its record width");
     check(hp_net_forward_f16in(n, x.data_ptr(), (int)b, dp, dl, nullptr, stream_of(x)), "hp_net_forward_f16in");
   } else {
-    TORCH_CHECK(x.scalar_type() == at::kFloat && x.size(3) == hp_net_input_channels_padded(n), "net_forward: x must be fp32 [b,h,w,c_pad]");
     check(hp_net_forward(n, fp(x), (int)b, dp, dl, nullptr, stream_of(x)), "hp_net_forward");
   }
   std::vector<Tensor> out;
@@ -213,6 +227,7 @@ std::vector<Tensor> net_forward_meta(int64_t net, const Tensor& x) {
   hp_net* n = resolve<hp_net>(net, kNet, "Net");
   int pose_dim = 0, n_logits = 0, n_features = 0;
   check(hp_net_output_dims(n, &pose_dim, &n_logits, &n_features), "hp_net_output_dims");
+  check_net_input(n, x);
   const auto o = x.options().dtype(at::kFloat);
   std::vector<Tensor> out;
   if (pose_dim > 0) out.push_back(at::empty({x.size(0), pose_dim}, o));

@@ -8,6 +8,7 @@ happens in the HIP library.  Each wrapper validates what the reference asserts
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -75,7 +76,10 @@ class MeshStore:
     """Device-resident object set: geometry/textures for the rasteriser and the padded
     mesh-point table for the projection kernels (``hp_mesh_store``)."""
 
-    def __init__(self, object_ds: RigidObjectDataset, device="cuda"):
+    def __init__(self, object_ds: RigidObjectDataset, device="cuda", backface_culling: Optional[bool] = None):
+        """``backface_culling``: ``False`` renders this object set two-sided everywhere, as the reference does -- the opt-out for
+        sets that may hold self-intersecting closed meshes (the per-component culling decision assumes they do not:
+        ``hp_mesh_store_set_backface_culling`` in the header); ``None`` = the library default (on)."""
         self.device = torch.device(device)
         self.object_ds = object_ds
         self.packed = PackedMeshes(object_ds)
@@ -94,6 +98,25 @@ class MeshStore:
             raise _ffi.HipLibraryError("hp_mesh_store_create: " + lib().hp_last_error().decode())
         self._point_ids: Dict[int, torch.Tensor] = {}
         self.radius = torch.as_tensor(p.radius, device=self.device)
+        self._followers: List["weakref.ReferenceType[MeshStore]"] = []  # the lane stores cloned from this one (clone_for_lane)
+        if backface_culling is not None:
+            self.set_backface_culling(bool(backface_culling))
+
+    def clone_for_lane(self) -> "MeshStore":
+        """A second store on the same object set (a lane's own rasteriser scratch) that FOLLOWS this one's render state: the
+        conventions record and the culling switch are copied now, and every later ``set_raster_conventions`` /
+        ``set_backface_culling`` on this store reaches the clone too -- all lanes of a predictor render identically whichever
+        lane runs a chunk."""
+        other = MeshStore(self.object_ds, self.device)
+        other.set_raster_conventions(self.get_raster_conventions())
+        other.set_backface_culling(self.get_backface_culling())
+        self._followers.append(weakref.ref(other))
+        return other
+
+    def _live_followers(self) -> List["MeshStore"]:
+        live = [(r, r()) for r in self._followers]
+        self._followers = [r for r, o in live if o is not None]
+        return [o for _, o in live if o is not None]
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -141,6 +164,8 @@ class MeshStore:
                                   int(d["lod_from"]), float(d["lod_bias"]), float(d["aniso_ratio_bias"]), (C.c_int * 3)(*d["normal_axis"]),
                                   (C.c_float * 3)(*d["normal_sign"]))
             check(lib().hp_mesh_store_set_raster_conventions(self.handle, C.byref(c)), "hp_mesh_store_set_raster_conventions")
+        for f in self._live_followers():
+            f.set_raster_conventions(conv)
         bump_graph_epoch()
 
     def get_raster_conventions(self) -> Dict:
@@ -155,8 +180,17 @@ class MeshStore:
         two-sided like the reference's for everything else).  Per store; returns the previous setting.  Default on;
         ``HP_RASTER_NO_CULL=1`` creates stores with it off."""
         prev = bool(lib().hp_mesh_store_set_backface_culling(self.handle, 1 if on else 0))
+        for f in self._live_followers():
+            f.set_backface_culling(on)
         bump_graph_epoch()
         return prev
+
+    def get_backface_culling(self) -> bool:
+        """The current setting (the C ABI answers a set with the previous value: set, then restore)."""
+        cur = bool(lib().hp_mesh_store_set_backface_culling(self.handle, 1))
+        if not cur:
+            lib().hp_mesh_store_set_backface_culling(self.handle, 0)
+        return cur
 
     def point_ids(self, n_points: int) -> torch.Tensor:
         """ids of ``sample_points(n, deterministic=True)`` (TB/lib3d/mesh_ops.py:74-84)."""
@@ -526,7 +560,7 @@ class Net:
 
     def set_conv_algo(self, name: Optional[str] = None):
         """Kernel families THIS network may use (``hp_net_set_conv_algo``; names of :data:`CONV_ALGOS`);
-        ``None`` returns it to the process-wide default."""
+        ``None`` returns it to ``auto``."""
         check(lib().hp_net_set_conv_algo(self.handle, -1 if name is None else CONV_ALGOS[name]), "hp_net_set_conv_algo")
         bump_graph_epoch()
 
@@ -647,15 +681,16 @@ def probe_mfma_rate(device, random_data: bool = True):
     return tf.value, mhz.value
 
 
-CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2, "winograd-1wave": 3, "winograd": 4, "split": 5, "winograd-split": 6}
+CONV_ALGOS = {"auto": 0, "direct": 1, "igemm": 2, "winograd-1wave": 3, "winograd": 4, "split": 5}
 
 
 def select_conv_algo(name: str = "auto") -> None:
-    """The process-wide DEFAULT of the conv kernel choice -- what ``conv2d_nhwc`` uses and what networks without a
-    choice of their own (:meth:`Net.set_conv_algo`) follow; parity tests / diagnostics:
-    ``auto`` = Winograd F(2x2,3x3) where it applies (two waves per SIMD), ``winograd-1wave`` = the same
-    with the one-wave-per-SIMD schedule of that kernel, ``direct`` = no Winograd, ``igemm`` = the
-    generic implicit-GEMM kernel only (``hp_conv_select_algo``)."""
+    """The kernel family of the SINGLE-LAYER entry point ``conv2d_nhwc`` (``hp_conv_select_algo``; parity tests and
+    ``tools/conv_fuzz.py`` walk the families with it).  Networks never read it -- a network's choice is
+    :meth:`Net.set_conv_algo`, default ``auto``.  ``auto`` = the split-fp16 kernels where they apply, else Winograd
+    F(2x2,3x3), else the patch-staged direct kernel, else the generic implicit GEMM; ``winograd`` = exact-fp32 arithmetic
+    only (``winograd-1wave``: the one-wave-per-SIMD schedule of that kernel); ``direct`` = no Winograd; ``igemm`` = the
+    generic implicit-GEMM kernel only; ``split`` = the split-fp16 kernels."""
     check(lib().hp_conv_select_algo(CONV_ALGOS[name]), "hp_conv_select_algo")
     bump_graph_epoch()
 

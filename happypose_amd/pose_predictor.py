@@ -540,6 +540,7 @@ class TwoLanePredictor:
     tiles.  Everything but ``forward`` (coarse scoring, attributes) is lane 0's."""
 
     MIN_BATCH = 32
+    CHUNKS_TAIL_SPLIT = True  # forward_chunks: tail K-slicing of the lanes' networks while whole chunks run side by side
 
     def __init__(self, lanes):
         assert len(lanes) >= 2
@@ -698,12 +699,20 @@ class TwoLanePredictor:
         for stream in used:
             stream.wait_stream(cur)
         outs = []
-        for c, (labels, TCO, im_ids) in enumerate(chunks):
-            assert len(labels) < self.MIN_BATCH, "forward_chunks is for batches that forward() would not split"
-            lane = self.lanes[c % n]
-            lane.use_graphs = self.use_graphs
-            with torch.cuda.stream(self.streams[c % n]):
-                outs.append(lane.forward(images, K, labels, TCO, n_iterations=n_iterations, im_ids=im_ids, **kw))
+        # Tail K-slicing stays ON here, unlike forward(): a chunk of 8 hypotheses is 40 - 160 tiles per layer, the lanes together
+        # do not fill 256 CUs, and the slices are what spreads a layer over the idle ones (E2E refiner stage, three lanes, chunks
+        # of 16: CHUNKS_TAIL_SPLIT on / off measured in CHANGELOG round 6); it also keeps a chunk's launches -- and so its bits --
+        # those of lane 0 running it alone.
+        self.backbone.set_tail_split(self.CHUNKS_TAIL_SPLIT)
+        try:
+            for c, (labels, TCO, im_ids) in enumerate(chunks):
+                assert len(labels) < self.MIN_BATCH, "forward_chunks is for batches that forward() would not split"
+                lane = self.lanes[c % n]
+                lane.use_graphs = self.use_graphs
+                with torch.cuda.stream(self.streams[c % n]):
+                    outs.append(lane.forward(images, K, labels, TCO, n_iterations=n_iterations, im_ids=im_ids, **kw))
+        finally:
+            self.backbone.set_tail_split(True)
         for stream in used:
             cur.wait_stream(stream)
         return outs

@@ -136,7 +136,7 @@ class BatchRenderer:
 
     def __init__(self, asset_dataset: RigidObjectDataset, n_workers: int = 8, preload_cache: bool = True,
                  split_objects: bool = False, device="cuda", store: Optional[ops.MeshStore] = None, msaa: bool = True,
-                 aniso: bool = True):
+                 aniso: bool = True, backface_culling: Optional[bool] = None):
         """The render state.  Default = the reference renderer's (``TB/renderer/panda3d_scene_renderer.py:68-71``):
         ``msaa``: colour / normals with 4x multisampling (``framebuffer-multisample 1``, ``multisamples 4``; semantics in
         ``oracle/csrc/oracle.c`` ``HP_R_MSAA4``); ``aniso``: ``texture-minfilter mipmap`` + ``texture-anisotropic-degree 16``
@@ -149,7 +149,8 @@ class BatchRenderer:
         self.msaa = bool(msaa)
         self.aniso = bool(aniso)
         self._object_dataset = asset_dataset
-        self.store = store if store is not None else ops.MeshStore(asset_dataset, device)
+        # backface_culling=False: two-sided renders everywhere (object sets with self-intersecting closed meshes, see ops.MeshStore)
+        self.store = store if store is not None else ops.MeshStore(asset_dataset, device, backface_culling=backface_culling)
         self.device = self.store.device
         self._is_closed = False
 
@@ -165,8 +166,10 @@ class BatchRenderer:
 
     def clone_for_lane(self) -> "BatchRenderer":
         """A renderer with the SAME render state on a mesh store of its own (the second lane of a
-        ``TwoLanePredictor`` writes its own rasteriser scratch)."""
-        return BatchRenderer(self._object_dataset, device=self.device, msaa=self.msaa, aniso=self.aniso)
+        ``TwoLanePredictor`` writes its own rasteriser scratch).  The clone's store follows this one's conventions record and
+        culling switch, now and after later ``store.set_raster_conventions`` / ``set_backface_culling`` calls
+        (``ops.MeshStore.clone_for_lane``)."""
+        return BatchRenderer(self._object_dataset, device=self.device, store=self.store.clone_for_lane(), msaa=self.msaa, aniso=self.aniso)
 
     def _lights(self, labels, light_datas, n):
         if light_datas is None:

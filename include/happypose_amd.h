@@ -28,6 +28,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations of this header -- and nothing else -- are its dynamic
+ * symbols (tests/test_abi.py: nm -D shows the hp_* entry points only). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define HP_OK 0
 #define HP_ERR_ARG -1
@@ -147,7 +152,12 @@ int hp_mesh_store_get_raster_conventions(const hp_mesh_store* store, hp_raster_c
  * component at hp_mesh_store_create, so nested shells, parts with flipped winding and open sheets each get their own
  * answer --, the camera is outside the object's bounding sphere and the sphere lies beyond the near plane.  The facing test
  * is the exact sign of the triangle's area on the 1/256-px vertex grid.  Pixels may differ from the two-sided render only
- * where a sample lies exactly on a silhouette edge.  Returns the previous setting (-1: null store). */
+ * where a sample lies exactly on a silhouette edge.  ASSUMPTION: a closed component does not intersect itself.  The edge test
+ * and the net signed volume cannot see a self-intersecting component with a lobe of the opposite winding: its visible faces
+ * would be culled (holes in rgb / depth / mask where the reference, two-sided, has none).  For object sets that may hold such
+ * meshes switch culling off on the store -- hp_mesh_store_set_backface_culling(store, 0) right after hp_mesh_store_create, or
+ * HP_RASTER_NO_CULL=1 for every store of the process; renders are then two-sided everywhere, ~25 % slower.
+ * Returns the previous setting (-1: null store). */
 int hp_mesh_store_set_backface_culling(hp_mesh_store* store, int on);
 
 int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
@@ -351,6 +361,12 @@ int hp_net_finalize(hp_net* net, int max_batch);
 /* Widths of the three outputs of a finalized network: pose_dim / n_logits are 0 when the checkpoint has no such head (what
  * PosePredictor.net_forward returns, MP/models/pose_rigid.py:352-374); the compiled operator library sizes its outputs with it. */
 int hp_net_output_dims(const hp_net* net, int* pose_dim, int* n_logits, int* n_features);
+/* The planned input map of a network: hp_net_forward strides its input by h * w * c_pad floats per sample (c_pad = channels
+ * rounded up to 4; the fp16 plan's record width is hp_net_input_channels_f16), so a caller -- the compiled operator library's
+ * net_forward and its Meta kernel -- checks a tensor's height and width against these before handing over the pointer
+ * (the reference's backbone takes any H x W, MP/models/pose_rigid.py:352-374; a plan is built for one).  device = the HIP
+ * device that was current in hp_net_create (weights and arena live there). */
+int hp_net_input_dims(const hp_net* net, int* h, int* w, int* c_pad, int* device);
 int hp_net_forward(hp_net* net, const float* d_x, int batch, float* d_pose, float* d_logits,
                    float* d_features, void* stream);
 /* Feature-pyramid networks (HP_ARCH_RESNET50_FPN): number of output maps ('0', '1', '2', '3', 'pool' of torchvision's
@@ -389,24 +405,21 @@ double hp_net_flops_per_sample(const hp_net* net);
  * layers, more where tiles / K are padded; in fp32-MFMA equivalents: an fp16 MFMA FLOP of the
  * split-fp16 layers counts 1/16, its share of matrix-pipe time) since the previous collect. */
 int hp_net_set_profiling(hp_net* net, int enabled);
-/* Diagnostics / parity tests: restrict the convolution kernels the dispatchers may pick
- * (the process-wide DEFAULT of networks that have no choice of their own, and the choice of hp_conv2d_nhwc).  AUTO = for 3x3 stride-1 layers the split-fp16 kernel (fp32 operands as two fp16 halves, three
- * fp16 MFMAs per product, fp32 accumulation: fp32-level accuracy while |activations| < 65504), else Winograd
- * F(2x2,3x3), else the patch-staged direct kernel, else the generic implicit GEMM; WINOGRAD = exact-fp32
- * arithmetic only; DIRECT = no Winograd either; IGEMM = generic kernel only.
- * Environment equivalents read at first use: HP_CONV_NO_SPLIT, HP_CONV_NO_WINOGRAD, HP_CONV_NO_PATCH. */
+/* Parity tests / layer-level users: the kernel family hp_conv2d_nhwc / hp_conv2d_nhwc_f16 -- the SINGLE-LAYER entry points, which
+ * have no network to carry a choice -- pick from.  Networks never read it (no process-wide state on a network's launch path:
+ * hp_net_set_conv_algo below).  AUTO = for 3x3 layers the split-fp16 kernels (fp32 operands as two fp16 halves, three fp16 MFMAs
+ * per product, fp32 accumulation: fp32-level accuracy while |activations| < 65504), else Winograd F(2x2,3x3), else the
+ * patch-staged direct kernel, else the generic implicit GEMM; WINOGRAD = exact-fp32 arithmetic only; DIRECT = no Winograd either;
+ * IGEMM = generic kernel only. */
 #define HP_CONV_ALGO_AUTO 0
 #define HP_CONV_ALGO_DIRECT 1
 #define HP_CONV_ALGO_IGEMM 2
 #define HP_CONV_ALGO_WINOGRAD_1WAVE 3 /* WINOGRAD, but the one-wave-per-SIMD schedule of the Winograd kernel */
 #define HP_CONV_ALGO_WINOGRAD 4 /* exact-fp32 kernels only: Winograd, else patch-staged, else generic */
 #define HP_CONV_ALGO_SPLIT 5 /* split-fp16 kernels (3 fp16 MFMAs per fp32 product) wherever they apply */
-#define HP_CONV_ALGO_WINO_SPLIT 6 /* SPLIT, with the 3x3 stride-1 layers (Cin >= 64) as Winograd F(2x2,3x3) on the split operands:
-                                     2.25x fewer products; measured SLOWER than the direct split kernels on MI355X (LDS-read bound,
-                                     DESIGN.md 4.1), kept selectable */
 int hp_conv_select_algo(int algo);
-/* The same choice for ONE network (what the predictors use: no process-wide state on the launch path, networks on
- * different host threads / streams do not interfere); algo = -1 returns the network to the process-wide default. */
+/* The choice of ONE network (what the predictors and bench.py's exact-fp32 pass use; networks on different host threads /
+ * streams do not interfere); algo = -1 returns the network to AUTO. */
 int hp_net_set_conv_algo(hp_net* net, int algo);
 /* The conv kernels cut the tiles of a partially filled last round along K so that one launch fills the GPU.  When
  * independent launches share the GPU (the two half-batch lanes of a predictor on two streams) the other stream fills
@@ -531,6 +544,9 @@ int hp_conv2d_nhwc_f16(const void* d_x, int n, int h, int w, int cin, const void
                        const void* d_pre_scale, const void* d_pre_shift, int relu, void* d_y,
                        void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -58,3 +58,61 @@ def test_argument_errors_reported_without_gpu():
         _ffi.check(rc, "hp_pose_update")
     assert not lib.hp_net_create(7, 6, 240, 320)
     assert not lib.hp_mesh_store_create(None, None, None, None, 0, None, 0, None, 0, None, 0, None, 0)
+
+
+def test_dynamic_symbols_are_the_header_only():
+    """-fvisibility=hidden + csrc/exports.map: ``nm -D`` of the library shows the ``hp_*`` entry points of the header and nothing
+    else (no ``hp::`` C++ helper, no kernel host stub)."""
+    import subprocess
+
+    from happypose_amd import _ffi
+
+    out = subprocess.run(["nm", "-D", "--defined-only", str(_ffi.lib_path())], check=True, capture_output=True, text=True).stdout
+    defined = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert defined == _declared_symbols(), sorted(set(defined) ^ set(_declared_symbols()))
+
+
+def test_no_packed_fp32_arithmetic_in_the_device_code():
+    """The build-time ISA check (happypose_amd/isa_check.py): no ``v_pk_fma/mul/add_f32`` in any gfx950 code
+    object of the shipped library outside the exact-fp32 Winograd kernels' hand-placed ones -- and the checker does bite: the
+    Winograd kernels, which do contain them, are found when the exception is lifted."""
+    import re
+
+    from happypose_amd import _ffi, isa_check
+
+    assert isa_check.packed_f32_instructions(_ffi.lib_path()) == {}
+    allowed, isa_check.ALLOWED_KERNELS = isa_check.ALLOWED_KERNELS, re.compile(r"$^")
+    try:
+        hits = isa_check.packed_f32_instructions(_ffi.lib_path())
+    finally:
+        isa_check.ALLOWED_KERNELS = allowed
+    assert hits and all(allowed.search(k) for k in hits), sorted(hits)[:5]
+
+
+def test_no_getenv_outside_the_debug_table():
+    """One table of developer switches (csrc/debug.h / debug.cpp), read once, thread-safe; no ``getenv`` on any launch path."""
+    for src in (ROOT / "happypose_amd" / "csrc").iterdir():
+        if src.suffix in (".hip", ".cpp", ".h") and src.name != "debug.cpp":
+            text = re.sub(r"//.*", "", src.read_text())
+            assert "getenv" not in text, src.name
+            assert not re.search(r"static\s+bool\s+(opted|done)", text), f"{src.name}: plain first-launch flag (use FirstLaunch)"
+
+
+def test_first_launch_and_debug_table_are_race_free(tmp_path):
+    """tests/host/first_launch_race.cpp under ThreadSanitizer: 16 host threads enter a kernel launcher's first-launch set-up
+    (``hp::FirstLaunch``) and read the debug table for the first time at once -- one set-up, no data race report."""
+    import os
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = tmp_path / "race"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__=1", "-I/opt/rocm/include",
+           str(ROOT / "tests" / "host" / "first_launch_race.cpp"), str(ROOT / "happypose_amd" / "csrc" / "debug.cpp"), "-o", str(exe), "-pthread"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    env = {**os.environ, "HP_PP_GRID": "64", "HP_NET_SYNC": "yes", "TSAN_OPTIONS": "halt_on_error=1 exitcode=66"}
+    for k in ("HP_PROFILE_LAYERS", "HP_CONV_NO_PP"):
+        env.pop(k, None)
+    r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.returncode, r.stdout[-500:], r.stderr[-2000:])

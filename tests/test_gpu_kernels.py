@@ -1123,6 +1123,13 @@ def test_torch_ops_match_ctypes_path(dev, scene_store):
     xin[..., :6] = torch.as_tensor(rs.rand(2, 240, 320, 6).astype(np.float32), device=dev)
     (pose,) = o.net_forward(torch_ops.ticket(net), xin)
     assert torch.equal(pose, net.forward(xin)[0])
+    # the op checks H and W against the planned map (hp_net_input_dims): a smaller tensor raises, on the device and on Meta
+    for bad in (xin[:, :200].contiguous(), xin[:, :, :300].contiguous(), torch.empty((2, 240, 320, 4), device=dev)):
+        with pytest.raises(RuntimeError, match="net_forward"):
+            o.net_forward(torch_ops.ticket(net), bad)
+        with pytest.raises(RuntimeError, match="net_forward"):
+            o.net_forward(torch_ops.ticket(net), torch.empty(bad.shape, device="meta"))
+    assert o.net_forward(torch_ops.ticket(net), torch.empty(xin.shape, device="meta"))[0].shape == pose.shape
 
     x = torch.as_tensor(rs.randn(2, 12, 16, 32).astype(np.float32), device=dev)
     wt = torch.as_tensor(rs.randn(64, 3, 3, 32).astype(np.float32) * 0.05, device=dev)
@@ -1253,29 +1260,3 @@ def test_split_fp16_small_activations_keep_their_bits(dev):
     n0.set_act_scale(False)
     fb = n0.forward(xin, want_pose=False, want_features=True)[2]
     assert float((fa - fb).abs().max() / fa.abs().max()) < 5e-6
-
-
-def test_backbone_winograd_split_vs_fp64(dev):
-    """``HP_CONV_ALGO_WINO_SPLIT``: the 3x3 stride-1 layers as Winograd F(2x2,3x3) on split-fp16 operands (conv_wino.hip, SPLIT
-    instantiation -- one v_mfma_f32_16x16x16_f16 triple per float4 of U / V).  Not the default (slower than the direct split
-    kernels: LDS-read bound), but it must be RIGHT: WideResNet-34 features against float64, Winograd's 2x error class."""
-    from happypose_amd import ops
-    from happypose_amd.synthetic import predictor_weights
-    from oracle import backbones as ob
-
-    w = predictor_weights(ob.predictor_param_shapes("resnet34", 6), seed=7)
-    x = np.random.RandomState(5).uniform(0, 1, size=(3, 6, 240, 320)).astype(np.float32)
-    with torch.no_grad():
-        ref = ob.net_forward(torch.as_tensor(x).double(), {k: torch.as_tensor(np.asarray(v)).double() if np.asarray(v).dtype.kind == "f" else
-                                                           torch.as_tensor(np.asarray(v)) for k, v in w.items()}, "resnet34", heads=("features",))["features"].numpy()
-    net = ops.Net("resnet34", 6, w, max_batch=3, device=dev)
-    xin = net.new_input(3)
-    xin[..., :6] = torch.as_tensor(x, device=dev).permute(0, 2, 3, 1)
-    scale = np.abs(ref).max(axis=1, keepdims=True)
-    f_split = net.forward(xin, want_pose=False, want_features=True)[2].cpu().numpy()
-    net.set_conv_algo("winograd-split")
-    f_ws = net.forward(xin, want_pose=False, want_features=True)[2].cpu().numpy()
-    assert net.status() == 0
-    e_split, e_ws = float((np.abs(f_split - ref) / scale).max()), float((np.abs(f_ws - ref) / scale).max())
-    assert e_split <= 2e-5 and e_ws <= 6e-5, (e_split, e_ws)
-    assert not np.array_equal(f_split, f_ws)  # the other kernels did run
