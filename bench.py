@@ -215,7 +215,7 @@ def e2e_oracle(job, cores=None):
 # poses (std; the coarse head of the bench worlds has COARSE_HEAD_SCALE = 1.0): the measured error of the healthy path with
 # head-room, as tests/test_gpu_pipeline.py::test_c5_coarse_scoring_vs_oracle (tools/probes/c5_parity_probe.py; a network with
 # one conv layer off by 1 % is outside them)
-COARSE_LOGIT_REL = {"f32": 0.1, "f16": 0.3}
+COARSE_LOGIT_REL = {"f32": 0.04, "f16": 0.10}
 
 
 def e2e_parity(product, ref, coarse_precision):

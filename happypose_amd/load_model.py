@@ -114,13 +114,23 @@ def load_pose_models(coarse_run_id: Optional[str], refiner_run_id: Optional[str]
     return load_model(coarse_run_id, coarse_precision), load_model(refiner_run_id, "f32"), mesh_db
 
 
+def default_coarse_precision(model_name: str) -> str:
+    """``"f16"`` for the multi-hypothesis configurations (BASELINE.json config 5 names fp16 for exactly this stage: 576 grid views
+    per object are SCORED and the five best kept -- the fp16 plan's logits stay within 0.05 of the oracle's spread over an
+    object's grid poses and pick the same five, ``tests/test_gpu_pipeline.py::test_c5_coarse_scoring_vs_oracle``), ``"f32"`` for
+    the single-hypothesis ones, whose coarse winner alone seeds the refiner."""
+    return "f16" if NAMED_MODELS[model_name]["inference_parameters"]["n_pose_hypotheses"] > 1 else "f32"
+
+
 def load_named_model(model_name: str, object_dataset: RigidObjectDataset, n_workers: int = 4, bsz_images: int = 128,
-                     models_root: Optional[Path] = None, device="cuda", coarse_precision: str = "f32") -> PoseEstimator:
+                     models_root: Optional[Path] = None, device="cuda", coarse_precision: Optional[str] = None) -> PoseEstimator:
     """``TB/utils/load_model.py:52-88``.  ``coarse_precision`` (beyond the reference's signature): ``"f16"`` plans the coarse /
-    scoring network in fp16 (BASELINE.json config 5: 576 views per object are SCORED, not regressed -- the stated tolerance is
-    5e-2 on a logit, tests/test_gpu_pipeline.py); the refiner always runs in fp32.  Measured on the end-to-end frame:
-    ``bench.py`` keys ``e2e`` / ``e2e_f16_coarse``, each with its parity against the oracle estimator."""
+    scoring network in fp16, ``"f32"`` in the reference's arithmetic; ``None`` = :func:`default_coarse_precision` (fp16 for the
+    multi-hypothesis configurations).  The refiner always runs in fp32.  Measured on the end-to-end frame: ``bench.py`` keys
+    ``e2e`` / ``e2e_f16_coarse``, each with its parity against the oracle estimator."""
     model = NAMED_MODELS[model_name]
+    if coarse_precision is None:
+        coarse_precision = default_coarse_precision(model_name)
     coarse_model, refiner_model, mesh_db = load_pose_models(
         coarse_run_id=model["coarse_run_id"], refiner_run_id=model["refiner_run_id"], object_dataset=object_dataset,
         force_panda3d_renderer=True, renderer_kwargs={"preload_cache": False, "split_objects": False, "n_workers": n_workers},

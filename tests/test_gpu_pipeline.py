@@ -550,10 +550,12 @@ def test_c3_full_size_vs_oracle(dev):
 # C5 / coarse scoring: the logits of an object's 576 grid poses against the fp32 CPU oracle, in units of the ORACLE'S OWN SPREAD
 # over those poses (their standard deviation; the bench world's head has update_scale 1.0 -- logits 5.5 .. 5.8, std 0.042 --,
 # an absolute tolerance says nothing about a quantity whose whole range is a few tenths).  Bounds = the measured error of the
-# healthy path with head-room (tools/probes/c5_parity_probe.py, CHANGELOG round 6); a network with ONE conv layer's weights x 1.01
-# must FAIL them (second half of the tests).
-C5_LOGIT_REL = {"f16": 0.3, "f32": 0.1}  # max |got - ref| / std(ref) over an object's 576 poses
-C5_FEAT_TOL_F16 = 2e-2  # fp16 plan: max |feature - ref| / max|ref| per sample at batch 576
+# healthy path with head-room (tools/probes/c5_parity_probe.py -> profiles/r06_c5_parity_probe.json: logits fp16 0.047 / fp32
+# 0.0098 of the spread -- the fp32 figure is a handful of views with a flipped silhouette pixel, its rms is 0.0011 --, features of
+# the fp16 plan 2.9e-4 of max|ref|); a network with ONE conv layer's weights x 1.01 must FAIL them (second half of the tests;
+# measured 0.096 / 0.061 of the spread, features 1.7e-3).
+C5_LOGIT_REL = {"f16": 0.07, "f32": 0.025}  # max |got - ref| / std(ref) over an object's 576 poses
+C5_FEAT_TOL_F16 = 6e-4  # fp16 plan: max |feature - ref| / max|ref| per sample at batch 576
 
 
 def _c5_reference(bench, scene, weights, store, n=576):

@@ -282,6 +282,10 @@ def test_load_cfg_restricted_yaml_and_named_models(tmp_path):
     assert m["megapose-1.0-RGB-multi-hypothesis-icp"]["inference_parameters"] == {
         "n_refiner_iterations": 5, "n_pose_hypotheses": 5, "run_depth_refiner": True}
     assert m["megapose-1.0-RGB"]["inference_parameters"] == {"n_refiner_iterations": 5, "n_pose_hypotheses": 1}
+    # the coarse / scoring network's default plan: fp16 where the five best of 576 scored views go on (BASELINE config 5)
+    assert {k: LM.default_coarse_precision(k) for k in m} == {
+        "megapose-1.0-RGB": "f32", "megapose-1.0-RGBD": "f32", "megapose-1.0-RGB-multi-hypothesis": "f16",
+        "megapose-1.0-RGB-multi-hypothesis-icp": "f16"}
 
 
 def test_legacy_keys_and_config_defaults_golden(golden_dir):
