@@ -370,9 +370,9 @@ def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2, rend
             "hypotheses_per_step": B, "lanes": n_lanes, "scratch_launches": int(_ops.scratch_launches())}
 
 
-def estimator_timing(model, images, K, labels, TCO0, device, steps, poses_direct):
-    """``CosyPoseEstimator.forward_refiner`` (bsz_objects = the whole table) on the job the headline times through
-    ``model.forward``: ms per step, and the largest difference of its final poses to the direct call's (0: same launches)."""
+def estimator_entry(model, images, K, labels, TCO0, device):
+    """``step()`` through the entry point: ``CosyPoseEstimator.forward_refiner`` (bsz_objects = the whole table) on the C2 job;
+    returns the final poses ``[B, 4, 4]`` like the direct call's ``iteration=5`` output."""
     import pandas as pd
 
     from happypose_amd.pose_estimator import CosyPoseEstimator, ObservationTensor
@@ -389,17 +389,22 @@ def estimator_timing(model, images, K, labels, TCO0, device, steps, poses_direct
         preds, _ = est.forward_refiner(obs, data, n_iterations=N_ITERS)
         return preds[f"iteration={N_ITERS}"].poses
 
+    return step
+
+
+def side_timing(fn, device, steps, poses_main, B):
+    """The OTHER way into the same job (the bare predictor when the headline goes through the estimator, and vice versa): ms per
+    step over ``steps`` steps, and the largest difference of its final poses to the headline's (0: the same launches)."""
     for _ in range(2):
-        out = step()
+        out = fn()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = step()
+        out = fn()
     torch.cuda.synchronize(device)
     ms = 1e3 * (time.perf_counter() - t0) / steps
     return {"ms_per_step": ms, "steps": steps, "value": B / (ms * 1e-3), "unit": "refined poses/s",
-            "max_abs_pose_diff_vs_direct_call": float((out - poses_direct[:B]).abs().max()),
-            "entry": "CosyPoseEstimator.forward_refiner(observation, data_TCO_input[128], n_iterations=5), bsz_objects=128"}
+            "max_abs_pose_diff_vs_headline": float((out[:B] - poses_main[:B]).abs().max())}
 
 
 def effective_cpu_count() -> int:
@@ -566,6 +571,10 @@ def main():
                     help="reference = the reference renderer's state (4x MSAA, mipmap + anisotropic-16; product default); single-sample = "
                          "one sample per pixel, bilinear level 0 (what rounds 1-2 measured)")
     ap.add_argument("--run-detector", action="store_true", help="E2E: the frame also goes through the Mask-RCNN detector (random weights)")
+    ap.add_argument("--entry", default="estimator", choices=["estimator", "predictor"],
+                    help="C2 on one GPU: what a step calls -- CosyPoseEstimator.forward_refiner (the drop-in entry point, SURVEY.md 0.8: the "
+                         "default, pandas bookkeeping and the numerical guard's status query included) or the bare predictor's forward; the "
+                         "other one is timed beside it (key `estimator`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the 3-step C3 / C5 runs appended to the C2 line")
     ap.add_argument("--no-cpu-1thread", action="store_true")
@@ -619,7 +628,18 @@ def main():
     labels = [store.labels[i] for i in scene["hyp_obj_ids"]]
     im_ids = torch.zeros(len(labels), dtype=torch.int32, device=device)
 
+    # C2 on one GPU: the step goes through the ENTRY POINT, CosyPoseEstimator.forward_refiner (CP/integrated/pose_estimator.py:249-356)
+    # on the 128-row hypothesis table, bsz_objects = 128 -- pandas bookkeeping, the per-iteration result tables and the guard's status
+    # query included (north_star: "run_inference_pipeline() stays the drop-in entry point"; SURVEY.md 0.8 names forward_refiner as
+    # what is timed).  --entry predictor times the bare model.forward instead; either way the other one is timed beside it.
+    via_estimator = args.workload == "C2" and world == 1 and args.entry == "estimator"
+    entry_step = None
+    if args.workload == "C2" and world == 1:
+        entry_step = estimator_entry(model, images, K, labels, TCO0, device)
+
     def step():
+        if via_estimator:
+            return entry_step()
         if args.workload == "C5":  # coarse scoring, one object (576 grid poses) per chunk and lane as in 8(e)
             ck = 576 * n_lanes
             scores = [model.forward_coarse(images, K, labels[i:i + ck], TCO0[i:i + ck], im_ids=im_ids[i:i + ck])["logits"]
@@ -694,12 +714,12 @@ def main():
         fence()
         all_gather_us = (time.perf_counter() - t_ag) / 20 * 1e6
 
-    # the same job through the ENTRY POINT: CosyPoseEstimator.forward_refiner (CP/integrated/pose_estimator.py:249-356) on the
-    # 128-row hypothesis table, bsz_objects = 128 -- pandas bookkeeping, chunking, the per-iteration result tables and the
-    # guard's status query included (north_star: "run_inference_pipeline() stays the drop-in entry point")
+    # the same job the OTHER way in (see `via_estimator` above), half as many steps
     estimator = None
-    if args.workload == "C2" and world == 1:
-        estimator = estimator_timing(model, images, K, labels, TCO0, device, max(3, args.steps // 2), poses)
+    if entry_step is not None:
+        def direct_step():
+            return model.forward(images, K, labels, TCO0, n_iterations=N_ITERS, im_ids=im_ids)[f"iteration={N_ITERS}"].TCO_output
+        estimator = side_timing(direct_step if via_estimator else entry_step, device, max(3, args.steps // 2), poses, B)
 
     ranks_block = None
     if world > 1:  # what the collective actually ran on: gathered from every rank
@@ -820,8 +840,17 @@ def main():
         if ranks_block is not None:
             line["ranks"] = ranks_block
         if estimator is not None:
-            line["estimator_ms_per_step"] = estimator["ms_per_step"]
-            line["estimator"] = dict(estimator, overhead_vs_predictor=estimator["ms_per_step"] / line["ms_per_step"] - 1.0)
+            # `value` is timed through `entry`; `estimator` holds both ways in and the entry point's cost over the bare predictor
+            est_ms, pred_ms = (line["ms_per_step"], estimator["ms_per_step"]) if via_estimator else (estimator["ms_per_step"], line["ms_per_step"])
+            line["entry"] = ("CosyPoseEstimator.forward_refiner(observation, data_TCO_input[128], n_iterations=5), bsz_objects=128" if via_estimator
+                             else "CosyPosePosePredictor.forward (two lanes)")
+            line["estimator_ms_per_step"] = est_ms
+            line["estimator"] = {"entry_ms_per_step": est_ms, "predictor_ms_per_step": pred_ms, "entry_value": B / (est_ms * 1e-3),
+                                 "predictor_value": B / (pred_ms * 1e-3), "unit": "refined poses/s", "overhead_vs_predictor": est_ms / pred_ms - 1.0,
+                                 "headline_is": "entry" if via_estimator else "predictor", "side_steps": estimator["steps"],
+                                 "max_abs_pose_diff_between_them": estimator["max_abs_pose_diff_vs_headline"],
+                                 "entry": "CosyPoseEstimator.forward_refiner(observation, data_TCO_input[128], n_iterations=5), bsz_objects=128 "
+                                          "(pandas bookkeeping, per-iteration result tables, the numerical guard's status query)"}
         line["arithmetic"] = ("3xf16-split products (22 significant bits), fp32 accumulate" if precision == "f32" else "fp16 products, fp32 accumulate")
         if precision == "f32":
             line["dtype_note"] = ("fp32 tensors and fp32 accumulation everywhere; the convolutions multiply fp16 hi/lo halves of the fp32 "

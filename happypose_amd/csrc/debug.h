@@ -23,6 +23,9 @@ enum DebugSwitch {
   DBG_RASTER_CHUNK_VIEWS,       // HP_RASTER_CHUNK_VIEWS=<n>: at most n views per rasteriser chunk (the tests' way into the chunked path)
   DBG_RASTER_CHUNK_SYNC,        // HP_RASTER_CHUNK_SYNC: synchronise the stream after every chunk
   DBG_RASTER_LIST_BUDGET_MB,    // HP_RASTER_LIST_BUDGET_MB=<n>: rasteriser scratch budget
+  DBG_RASTER_CANARY,            // HP_RASTER_CANARY: every rasteriser call first fills its set-up records and transformed vertices with 0xFF
+                                // bytes (NaN as fp32) and the scratch addresses go to stderr when allocated: a read of anything the call
+                                // itself did not write shows up as NaN pixels (tools/probes/two_lane_repro.py)
   DBG_COUNT
 };
 

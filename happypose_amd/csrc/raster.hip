@@ -1530,6 +1530,9 @@ static int raster_scratch(hp::MeshStore* ms, int n, int n_bands, hipStream_t st,
   if (!rc) rc = grow((void**)&ms->recs, &ms->recs_bytes, need_rec, false);
   if (!rc) rc = grow((void**)&ms->xverts, &ms->xverts_bytes, need_xv, false);
   ms->scratch_generation += 1;
+  if (hp::dbg(hp::DBG_RASTER_CANARY))
+    std::fprintf(stderr, "[hp raster scratch] store %p: bin_list %p (%zu B) bin_count %p recs %p (%zu B) xverts %p (%zu B)\n", (void*)ms, (void*)ms->bin_list,
+                 ms->bin_list_bytes, (void*)ms->bin_count, (void*)ms->recs, ms->recs_bytes, (void*)ms->xverts, ms->xverts_bytes);
   return rc;
 }
 
@@ -1622,6 +1625,10 @@ static int launch_raster(const hp_mesh_store* store, RasterArgs a, int n, bool c
   {
     const int rc = raster_scratch(ms, n, a.n_bands, st, &chunk);
     if (rc) return rc;
+  }
+  if (hp::dbg(hp::DBG_RASTER_CANARY)) {  // diagnostics: whatever this call reads without having written it is NaN
+    HP_CHECK_HIP(hipMemsetAsync(ms->recs, 0xFF, ms->recs_bytes, st));
+    HP_CHECK_HIP(hipMemsetAsync(ms->xverts, 0xFF, ms->xverts_bytes, st));
   }
   a.bin_list = ms->bin_list;
   a.bin_count = ms->bin_count;

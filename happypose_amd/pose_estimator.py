@@ -262,7 +262,13 @@ class _EstimatorBase:
         # slices of the table's columns: the launches of a chunk are on their way before any pandas work happens
         # (the frames below are built while the GPU runs; `data_TCO_input[ids]` cost a gather + a frame per chunk)
         bounds = [(a, min(e, a + bsz)) for a in range(s, e, bsz)]
-        chunks = [(labels_all[a:b], poses_all[a:b], torch.as_tensor(im_all_host[a:b], device=self.device)) for a, b in bounds]
+        # ONE host -> device copy of the frame ids, BEFORE the stage's launches: a pageable H2D copy waits for everything queued
+        # ahead of it on its stream, so issued after the launches (as it was) it blocked the host for the whole stage and every
+        # line of pandas bookkeeping below ran with the GPU idle (round 6: 0.7 of 22.8 ms per C2 step,
+        # tools/probes/estimator_overhead.py).  Now the bookkeeping runs under the stage's kernels; the only wait is the guard's.
+        im_all = torch.as_tensor(im_all_host, device=self.device)
+        K_all = observation.K.to(self.device)[im_all.long()]  # PosePredictorOutput.K: the intrinsics of each hypothesis' frame
+        chunks = [(labels_all[a:b], poses_all[a:b], im_all[a:b]) for a, b in bounds]
         t0 = time.time()
         if len(chunks) > 1 and bsz < getattr(model, "MIN_BATCH", 0) and hasattr(model, "forward_chunks"):
             # chunks too small to be split over the model's lanes run side by side, one whole chunk per lane
@@ -299,8 +305,6 @@ class _EstimatorBase:
                 for i, (_, width, shape) in enumerate(self._ITER_COLS):
                     table[k][i] = full[:, c0:c0 + width].reshape((B,) + shape)
                     c0 += width
-        im_all = torch.as_tensor(df_all["batch_im_id"].values, device=self.device).long()
-        K_all = observation.K.to(self.device)[im_all]  # PosePredictorOutput.K: the intrinsics of each hypothesis' frame
         preds = {}
         for k, ts in table.items():
             named = {name: t for (name, _, _), t in zip(self._ITER_COLS, ts)}

@@ -72,7 +72,8 @@ for r in range(runs):
             if detail is None:
                 d = (ref[key] != cur[key])
                 detail = dict(run=r, key=list(key), n_diff=int(d.sum()), rows=[int(v) for v in d.reshape(d.shape[0], -1).any(1).nonzero().flatten()[:10]],
-                              max_abs=float((ref[key].float() - cur[key].float()).abs().max()))
+                              max_abs=float((ref[key].float() - cur[key].float()).abs().max()),
+                              nan_in_cur=int(torch.isnan(cur[key].float()).sum()), nan_in_ref=int(torch.isnan(ref[key].float()).sum()))
                 if key[1] in ("renders", "images_crop"):
                     detail["channels"] = [int(c) for c in d.any(0).reshape(d.shape[1], -1).any(1).nonzero().flatten()]
                     where = d.nonzero()[:2000]
@@ -88,5 +89,6 @@ for r in range(runs):
                     detail["ref_vals"] = [[float(v) for v in ref[key][a, b, c]] for a, b, c in pix[:4]]
                     detail["cur_vals"] = [[float(v) for v in cur[key][a, b, c]] for a, b, c in pix[:4]]
             break
-print(json.dumps(dict(runs=runs, lanes=lanes, graphs=graphs, cull=not os.environ.get("HP_RASTER_NO_CULL"), fields_compared=sorted({k[1] for k in ref}),
+nan_anywhere = int(sum(int(torch.isnan(v.float()).sum()) for v in ref.values()))
+print(json.dumps(dict(runs=runs, lanes=lanes, graphs=graphs, nan_in_reference_snapshot=nan_anywhere, canary=bool(os.environ.get("HP_RASTER_CANARY")), cull=not os.environ.get("HP_RASTER_NO_CULL"), fields_compared=sorted({k[1] for k in ref}),
                       first_difference_tally=dict(tally), first=detail)))
