@@ -635,409 +635,11 @@ __global__ __launch_bounds__(kPPThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// ONE WAVE PER SIMD (round 6, `conv3x3_pp1`): the same 256 x 128 tile, LDS rows, weight layout, items and epilogue as conv3x3_pp, run
-// by FOUR waves with the whole 512-register file each (amdgpu_waves_per_eu(1, 1): the 128 accumulator registers of a 128 x 64 wave
-// tile go to AGPRs).  Why: a 64 x 64 wave tile reads 16 operand fragments per 24 (split) / 16 (fp16) MFMAs -- 128 KB of LDS reads per
-// tap and workgroup, 1024 LDS cycles against 1536 / 1024 cycles of matrix time: the fp16 mode is LDS-bound outright (measured 0.78
-// busy inside the K loop) and the split mode has no slack for its staging stores (0.85 - 0.91).  A 128 x 64 wave tile reads 24
-// fragments per 48 / 32 MFMAs: 96 KB, 768 cycles per tap.  There is no partner wave to hide the LDS round trip, so the loop is
-// software-pipelined by HALF a tap instead: a tap's MFMAs fall into two halves over disjoint channels of the chunk (k-steps), each
-// with its own 12 fragments (48 registers); while half A of tap t multiplies, half B of tap t is read, and while half B multiplies,
-// half A of tap t + 1 is read, the weights of tap t + 2 go from registers to LDS and those of tap t + 4 are fetched.  One
-// workgroup barrier per tap, between the halves (ping-pong: two per tap and wave group).  Arch VGPRs hold two half sets of
-// fragments + the staging registers (a wave has at most 256 of them, whatever the file size), AGPRs the 128 accumulators.
-constexpr int kP1Threads = 256;
-#ifndef HP_P1_MFMA_PER_GROUP
-#define HP_P1_MFMA_PER_GROUP (MODE == MODE_SPLIT ? 2 : 1)  // MFMAs per scheduling group of a half tap (24 / 16 MFMAs in 12 groups ... fp16: 16 in 12: 1, then the rest)
-#endif
-constexpr int MT1 = 4;  // M tiles of a wave: 128 x 64 wave tile, waves 2 (M) x 2 (N)
-
-template <int MODE>
-struct PP1 {
-  static constexpr int BN = 128, BMT = 256;
-  static constexpr int CKC = MODE == MODE_SPLIT ? 32 : 64;
-  static constexpr int TPR = MODE == MODE_SPLIT ? 4 : 8;
-  static constexpr int PROWS = kP1Threads / TPR;
-  static constexpr int ESZ = MODE == MODE_SPLIT ? 4 : 2;
-  static int P(int W) { return BMT + 2 * W + 2; }
-  static int npc(int W) { return (P(W) + PROWS - 1) / PROWS; }
-  static size_t lds_bytes(int W) { return ((size_t)2 * P(W) * LDH + 2 * (size_t)BN * LDH + LDH) * 2 + 2 * 512 * 4; }
-};
-
-template <int MODE, bool PRE, int NPC>
-__global__ __launch_bounds__(kP1Threads) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_pp1(ConvArgs a, int P) {
-  using T = PP1<MODE>;
-  constexpr int BN = T::BN, BMT = T::BMT, NT = 2;
-  constexpr int CKC = T::CKC, TPR = T::TPR, PROWS = T::PROWS, ESZ = T::ESZ;
-  constexpr int NB = BN * 8 / kP1Threads;  // 16-B weight pieces per thread and tap (4)
-  constexpr int BROWS = kP1Threads / 8;    // weight rows per staging pass (32)
-  constexpr int LPT = (NPC + 6) / 7;       // patch staging passes issued per tap (taps 0 .. 6 load, tap 7 stores)
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  _Float16* const patch = reinterpret_cast<_Float16*>(lds_raw);  // [2][P][LDH]
-  _Float16* const Bs = patch + 2 * P * LDH;                        // [2][BN][LDH]
-  _Float16* const zrow = Bs + 2 * BN * LDH;                        // [LDH] zeros: what a masked tap reads
-  float act_sx = 1.f, act_inv = 1.f;
-  if constexpr (MODE == MODE_SPLIT) conv_act_scale(a, act_sx, act_inv);
-  float* const pre_lds = reinterpret_cast<float*>(zrow + LDH);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int W = a.W, H = a.H, Cin = a.Cin;
-  const int ncc_all = Cin / CKC;
-  const __amdgpu_buffer_rsrc_t xrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(a.M * Cin * ESZ), 0x00020000);
-  const int64_t wrow = MODE == MODE_SPLIT ? (int64_t)18 * Cin : (int64_t)a.Kpad;  // halves per cout
-  const __amdgpu_buffer_rsrc_t wrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)((int64_t)a.Cout * wrow * 2), 0x00020000);
-
-  const int pk = tid % TPR, pr0 = tid / TPR;
-  _Float16* const Pst = patch + pr0 * LDH + 8 * pk;
-  const int bk = tid & 7, br0 = tid >> 3;
-  _Float16* const Bst = Bs + br0 * LDH + 8 * bk;
-  if (tid < LDH / 2) reinterpret_cast<unsigned*>(zrow)[tid] = 0u;
-  if (PRE) {
-    if constexpr (MODE == MODE_SPLIT) {
-      for (int i = tid; i < Cin; i += kP1Threads) { pre_lds[i] = a.pre_scale[i] * act_sx; pre_lds[Cin + i] = a.pre_shift[i] * act_sx; }
-    } else {
-      _Float16* const ph = reinterpret_cast<_Float16*>(pre_lds);
-      for (int i = tid; i < Cin; i += kP1Threads) {
-        ph[i] = reinterpret_cast<const _Float16*>(a.pre_scale)[i];
-        ph[Cin + i] = reinterpret_cast<const _Float16*>(a.pre_shift)[i];
-      }
-    }
-    __syncthreads();
-  }
-  auto w_soff = [&](int cc, int tap) -> unsigned {
-    return MODE == MODE_SPLIT ? (unsigned)((cc * 9 + tap) * 128) : (unsigned)((tap * Cin + cc * CKC) * 2);
-  };
-  const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
-  const int frow = lane & 31, fk = 8 * (lane >> 5);
-  const int srow = 16 * ((frow >> 2) & 1) + 4 * (frow >> 3) + (frow & 3);  // see conv3x3_pp: 16 consecutive couts per lane
-  const _Float16* const Bfr = Bs + (wn + srow) * LDH + fk;
-  const _Float16* const Afr0 = patch + (wm + frow + W + 1) * LDH + fk;  // M tile mt: + mt * 32 rows
-  const _Float16* const Zfr = zrow + fk;
-
-  const int nvb = 8 * (a.sk_regular / 8 + (a.sk_tail_items + 7) / 8);
-  int64_t gp0 = 0;
-  unsigned wvoff[NB];
-  unsigned vmask[MT1];
-  int cc_begin = 0, ncc = 0;
-  struct Item { int lin, slice, n0; bool split; int64_t m0; };
-  auto opaque_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
-  auto opaque_args = [&]() { KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p; };
-#else
-  typedef const ConvArgs* KArgs;
-  auto opaque_args = [&]() { return &a; };
-#endif
-  auto decode = [&](int vb, Item& it) -> bool {
-    if (vb >= nvb) return false;
-    const KArgs ka = opaque_args();
-    const ConvArgs a = *ka;
-    const int t_ = opaque_tid();
-    const int br0 = t_ >> 3, bk = t_ & 7, frow = t_ & 31, wave_ = t_ >> 6;
-    const int wm = (wave_ >> 1) * 128;
-    const int pr0 = t_ / TPR;
-    const int rpx = a.sk_regular / 8, tpx = (a.sk_tail_items + 7) / 8;
-    const int xcd = vb % 8, li = vb / 8;
-    it.slice = 0; it.split = false;
-    if (li < rpx) {
-      it.lin = xcd * rpx + li;
-    } else {
-      const int ti = xcd * tpx + (li - rpx);
-      if (li - rpx >= tpx || ti >= a.sk_tail_items) return false;
-      it.lin = a.sk_regular + ti / a.sk_S;
-      it.slice = ti % a.sk_S;
-      it.split = a.sk_S > 1;
-    }
-    const int tile_m = fdiv(it.lin, a.fd_tn), tile_n = it.lin - tile_m * a.tiles_n;
-    it.m0 = (int64_t)tile_m * BMT;
-    it.n0 = tile_n * BN;
-    cc_begin = it.split ? it.slice * ncc_all / a.sk_S : 0;
-    ncc = it.split ? (it.slice + 1) * ncc_all / a.sk_S : ncc_all;
-    gp0 = it.m0 - (W + 1) + pr0;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) wvoff[i] = (unsigned)(((int64_t)(it.n0 + br0 + BROWS * i) * wrow + 8 * bk) * 2);
-#pragma unroll
-    for (int mt = 0; mt < MT1; ++mt) {
-      const int64_t g = it.m0 + wm + mt * 32 + frow;
-      unsigned mk = 0;
-      if (g < a.M) {
-        const int rem = (int)g - fdiv((int)g, a.fd_howo) * (H * W);
-        const int oh = fdiv(rem, a.fd_wo), ow = rem - oh * W;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
-          mk |= ((((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W)) ? 1u : 0u) << t;
-        }
-      }
-      vmask[mt] = mk;
-    }
-    return true;
-  };
-  auto patch_voff = [&](int j) -> unsigned {
-    const int64_t gp = gp0 + PROWS * j;
-    return (pr0 + PROWS * j < P && gp >= 0 && gp < a.M) ? (unsigned)((gp * Cin + 8 * pk) * ESZ) : kOob;
-  };
-
-  pp_floatx16 acc[MT1][NT];
-  pp_floatx4 prf[MODE == MODE_SPLIT ? NPC : 1][2];
-  pp_halfx8 prh[MODE == MODE_F16 ? NPC : 1];
-  pp_halfx8 rb[2][NB];
-  pp_halfx8 fa[2][2][MT1], fb[2][2][NT];  // [half set][hi / lo (split) or k-quarter (fp16)][tile]: operand fragments of half a tap
-  auto load_patch = [&](int j, int cc) {
-    const unsigned vo = patch_voff(j);
-    if constexpr (MODE == MODE_SPLIT) {
-      prf[j][0] = ldf4(xrsrc, vo, (unsigned)(cc * CKC * 4));
-      prf[j][1] = ldf4(xrsrc, vo, (unsigned)(cc * CKC * 4 + 16));
-    } else {
-      prh[j] = ldh8(xrsrc, vo, (unsigned)(cc * CKC * 2));
-    }
-  };
-  auto store_patch = [&](int cc, int pbuf) {
-    _Float16* const dst = Pst + pbuf * P * LDH;
-    if constexpr (MODE == MODE_SPLIT) {
-      pp_floatx4 ps[2], pb[2];
-      if (PRE) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          ps[h] = *reinterpret_cast<const pp_floatx4*>(pre_lds + cc * CKC + 8 * pk + 4 * h);
-          pb[h] = *reinterpret_cast<const pp_floatx4*>(pre_lds + Cin + cc * CKC + 8 * pk + 4 * h);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NPC; ++j) {
-        if (pr0 + PROWS * j < P) {
-          const bool real = patch_voff(j) != kOob;
-          pp_halfx4 hi[2], lo[2];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            pp_floatx4 v = prf[j][h];
-            if (PRE) {
-              v = __builtin_elementwise_max(v * ps[h] + pb[h], pp_floatx4{0.f, 0.f, 0.f, 0.f});
-              if (!real) v = pp_floatx4{0.f, 0.f, 0.f, 0.f};
-            } else {
-              v = v * act_sx;
-            }
-            hi[h] = __builtin_convertvector(v, pp_halfx4);
-            lo[h] = __builtin_convertvector(v - __builtin_convertvector(hi[h], pp_floatx4), pp_halfx4);
-          }
-          *reinterpret_cast<pp_halfx8*>(dst + PROWS * j * LDH) = __builtin_shufflevector(hi[0], hi[1], 0, 1, 2, 3, 4, 5, 6, 7);
-          *reinterpret_cast<pp_halfx8*>(dst + PROWS * j * LDH + 32) = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-      }
-    } else {
-      pp_halfx8 ps, pb;
-      if (PRE) {
-        ps = *reinterpret_cast<const pp_halfx8*>(reinterpret_cast<const _Float16*>(pre_lds) + cc * CKC + 8 * pk);
-        pb = *reinterpret_cast<const pp_halfx8*>(reinterpret_cast<const _Float16*>(pre_lds) + Cin + cc * CKC + 8 * pk);
-      }
-#pragma unroll
-      for (int j = 0; j < NPC; ++j) {
-        if (pr0 + PROWS * j < P) {
-          pp_halfx8 v = prh[j];
-          if (PRE) {
-            const pp_halfx8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-            v = __builtin_elementwise_max(v * ps + pb, zero);
-            if (patch_voff(j) == kOob) v = zero;
-          }
-          *reinterpret_cast<pp_halfx8*>(dst + PROWS * j * LDH) = v;
-        }
-      }
-    }
-  };
-  auto load_b = [&](int set, int cc, int tap) {  // clamped to the layer's last tap: the tail of an item re-reads it
-    if (cc >= ncc_all) { cc = ncc_all - 1; tap = 8; }
-    const unsigned so = w_soff(cc, tap);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rb[set][i] = ldh8(wrsrc, wvoff[i], so);
-  };
-  auto store_b = [&](int set, int buf) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<pp_halfx8*>(Bst + buf * BN * LDH + BROWS * i * LDH) = rb[set][i];
-  };
-  auto tap_at = [&](int cc, int tap, int d, int& c2, int& t2) {
-    t2 = tap + d; c2 = cc;
-    while (t2 >= 9) { t2 -= 9; ++c2; }
-  };
-  auto issue_first_loads = [&]() {
-#pragma unroll
-    for (int j = 0; j < NPC; ++j) load_patch(j, cc_begin);
-    load_b(0, cc_begin, 0);
-    load_b(1, cc_begin, 1);
-  };
-  // the 12 operand fragments of half `half` of tap `tap` (patch buffer pq, weight buffer wbuf) -> half set `half`.  Split mode: half
-  // h = channels 16 h .. 16 h + 15 of the chunk, fragments q = h (hi halves) and 2 + h (lo halves); fp16: k-quarters 2 h, 2 h + 1.
-  // The tap's row shift is laundered (one SGPR, re-derived here): left visible, the compiler hoists the shifted addresses of the
-  // 18 unrolled taps out of the chunk loop and keeps them live across it.
-  auto read_half = [&](auto hf, int tap, int pq, int wbuf) {
-    constexpr int h = decltype(hf)::value;
-    constexpr int q0 = MODE == MODE_SPLIT ? h : 2 * h, q1 = MODE == MODE_SPLIT ? 2 + h : 2 * h + 1;
-    int doff = ((tap / 3 - 1) * W + (tap % 3 - 1) + pq * P) * LDH;
-    asm volatile("" : "+s"(doff));
-    const _Float16* const At = Afr0 + doff;
-#pragma unroll
-    for (int i = 0; i < MT1; ++i) {
-      unsigned vm = vmask[i];
-      asm volatile("" : "+v"(vm));
-      const _Float16* const Ab = ((vm >> tap) & 1u) ? At + i * 32 * LDH : Zfr;
-      fa[h][0][i] = *reinterpret_cast<const pp_halfx8*>(Ab + q0 * 16);
-      fa[h][1][i] = *reinterpret_cast<const pp_halfx8*>(Ab + q1 * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      fb[h][0][i] = *reinterpret_cast<const pp_halfx8*>(Bfr + wbuf * BN * LDH + i * 32 * LDH + q0 * 16);
-      fb[h][1][i] = *reinterpret_cast<const pp_halfx8*>(Bfr + wbuf * BN * LDH + i * 32 * LDH + q1 * 16);
-    }
-  };
-  auto mm = [&](const pp_halfx8 (&x)[MT1], const pp_halfx8 (&y)[NT]) {
-#pragma unroll
-    for (int mi = 0; mi < MT1; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NT; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(y[ni], x[mi], acc[mi][ni], 0, 0, 0);  // D[cout][pixel]
-  };
-  auto mm_half = [&](auto hf) {
-    constexpr int h = decltype(hf)::value;
-    if constexpr (MODE == MODE_SPLIT) {
-      mm(fa[h][0], fb[h][0]); mm(fa[h][0], fb[h][1]); mm(fa[h][1], fb[h][0]);  // hi hi + hi lo + lo hi
-    } else {
-      mm(fa[h][0], fb[h][0]); mm(fa[h][1], fb[h][1]);
-    }
-  };
-  constexpr std::integral_constant<int, 0> HA{};
-  constexpr std::integral_constant<int, 1> HB{};
-
-  // Tap (cc, tap) with parity Pb of its index inside the item (= its weight buffer) and patch buffer PQ.  On entry: half A of this
-  // tap in its registers (read by the previous tap's second half / the prologue), weights of tap + 1 stored to LDS buffer 1 - Pb by
-  // the previous tap (not yet published), weights of tap + 2 in register set Pb, those of tap + 3 on their way into set 1 - Pb.
-  auto tap_step = [&](int cc, auto tp, auto par, auto ppar) {
-    constexpr int tap = decltype(tp)::value;
-    constexpr int Pb = decltype(par)::value;
-    constexpr int PQ = decltype(ppar)::value;
-    const bool next_chunk = cc + 1 < ncc;
-    // ---- first half: read half B of this tap, multiply half A
-    read_half(HB, tap, PQ, Pb);
-#pragma unroll
-    for (int j = 0; j < NPC; ++j)  // the next chunk's patch: LPT staging passes per tap on taps 0 .. 6, converted and stored by tap 7
-      if (j / LPT == tap) load_patch(j, next_chunk ? cc + 1 : cc);
-    mm_half(HA);
-    // One wave per SIMD: nothing else fills the matrix pipe while this wave issues anything but an MFMA, so every LDS / VMEM / VALU
-    // instruction of the half must sit in the 32-cycle shadow of an MFMA: two MFMAs, one fragment read, (one staging access,) two
-    // VALU, twelve times.  (Issued as a burst in front of the MFMAs -- a scheduling fence there -- the half took 1350 cycles
-    // instead of 768; left to the scheduler, part of the reads sink to the end of the half, in front of the wait.)
-#pragma unroll
-    for (int g = 0; g < 12; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, HP_P1_MFMA_PER_GROUP, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (the next chunk's patch, taps 0 .. 6)
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // half B is in registers, my staging stores of the previous tap are in LDS
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();  // everybody's: this tap's LDS reads are over (weight buffer Pb is free), buffer 1 - Pb holds tap + 1
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- second half: read half A of the next tap (the next chunk's patch was stored by tap 7), stage weights, multiply half B
-    if (tap < 8) read_half(HA, tap + 1, PQ, 1 - Pb);
-    else read_half(HA, 0, 1 - PQ, 1 - Pb);
-    store_b(Pb, Pb);  // tap + 2: registers -> LDS buffer Pb
-    {
-      int c4, t4;
-      tap_at(cc, tap, 4, c4, t4);
-      load_b(Pb, c4, t4);  // tap + 4: global -> that register set
-    }
-    if (tap == 7 && next_chunk) store_patch(cc + 1, 1 - PQ);
-    mm_half(HB);
-#pragma unroll
-    for (int g = 0; g < 12; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, HP_P1_MFMA_PER_GROUP, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-      __builtin_amdgcn_sched_group_barrier(0x200, tap == 7 ? 2 : 1, 0);  // DS write (weights; tap 7: + the next chunk's patch)
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (weights of tap + 4)
-      __builtin_amdgcn_sched_group_barrier(0x002, tap == 7 ? 12 : 2, 0);  // VALU (tap 7: the patch's BN + ReLU, split and packing)
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto chunk = [&](int cc, auto c0) {
-    constexpr int C0 = decltype(c0)::value;
-    using E = std::integral_constant<int, C0>;
-    using O = std::integral_constant<int, 1 - C0>;
-    using Q = std::integral_constant<int, C0>;
-#define HP_TAP(t_) std::integral_constant<int, t_>{}
-    tap_step(cc, HP_TAP(0), E{}, Q{}); tap_step(cc, HP_TAP(1), O{}, Q{}); tap_step(cc, HP_TAP(2), E{}, Q{});
-    tap_step(cc, HP_TAP(3), O{}, Q{}); tap_step(cc, HP_TAP(4), E{}, Q{}); tap_step(cc, HP_TAP(5), O{}, Q{});
-    tap_step(cc, HP_TAP(6), E{}, Q{}); tap_step(cc, HP_TAP(7), O{}, Q{}); tap_step(cc, HP_TAP(8), E{}, Q{});
-#undef HP_TAP
-  };
-
-  Item cur{};
-  int vb = blockIdx.x;
-  bool have = decode(vb, cur);
-  if (have) issue_first_loads();
-  while (have) {
-#ifdef HP_PP_STAMPS
-    const unsigned long long st_p0 = __builtin_readcyclecounter();
-#endif
-#pragma unroll
-    for (int i = 0; i < MT1; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // ---- prologue: patch of the first chunk and the weights of tap 0 -> LDS, fragments of tap 0 -> set 0, weights of tap 1 -> LDS
-    store_patch(cc_begin, 0);
-    store_b(0, 0);
-    load_b(0, cc_begin, 2);
-    __syncthreads();
-    read_half(HA, 0, 0, 0);
-    store_b(1, 1);
-    load_b(1, cc_begin, 3);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#ifdef HP_PP_STAMPS
-    const unsigned long long st_t0 = __builtin_readcyclecounter(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    int cc = cc_begin;
-    for (; cc + 1 < ncc; cc += 2) {
-      chunk(cc, std::integral_constant<int, 0>{});
-      chunk(cc + 1, std::integral_constant<int, 1>{});
-    }
-    if (cc < ncc) chunk(cc, std::integral_constant<int, 0>{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the trailing (unused) fragment reads and staging stores of the last tap
-    __builtin_amdgcn_s_barrier();  // everybody is past its last LDS access: the buffers are free for the next item's prologue
-#ifdef HP_PP_STAMPS
-    if (tid == 0) {
-      atomicAdd(&g_pp_stamps[0], __builtin_readcyclecounter() - st_t0);
-      atomicAdd(&g_pp_stamps[1], __builtin_amdgcn_s_memrealtime() - st_r0);
-      atomicAdd(&g_pp_stamps[2], (unsigned long long)((ncc - cc_begin) * 9));
-      atomicAdd(&g_pp_stamps[3], 1ull);
-      atomicAdd(&g_pp_stamps[4], st_t0 - st_p0);
-    }
-    const unsigned long long st_e0 = __builtin_readcyclecounter();
-#endif
-    Item nxt{};
-    vb += (int)gridDim.x;
-    bool finish = true, issued = false;
-    const ConvArgs ea = *opaque_args();
-    if (cur.split) finish = splitk_reduce_sc1<BMT, BN, MT1, NT, kP1Threads>(ea, acc, cur.lin - ea.sk_regular, cur.slice);
-    auto prefetch_next = [&]() {
-      have = decode(vb, nxt);
-      if (have) issue_first_loads();
-      issued = true;
-    };
-    if (finish) {
-      const int t_ = opaque_tid(), wave_ = t_ >> 6;
-      pp_epilogue_direct<MODE, NT, MT1>(ea, acc, cur.m0, cur.n0, (wave_ >> 1) * 128, (wave_ & 1) * 64, act_inv, t_ & 63, prefetch_next);
-    }
-    if (!issued) prefetch_next();
-#ifdef HP_PP_STAMPS
-    if (tid == 0) atomicAdd(&g_pp_stamps[5], __builtin_readcyclecounter() - st_e0);
-#endif
-    cur = nxt;
-  }
-}
-
+// (Round 6: `conv3x3_pp1`, the same tile by FOUR waves -- one per SIMD with the whole register file, 128 x 64 wave tiles, 24 fragment
+// reads per 48 MFMAs, a half-tap software pipeline -- was built here, parity-green, and deleted: 2300 - 2600 cycles per tap against
+// 1650 - 1750.  The non-MFMA instructions of a tap do not hide in the shadow of the same wave's MFMAs on this machine; only a second
+// wave of the SIMD issuing them keeps the matrix pipe busy.  profiles/r06_pp1_one_wave_per_simd.txt; the source is in this file's
+// history.)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 3x3 / STRIDE-2 / pad-1 layers (the first conv of layer2 / 3 / 4) on the same skeleton (round 4).  conv3x3s2_split_f32
@@ -1397,40 +999,6 @@ int launch_pp_nt(const ConvArgs& a, hipStream_t stream) {
   return fail(HP_ERR_ARG, "conv3x3_pp: map too wide for the staged patch");
 }
 
-// one wave per SIMD (conv3x3_pp1): Cout % 128 == 0 layers whose staged patch fits NPC passes of the 256-thread workgroup
-template <int MODE, bool PRE, int NPC>
-int launch_pp1_variant(ConvArgs args, hipStream_t stream) {
-  using T = PP1<MODE>;
-  static FirstLaunch fl;
-  if (const int rc0 = fl.once([](FirstLaunch& s) {
-        HP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp1<MODE, PRE, NPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         159 * 1024));
-        s.spills = note_kernel(reinterpret_cast<const void*>(&conv3x3_pp1<MODE, PRE, NPC>));
-        return HP_OK;
-      }))
-    return rc0;
-  if (fl.spills) count_scratch_launch();
-  args.tiles_m = (int)((args.M + T::BMT - 1) / T::BMT);
-  args.tiles_n = args.Cout / T::BN;
-  args.fd_howo = make_fastdiv((unsigned)(args.H * args.W));
-  args.fd_wo = make_fastdiv((unsigned)args.W);
-  args.fd_tn = make_fastdiv((unsigned)args.tiles_n);
-  const int rc = conv_split_plan_tail(args, args.tiles_m * args.tiles_n, args.Cin / T::CKC, (size_t)T::BMT * T::BN, 1, stream);
-  if (rc) return rc;
-  const int per_xcd = args.sk_regular / 8 + (args.sk_tail_items + 7) / 8;
-  const int cap = dbg(DBG_PP_GRID) > 0 ? std::max(8, dbg(DBG_PP_GRID) / 8 * 8) : conv_num_cus() / 8 * 8;
-  const int grid = std::min(8 * per_xcd, cap);
-  hipLaunchKernelGGL((conv3x3_pp1<MODE, PRE, NPC>), dim3(grid), dim3(kP1Threads), T::lds_bytes(args.W), stream, args, T::P(args.W));
-  return check_launch("conv3x3_pp1");
-}
-template <int MODE>
-constexpr int pp1_npc() { return MODE == MODE_SPLIT ? 6 : 11; }
-template <int MODE>
-bool pp1_ok(int W, int Cin, int Cout) {  // on top of pp_shape_ok<MODE, 2>
-  using T = PP1<MODE>;
-  return dbg(DBG_CONV_PP1) != 0 && Cout % T::BN == 0 && Cin % T::CKC == 0 && T::npc(W) <= pp1_npc<MODE>() && T::lds_bytes(W) <= 159 * 1024;
-}
-
 template <int MODE, int NT>
 bool pp_shape_ok(int W, int Cin, int Cout, int stride, int pad, int kh, int kw) {
   using T = PP<MODE, NT>;
@@ -1491,9 +1059,6 @@ bool conv_pp_split_applicable(const ConvArgs& a, int kh, int kw) {
 int launch_conv_pp_split(const ConvArgs& a, hipStream_t stream) {
   if (pp_wide64_ok(a, 3, 3))
     return a.pre_scale ? launch_pp_variant<MODE_SPLIT, true, 6, 2, true>(a, stream) : launch_pp_variant<MODE_SPLIT, false, 6, 2, true>(a, stream);
-  if (pp1_ok<MODE_SPLIT>(a.W, a.Cin, a.Cout))
-    return a.pre_scale ? launch_pp1_variant<MODE_SPLIT, true, pp1_npc<MODE_SPLIT>()>(a, stream)
-                       : launch_pp1_variant<MODE_SPLIT, false, pp1_npc<MODE_SPLIT>()>(a, stream);
   return a.pre_scale ? launch_pp_nt<MODE_SPLIT, true, 2>(a, stream) : launch_pp_nt<MODE_SPLIT, false, 2>(a, stream);
 }
 
@@ -1521,9 +1086,6 @@ int launch_conv_pp_f16(const ConvArgsH& h, hipStream_t stream) {
   a.Kpad = h.Kpad; a.relu = h.relu; a.no_tail_split = h.no_tail_split;
   if (pp_f16_wide64_ok(h))
     return h.pre_scale ? launch_pp_variant<MODE_F16, true, 11, 2, true>(a, stream) : launch_pp_variant<MODE_F16, false, 11, 2, true>(a, stream);
-  if (pp1_ok<MODE_F16>(a.W, a.Cin, a.Cout))
-    return h.pre_scale ? launch_pp1_variant<MODE_F16, true, pp1_npc<MODE_F16>()>(a, stream)
-                       : launch_pp1_variant<MODE_F16, false, pp1_npc<MODE_F16>()>(a, stream);
   return h.pre_scale ? launch_pp_nt<MODE_F16, true, 2>(a, stream) : launch_pp_nt<MODE_F16, false, 2>(a, stream);
 }
 

@@ -12,7 +12,7 @@ int dbg(DebugSwitch s) {
     int v[DBG_COUNT];
     Table() {
       static const char* const names[DBG_COUNT] = {
-          "HP_PROFILE_LAYERS", "HP_NET_SYNC", "HP_NET_NO_SHORTCUT_FUSION", "HP_CONV_NO_PP", "HP_CONV_PP1", "HP_CONV_NO_PP_S2", "HP_CONV_NO_SPLITK", "HP_PP_GRID",
+          "HP_PROFILE_LAYERS", "HP_NET_SYNC", "HP_NET_NO_SHORTCUT_FUSION", "HP_CONV_NO_PP", "HP_CONV_NO_PP_S2", "HP_CONV_NO_SPLITK", "HP_PP_GRID",
           "HP_STEM7_F16_OLD", "HP_STEM5_OLD", "HP_NO_MBCONV_FRONT", "HP_RASTER_NO_CULL", "HP_RASTER_CHUNK_VIEWS", "HP_RASTER_CHUNK_SYNC",
           "HP_RASTER_LIST_BUDGET_MB", "HP_RASTER_CANARY"};
       for (int i = 0; i < DBG_COUNT; ++i) {

@@ -13,7 +13,6 @@ enum DebugSwitch {
   DBG_NET_SYNC,                 // HP_NET_SYNC: synchronise after every launch of a forward (fault isolation)
   DBG_NET_NO_SHORTCUT_FUSION,   // HP_NET_NO_SHORTCUT_FUSION: 1x1 shortcuts as their own launches (A/B test of the fused items)
   DBG_CONV_NO_PP,               // HP_CONV_NO_PP: conv3x3_split_f32 instead of the ping-pong kernels
-  DBG_CONV_PP1,                 // HP_CONV_PP1: the one-wave-per-SIMD 3x3 kernel (conv3x3_pp1) instead of the ping-pong one (A/B, round 6)
   DBG_CONV_NO_PP_S2,            // HP_CONV_NO_PP_S2: conv3x3s2_split_f32 instead of conv3x3s2_pp
   DBG_CONV_NO_SPLITK,           // HP_CONV_NO_SPLITK: no K-sliced tail tiles (process-wide; per network: hp_net_set_tail_split)
   DBG_PP_GRID,                  // HP_PP_GRID=<n>: persistent grid of n workgroups (tools/conv_fuzz.py: many items per workgroup)
