@@ -97,6 +97,7 @@ class MeshStore:
         if not self._h:
             raise _ffi.HipLibraryError("hp_mesh_store_create: " + lib().hp_last_error().decode())
         self._point_ids: Dict[int, torch.Tensor] = {}
+        self._ids_cache: Dict[tuple, torch.Tensor] = {}
         self.radius = torch.as_tensor(p.radius, device=self.device)
         self._followers: List["weakref.ReferenceType[MeshStore]"] = []  # the lane stores cloned from this one (clone_for_lane)
         if backface_culling is not None:
@@ -131,7 +132,15 @@ class MeshStore:
         return C.c_void_p(self._h)
 
     def ids_of(self, labels: Sequence[str]) -> torch.Tensor:
-        return torch.as_tensor([self.label_to_id[l] for l in labels], dtype=torch.int32, device=self.device)
+        """Object ids of ``labels`` on the device.  The last few label lists are remembered: a refiner is called frame after frame
+        with the same table, and the host-to-device copy of the ids sits in front of a call's first launch."""
+        key = tuple(labels)
+        hit = self._ids_cache.get(key)
+        if hit is None:
+            if len(self._ids_cache) >= 16:
+                self._ids_cache.pop(next(iter(self._ids_cache)))
+            hit = self._ids_cache[key] = torch.as_tensor([self.label_to_id[l] for l in labels], dtype=torch.int32, device=self.device)
+        return hit
 
     def reserve_raster(self, n_views: int, resolution: Tuple[int, int] = (240, 320), msaa: bool = False) -> None:
         """Size the rasteriser scratch for ``n_views`` views per call once (``hp_mesh_store_reserve_raster``): later
