@@ -237,8 +237,14 @@ class _EstimatorBase:
 
     def _run_model_chunks(self, model, observation, data_TCO_input, n_iterations, bsz, tag,
                           keep_all_outputs=False, **kw) -> Tuple[dict, dict]:
-        return self._guarded(model, lambda: self._run_model_chunks_once(
+        t_start = time.time()
+        preds, extra = self._guarded(model, lambda: self._run_model_chunks_once(
             model, observation, data_TCO_input, n_iterations, bsz, tag, keep_all_outputs, **kw))
+        # the stage's wall time INCLUDING the guard's stream synchronisation: the bookkeeping inside runs under the kernels, so
+        # without it "time" would be the host's enqueue time and the GPU's share of the stage would be booked on whatever
+        # synchronises next (the reference's per-stage `time` keys, MP/inference/pose_estimator.py:196-220, are wall times)
+        extra["time"] = time.time() - t_start
+        return preds, extra
 
     _ITER_COLS = (("poses", 16, (4, 4)), ("poses_input", 16, (4, 4)), ("K_crop", 9, (3, 3)), ("boxes_rend", 4, (4,)),
                   ("boxes_crop", 4, (4,)))
