@@ -315,7 +315,7 @@ def recorded_traffic(kind="conv"):
         return None, None
 
 
-def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2, renderer_kw=None, arch="resnet34"):
+def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2, renderer_kw=None, arch="resnet34", graphs=False):
     """A short run of another BASELINE.json config in the same process (C3: MegaPose RGB-D refiner, fp32; C5: coarse
     scoring in fp16; C2 again in another render state): ``{value, unit, ms_per_step, frac, algorithmic_tflops, steps}`` --
     the driver-visible twin of ``bench.py --workload C3|C5`` / ``--render-state single-sample``."""
@@ -346,16 +346,38 @@ def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2, rend
     torch.cuda.synchronize(device)
     gc.collect()
     gc.disable()
+    replayed = False
     try:
         step()
-        model.backbone.set_profiling(True)
+        if graphs and workload != "C5":
+            # each lane replays its step as a captured hipGraph (happypose_amd/graphs.py; create_*_model(graphs=True)): the timed pass is
+            # the replay, the roofline's per-launch timing comes from the same steps run once more eagerly (events cannot be recorded
+            # inside a replayed graph) -- as `bench.py --graphs on` does for the headline
+            try:
+                model.use_graphs = True
+                step(); step()
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    out = step()
+                torch.cuda.synchronize(device)
+                elapsed, replayed = time.perf_counter() - t0, True
+            except Exception:
+                replayed = False
+            model.use_graphs = False
+        model.backbone.set_profiling(True)  # (also drops captured graphs)
+        if replayed:
+            step()
+            model.backbone.profile_collect(); model.backbone.profile_intervals()
         torch.cuda.synchronize(device)
         _ops.profile_mark_reference(device)
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
         torch.cuda.synchronize(device)
-        elapsed = time.perf_counter() - t0
+        eager_elapsed = time.perf_counter() - t0
+        if not replayed:
+            elapsed = eager_elapsed
     finally:
         gc.enable()
     conv_ms = union_ms(model.backbone.profile_intervals())
@@ -364,10 +386,14 @@ def quick_workload(device, workload, precision, n_lanes, steps=3, warmup=2, rend
     assert torch.isfinite(out).all() and model.numerics_status() == 0
     sec = conv_ms * 1e-3
     executed_f16 = (16.0 if precision == "f32" else 1.0) * mfma_flops / sec / 1e12 if sec > 0 else 0.0
-    return {"value": B * steps / elapsed, "unit": "refined poses/s" if workload != "C5" else "views/s", "dtype": precision,
-            "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "frac": executed_f16 / PEAK_F16_MFMA_TFLOPS,
-            "algorithmic_tflops": conv_flops / sec / 1e12 if sec > 0 else 0.0, "conv_time_share": sec / elapsed,
-            "hypotheses_per_step": B, "lanes": n_lanes, "scratch_launches": int(_ops.scratch_launches())}
+    res = {"value": B * steps / elapsed, "unit": "refined poses/s" if workload != "C5" else "views/s", "dtype": precision,
+           "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "frac": executed_f16 / PEAK_F16_MFMA_TFLOPS,
+           "algorithmic_tflops": conv_flops / sec / 1e12 if sec > 0 else 0.0, "conv_time_share": sec / eager_elapsed,
+           "hypotheses_per_step": B, "lanes": n_lanes, "scratch_launches": int(_ops.scratch_launches())}
+    if replayed:
+        res["graphs"] = "each lane replays its 5-iteration step as a captured hipGraph; frac / conv_time_share from the same steps run eagerly"
+        res["eager_value"] = B * steps / eager_elapsed
+    return res
 
 
 def estimator_entry(model, images, K, labels, TCO0, device):
@@ -892,7 +918,9 @@ def main():
             if args.arch == "resnet34" and precision == "f32":
                 # C2 on the backbone the released CosyPose checkpoints use (CP/models/efficientnet.py), 3 steps
                 try:
-                    line["c2_efficientnet_b3"] = quick_workload(device, "C2", "f32", args.lanes or EFFICIENTNET_LANES, steps=3, arch="efficientnet-b3")
+                    # 153 launches of 5 - 130 us per forward and lane: the one workload whose step is bound by launch hand-over enough for
+                    # graph replay to matter (round 5: 3083 vs 2913 poses/s) -- replayed, with the eager number beside it
+                    line["c2_efficientnet_b3"] = quick_workload(device, "C2", "f32", args.lanes or EFFICIENTNET_LANES, steps=3, arch="efficientnet-b3", graphs=True)
                 except Exception as e:
                     line["c2_efficientnet_b3"] = {"error": f"{type(e).__name__}: {e}"}
                 # the whole PoseEstimator.run_inference_pipeline on one frame (bench.py --workload E2E), detector included

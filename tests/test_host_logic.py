@@ -445,3 +445,32 @@ def test_estimator_hands_small_chunks_to_the_lanes():
     LaneModel.MIN_BATCH = 8          # chunks AT the threshold are forward()'s to split over the lanes
     _, log = run(LaneModel(), 8)
     assert log == [("call", 8), ("call", 8), ("call", 5)]
+
+
+def test_bench_e2e_parity_is_relative_to_the_oracle_spread():
+    """``bench.e2e_parity``: coarse logits are judged in units of the ORACLE's standard deviation over a detection's grid poses (an
+    absolute tolerance was blind on the synthetic world), per detection; the top-5 sets and the final poses as before."""
+    import importlib
+    import sys
+
+    root = str(Path(__file__).resolve().parent.parent)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    rs = np.random.RandomState(0)
+    n_det, n_grid = 3, 48
+    inst = np.repeat(np.arange(n_det), n_grid)
+    cl = (5.6 + 0.05 * rs.normal(size=n_det * n_grid)) * np.repeat([1.0, 1.0, 1.0], n_grid)
+    T = np.tile(np.eye(4, dtype=np.float32), (n_det, 1, 1))
+    ref = {"coarse_df": pd.DataFrame({"coarse_logit": cl, "instance_id": inst}),
+           "filtered_df": pd.DataFrame({"hypothesis_id": list(range(5)) * n_det}),
+           "final_df": pd.DataFrame({"label": [f"obj{i}" for i in range(n_det)], "hypothesis_id": [1, 2, 3]}), "final_TCO": T}
+    good = dict(coarse_logit=cl + 0.0003 * rs.normal(size=cl.shape), filtered_hyp=list(range(5)) * n_det, final_labels=[f"obj{i}" for i in range(n_det)],
+                final_hyp=[1, 2, 3], final_poses=T.copy())
+    p = bench.e2e_parity(good, ref, "f32")
+    assert p["ok"] and p["final_hypothesis_agrees"] == n_det and p["coarse_logit_max_diff_over_spread"] < bench.COARSE_LOGIT_REL["f32"]
+    assert len(p["coarse_logit_spread_per_detection"]) == n_det and all(0.03 < x < 0.07 for x in p["coarse_logit_spread_per_detection"])
+    # a constant offset of a fifth of the spread on ONE detection: far inside the old absolute 5e-3 ... 5e-2, outside the relative bound
+    bad = dict(good, coarse_logit=cl + np.where(inst == 1, 0.2 * cl[inst == 1].std(), 0.0))
+    q = bench.e2e_parity(bad, ref, "f16")
+    assert not q["ok"] and q["coarse_logit_max_diff_over_spread"] > bench.COARSE_LOGIT_REL["f16"] and q["coarse_logit_max_abs_diff"] < 2e-2
