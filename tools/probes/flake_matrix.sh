@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-process flake statistics of two-lane graph replays under environment switches: each setting gets P fresh processes of
 # R runs (the condition that makes a process flaky is established at start-up: rates are 0 or ~5 % per process).
-#   tools/probes/flake_matrix.sh "HP_X=1" "HP_CONV_NO_ACT_SCALE=1" ...
+#   tools/probes/flake_matrix.sh "HP_X=1" "HP_RASTER_NO_CULL=1" ... (switches of csrc/debug.h)
 cd $GRAFT_REPO_ROOT
 P=${P:-5}; R=${R:-150}
 for e in "$@"; do
