@@ -1,4 +1,5 @@
 #!/bin/bash
+# (build the packed variant first: HP_BUILD_VARIANT=pk HP_BUILD_DROP_FLAGS="-packed-fp32-ops" python -m happypose_amd.build)
 # Round 6, GPU call 1: the C5 / fp16 parity probe, the GPU suite on the new build (no packed fp32, hidden visibility, debug table),
 # A/B of the packed-fp32 build (lib_pk: the round-5 flags) against it, A/B of tail K-slicing inside forward_chunks.
 cd "${GRAFT_REPO_ROOT:-.}"

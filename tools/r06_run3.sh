@@ -1,4 +1,5 @@
 #!/bin/bash
+# (build the SLP variant first, in the build container: HP_BUILD_VARIANT=slp HP_BUILD_DROP_FLAGS="-packed-fp32-ops -fno-slp-vectorize" python -m happypose_amd.build)
 # Round 6, GPU call 3: (a) the packed-fp32 finding, verdict item 5(b): the SLP build (lib_slp: the vectoriser on, packed fp32 allowed --
 # the build that differed in 1 - 13 % of its two-lane steps in round 5) alone and with HP_RASTER_CANARY=1 (set-up records and
 # transformed vertices filled with NaN before every rasteriser call, scratch addresses logged): do differing steps read something
