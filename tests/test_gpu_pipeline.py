@@ -715,6 +715,66 @@ def test_run_inference_pipeline_vs_oracle_estimator(dev, world):
     assert decisive, "choose weights whose coarse logits separate the top ranks (test world)"
 
 
+def test_run_inference_pipeline_f16_coarse_vs_oracle_estimator(dev, world):
+    """The default of the multi-hypothesis models since round 6 (``load_model.default_coarse_precision``): coarse / scoring network
+    on the fp16 plan, refiner in fp32, through the whole ``run_inference_pipeline`` -- against the fp32 CPU oracle estimator: coarse
+    and scoring logits within ``C5_LOGIT_REL["f16"]`` of the oracle's spread per detection (measured 0.014 - 0.030 on this world's 72-pose
+    grids), and wherever the fp16 scores pick the oracle's hypotheses (they must, where the oracle's margins
+    exceed twice the measured error) the refined and final poses within the fp32 pose tolerances."""
+    from happypose_amd.models import create_model_pose
+    from happypose_amd.pose_estimator import ObservationTensor, PoseEstimator, make_detections_from_object_data
+    from oracle import geometry as G
+    from oracle.estimator import OracleEstimator
+    from oracle.pipeline import OraclePredictor
+
+    sc, store = world["scene"], world["store"]
+    ccfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=1, multiview_type="TCO", render_normals=True,
+                predict_rendered_views_logits=True, predict_pose_update=False, depth_augmentation=False)
+    rcfg = dict(backbone_str="vanilla_resnet34", n_rendered_views=4, multiview_type="front_3views", render_normals=True,
+                depth_augmentation=False)
+    wc = _weights("vanilla_resnet34", 9, pose=False, logits=1, seed=9, scale=1.0)
+    wr = _weights("vanilla_resnet34", 27, seed=2)
+    coarse = create_model_pose(ccfg, world["renderer"], state_dict=wc, max_batch=72, precision="f16")
+    refiner = create_model_pose(rcfg, world["renderer"], state_dict=wr, max_batch=8)
+    obs = ObservationTensor(torch.as_tensor(sc["images"][:, :3].copy(), device=dev), torch.as_tensor(sc["K"], device=dev))
+    pts = store.mesh_db.points[sc["det_obj_ids"]]
+    boxes = G.boxes_from_uv(G.project_points(pts, np.repeat(sc["K"], 3, 0), sc["TCO_det"]))
+    labels = _labels(world, sc["det_obj_ids"])
+    det = make_detections_from_object_data(labels, boxes)
+    est = PoseEstimator(refiner_model=refiner, coarse_model=coarse, bsz_objects=8, bsz_images=72, SO3_grid_size=72)
+    final, extra = est.run_inference_pipeline(obs, detections=det.to(dev), n_refiner_iterations=2, n_pose_hypotheses=2)
+
+    oc = OraclePredictor(wc, store.packed, store.mesh_db.points, arch="vanilla_resnet34", render_normals=True)
+    orf = OraclePredictor(wr, store.packed, store.mesh_db.points, arch="vanilla_resnet34", n_views=4,
+                          multiview_type="TCO+front_3views", render_normals=True)
+    ref = OracleEstimator(orf, oc, store.labels, SO3_grid_size=72, bsz_objects=8, bsz_images=72).run_inference_pipeline(
+        sc["images"][:, :3], sc["K"], labels, boxes, n_refiner_iterations=2, n_pose_hypotheses=2, instance_id=np.arange(3))
+    rl = ref["coarse_df"]["coarse_logit"].values.reshape(3, 72)
+    cl = extra["coarse"]["preds"].infos.coarse_logit.values.reshape(3, 72)
+    spread = rl.std(axis=1)
+    err = np.abs(cl - rl).max(axis=1)
+    assert (err <= C5_LOGIT_REL["f16"] * spread).all(), (err, spread, err / spread)
+    srt = -np.sort(-rl, axis=1)
+    decisive = bool((srt[:, 0] - srt[:, 1] > 2 * err).all() and (srt[:, 1] - srt[:, 2] > 2 * err).all())
+    f = extra["coarse_filter"]["preds"]
+    print("f16 coarse pipeline: logit error / spread per detection", (err / spread).round(4).tolist(), "spread", spread.round(4).tolist(), "decisive", decisive,
+          "same top-2 as the oracle", f.infos.hypothesis_id.tolist() == ref["filtered_df"]["hypothesis_id"].tolist(),
+          "same final", final.infos.hypothesis_id.tolist() == ref["final_df"]["hypothesis_id"].tolist())
+    if decisive:  # the oracle's top two of every detection stand clear of the fp16 error: same hypotheses, same order
+        assert f.infos.hypothesis_id.tolist() == ref["filtered_df"]["hypothesis_id"].tolist()
+    if f.infos.hypothesis_id.tolist() == ref["filtered_df"]["hypothesis_id"].tolist():
+        for n in (1, 2):  # the refiner is fp32: its poses meet the fp32 tolerances
+            dt, dr = _pose_err(extra["refiner_all_hypotheses"]["preds"][f"iteration={n}"].poses.cpu().numpy(),
+                               ref["refiner_iterations"][n - 1]["TCO_output"])
+            assert dt <= T_TOL and dr <= R_TOL, (n, dt, dr)
+        pl, rp = extra["scoring"]["preds"].infos.pose_logit.values, ref["scored_df"]["pose_logit"].values
+        assert np.abs(pl - rp).max() <= C5_LOGIT_REL["f16"] * spread.max(), (np.abs(pl - rp).max(), spread)
+        if final.infos.hypothesis_id.tolist() == ref["final_df"]["hypothesis_id"].tolist():
+            dt, dr = _pose_err(final.poses.cpu().numpy(), ref["final_TCO"])
+            assert dt <= T_TOL and dr <= R_TOL, (dt, dr)
+    assert final.infos.label.tolist() == ref["final_df"]["label"].tolist()
+
+
 def test_run_inference_pipeline_vs_reference_golden_g10(dev, golden_dir):
     """The product's run_inference_pipeline against outputs of the REFERENCE's own PoseEstimator.run_inference_pipeline
     (golden G10, tools/gen_golden_loop.py: the reference's orchestrator, loop and backbones executing, with roi_align /
