@@ -107,6 +107,7 @@ _PROTOS = {
     "hp_mesh_store_set_raster_conventions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hp_mesh_store_get_raster_conventions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hp_mesh_store_set_backface_culling": (C.c_int, [C.c_void_p, C.c_int]),
+    "hp_mesh_store_get_backface_culling": (C.c_int, [C.c_void_p]),
     "hp_profile_mark_reference": (C.c_int, [C.c_void_p]),
     "hp_net_profile_intervals": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "hp_conv_select_algo": (C.c_int, [C.c_int]),

@@ -1699,6 +1699,8 @@ extern "C" int hp_mesh_store_set_backface_culling(hp_mesh_store* store, int on) 
   return prev;
 }
 
+extern "C" int hp_mesh_store_get_backface_culling(const hp_mesh_store* store) { return store ? (store->backface_culling ? 1 : 0) : -1; }
+
 extern "C" int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
                             const int32_t* d_obj_ids, const float* d_TCO, const float* d_K,
                             const float* d_ambient, int n_lights, const float* d_light_pos,

@@ -133,7 +133,8 @@ class MeshStore:
 
     def ids_of(self, labels: Sequence[str]) -> torch.Tensor:
         """Object ids of ``labels`` on the device.  The last few label lists are remembered: a refiner is called frame after frame
-        with the same table, and the host-to-device copy of the ids sits in front of a call's first launch."""
+        with the same table, and the host-to-device copy of the ids sits in front of a call's first launch.  The tensor is SHARED
+        between the calls that ask for the same labels: read-only for the callers (they slice it and hand it to kernels)."""
         key = tuple(labels)
         hit = self._ids_cache.get(key)
         if hit is None:
@@ -195,11 +196,8 @@ class MeshStore:
         return prev
 
     def get_backface_culling(self) -> bool:
-        """The current setting (the C ABI answers a set with the previous value: set, then restore)."""
-        cur = bool(lib().hp_mesh_store_set_backface_culling(self.handle, 1))
-        if not cur:
-            lib().hp_mesh_store_set_backface_culling(self.handle, 0)
-        return cur
+        """``hp_mesh_store_get_backface_culling``: the current setting."""
+        return bool(lib().hp_mesh_store_get_backface_culling(self.handle))
 
     def point_ids(self, n_points: int) -> torch.Tensor:
         """ids of ``sample_points(n, deterministic=True)`` (TB/lib3d/mesh_ops.py:74-84)."""

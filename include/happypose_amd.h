@@ -159,6 +159,8 @@ int hp_mesh_store_get_raster_conventions(const hp_mesh_store* store, hp_raster_c
  * HP_RASTER_NO_CULL=1 for every store of the process; renders are then two-sided everywhere, ~25 % slower.
  * Returns the previous setting (-1: null store). */
 int hp_mesh_store_set_backface_culling(hp_mesh_store* store, int on);
+/* The current setting (1 / 0; -1: null store): what a lane's store copies from the store it was cloned from. */
+int hp_mesh_store_get_backface_culling(const hp_mesh_store* store);
 
 int hp_rasterize(const hp_mesh_store* store, int n, int views_per_item,
                  const int32_t* d_obj_ids /* [n / views_per_item] */,
